@@ -1,0 +1,95 @@
+"""Seeded synthetic scenes.  The reference ships no data files
+(`bridge.obj`, `cross.obj`, `init/*.txt` are an external download, reference
+README.md:24-32), so every scene here is generated, in *solver units* (i.e. after the
+x5 scaling that Main/multiPathPlanning3D.cpp:107,536 applies to multi-UAV inputs).
+
+Each scene is a dict:
+  mode       0 = single-UAV path (admmPathPlanning3D), 1 = multi-UAV decoupled
+  U, P       robots, pieces (= waypoints - 1)
+  waypoints  float64 [U, P+1, 3]
+  cloud      float64 [N, 3]   obstacle point cloud
+  ks         1e-8 (single, admmPathPlanning3D.cpp:477) / 1e-3 (multi, multiPathPlanning3D.cpp:596)
+"""
+import numpy as np
+
+
+def scn_a(n_points=32768, seed=12345, pieces=5):
+    """SCN-A (BASELINE configs 1-2): one UAV through a tube in a uniform cloud."""
+    rng = np.random.default_rng(seed)
+    pts = np.empty((0, 3))
+    while pts.shape[0] < n_points:
+        c = rng.uniform(-3.0, 3.0, size=(2 * n_points, 3))
+        keep = (c[:, 1] - 0.8 * np.sin(c[:, 0])) ** 2 + c[:, 2] ** 2 > 0.45 ** 2
+        pts = np.concatenate([pts, c[keep]], axis=0)
+    cloud = np.ascontiguousarray(pts[:n_points])
+    xs = np.linspace(2.7, -2.7, pieces + 1)
+    wp = np.stack([xs, 0.8 * np.sin(xs), np.zeros_like(xs)], axis=1)[None]
+    return dict(name="SCN-A", mode=0, U=1, P=pieces, waypoints=np.ascontiguousarray(wp), cloud=cloud, ks=1e-8)
+
+
+def crossing(U, n_points, seed=777, pieces=5, name=None):
+    """SCN-B/C/D family: U robots on a circle of radius 10 fly to the antipodal point,
+    stacked 0.25 apart in z; cloud = two slabs just below / above the robot layer."""
+    rng = np.random.default_rng(seed)
+    wp = np.zeros((U, pieces + 1, 3))
+    for u in range(U):
+        th = np.pi * u / U
+        a = np.array([10 * np.cos(th), 10 * np.sin(th), 0.25 * u])
+        b = np.array([-10 * np.cos(th), -10 * np.sin(th), 0.25 * u])
+        for k in range(pieces + 1):
+            wp[u, k] = a + (b - a) * (k / pieces)
+    xy = rng.uniform(-12.0, 12.0, size=(n_points, 2))
+    r = rng.uniform(0.0, 1.0, size=n_points)
+    top = 0.25 * (U - 1) + 0.16 + 0.3 * r
+    bot = -0.16 - 0.3 * r
+    z = np.where(np.arange(n_points) % 2 == 0, bot, top)
+    cloud = np.ascontiguousarray(np.concatenate([xy, z[:, None]], axis=1))
+    return dict(name=name or f"crossing-U{U}-N{n_points}", mode=1, U=U, P=pieces,
+                waypoints=wp, cloud=cloud, ks=1e-3)
+
+
+def scn_b():
+    return crossing(8, 20000, seed=777, name="SCN-B")
+
+
+def scn_c():
+    return crossing(64, 100000, seed=777, name="SCN-C")
+
+
+def scn_d():
+    return crossing(256, 1000000, seed=777, name="SCN-D")
+
+
+def tiny(mode=1, U=3, n_points=600, seed=5):
+    """Small scene for fast oracle-vs-HIP unit tests."""
+    if mode == 0:
+        s = scn_a(n_points=n_points, seed=seed)
+        s["name"] = "tiny-single"
+        return s
+    s = crossing(U, n_points, seed=seed, name="tiny-multi")
+    return s
+
+
+# Shipped Config_File/3D.json values (reference "Config File/3D.json")
+DEFAULT_PARAMS = dict(res=8, vel_limit=2.0, acc_limit=2.0, lam=10.0, margin=0.1, offset=0.1,
+                      stop=1e-2, mu=0.1, kt=1.0, piece_time0=20.0)
+
+
+def write_reference_files(scene, root, mesh_name):
+    """Emit the scene in the reference's on-disk formats (OBJ `v` lines, init file), so the
+    CLIs can be exercised: model/{single,multiple}/<mesh>, init/<mesh>_init_file.txt.
+    Multi-UAV inputs are divided by 5 because the reader multiplies by 5."""
+    import os
+    multi = scene["mode"] == 1
+    sub = "multiple" if multi else "single"
+    os.makedirs(os.path.join(root, "model", sub), exist_ok=True)
+    os.makedirs(os.path.join(root, "init"), exist_ok=True)
+    os.makedirs(os.path.join(root, "result"), exist_ok=True)
+    scale = 0.2 if multi else 1.0
+    with open(os.path.join(root, "model", sub, mesh_name), "w") as f:
+        for p in scene["cloud"] * scale:
+            f.write("v %.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
+    with open(os.path.join(root, "init", mesh_name + "_init_file.txt"), "w") as f:
+        wp = scene["waypoints"] * scale
+        for k in range(wp.shape[1]):
+            f.write(" ".join("%.17g" % v for u in range(wp.shape[0]) for v in wp[u, k]) + "\n")
