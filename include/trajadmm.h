@@ -1,0 +1,129 @@
+/* trajadmm.h -- C ABI of the MI355X-native ADMM inner loop (libtrajadmm.so).
+ *
+ * Drop-in boundary for the hot path of ruiqini/traj-opt-admm.  The reference has no plugin or
+ * FFI layer; its narrowest seam is one static call per ADMM iteration from the two mains plus
+ * ~30 namespace-scope globals (HighOrderCCD/Utils/CCDUtils.cpp:5-44).  Each entry point below
+ * names the reference interface it replaces.  Plain pointers and sizes only; no C++ or torch
+ * types.  All matrices use the reference's Eigen layout: column-major, i.e. a T x 3 control net
+ * is stored as [x_0..x_{T-1}, y_0.., z_0..].
+ *
+ * A context owns all device memory (state, BVH, scratch) on one GPU; state stays resident in
+ * HBM between calls.  Calls on one context must be serialised by the caller.  Every function
+ * returns TJ_OK or a negative TJ_ERR_* code; tj_last_error() gives the message.
+ * The library has NO CPU fallback: without a usable HIP device tj_create fails.
+ */
+#ifndef TRAJADMM_H
+#define TRAJADMM_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tj_ctx tj_ctx;
+
+enum {
+  TJ_OK = 0,
+  TJ_ERR_INVALID = -1,      /* bad argument / call order */
+  TJ_ERR_DEVICE = -2,       /* HIP runtime failure or no device */
+  TJ_ERR_CAPACITY = -3,     /* a device-side list overflowed (raise cap_* in tj_params) */
+  TJ_ERR_NO_PROGRESS = -4,  /* a back-off / Newton / Armijo loop hit its iteration cap: infeasible state
+                               (the reference would spin forever: Step.h:83-97, Optimal_plane.h:23) */
+  TJ_ERR_UNSUPPORTED = -5
+};
+
+enum { TJ_MODE_SINGLE = 0,      /* Optimization3D_admm::optimization            (Optimization3D_admm.h:29-33)  */
+       TJ_MODE_MULTI_DECOUPLE = 1 /* Optimization3D_multi::optimization_decouple (Optimization3D_multi.h:29-33) */ };
+
+/* Replaces the parameter globals of CCDUtils.cpp:5-44 that the mains fill from Config_File/3D.json
+ * (Main/admmPathPlanning3D.cpp:368-397, Main/multiPathPlanning3D.cpp:478-511) and hard-code
+ * (ks, kt: admmPathPlanning3D.cpp:477-478, multiPathPlanning3D.cpp:596-597). */
+typedef struct tj_params {
+  int mode;            /* TJ_MODE_* */
+  int uav_num;         /* global `uav_num` */
+  int piece_num;       /* global `piece_num` (= waypoints - 1) */
+  int res;             /* "res": segments per piece */
+  double lambda;       /* "lambda" */
+  double margin;       /* "margin" */
+  double offset;       /* "offset" */
+  double mu;           /* "mu" */
+  double vel_limit;    /* "vel_limit" */
+  double acc_limit;    /* "acc_limit" */
+  double ks;           /* 1e-8 single / 1e-3 multi */
+  double kt;           /* 1 */
+  double stop;         /* "stop": device-side stop test iter>1 && gnorm<stop; <=0 disables it */
+  int device;          /* HIP device ordinal */
+  int rank, world;     /* robot sharding: this context owns robots [rank*U/world, (rank+1)*U/world) */
+  int cap_obs;         /* max obstacle planes per (robot, segment); 0 = default 256 */
+  int cap_self;        /* max inter-robot planes per (robot, segment); 0 = default uav_num */
+  int cap_pairs;       /* max inter-robot CCD candidate pairs per segment; 0 = default */
+} tj_params;
+
+/* Fills *p with the shipped 3D.json values ("Config File/3D.json") and the mode's ks/kt. */
+void tj_default_params(tj_params* p, int mode, int uav_num, int piece_num);
+
+int tj_create(const tj_params* p, tj_ctx** out);
+void tj_destroy(tj_ctx* c);
+const char* tj_last_error(const tj_ctx* c);
+
+/* Replaces BVH::InitPointcloud (HighOrderCCD/BVH/BVH.cpp:53-93) + vertex_list: uploads the
+ * obstacle cloud (row-major n x 3) and builds the static device BVH.  n may be 0 ("init_ob":0). */
+int tj_set_cloud(tj_ctx* c, const double* xyz, int n);
+
+/* Replaces init_variable (Main/admmPathPlanning3D.cpp:249-353 single,
+ * Main/multiPathPlanning3D.cpp:342-467 multi): waypoints is [uav_num][piece_num+1][3], already
+ * in solver units; builds spline, p_slack = C x, zero duals, t_slack = piece_time = piece_time0,
+ * and resets the iteration counter. */
+int tj_init_state(tj_ctx* c, const double* waypoints, double piece_time0);
+
+/* State of robot u: the six by-reference arguments of the reference call
+ * (spline T x 3, p_slack / p_lambda 6P x 3 column-major, t_slack / t_lambda P, piece_time). */
+int tj_get_state(tj_ctx* c, int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time);
+int tj_set_state(tj_ctx* c, int u, const double* spline, const double* p_slack, const double* p_lambda, const double* t_slack, const double* t_lambda, double piece_time);
+
+/* The hot path.  Runs up to n_iters ADMM iterations entirely on the device (one call of
+ * Optimization3D_admm::optimization / Optimization3D_multi::optimization_decouple each), with the
+ * mains' stop test evaluated on the device before every iteration.  Outputs (any may be NULL):
+ * gnorm = reference global `gnorm` after the last executed iteration, iters_total = reference
+ * global `iter`, converged = stop test fired. */
+int tj_iterate(tj_ctx* c, int n_iters, double* gnorm, int* iters_total, int* converged);
+
+/* Same work, asynchronous: enqueue only (no host sync, no read-back).  tj_sync waits. */
+int tj_iterate_async(tj_ctx* c, int n_iters);
+int tj_sync(tj_ctx* c);
+/* Stream the context enqueues on (hipStream_t as void*), for event timing by the caller. */
+void* tj_stream(tj_ctx* c);
+
+/* ---- stage-level access (teacher-forced parity tests, profiling) ---------------------------- */
+enum { TJ_STAGE_BEGIN = 0, TJ_STAGE_PLANES_OBS = 1, TJ_STAGE_PLANES_SELF = 2, TJ_STAGE_GRAD = 3, TJ_STAGE_XSOLVE = 4,
+       TJ_STAGE_CCD_PREP = 5, TJ_STAGE_CCD_OBS = 6, TJ_STAGE_CCD_SELF = 7, TJ_STAGE_LINESEARCH = 8, TJ_STAGE_SLACK = 9, TJ_STAGE_END = 10 };
+int tj_run_stage(tj_ctx* c, int stage);
+/* planes of robot u: counts[S] (obstacle planes first, then inter-robot), planes[total][4] = (cx,cy,cz,d);
+ * returns total (>=0) or an error; planes may be NULL to query the size. */
+int tj_get_planes(tj_ctx* c, int u, int* counts_obs, int* counts_self, double* planes, int cap);
+/* teacher forcing: overwrite robot u's plane lists (obstacle list only is used; self list emptied) */
+int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes);
+int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, double* wolfe, double* gn);
+int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361);
+int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_armijo);
+
+/* counters since tj_init_state, for the algorithmic-byte model */
+typedef struct tj_stats {
+  unsigned long long iters, nodes_dcd, nodes_ccd, cand_dcd, cand_ccd, planes_obs, planes_self, energy_evals, pair_tests;
+  int order_ambiguous; /* segments whose inter-robot clamp could depend on pair order (diagnostic) */
+  int error_bits;
+} tj_stats;
+int tj_get_stats(tj_ctx* c, tj_stats* s);
+
+/* ---- robot sharding across GPUs (one context per rank) -------------------------------------- */
+/* Device pointers + element counts of the two buffers that must be all-gathered per iteration
+ * (robot-major, so a rank's owned robots are one contiguous slice): what = 0 control points
+ * (spline, 3T doubles per robot), what = 1 search directions (3T + 4 doubles per robot:
+ * direction, t_direction, wolfe, |g|, pad). */
+int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_robot, int* first_owned, int* n_owned);
+/* Iteration split for external collectives: phase 0 = up to the point where all control points
+ * are needed, 1 = ... see INTEGRATION.md. */
+int tj_iterate_phase(tj_ctx* c, int phase);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

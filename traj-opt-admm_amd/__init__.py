@@ -1,0 +1,238 @@
+"""Python host-side mirror of the C ABI in include/trajadmm.h (libtrajadmm.so).
+
+The reference is compiled C++ with no Python layer; this module exists for the test-suite,
+bench.py and for Python callers, and is a thin ctypes binding -- all numerics run in the HIP
+kernels behind the C ABI.  There is NO CPU fallback: importing works anywhere (so that
+`-m "not gpu"` tests can check the exported symbols), but creating a `Solver` without the
+built library or without a HIP device raises.
+
+Method names follow the reference's driver vocabulary
+(Optimization3D_multi::optimization_decouple and its stages, Optimization3D_multi.h:29-118).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from . import scenes  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrajadmm.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+EXPORTS = [
+    "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_init_state", "tj_get_state",
+    "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
+    "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
+    "tj_iterate_phase",
+]
+
+STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
+
+
+class TjParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("uav_num", C.c_int), ("piece_num", C.c_int), ("res", C.c_int),
+                ("lambda_", C.c_double), ("margin", C.c_double), ("offset", C.c_double), ("mu", C.c_double),
+                ("vel_limit", C.c_double), ("acc_limit", C.c_double), ("ks", C.c_double), ("kt", C.c_double),
+                ("stop", C.c_double), ("device", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+                ("cap_obs", C.c_int), ("cap_self", C.c_int), ("cap_pairs", C.c_int)]
+
+
+class TjStats(C.Structure):
+    _fields_ = [(n, C.c_ulonglong) for n in ("iters", "nodes_dcd", "nodes_ccd", "cand_dcd", "cand_ccd", "planes_obs",
+                                             "planes_self", "energy_evals", "pair_tests")] + \
+               [("order_ambiguous", C.c_int), ("error_bits", C.c_int)]
+
+
+class TrajAdmmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libtrajadmm.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TrajAdmmError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.tj_last_error.restype = C.c_char_p
+        _lib.tj_stream.restype = C.c_void_p
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+class Solver:
+    """One ADMM problem resident on one GPU (one `tj_ctx`)."""
+
+    def __init__(self, scene, params=None, device=0, rank=0, world=1, stop=None, **caps):
+        self.lib = load_library()
+        p = dict(scenes.DEFAULT_PARAMS)
+        if params:
+            p.update(params)
+        self.params = p
+        self.mode, self.U, self.P = scene["mode"], scene["U"], scene["P"]
+        self.res = p["res"]
+        self.S, self.T = self.P * self.res, 3 * self.P + 3
+        tp = TjParams()
+        self.lib.tj_default_params(C.byref(tp), self.mode, self.U, self.P)
+        tp.res = self.res
+        tp.lambda_, tp.margin, tp.offset, tp.mu = p["lam"], p["margin"], p["offset"], p["mu"]
+        tp.vel_limit, tp.acc_limit, tp.ks, tp.kt = p["vel_limit"], p["acc_limit"], scene["ks"], p["kt"]
+        tp.stop = p["stop"] if stop is None else stop
+        tp.device, tp.rank, tp.world = device, rank, world
+        for k, v in caps.items():
+            setattr(tp, k, v)
+        self._ctx = C.c_void_p()
+        rc = self.lib.tj_create(C.byref(tp), C.byref(self._ctx))
+        self._check(rc)
+        cloud = np.ascontiguousarray(scene["cloud"], dtype=np.float64).reshape(-1, 3)
+        self.N = cloud.shape[0]
+        self._check(self.lib.tj_set_cloud(self._ctx, _d(cloud), C.c_int(self.N)))
+        self._wp = np.ascontiguousarray(scene["waypoints"], dtype=np.float64)
+        self._pt0 = float(p["piece_time0"])
+        self.reset()
+
+    def reset(self):
+        """init_variable: back to the initial trajectory, iteration counter 0."""
+        self._check(self.lib.tj_init_state(self._ctx, _d(self._wp), C.c_double(self._pt0)))
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self.lib.tj_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self.lib.tj_last_error(self._ctx).decode() if self._ctx.value else "tj_create failed"
+            raise TrajAdmmError(f"libtrajadmm error {rc}: {msg}")
+        return rc
+
+    # ---- state ---------------------------------------------------------------------------
+    def get_state(self):
+        U, P, T = self.U, self.P, self.T
+        st = dict(spline=np.zeros((U, 3, T)), p_slack=np.zeros((U, 3, 6 * P)), p_lambda=np.zeros((U, 3, 6 * P)),
+                  t_slack=np.zeros((U, P)), t_lambda=np.zeros((U, P)), piece_time=np.zeros(U))
+        for u in range(U):
+            pt = C.c_double()
+            self._check(self.lib.tj_get_state(self._ctx, u, _d(st["spline"][u]), _d(st["p_slack"][u]), _d(st["p_lambda"][u]),
+                                              _d(st["t_slack"][u]), _d(st["t_lambda"][u]), C.byref(pt)))
+            st["piece_time"][u] = pt.value
+        return st
+
+    def set_state(self, st):
+        for u in range(self.U):
+            a = [np.ascontiguousarray(st[k][u], dtype=np.float64) for k in ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda")]
+            self._check(self.lib.tj_set_state(self._ctx, u, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(a[4]), C.c_double(float(st["piece_time"][u]))))
+
+    # ---- hot path ------------------------------------------------------------------------
+    def iterate(self, n=1):
+        """n ADMM iterations on the device; returns (gnorm, iter, converged)."""
+        g, it, cv = C.c_double(), C.c_int(), C.c_int()
+        self._check(self.lib.tj_iterate(self._ctx, C.c_int(n), C.byref(g), C.byref(it), C.byref(cv)))
+        return g.value, it.value, bool(cv.value)
+
+    def iterate_async(self, n=1):
+        self._check(self.lib.tj_iterate_async(self._ctx, C.c_int(n)))
+
+    def sync(self):
+        self._check(self.lib.tj_sync(self._ctx))
+
+    def stream(self):
+        return self.lib.tj_stream(self._ctx)
+
+    def run_stage(self, name):
+        self._check(self.lib.tj_run_stage(self._ctx, C.c_int(STAGES[name])))
+
+    def iterate_phase(self, phase):
+        self._check(self.lib.tj_iterate_phase(self._ctx, C.c_int(phase)))
+
+    # ---- stage-level views (same shapes as oracle.pyoracle.Engine) ---------------------------
+    def stage_planes(self):
+        self.run_stage("begin")
+        self.run_stage("planes_obs")
+        self.run_stage("planes_self")
+        return self.get_planes()
+
+    def get_planes(self):
+        counts = np.zeros((self.U, self.S), dtype=np.int32)
+        chunks = []
+        for u in range(self.U):
+            co = np.zeros(self.S, dtype=np.int32); cs = np.zeros(self.S, dtype=np.int32)
+            n = self._check(self.lib.tj_get_planes(self._ctx, u, _i(co), _i(cs), None, 0))
+            buf = np.zeros((max(n, 1), 4))
+            self._check(self.lib.tj_get_planes(self._ctx, u, _i(co), _i(cs), _d(buf), C.c_int(n)))
+            counts[u] = co + cs
+            chunks.append(buf[:n])
+        return counts, np.concatenate(chunks, axis=0)
+
+    def set_planes(self, counts, planes):
+        counts = np.ascontiguousarray(counts, dtype=np.int32).reshape(self.U, self.S)
+        planes = np.ascontiguousarray(planes, dtype=np.float64).reshape(-1, 4)
+        w = 0
+        for u in range(self.U):
+            n = int(counts[u].sum())
+            blk = np.ascontiguousarray(planes[w:w + n]) if n else np.zeros((1, 4))
+            self._check(self.lib.tj_set_planes(self._ctx, u, _i(np.ascontiguousarray(counts[u])), _d(blk)))
+            w += n
+
+    def stage_direction(self):
+        self.run_stage("grad")
+        self.run_stage("xsolve")
+        out = dict(direction=np.zeros((self.U, 3, self.T)), t_direction=np.zeros(self.U), wolfe=np.zeros(self.U), gn=np.zeros(self.U))
+        for u in range(self.U):
+            a, b, c = C.c_double(), C.c_double(), C.c_double()
+            self._check(self.lib.tj_get_direction(self._ctx, u, _d(out["direction"][u]), C.byref(a), C.byref(b), C.byref(c)))
+            out["t_direction"][u], out["wolfe"][u], out["gn"][u] = a.value, b.value, c.value
+        out["gnorm"] = float(np.sum(out["gn"]) / self.U) if self.mode == 1 else float(out["gn"][0])
+        return out
+
+    def local_grad(self, u, sp):
+        g = np.zeros(19); h = np.zeros((19, 19))
+        self._check(self.lib.tj_get_local_grad(self._ctx, u, sp, _d(g), _d(h)))
+        return g, h
+
+    def stage_steps(self):
+        self.run_stage("ccd_prep")
+        self.run_stage("ccd_obs")
+        self.run_stage("ccd_self")
+        a = np.zeros(self.U); b = np.zeros(self.U)
+        self._check(self.lib.tj_get_steps(self._ctx, _d(a), _d(b), None))
+        return a, b
+
+    def stage_linesearch(self):
+        self.run_stage("linesearch")
+        s = np.zeros(self.U)
+        self._check(self.lib.tj_get_steps(self._ctx, None, None, _d(s)))
+        return s
+
+    def stage_slack(self):
+        self.run_stage("slack")
+        self.run_stage("end")
+
+    def stats(self):
+        s = TjStats()
+        self._check(self.lib.tj_get_stats(self._ctx, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in TjStats._fields_}
+
+    def exchange_buffer(self, what):
+        ptr, per, first, n = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.tj_exchange_buffer(self._ctx, what, C.byref(ptr), C.byref(per), C.byref(first), C.byref(n)))
+        return ptr.value, per.value, first.value, n.value

@@ -1,0 +1,126 @@
+// dev_common.h -- device-side view of the solver (all pointers are HBM-resident), wave64
+// helpers and small geometry routines shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_gjk.h"
+
+namespace tj {
+
+constexpr int WAVE = 64;
+constexpr int LOOP_CAP = 200;      // bound on every data-dependent device loop (the reference has none)
+constexpr int MAX_LEVELS = 12;     // 8-ary levels of the static BVH: 8^12 leaves
+constexpr int FRONT_CAP = 1024;    // BFS frontier capacity per wave (LDS)
+
+// error bits (Ctl::error)
+enum : int {
+  ERR_PLANE_OVERFLOW = 1,    // more separating planes for one segment than the configured capacity
+  ERR_FRONT_OVERFLOW = 2,    // BVH frontier overflow (query box far larger than expected)
+  ERR_LOOP_CAP = 4,          // a back-off / Newton / Armijo loop hit LOOP_CAP (infeasible state)
+  ERR_PAIR_OVERFLOW = 8,     // inter-robot CCD survivor list overflow
+};
+
+struct Ctl {
+  int iter;            // completed iterations (reference global `iter`)
+  int done;            // stop test fired: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
+  int error;           // ERR_* bits
+  int order_ambiguous; // segments whose inter-robot CCD result depended on pair order (see k_ccd_self_seq)
+  double gnorm;        // reference global `gnorm`
+  // statistics for the algorithmic-byte model; accumulated over iterations
+  unsigned long long nodes_dcd, nodes_ccd, cand_dcd, cand_ccd, planes_obs, planes_self, energy_evals, pair_tests;
+};
+
+struct Dev {
+  // ---- parameters (3D.json + hard-coded constants of the mains) ----
+  int mode, U, P, res, S, T, N;
+  int u0, u1;  // robots owned by this rank: [u0,u1)
+  double lambda, margin, offset, mu, vel_limit, acc_limit, ks, kt, stop;
+  int cap_obs, cap_self, cap_pairs;
+  // ---- tables (row-major 6x6) ----
+  const double* basis;    // [S][36]
+  const double* convert;  // [P][36]
+  const double* mdyn;     // [36]
+  const double* kdop;     // [49][3]
+  const double* pow08;    // [LOOP_CAP+1]  0.8^k by repeated multiplication
+  // ---- obstacle cloud: Morton-sorted points + implicit 8-ary box hierarchy ----
+  const double *px, *py, *pz;   // [Npad] sorted, padded with +inf
+  int nlevels;                  // level 0 = boxes over 8 consecutive points; top level has <= 64 boxes
+  int lvl_off[MAX_LEVELS], lvl_n[MAX_LEVELS];
+  const double* boxes;          // [total][6] lo.xyz hi.xyz, padded slots are empty (lo=+inf, hi=-inf)
+  // ---- ADMM state, column-major per robot like the reference's Eigen matrices ----
+  double *spline;      // [U][3][T]
+  double *p_slack;     // [U][3][6P]
+  double *p_lambda;    // [U][3][6P]
+  double *t_slack;     // [U][P]
+  double *t_lambda;    // [U][P]
+  double *piece_time;  // [U]
+  // ---- per-iteration intermediates ----
+  double *oplanes; int *ocount;   // obstacle planes  [U][S][cap_obs][4], [U][S]
+  double *splanes; int *scount;   // inter-robot planes [U][S][cap_self][4], [U][S]
+  double *lg, *lh;                // per-piece gradient [U][P][19] and Hessian [U][P][361] (after PSD repair)
+  // search direction record per robot, robot-major so a rank's robots are one slice for the
+  // all-gather: [U][xs], xs = 3T+4 : direction (T x 3 col-major), t_direction, wolfe, |g|, pad
+  double *xdir; int xs;
+  __host__ __device__ double* dirp(int u) const { return xdir + (size_t)u * xs; }
+  __host__ __device__ double& tdir(int u) const { return xdir[(size_t)u * xs + 3 * T]; }
+  __host__ __device__ double& wolfe(int u) const { return xdir[(size_t)u * xs + 3 * T + 1]; }
+  __host__ __device__ double& gn(int u) const { return xdir[(size_t)u * xs + 3 * T + 2]; }
+  int *k_obs, *k_self;            // [U] exponents: step = 0.8^k
+  double *step_out;               // [U] accepted Armijo step (diagnostics)
+  double *ccdinfo;                // [U][S][CCD_STRIDE] swept-hull cache of the current direction
+  int *pair_list; int *pair_count;   // [S][cap_pairs][2], [S]
+  Ctl* ctl;
+};
+constexpr int CCD_STRIDE = 18 + 18 + 6 + 6 + 98;  // P, D, obstacle box, pair box, 49 k-DOP intervals (lo,hi)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int prefix_count(unsigned long long m) { return __popcll(m & ((1ull << lane_id()) - 1ull)); }
+
+// hull of segment tr of a T x 3 column-major control net: out[j*3+a] = sum_k basis[j][k] * net[3*piece+k][a]
+// accumulated in k order from zero, as every variant in the reference does (e.g. Energy_admm.h:116-129)
+__device__ __forceinline__ double hull_entry(const Dev& D, const double* net, int tr, int j, int a) {
+  const double* B = D.basis + (size_t)tr * 36 + j * 6;
+  const double* col = net + (tr / D.res) * 3 + D.T * a;
+  double acc = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc += B[k] * col[k];
+  return acc;
+}
+__device__ __forceinline__ double seg_weight(const Dev& D, int tr) {
+  int k = tr % D.res;
+  return (k + 1) / double(D.res) - k / double(D.res);
+}
+__device__ __forceinline__ double norm3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
+
+// barrier b(d) = -(d-m)^2 ln(d/m) and its derivatives (Energy_admm.h:84-88, Gradient_admm.h:380-384)
+__device__ __forceinline__ double barrier(double w, double d, double m) { return -w * (d - m) * (d - m) * log(d / m); }
+__device__ __forceinline__ void barrier_d(double w, double d, double m, double& e1, double& e2) {
+  e1 = -w * (2 * (d - m) * log(d / m) + (d - m) * (d - m) / d);
+  e2 = -w * (2 * log(d / m) + 4 * (d - m) / d - (d - m) * (d - m) / (d * d));
+}
+
+// Sum in the association order of Eigen's 2-wide vectorised reduction (Redux.h) -- used for the
+// few scalars that feed Armijo / stop decisions (wolfe, |g|, consensus norms).
+__device__ inline double esum(const double* e, int n) {
+  if (n == 0) return 0;
+  int a2 = (n / 4) * 4, a1 = (n / 2) * 2;
+  double r;
+  if (a1) {
+    double r0a = e[0], r0b = e[1];
+    if (a1 > 2) {
+      double r1a = e[2], r1b = e[3];
+      for (int i = 4; i < a2; i += 4) { r0a += e[i]; r0b += e[i + 1]; r1a += e[i + 2]; r1b += e[i + 3]; }
+      r0a += r1a; r0b += r1b;
+      if (a1 > a2) { r0a += e[a2]; r0b += e[a2 + 1]; }
+    }
+    r = r0a + r0b;
+    for (int i = a1; i < n; i++) r += e[i];
+  } else {
+    r = e[0];
+    for (int i = 1; i < n; i++) r += e[i];
+  }
+  return r;
+}
+
+}  // namespace tj

@@ -1,0 +1,319 @@
+// dev_gjk.h -- device GJK (signed-volumes sub-algorithm) for gfx950, fp64, one query per lane.
+//
+// Replaces the reference's patched openGJK (lib/opengjk/src/openGJK.c:754-852, "Fast" build,
+// returns the witness vector) on the hot path.  It is used by the separating-plane kernels
+// (Separate.h:18-304) and by the CCD step kernels (CCD.h:116-352).
+//
+// GPU shape: bodies are never materialised as pointer tables.  A body is a small functor that
+// yields vertex i on demand from LDS-staged hulls (wave-uniform, broadcast reads) or from
+// registers (an obstacle point), and a swept hull {P, P + t*D} is generated on the fly so a
+// CCD back-off loop does not rewrite 12 points per trial.  The simplex lives in registers; all
+// vertex moves are expressed as whole-struct selects so nothing is indexed dynamically.
+//
+// The witness vector is only eps_rel = 1e-5 accurate, therefore the *decision path* must be the
+// reference's: each floating-point expression keeps the reference's association order, the TU
+// is compiled with -ffp-contract=off, and fp64 divide/sqrt are IEEE on gfx950, so results are
+// bit-identical to the CPU reference (pinned by tests/golden/gjk_kat.npz).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tj {
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double sq(const V3& a) { double n = 0; n += a.x * a.x; n += a.y * a.y; n += a.z * a.z; return n; }
+__device__ __forceinline__ double comp(const V3& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+__device__ __forceinline__ bool same_sign(double a, double b) { return (a > 0) == (b > 0); }
+
+// ---- bodies ---------------------------------------------------------------------------------
+struct BodyPoint {  // one obstacle point held in registers
+  V3 q;
+  static constexpr int N = 1;
+  __device__ __forceinline__ V3 get(int) const { return q; }
+};
+struct BodyHull {  // 6 control points of one Bezier segment, row-major [6][3] (LDS or global)
+  const double* p;
+  static constexpr int N = 6;
+  __device__ __forceinline__ V3 get(int i) const { return V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+};
+struct BodySwept {  // conv{P, P + t*D}: 12 points (CCD.h:119-120), never stored
+  const double* p; const double* d; double t;
+  static constexpr int N = 12;
+  __device__ __forceinline__ V3 get(int i) const {
+    int j = i < 6 ? i : i - 6;
+    double s = i < 6 ? 0.0 : t;
+    return V3{p[3 * j] + s * d[3 * j], p[3 * j + 1] + s * d[3 * j + 1], p[3 * j + 2] + s * d[3 * j + 2]};
+  }
+};
+
+// ---- simplex in registers --------------------------------------------------------------------
+struct Simplex {
+  int n;
+  V3 v0, v1, v2, v3;
+  int w0, w1, w2, w3;
+  double l0, l1, l2, l3;
+};
+__device__ __forceinline__ V3 sx_v(const Simplex& s, int i) { return i == 0 ? s.v0 : (i == 1 ? s.v1 : (i == 2 ? s.v2 : s.v3)); }
+__device__ __forceinline__ void sx_set_v(Simplex& s, int i, const V3& p) { if (i == 0) s.v0 = p; else if (i == 1) s.v1 = p; else if (i == 2) s.v2 = p; else s.v3 = p; }
+__device__ __forceinline__ int sx_w(const Simplex& s, int i) { return i == 0 ? s.w0 : (i == 1 ? s.w1 : (i == 2 ? s.w2 : s.w3)); }
+__device__ __forceinline__ void sx_set_w(Simplex& s, int i, int w) { if (i == 0) s.w0 = w; else if (i == 1) s.w1 = w; else if (i == 2) s.w2 = w; else s.w3 = w; }
+__device__ __forceinline__ double sx_l(const Simplex& s, int i) { return i == 0 ? s.l0 : (i == 1 ? s.l1 : (i == 2 ? s.l2 : s.l3)); }
+__device__ __forceinline__ void sx_set_l(Simplex& s, int i, double l) { if (i == 0) s.l0 = l; else if (i == 1) s.l1 = l; else if (i == 2) s.l2 = l; else s.l3 = l; }
+
+// sum_i lambda_i v_i, accumulated from zero in vertex order (openGJK.c:157-162)
+__device__ __forceinline__ V3 sx_point(const Simplex& s) {
+  V3 r{0, 0, 0};
+  r.x += s.l0 * s.v0.x; r.y += s.l0 * s.v0.y; r.z += s.l0 * s.v0.z;
+  if (s.n > 1) { r.x += s.l1 * s.v1.x; r.y += s.l1 * s.v1.y; r.z += s.l1 * s.v1.z; }
+  if (s.n > 2) { r.x += s.l2 * s.v2.x; r.y += s.l2 * s.v2.y; r.z += s.l2 * s.v2.z; }
+  if (s.n > 3) { r.x += s.l3 * s.v3.x; r.y += s.l3 * s.v3.y; r.z += s.l3 * s.v3.z; }
+  return r;
+}
+
+// segment {v0 = B, v1 = A} (openGJK.c:82-163)
+__device__ __noinline__ void gjk_seg(Simplex& s) {
+  const V3 b = s.v0, a = s.v1;
+  const V3 t{b.x - a.x, b.y - a.y, b.z - a.z};
+  const double f0 = fabs(t.x), f1 = fabs(t.y), f2 = fabs(t.z);
+  int I = 1;
+  if (f0 > f1) I = (f0 > f2) ? 0 : 2;
+  else if (f0 < f1) I = (f1 > f2) ? 1 : 2;
+  else if (f0 < f2) I = 2;
+  else if (f1 < f2) I = 2;
+  const double aI = comp(a, I), bI = comp(b, I), tI = comp(t, I);
+  const double pt = dot(b, t) / dot(t, t) * (aI - bI) + bI;
+  const double det_ap = aI - pt, det_pb = pt - bI;
+  const int F0 = same_sign(tI, -1 * det_ap), F1 = same_sign(tI, -1 * det_pb);
+  if (F0 + F1 == 2) {
+    s.l0 = det_ap * -1.0 / tI; s.l1 = 1 - s.l0; s.w0 = 0; s.w1 = 1; s.n = 2;
+  } else if (F0 == 0) {
+    s.l0 = 1; s.w0 = 0; s.n = 1; s.v0 = s.v1;
+  } else {
+    s.l0 = 1; s.w0 = 1; s.n = 1;
+  }
+}
+
+// triangle {v0 = C, v1 = B, v2 = A} (openGJK.c:168-393)
+__device__ __noinline__ void gjk_tri(Simplex& s) {
+  const V3 c = s.v0, b = s.v1, a = s.v2;
+  const V3 s21{b.x - a.x, b.y - a.y, b.z - a.z}, s31{c.x - a.x, c.y - a.y, c.z - a.z};
+  // cofactors of the projected triangle, cyclic (k,l) = (1,2),(2,0),(0,1); sign (-1)^i
+  const double nu0 = 1.0 * (b.y * c.z + a.y * b.z + c.y * a.z - b.y * a.z - c.y * b.z - a.y * c.z);
+  const double nu1 = -1.0 * (b.z * c.x + a.z * b.x + c.z * a.x - b.z * a.x - c.z * b.x - a.z * c.x);
+  const double nu2 = 1.0 * (b.x * c.y + a.x * b.y + c.x * a.y - b.x * a.y - c.x * b.y - a.x * c.y);
+  const double f0 = fabs(nu0), f1 = fabs(nu1), f2 = fabs(nu2);
+  int I = 1, J0 = -1, J1 = 0;  // J0 = -1: the reference reads out of bounds here; see oracle/orc_gjk.cpp
+  if (f0 > f1) { if (f0 > f2) { I = 0; J0 = 1; J1 = 2; } else { I = 2; J0 = 0; J1 = 1; } }
+  else if (f0 < f1) { if (f1 > f2) { I = 1; J0 = 0; J1 = 2; } else { I = 2; J0 = 0; J1 = 1; } }
+  else if (f0 < f2) { I = 2; J0 = 0; J1 = 1; }
+  const double nu_max = I == 0 ? nu0 : (I == 1 ? nu1 : nu2);
+  V3 n;
+  double nn = 0;
+  n.x = s21.y * s31.z - s21.z * s31.y; nn += n.x * n.x;
+  n.y = s21.z * s31.x - s21.x * s31.z; nn += n.y * n.y;
+  n.z = s21.x * s31.y - s21.y * s31.x; nn += n.z * n.z;
+  const double inv_len = 1 / sqrt(nn);
+  n.x = n.x * inv_len; n.y = n.y * inv_len; n.z = n.z * inv_len;
+  const double dna = dot(n, a);
+  auto at = [](const V3& p, int j) { return j < 0 ? 0.0 : comp(p, j); };
+  const double pp0 = dna * at(n, J0), pp1 = dna * at(n, J1);
+  const double sa0 = at(a, J0), sa1 = at(a, J1), sb0 = at(b, J0), sb1 = at(b, J1), sc0 = at(c, J0), sc1 = at(c, J1);
+  // (k,l) = (b,c), (c,a), (a,b)
+  const double B0 = pp0 * sb1 + pp1 * sc0 + sb0 * sc1 - pp0 * sc1 - pp1 * sb0 - sc0 * sb1;
+  const double B1 = pp0 * sc1 + pp1 * sa0 + sc0 * sa1 - pp0 * sa1 - pp1 * sc0 - sa0 * sc1;
+  const double B2 = pp0 * sa1 + pp1 * sb0 + sa0 * sb1 - pp0 * sb1 - pp1 * sa0 - sb0 * sa1;
+  const int F0 = same_sign(nu_max, B0), F1 = same_sign(nu_max, B1), F2 = same_sign(nu_max, B2);
+
+  if (F1 + F2 == 0 || isnan(n.x)) {
+    Simplex aux;
+    aux.n = 2; aux.v0 = s.v1; aux.v1 = s.v2;
+    s.n = 2; s.v1 = s.v2;
+    gjk_seg(aux);
+    gjk_seg(s);
+    const V3 vt = sx_point(aux), v = sx_point(s);
+    if (dot(v, v) < dot(vt, vt)) {
+      if (s.n > 1) s.w1 = s.w1 + 1;
+    } else {  // labels and weights from the auxiliary segment, vertices stay (reference quirk)
+      s.n = aux.n; s.l0 = aux.l0; s.w0 = aux.w0;
+      if (s.n > 1) { s.l1 = aux.l1; s.w1 = aux.w1; }
+    }
+  } else if (F0 + F1 + F2 == 3) {
+    const double inv = 1 / nu_max;
+    s.l0 = B2 * inv; s.l1 = B1 * inv; s.l2 = 1 - s.l0 - s.l1;
+    s.w0 = 0; s.w1 = 1; s.w2 = 2; s.n = 3;
+  } else if (F2 == 0) {
+    s.n = 2; s.v0 = s.v1; s.v1 = s.v2;
+    gjk_seg(s);
+  } else if (F1 == 0) {
+    s.n = 2; s.v1 = s.v2;
+    gjk_seg(s);
+    if (s.n > 1) s.w1 = s.w1 + 1;
+  } else {
+    s.n = 2;
+    gjk_seg(s);
+  }
+}
+
+__device__ __forceinline__ int tri_lut(int i) {  // {3,3,3, 1,2,2, 0,0,1}
+  return (0x100221333 >> (4 * i)) & 0xF;
+}
+__device__ __forceinline__ double det3x(const V3& p, const V3& q, const V3& r) {
+  return p.x * q.y * r.z + p.y * q.z * r.x + p.z * q.x * r.y - p.z * q.y * r.x - p.y * q.x * r.z - p.x * q.z * r.y;
+}
+
+// tetrahedron {v0 = D, v1 = C, v2 = B, v3 = A} (openGJK.c:398-711)
+__device__ __noinline__ void gjk_tet(Simplex& s) {
+  const V3 d = s.v0, c = s.v1, b = s.v2, a = s.v3;
+  const double B0 = -1 * det3x(b, c, d);
+  const double B1 = +1 * det3x(a, c, d);
+  const double B2 = -1 * det3x(a, b, d);
+  const double B3 = +1 * det3x(a, b, c);
+  const double detM = B0 + B1 + B2 + B3;
+  int F0 = 1, F1 = 1, F2 = 1, F3 = 1;
+  const double eps = 1e-13;
+  if (fabs(detM) < eps) {
+    if (fabs(B2) < eps && fabs(B3) < eps) F1 = 0;
+    else if (fabs(B1) < eps && fabs(B3) < eps) F2 = 0;
+    else if (fabs(B1) < eps && fabs(B2) < eps) F3 = 0;
+    else if (fabs(B0) < eps && fabs(B3) < eps) F1 = 0;
+    else if (fabs(B0) < eps && fabs(B2) < eps) F1 = 0;
+    else if (fabs(B0) < eps && fabs(B1) < eps) F2 = 0;
+    else { F0 = F1 = F2 = F3 = 0; }
+  } else {
+    F0 = same_sign(detM, B0); F1 = same_sign(detM, B1); F2 = same_sign(detM, B2); F3 = same_sign(detM, B3);
+  }
+  const int facing = F1 + F2 + F3;
+  if (F0 + facing == 4) {
+    const double inv = 1 / detM;
+    s.l3 = B0 * inv; s.l2 = B1 * inv; s.l1 = B2 * inv; s.l0 = 1 - s.l1 - s.l2 - s.l3;
+    s.w0 = 0; s.w1 = 1; s.w2 = 2; s.w3 = 3; s.n = 4;
+  } else if (facing == 0) {
+    int id0 = 0, id1 = 0, id2 = 0, nbest = 0;
+    double lb0 = 0, lb1 = 0, lb2 = 0, best = 0;
+    for (int i = 0; i < 3; ++i) {
+      Simplex aux;
+      aux.n = 3;
+      aux.v2 = sx_v(s, tri_lut(i));
+      aux.v1 = sx_v(s, tri_lut(i + 3));
+      aux.v0 = sx_v(s, tri_lut(i + 6));
+      gjk_tri(aux);
+      const V3 vt = sx_point(aux);
+      const double dd = dot(vt, vt);
+      if (i == 0 || dd < best) {
+        best = dd; nbest = aux.n;
+        id0 = tri_lut(i + aux.w0 * 3); lb0 = aux.l0;
+        if (nbest > 1) { id1 = tri_lut(i + aux.w1 * 3); lb1 = aux.l1; }
+        if (nbest > 2) { id2 = tri_lut(i + aux.w2 * 3); lb2 = aux.l2; }
+      }
+    }
+    const Simplex keep = s;
+    s.n = nbest;
+    sx_set_v(s, nbest - 1, sx_v(keep, id0)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
+    if (nbest > 1) { sx_set_v(s, nbest - 2, sx_v(keep, id1)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
+    if (nbest > 2) { sx_set_v(s, nbest - 3, sx_v(keep, id2)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
+  } else if (facing == 1) {
+    Simplex aux;
+    aux.n = 3;
+    double best = 0;
+    int used = 0, first = 0, second = 0;
+    if (F1 == 0) {  // ACD
+      aux.v0 = s.v0; aux.v1 = s.v1; aux.v2 = s.v3;
+      gjk_tri(aux);
+      const V3 vt = sx_point(aux); best = dot(vt, vt);
+      used = 1; first = 0;
+    }
+    if (F2 == 0) {  // ABD
+      if (!used) {
+        aux.v0 = s.v0; aux.v1 = s.v2; aux.v2 = s.v3;
+        gjk_tri(aux);
+        const V3 vt = sx_point(aux); best = dot(vt, vt);
+        first = 1;
+      } else {
+        s.n = 3; s.v1 = s.v2; s.v2 = s.v3;
+        gjk_tri(s);
+        second = 1;
+      }
+    }
+    if (F3 == 0) {  // ABC
+      s.n = 3; s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3;
+      gjk_tri(s);
+      second = 2;
+    }
+    const V3 v = sx_point(s);
+    if (dot(v, v) < best) {
+      for (int i = 0; i < s.n; ++i) sx_set_w(s, s.n - 1 - i, tri_lut(second + sx_w(s, i) * 3));  // in place, as the reference
+    } else {
+      s.n = aux.n; s.v0 = aux.v0; s.v1 = aux.v1; s.v2 = aux.v2;
+      s.l0 = aux.l0; s.l1 = aux.l1; s.l2 = aux.l2;
+      for (int i = 0; i < s.n; ++i) sx_set_w(s, aux.n - 1 - i, tri_lut(first + sx_w(aux, i) * 3));
+    }
+  } else if (facing == 2) {
+    if (F1 == 0) {
+      s.n = 3; s.v2 = s.v3;
+      gjk_tri(s);
+    } else if (F2 == 0) {
+      s.n = 3; s.v1 = s.v2; s.v2 = s.v3;
+      gjk_tri(s);
+      if (s.n > 2) s.w2 = s.w2 + 1;
+    } else if (F3 == 0) {
+      s.n = 3; s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3;
+      gjk_tri(s);
+    }
+  } else {
+    s.n = 3;
+    gjk_tri(s);
+    s.w0 = s.w0 + 1;
+    if (s.n > 1) s.w1 = s.w1 + 1;
+    if (s.n > 2) s.w2 = s.w2 + 1;
+  }
+}
+
+// "sticky" support: keep the previous support unless some vertex is strictly better, first
+// maximum wins (openGJK.c:714-737)
+template <class Body>
+__device__ __forceinline__ void support(const Body& body, const V3& dir, V3& cur) {
+  double best = dot(cur, dir);
+  V3 pick = cur;
+#pragma unroll 1
+  for (int i = 0; i < Body::N; ++i) {
+    const V3 p = body.get(i);
+    const double sd = dot(p, dir);
+    if (sd > best) { best = sd; pick = p; }
+  }
+  cur = pick;
+}
+
+// witness vector of conv(b1) - conv(b2) (openGJK.c:754-852)
+template <class B1, class B2>
+__device__ V3 gjk(const B1& b1, const B2& b2) {
+  const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
+  Simplex s;
+  V3 s1 = b1.get(0), s2 = b2.get(0);
+  V3 v{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
+  s.n = 1; s.v0 = v;
+  s.v1 = s.v2 = s.v3 = V3{0, 0, 0};
+  s.w0 = s.w1 = s.w2 = s.w3 = 0; s.l0 = s.l1 = s.l2 = s.l3 = 0;
+  double wmax2 = 0;
+  int k = 0;
+  do {
+    k++;
+    const V3 vm{-v.x, -v.y, -v.z};
+    support(b1, vm, s1);
+    support(b2, v, s2);
+    const V3 w{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
+    if ((sq(v) - dot(v, w)) <= eps_rel2 * sq(v)) break;
+    if (sq(v) < eps_rel2) break;
+    sx_set_v(s, s.n, w);
+    s.n++;
+    if (s.n == 4) gjk_tet(s); else if (s.n == 3) gjk_tri(s); else gjk_seg(s);
+    v = sx_point(s);
+    { double t = sq(s.v0); if (t > wmax2) wmax2 = t; }
+    if (s.n > 1) { double t = sq(s.v1); if (t > wmax2) wmax2 = t; }
+    if (s.n > 2) { double t = sq(s.v2); if (t > wmax2) wmax2 = t; }
+    if (s.n > 3) { double t = sq(s.v3); if (t > wmax2) wmax2 = t; }
+    if (sq(v) <= (eps_tot * eps_tot * wmax2)) break;
+  } while ((s.n != 4) && (k != 50));
+  return v;
+}
+
+}  // namespace tj

@@ -1,0 +1,308 @@
+// kernels_newton.h -- the x-update's Newton system.
+//
+//   k_grad    one workgroup per (robot, piece): 19-vector gradient and 19x19 Hessian of the
+//             augmented Lagrangian restricted to that piece, with the reference's per-piece PSD
+//             repair.  Replaces Gradient_admm::local_spline_gradient (Gradient_admm.h:67-164),
+//             local_plane_barrier_gradient (:331-407), local_bound_gradient (:409-572) and the
+//             LLT / eigen-shift block of global_spline_gradient (:38-53).
+//   k_xsolve  one workgroup per robot: overlap-add of the piece blocks (Gradient_admm.h:55-62),
+//             removal of the fixed end control points, dense Cholesky in LDS with eigen-shift
+//             fallback, solve, wolfe and |g|.  Replaces spline_descent_direction
+//             (Optimization3D_multi.h:659-752, Optimization3D_admm.h:400-503).
+//
+// GPU shape: one thread owns one lower-triangle Hessian entry and walks the (control point,
+// plane) terms in the reference's order, so every entry is accumulated in exactly the sequence
+// the reference uses -- no atomics, no reduction trees, bitwise reproducible.  Barrier
+// derivatives (the only transcendental work) are computed once per (plane, control point) by
+// the whole block and staged through LDS.  The Kronecker selector matrices A_list / A_vel_list /
+// A_acc_list of the reference are never formed: A[tr][j] * c == basis(j,:)^T (x) c.
+#pragma once
+#include "dev_common.h"
+#include "dev_linalg.h"
+
+namespace tj {
+
+constexpr int GRAD_THREADS = 192;
+
+// dynamic LDS layout of k_grad, in doubles; npl = cap_obs + cap_self
+__host__ __device__ inline size_t grad_lds_doubles(int npl) { return 18 + 36 + 4 * (size_t)npl + 12 * (size_t)npl + 9 * (3 + 3 + 9 + 6 + 2) + 9 + 361 + 361 + 19 + 4 * 19 + 8; }
+
+__global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
+  if (D.ctl->done) return;
+  extern __shared__ double sm[];
+  const int npl = D.cap_obs + D.cap_self;
+  double* P = sm;                 // [18] hull of the current segment, row-major [6][3]
+  double* Bs = P + 18;            // [36] its basis
+  double* pc = Bs + 36;           // [npl][4] planes
+  double* E1 = pc + 4 * npl;      // [6][npl]
+  double* E2 = E1 + 6 * npl;      // [6][npl]  (0 when inactive)
+  double* bt = E2 + 6 * npl;      // 9 bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
+  double* bact = bt + 9 * 23;     // [9] active flags
+  double* H = bact + 9;           // [361]
+  double* W = H + 361;            // [361] scratch copy for Cholesky / eigenvalue
+  double* g = W + 361;            // [19]
+  double* scr = g + 19;           // [4*19] d,e,v,p
+
+  const int tid = threadIdx.x;
+  const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
+  const double* net = D.spline + (size_t)u * 3 * D.T;
+  const double m = D.margin, pt = D.piece_time[u];
+
+  // role of this thread
+  int hi_ = -1, hk_ = -1;  // Hessian entry (row >= col) for tid < 171
+  if (tid < 171) { int i = 0; while ((i + 1) * (i + 2) / 2 <= tid) i++; hi_ = i; hk_ = tid - i * (i + 1) / 2; }
+  const int vr = (tid >= 171 && tid < 189) ? tid - 171 : -1;  // gradient / time-column entry
+  const bool scal = tid == 189;
+  const int ai = hi_ >= 0 ? hi_ / 3 : 0, qi = hi_ >= 0 ? hi_ % 3 : 0, ak = hk_ >= 0 ? hk_ / 3 : 0, qk = hk_ >= 0 ? hk_ % 3 : 0;
+  const int av = vr >= 0 ? vr / 3 : 0, qv = vr >= 0 ? vr % 3 : 0;
+  double Hacc = 0, gacc = 0, pacc = 0, gt = 0, ht = 0;
+
+  // ---- plane barrier terms, segment by segment (Gradient_admm.h:85-105, :331-407) ----
+  for (int i = 0; i < D.res; i++) {
+    const int tr = sp * D.res + i;
+    const int no = D.ocount[u * D.S + tr], ns = (D.mode == 1) ? D.scount[u * D.S + tr] : 0;
+    const int n = no + ns;
+    if (n == 0) continue;
+    const double w = seg_weight(D, tr);
+    __syncthreads();
+    if (tid < 18) P[tid] = hull_entry(D, net, tr, tid / 3, tid % 3);
+    if (tid >= 64 && tid < 100) Bs[tid - 64] = D.basis[(size_t)tr * 36 + tid - 64];
+    for (int k = tid; k < 4 * n; k += GRAD_THREADS) {
+      const int pl = k / 4, c = k % 4;
+      pc[k] = pl < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + pl) * 4 + c]
+                      : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (pl - no)) * 4 + c];
+    }
+    __syncthreads();
+    for (int it = tid; it < 6 * n; it += GRAD_THREADS) {
+      const int j = it / n, k = it % n;
+      const double d = P[3 * j] * pc[4 * k] + P[3 * j + 1] * pc[4 * k + 1] + P[3 * j + 2] * pc[4 * k + 2] + pc[4 * k + 3];
+      double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
+      if (d < m) barrier_d(w, d, m, e1, e2);
+      E1[j * n + k] = e1; E2[j * n + k] = e2;
+    }
+    __syncthreads();
+    if (hi_ >= 0) {
+      double seg = 0;
+      for (int j = 0; j < 6; j++) {
+        const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
+        for (int k = 0; k < n; k++) {
+          const double dxi = bi * pc[4 * k + qi], dxk = bk * pc[4 * k + qk];
+          seg += (E2[j * n + k] * dxi) * dxk;
+        }
+      }
+      Hacc += seg;
+    } else if (vr >= 0) {
+      double seg = 0;
+      for (int j = 0; j < 6; j++) {
+        const double bv = Bs[j * 6 + av];
+        for (int k = 0; k < n; k++) {
+          seg += E1[j * n + k] * (bv * pc[4 * k + qv]);
+        }
+      }
+      gacc += seg;
+    }
+  }
+
+  // ---- velocity / acceleration barrier terms (Gradient_admm.h:107-129, :409-572) ----
+  for (int i = 0; i < D.res; i++) {
+    const int tr = sp * D.res + i;
+    const double w = seg_weight(D, tr);
+    __syncthreads();
+    if (tid < 18) P[tid] = hull_entry(D, net, tr, tid / 3, tid % 3);
+    if (tid >= 64 && tid < 100) Bs[tid - 64] = D.basis[(size_t)tr * 36 + tid - 64];
+    __syncthreads();
+    if (tid < 9) {
+      double* t = bt + tid * 23;
+      double Dv[3], len, d, coef, e1 = 0, e2 = 0, e3 = 0, tg = 0, th = 0;
+      bool act;
+      if (tid < 5) {
+        const int j = tid;
+        for (int a = 0; a < 3; a++) Dv[a] = P[3 * (j + 1) + a] - P[3 * j + a];
+        len = norm3(Dv[0], Dv[1], Dv[2]);
+        const double v = 5 * len / w;
+        d = D.vel_limit - v / pt;
+        act = d < m;
+        if (act) {
+          barrier_d(w, d, m, e1, e2);
+          tg = e1 * v / (pt * pt);
+          th = -2 * e1 * v / pow(pt, 3.0) + e2 * v * v / pow(pt, 4.0);
+          coef = -5 / (w * pt);
+          e3 = -e1 / pt + e2 * (D.vel_limit - d) / pt;
+          for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 1) * 6 + a] - Bs[j * 6 + a];
+        }
+      } else {
+        const int j = tid - 5;
+        for (int a = 0; a < 3; a++) Dv[a] = P[3 * (j + 2) + a] - 2 * P[3 * (j + 1) + a] + P[3 * j + a];
+        len = norm3(Dv[0], Dv[1], Dv[2]);
+        const double acc = 20 * len / (w * w);
+        d = D.acc_limit - acc / (pt * pt);
+        act = d < m;
+        if (act) {
+          barrier_d(w, d, m, e1, e2);
+          tg = 2 * e1 * acc / pow(pt, 3.0);
+          th = -6 * e1 * acc / pow(pt, 4.0) + 4 * e2 * acc * acc / pow(pt, 6.0);
+          const double wp = w * pt;
+          coef = -20 / (wp * wp);
+          e3 = -2 * e1 / pt + 2 * e2 * (D.acc_limit - d) / pt;
+          for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 2) * 6 + a] - 2 * Bs[(j + 1) * 6 + a] + Bs[j * 6 + a];
+        }
+      }
+      bact[tid] = act ? 1.0 : 0.0;
+      if (act) {
+        const double len3 = pow(len, 3.0);
+        t[0] = e1; t[1] = e2; t[2] = e3;
+        for (int q = 0; q < 3; q++) t[3 + q] = coef * Dv[q] / len;
+        for (int q = 0; q < 3; q++) for (int s = 0; s < 3; s++) t[6 + 3 * q + s] = coef * ((q == s ? 1.0 : 0.0) / len - Dv[q] * Dv[s] / len3);
+        t[21] = tg; t[22] = th;
+      }
+    }
+    __syncthreads();
+    if (hi_ >= 0) {
+      double seg = 0;
+      for (int b = 0; b < 9; b++) {
+        if (bact[b] == 0.0) continue;
+        const double* t = bt + b * 23;
+        const double dxi = t[3 + qi] * t[15 + ai], dxk = t[3 + qk] * t[15 + ak];
+        const double s = t[1] * dxi, lft = t[0] * t[15 + ai];
+        seg = (seg + s * dxk) + (lft * t[6 + 3 * qi + qk]) * t[15 + ak];
+      }
+      Hacc += seg;
+    } else if (vr >= 0) {
+      double sg = 0, spp = 0;
+      for (int b = 0; b < 9; b++) {
+        if (bact[b] == 0.0) continue;
+        const double* t = bt + b * 23;
+        const double dx = t[3 + qv] * t[15 + av];
+        sg += t[0] * dx; spp += t[2] * dx;
+      }
+      gacc += sg; pacc += spp;
+    } else if (scal) {
+      double sg = 0, sh = 0;
+      for (int b = 0; b < 9; b++) { if (bact[b] == 0.0) continue; sg += bt[b * 23 + 21]; sh += bt[b * 23 + 22]; }
+      gt += sg; ht += sh;
+    }
+  }
+  __syncthreads();
+
+  // ---- scale by lambda, add consensus + dual terms (Gradient_admm.h:132-163) ----
+  const double* C = D.convert + (size_t)sp * 36;
+  const int P6 = 6 * D.P;
+  double* delta = scr;          // [18] col-major 6x3: C x - z   (scr reused later)
+  double* lamb = scr + 18;      // [18]
+  if (tid < 18) {
+    const int j = tid % 6, a = tid / 6;
+    double acc = 0;
+    for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + D.T * a];
+    delta[j + 6 * a] = acc - D.p_slack[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
+    lamb[j + 6 * a] = D.p_lambda[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
+  }
+  __syncthreads();
+  if (hi_ >= 0) {
+    double h = Hacc * D.lambda;
+    if (qi == qk) {
+      double mab = 0;
+      for (int j = 0; j < 6; j++) mab += C[j * 6 + ai] * C[j * 6 + ak];
+      h += D.mu * mab;
+    }
+    H[hi_ * 19 + hk_] = h; H[hk_ * 19 + hi_] = h;
+  } else if (vr >= 0) {
+    double x1 = 0, x2 = 0;
+    for (int j = 0; j < 6; j++) { x1 += C[j * 6 + av] * delta[j + 6 * qv]; x2 += C[j * 6 + av] * lamb[j + 6 * qv]; }
+    g[vr] = gacc * D.lambda + (D.mu * x1 + x2);
+    const double pc_ = pacc * D.lambda;
+    H[vr * 19 + 18] = pc_; H[18 * 19 + vr] = pc_;
+  } else if (scal) {
+    g[18] = gt * D.lambda + (D.mu * (pt - D.t_slack[u * D.P + sp]) + D.t_lambda[u * D.P + sp]);
+    H[18 * 19 + 18] = ht * D.lambda + D.mu;
+  }
+  __syncthreads();
+
+  // ---- PSD repair: only if LLT fails and lambda_min < 0 (Gradient_admm.h:38-53) ----
+  for (int idx = tid; idx < 361; idx += GRAD_THREADS) W[idx] = H[idx];
+  __syncthreads();
+  if (!chol_lds(W, 19, tid, GRAD_THREADS)) {
+    __syncthreads();
+    for (int idx = tid; idx < 361; idx += GRAD_THREADS) W[idx] = H[idx];
+    __syncthreads();
+    const double ev = min_eig_lds(W, 19, scr, scr + 19, scr + 38, scr + 57, tid, GRAD_THREADS);
+    if (ev < 0 && tid < 19) H[tid * 19 + tid] = H[tid * 19 + tid] - ev * 1.0 + 0.01 * 1.0;
+    __syncthreads();
+  }
+  double* og = D.lg + ((size_t)u * D.P + sp) * 19;
+  double* oh = D.lh + ((size_t)u * D.P + sp) * 361;
+  if (tid < 19) og[tid] = g[tid];
+  for (int idx = tid; idx < 361; idx += GRAD_THREADS) oh[idx] = H[idx];
+}
+
+// ---- per-robot reduced Newton solve -------------------------------------------------------------
+constexpr int XS_THREADS = 256;
+__host__ __device__ inline size_t xsolve_lds_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16; }
+
+__global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
+  if (D.ctl->done) return;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x;
+  const int u = D.u0 + blockIdx.x;
+  const int T = D.T, m = 3 * (T - 4), n = m + 1;  // n = 9P-2
+  double* H = sm;            // [n*n] reduced Hessian (symmetric)
+  double* L = H + n * n;     // [n*n] factor / eigen scratch
+  double* g0 = L + n * n;    // [n]
+  double* x0 = g0 + n;       // [n]
+  double* scr = x0 + n;      // [6n]
+
+  // overlap-add of piece blocks; global index of local (sp, a) is 9*sp + a, time is 3T.
+  // Reduced index r = global - 6 for 6 <= global < 3T-6, time -> m.
+  for (int idx = tid; idx < n * n; idx += XS_THREADS) H[idx] = 0;
+  for (int i = tid; i < n; i += XS_THREADS) g0[i] = 0;
+  __syncthreads();
+  for (int sp = 0; sp < D.P; sp++) {  // pieces in order: each entry receives its (at most two) block terms in piece order
+    const double* lg = D.lg + ((size_t)u * D.P + sp) * 19;
+    const double* lh = D.lh + ((size_t)u * D.P + sp) * 361;
+    for (int idx = tid; idx < 361; idx += XS_THREADS) {
+      const int a = idx / 19, b = idx % 19;
+      const int ga = a < 18 ? 9 * sp + a : 3 * T, gb = b < 18 ? 9 * sp + b : 3 * T;
+      const int ra = ga == 3 * T ? m : ga - 6, rb = gb == 3 * T ? m : gb - 6;
+      if (ra < 0 || rb < 0 || (ga != 3 * T && ga >= 3 * T - 6) || (gb != 3 * T && gb >= 3 * T - 6)) continue;
+      H[ra * n + rb] += lh[idx];
+    }
+    if (tid < 19) {
+      const int ga = tid < 18 ? 9 * sp + tid : 3 * T;
+      const int ra = ga == 3 * T ? m : ga - 6;
+      if (!(ra < 0 || (ga != 3 * T && ga >= 3 * T - 6))) g0[ra] += lg[tid];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
+  __syncthreads();
+  if (!chol_lds(L, n, tid, XS_THREADS)) {
+    __syncthreads();
+    if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
+      for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
+      __syncthreads();
+      const double ev = min_eig_lds(L, n, scr, scr + n, scr + 2 * n, scr + 3 * n, tid, XS_THREADS);
+      if (ev < 0) for (int i = tid; i < n; i += XS_THREADS) H[i * n + i] = H[i * n + i] - ev * 1.0 + 0.01 * 1.0;
+      __syncthreads();
+    }
+    for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
+    __syncthreads();
+    chol_lds(L, n, tid, XS_THREADS);  // like the reference, the second factorisation is not re-checked
+    __syncthreads();
+  }
+  chol_solve_lds(L, n, g0, x0, tid, XS_THREADS);
+  for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
+  __syncthreads();
+  for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
+  __syncthreads();
+  double* dir = D.dirp(u);
+  for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
+    const int row = idx % T, a = idx / T;
+    dir[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0;
+  }
+  if (tid == 0) {
+    D.wolfe(u) = -esum(scr, n);
+    D.gn(u) = sqrt(esum(scr + n, n));
+    D.tdir(u) = x0[m];
+  }
+}
+
+}  // namespace tj

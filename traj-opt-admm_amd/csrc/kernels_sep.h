@@ -1,0 +1,297 @@
+// kernels_sep.h -- separating-plane construction ("z-update: GJK separating-plane projection"
+// in BASELINE.json's vocabulary).
+//
+//   k_sep_obs   one wavefront per (robot, Bezier segment): hull -> static-BVH query -> 49-axis
+//               k-DOP cull -> GJK -> plane (c,d).  Replaces BVH::DCDCollision (BVH.cpp:149-193),
+//               aabb::Tree::query (AABB.cc:608-667), CCD::KDOPDCD (CCD.h:354-413) and
+//               Separate::opengjk (Separate.h:18-163) as sequenced by separate_plane
+//               (Optimization3D_multi.h:176-235 / Optimization3D_admm.h:69-197).
+//   k_sep_self  one wavefront per (robot, segment), lanes over the other robots: box test,
+//               k-DOP, hull-hull GJK, 1-D Newton on the offset.  Replaces separate_self
+//               (Optimization3D_multi.h:237-342), BVH::SelfDCDCollision (BVH.cpp:252-287),
+//               CCD::SelfKDOPDCD (CCD.h:535-587), Separate::selfgjk (Separate.h:165-304) and
+//               Optimal_plane::optimal_d (Optimal_plane.h:13-71).
+//
+// The BVH is an implicit 8-ary box hierarchy over Morton-sorted points.  A wave walks it level
+// by level: 64 lanes test 8 frontier nodes x 8 children per step (coalesced 48-B boxes, 384 B per
+// parent), survivors are compacted into the next frontier with ballot + popcount.  The tree
+// shape is free: the candidate SET is defined by the reference's leaf predicate
+// (AABB.cc:141, touching counts) which is evaluated here on the points themselves in fp64.
+#pragma once
+#include "dev_common.h"
+
+namespace tj {
+
+struct QBox { double lo[3], hi[3]; };
+
+__device__ __forceinline__ bool box_hit(const double* b, const QBox& q, double m) {
+  // query.overlaps(node): reject if node.hi + m < q.lo or node.lo > q.hi + m on any axis
+  bool hit = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++) hit = hit && !(b[3 + k] + m < q.lo[k] || b[k] > q.hi[k] + m);
+  return hit;
+}
+
+// Wave-cooperative query.  `process(pt)` is called by all 64 lanes with a candidate point index
+// (or -1) and may use wave collectives.  Returns candidates found; adds visited boxes to *visits.
+template <class F>
+__device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb, int* cand, unsigned long long* visits, F&& process) {
+  const int lane = lane_id();
+  if (D.N == 0) return 0;
+  int top = D.nlevels - 1;
+  int count = 0;
+  unsigned long long nv = 0;
+  {
+    const int n = D.lvl_n[top];
+    bool hit = false;
+    if (lane < n) hit = box_hit(D.boxes + (size_t)(D.lvl_off[top] + lane) * 6, q, m);
+    const unsigned long long mask = ballot(hit);
+    if (hit) fa[prefix_count(mask)] = lane;
+    count = __popcll(mask);
+    nv += n;
+  }
+  __syncthreads();
+  int* cur = fa; int* nxt = fb;
+  for (int lv = top - 1; lv >= 0; lv--) {
+    int ncount = 0;
+    const int nl = D.lvl_n[lv];
+    for (int base = 0; base < count; base += 8) {
+      const int slot = base + (lane >> 3);
+      bool hit = false; int child = -1;
+      if (slot < count) {
+        child = cur[slot] * 8 + (lane & 7);
+        if (child < nl) hit = box_hit(D.boxes + (size_t)(D.lvl_off[lv] + child) * 6, q, m);
+      }
+      const unsigned long long mask = ballot(hit);
+      const int tot = __popcll(mask);
+      if (ncount + tot > FRONT_CAP) { if (lane == 0) atomicOr(&D.ctl->error, ERR_FRONT_OVERFLOW); break; }
+      if (hit) nxt[ncount + prefix_count(mask)] = child;
+      ncount += tot;
+      nv += 8 * min(8, count - base);
+    }
+    __syncthreads();
+    int* t = cur; cur = nxt; nxt = t;
+    count = ncount;
+  }
+  int nc = 0, found = 0;
+  for (int base = 0; base < count; base += 8) {
+    const int slot = base + (lane >> 3);
+    bool hit = false; int pt = -1;
+    if (slot < count) {
+      pt = cur[slot] * 8 + (lane & 7);
+      if (pt < D.N) {
+        const double x = D.px[pt], y = D.py[pt], z = D.pz[pt];
+        hit = !(x + m < q.lo[0] || x > q.hi[0] + m) && !(y + m < q.lo[1] || y > q.hi[1] + m) && !(z + m < q.lo[2] || z > q.hi[2] + m);
+      }
+    }
+    const unsigned long long mask = ballot(hit);
+    if (hit) cand[nc + prefix_count(mask)] = pt;
+    nc += __popcll(mask);
+    found += __popcll(mask);
+    __syncthreads();
+    if (nc >= 64) {
+      process(cand[lane]);
+      const int left = nc - 64;
+      const int keep = lane < left ? cand[64 + lane] : 0;
+      __syncthreads();
+      if (lane < left) cand[lane] = keep;
+      nc = left;
+      __syncthreads();
+    }
+  }
+  if (nc > 0) process(lane < nc ? cand[lane] : -1);
+  if (visits) *visits += nv;
+  return found;
+}
+
+// 49-axis intervals of n points stored row-major [n][3] (CCD.h:373-390); lanes 0..48
+__device__ __forceinline__ void kdop_intervals(const Dev& D, const double* pts, int n, double* klo, double* khi) {
+  const int lane = lane_id();
+  if (lane < 49) {
+    const double x = D.kdop[3 * lane], y = D.kdop[3 * lane + 1], z = D.kdop[3 * lane + 2];
+    double up = -INFINITY, lo = INFINITY;
+    for (int i = 0; i < n; i++) {
+      const double lv = x * pts[3 * i] + y * pts[3 * i + 1] + z * pts[3 * i + 2];
+      if (lv < lo) lo = lv;
+      if (lv > up) up = lv;
+    }
+    klo[lane] = lo; khi[lane] = up;
+  }
+}
+// point vs cached hull intervals
+__device__ __forceinline__ bool kdop_point_pass(const Dev& D, const double* klo, const double* khi, const V3& q, double d) {
+  for (int k = 0; k < 49; k++) {
+    const double lv = D.kdop[3 * k] * q.x + D.kdop[3 * k + 1] * q.y + D.kdop[3 * k + 2] * q.z;
+    if (lv < klo[k] - d || khi[k] < lv - d) return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
+  if (D.ctl->done) return;
+  const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
+  const int lane = lane_id();
+  __shared__ double P[18];
+  __shared__ double klo[49], khi[49];
+  __shared__ int fa[FRONT_CAP], fb[FRONT_CAP], cand[128];
+  const double* net = D.spline + (size_t)u * 3 * D.T;
+  if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
+  __syncthreads();
+  kdop_intervals(D, P, 6, klo, khi);
+  QBox q;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int j = 0; j < 6; j++) { const double v = P[3 * j + k]; if (v < lo) lo = v; if (v > hi) hi = v; }
+    q.lo[k] = lo; q.hi[k] = hi;
+  }
+  __syncthreads();
+  const double dist = D.offset + D.margin;
+  double* out = D.oplanes + ((size_t)u * D.S + tr) * D.cap_obs * 4;
+  int base = 0;
+  unsigned long long visits = 0;
+  const int found = bvh_query(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
+    bool ok = false;
+    double c0 = 0, c1 = 0, c2 = 0, dd = 0;
+    if (pt >= 0) {
+      const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
+      if (kdop_point_pass(D, klo, khi, qp, dist)) {
+        const V3 v = gjk(BodyHull{P}, BodyPoint{qp});
+        const double cn = norm3(v.x, v.y, v.z);
+        if (!(cn > dist)) {
+          c0 = v.x / cn; c1 = v.y / cn; c2 = v.z / cn;
+          const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
+          dd = d0 - D.offset;
+          ok = true;
+        }
+      }
+    }
+    const unsigned long long mask = ballot(ok);
+    const int idx = base + prefix_count(mask);
+    if (ok) {
+      if (idx < D.cap_obs) { out[4 * idx] = c0; out[4 * idx + 1] = c1; out[4 * idx + 2] = c2; out[4 * idx + 3] = dd; }
+      else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
+    }
+    base += __popcll(mask);
+  });
+  if (lane == 0) {
+    D.ocount[u * D.S + tr] = min(base, D.cap_obs);
+    atomicAdd(&D.ctl->nodes_dcd, visits);
+    atomicAdd(&D.ctl->cand_dcd, (unsigned long long)found);
+    atomicAdd(&D.ctl->planes_obs, (unsigned long long)base);
+  }
+}
+
+// ---- inter-robot planes ------------------------------------------------------------------------
+__device__ __forceinline__ double dot_fixed3(double c0, double c1, double c2, const double* r) { return c0 * r[0] + (c1 * r[1] + c2 * r[2]); }  // Eigen unrolled 3-term order (Separate.h:268,276)
+
+__global__ __launch_bounds__(64) void k_sep_self(Dev D) {
+  if (D.ctl->done) return;
+  const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
+  const int lane = lane_id();
+  __shared__ double myP[18];
+  __shared__ double oth[64 * 18];
+  if (lane < 18) myP[lane] = hull_entry(D, D.spline + (size_t)u * 3 * D.T, tr, lane / 3, lane % 3);
+  __syncthreads();
+  double mlo[3], mhi[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int j = 0; j < 6; j++) { const double v = myP[3 * j + k]; if (v < lo) lo = v; if (v > hi) hi = v; }
+    mlo[k] = lo; mhi[k] = hi;
+  }
+  const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
+  double* out = D.splanes + ((size_t)u * D.S + tr) * D.cap_self * 4;
+  int base = 0;
+  unsigned long long tests = 0;
+  for (int q0 = 0; q0 < D.U; q0 += 64) {
+    const int q = q0 + lane;
+    bool ok = false;
+    double c0 = 0, c1 = 0, c2 = 0, dd = 0;
+    if (q < D.U && q != u) {
+      double* Q = oth + lane * 18;
+      const double* netq = D.spline + (size_t)q * 3 * D.T;
+      double qlo[3] = {INFINITY, INFINITY, INFINITY}, qhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (int j = 0; j < 6; j++)
+        for (int a = 0; a < 3; a++) {
+          const double v = hull_entry(D, netq, tr, j, a);
+          Q[3 * j + a] = v;
+          if (v < qlo[a]) qlo[a] = v;
+          if (v > qhi[a]) qhi[a] = v;
+        }
+      bool hit = true;
+#pragma unroll
+      for (int k = 0; k < 3; k++) hit = hit && !(qhi[k] + dist < mlo[k] || qlo[k] > mhi[k] + dist);
+      if (hit) {
+        const double* A = (u < q) ? myP : Q;  // body 1 is always the lower robot index
+        const double* Bq = (u < q) ? Q : myP;
+        bool pass = true;
+        for (int k = 0; k < 49 && pass; k++) {
+          const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+          double upA = -INFINITY, loA = INFINITY, upB = -INFINITY, loB = INFINITY;
+          for (int i = 0; i < 6; i++) {
+            const double la = x * A[3 * i] + y * A[3 * i + 1] + z * A[3 * i + 2];
+            if (la < loA) loA = la; if (la > upA) upA = la;
+            const double lb = x * Bq[3 * i] + y * Bq[3 * i + 1] + z * Bq[3 * i + 2];
+            if (lb < loB) loB = lb; if (lb > upB) upB = lb;
+          }
+          if (upB < loA - dist || upA < loB - dist) pass = false;
+        }
+        if (pass) {
+          const V3 v = gjk(BodyHull{A}, BodyHull{Bq});
+          const double cn = norm3(v.x, v.y, v.z);
+          if (!(cn > dist)) {
+            const double e0 = v.x / cn, e1c = v.y / cn, e2c = v.z / cn;
+            double d0 = INFINITY, d1 = -INFINITY;
+            for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, Bq + 3 * i); if (d0 > t) d0 = t; }
+            for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, A + 3 * i); if (d1 < t) d1 = t; }
+            double dpl = 0.5 * (d0 + d1);
+            // Optimal_plane::optimal_d: Newton on the offset until |grad| < 1e-2
+            int it = 0;
+            for (; it < LOOP_CAP; it++) {
+              double grad = 0, hess = 0;
+              for (int j = 0; j < 6; j++) {
+                const double ds = (A[3 * j] * e0 + A[3 * j + 1] * e1c + A[3 * j + 2] * e2c) + dpl - 0.5 * off;
+                if (ds < m) {
+                  const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
+                  const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+                  grad += g1; hess += g2;
+                }
+              }
+              for (int j = 0; j < 6; j++) {
+                const double ds = -(Bq[3 * j] * e0 + Bq[3 * j + 1] * e1c + Bq[3 * j + 2] * e2c) - dpl - 0.5 * off;
+                if (ds < m) {
+                  const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
+                  const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+                  grad += -g1; hess += g2;
+                }
+              }
+              const double dir = -grad / hess;
+              dpl = dpl + 1.0 * dir;
+              if (fabs(grad) < 1e-2) break;
+            }
+            if (it == LOOP_CAP) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+            if (u < q) { c0 = e0; c1 = e1c; c2 = e2c; dd = dpl - 0.5 * off; }
+            else { c0 = -e0; c1 = -e1c; c2 = -e2c; dd = -dpl - 0.5 * off; }
+            ok = true;
+          }
+        }
+      }
+    }
+    const unsigned long long mask = ballot(ok);
+    const int idx = base + prefix_count(mask);
+    if (ok) {
+      if (idx < D.cap_self) { out[4 * idx] = c0; out[4 * idx + 1] = c1; out[4 * idx + 2] = c2; out[4 * idx + 3] = dd; }
+      else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
+    }
+    base += __popcll(mask);
+    tests += min(64, D.U - q0);
+  }
+  if (lane == 0) {
+    D.scount[u * D.S + tr] = min(base, D.cap_self);
+    atomicAdd(&D.ctl->planes_self, (unsigned long long)base);
+    atomicAdd(&D.ctl->pair_tests, tests);
+  }
+}
+
+}  // namespace tj

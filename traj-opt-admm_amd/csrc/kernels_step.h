@@ -1,0 +1,481 @@
+// kernels_step.h -- CCD step clamps, the Armijo line search on the x-objective, and the slack (z)
+// + dual update.
+//
+//   k_ccd_prep      per (robot, segment): hull P, direction hull D, query boxes and the 49-axis
+//                   intervals of the swept hull at step 1, cached for the two CCD kernels
+//                   (BVH::CCDCollision BVH.cpp:195-250, SelfCCDCollision :289-330, CCD::KDOPCCD
+//                   CCD.h:416-473, SelfKDOPCCD :475-533)
+//   k_ccd_obs       Step::position_step (Step.h:21-110): per candidate cloud point the smallest
+//                   exponent k with conv{P, P+0.8^k D} farther than `offset`; atomicMax per robot.
+//                   The reference's running-step loop yields max_k over candidates because swept
+//                   hulls are nested in k, so the result is order independent.
+//   k_ccd_self_*    Step::self_step (Step.h:184-256).  Phase A (parallel, per segment) keeps the
+//                   robot pairs whose swept boxes and k-DOPs overlap at full step -- a superset of
+//                   every pair the reference can act on, since k-DOP separation implies GJK
+//                   separation.  Phase B (one wave, sequential) replays the reference's ORDER
+//                   DEPENDENT joint back-off over those few pairs, segment by segment.
+//   k_linesearch    spline_line_search (Optimization3D_multi.h:754-811, _admm.h:505-557) with
+//                   Energy_admm::spline_energy (Energy_admm.h:16-170) evaluated by the whole block.
+//   k_slack         update_slack_lambda (Optimization3D_multi.h:344-506): per piece Newton step on
+//                   (z, t_z) with Armijo, then the dual ascent on (Lambda, tau).
+#pragma once
+#include "dev_common.h"
+#include "dev_linalg.h"
+#include "kernels_sep.h"
+
+namespace tj {
+
+__global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
+  if (D.ctl->done) return;
+  const int u = blockIdx.x / D.S, tr = blockIdx.x % D.S;  // ALL robots: the pair clamp is replicated per rank
+  const int lane = lane_id();
+  __shared__ double sh[18 * 3 + 18];
+  double* P = sh; double* Dh = sh + 18; double* PD = sh + 36; double* PS = sh + 54;
+  const double* net = D.spline + (size_t)u * 3 * D.T;
+  const double* dir = D.dirp(u);
+  if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
+  else if (lane < 36) Dh[lane - 18] = hull_entry(D, dir, tr, (lane - 18) / 3, (lane - 18) % 3);
+  else if (lane < 54) {  // basis * (bz + bz_d), the box the reference uses for the cloud query
+    const int j = (lane - 36) / 3, a = (lane - 36) % 3;
+    const double* B = D.basis + (size_t)tr * 36 + j * 6;
+    const int r0 = (tr / D.res) * 3 + D.T * a;
+    double acc = 0;
+    for (int k = 0; k < 6; k++) acc += B[k] * (net[r0 + k] + dir[r0 + k]);
+    PD[lane - 36] = acc;
+  }
+  __syncthreads();
+  if (lane < 18) PS[lane] = P[lane] + Dh[lane];  // (P + D) used by the pair box and by the k-DOP at step 1
+  __syncthreads();
+  double* o = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
+  if (lane < 18) { o[lane] = P[lane]; o[18 + lane] = Dh[lane]; }
+  if (lane < 3) {
+    double lo = INFINITY, hi = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
+    for (int j = 0; j < 6; j++) {
+      double v = P[3 * j + lane]; if (v < lo) lo = v; if (v > hi) hi = v; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
+      v = PD[3 * j + lane]; if (v < lo) lo = v; if (v > hi) hi = v;
+      v = PS[3 * j + lane]; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
+    }
+    o[36 + lane] = lo; o[39 + lane] = hi; o[42 + lane] = lo2; o[45 + lane] = hi2;
+  }
+  if (lane < 49) {
+    const double x = D.kdop[3 * lane], y = D.kdop[3 * lane + 1], z = D.kdop[3 * lane + 2];
+    double up = -INFINITY, lo = INFINITY;
+    for (int i = 0; i < 6; i++) { const double lv = x * P[3 * i] + y * P[3 * i + 1] + z * P[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+    for (int i = 0; i < 6; i++) { const double lv = x * PS[3 * i] + y * PS[3 * i + 1] + z * PS[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+    o[48 + lane] = lo; o[97 + lane] = up;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
+  if (D.ctl->done) return;
+  const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
+  const int lane = lane_id();
+  __shared__ double info[CCD_STRIDE];
+  __shared__ int fa[FRONT_CAP], fb[FRONT_CAP], cand[128];
+  const double* src = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
+  for (int i = lane; i < CCD_STRIDE; i += 64) info[i] = src[i];
+  __syncthreads();
+  QBox q;
+  for (int k = 0; k < 3; k++) { q.lo[k] = info[36 + k]; q.hi[k] = info[39 + k]; }
+  const double off = D.offset;
+  unsigned long long visits = 0;
+  int kmax = 0;
+  const int found = bvh_query(D, q, off, fa, fb, cand, &visits, [&](int pt) {
+    if (pt >= 0) {
+      const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
+      if (kdop_point_pass(D, info + 48, info + 97, qp, off)) {
+        int k = max(kmax, atomicAdd(&D.k_obs[u], 0));  // any earlier value is a valid lower bound
+        while (k < LOOP_CAP) {
+          const V3 v = gjk(BodySwept{info, info + 18, D.pow08[k]}, BodyPoint{qp});
+          if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off * off)) break;
+          k++;
+        }
+        if (k >= LOOP_CAP) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+        if (k > kmax) { kmax = k; atomicMax(&D.k_obs[u], k); }
+      }
+    }
+  });
+  if (lane == 0) { atomicAdd(&D.ctl->nodes_ccd, visits); atomicAdd(&D.ctl->cand_ccd, (unsigned long long)found); }
+}
+
+// Phase A: one wave per segment; pairs in lexicographic order, 64 per step.
+__global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
+  if (D.ctl->done) return;
+  const int tr = blockIdx.x, lane = lane_id();
+  const int U = D.U;
+  const long long npairs = (long long)U * (U - 1) / 2;
+  int base = 0;
+  int* out = D.pair_list + (size_t)tr * D.cap_pairs * 2;
+  const double off = D.offset;
+  for (long long c0 = 0; c0 < npairs; c0 += 64) {
+    const long long idx = c0 + lane;
+    bool ok = false; int p0 = 0, p1 = 0;
+    if (idx < npairs) {
+      // idx -> (p0,p1), p0<p1, row-major over the strict upper triangle
+      long long rem = idx; p0 = 0;
+      // closed form with a correction step
+      double fp = ((2.0 * U - 1.0) - sqrt((2.0 * U - 1.0) * (2.0 * U - 1.0) - 8.0 * (double)idx)) * 0.5;
+      p0 = (int)fp; if (p0 < 0) p0 = 0; if (p0 > U - 2) p0 = U - 2;
+      while (p0 > 0 && (long long)p0 * (2 * U - p0 - 1) / 2 > idx) p0--;
+      while ((long long)(p0 + 1) * (2 * U - p0 - 2) / 2 <= idx) p0++;
+      rem = idx - (long long)p0 * (2 * U - p0 - 1) / 2;
+      p1 = p0 + 1 + (int)rem;
+      const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
+      const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
+      bool hit = true;
+      for (int k = 0; k < 3; k++) hit = hit && !(a[45 + k] + off < b[42 + k] || a[42 + k] > b[45 + k] + off);
+      if (hit) {
+        bool pass = true;
+        for (int k = 0; k < 49 && pass; k++) if (b[97 + k] < a[48 + k] - off || a[97 + k] < b[48 + k] - off) pass = false;
+        ok = pass;
+      }
+    }
+    const unsigned long long mask = ballot(ok);
+    const int w = base + prefix_count(mask);
+    if (ok) {
+      if (w < D.cap_pairs) { out[2 * w] = p0; out[2 * w + 1] = p1; }
+      else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
+    }
+    base += __popcll(mask);
+  }
+  if (lane == 0) D.pair_count[tr] = min(base, D.cap_pairs);
+}
+
+// Phase B + gnorm.  One workgroup of one wave; control flow is wave uniform.
+__global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
+  if (D.ctl->done) return;
+  const int lane = lane_id();
+  extern __shared__ int ks[];  // [U] exponents, [U] last segment in which the robot appeared
+  int* seen = ks + D.U;
+  for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
+  __syncthreads();
+  if (D.mode == 1) {
+    const double off2 = D.offset * D.offset;
+    int ambiguous = 0;
+    for (int tr = 0; tr < D.S; tr++) {
+      const int n = D.pair_count[tr];
+      bool seg_hit = false, seg_share = false;
+      for (int i = 0; i < n; i++) {
+        const int p0 = D.pair_list[((size_t)tr * D.cap_pairs + i) * 2], p1 = D.pair_list[((size_t)tr * D.cap_pairs + i) * 2 + 1];
+        const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
+        const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
+        int k0 = ks[p0], k1 = ks[p1];
+        if (seen[p0] == tr || seen[p1] == tr) seg_share = true;
+        __syncthreads();
+        if (lane == 0) { seen[p0] = tr; seen[p1] = tr; }
+        int guard = 0;
+        while (guard++ < LOOP_CAP) {
+          const V3 v = gjk(BodySwept{a, a + 18, D.pow08[min(k0, LOOP_CAP)]}, BodySwept{b, b + 18, D.pow08[min(k1, LOOP_CAP)]});
+          if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off2)) break;
+          k0++; k1++; seg_hit = true;
+        }
+        if (guard > LOOP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+        __syncthreads();
+        if (lane == 0) { ks[p0] = k0; ks[p1] = k1; }
+        __syncthreads();
+      }
+      if (seg_hit && seg_share) ambiguous++;
+    }
+    if (lane == 0 && ambiguous) atomicAdd(&D.ctl->order_ambiguous, ambiguous);
+  }
+  __syncthreads();
+  for (int i = lane; i < D.U; i += 64) D.k_self[i] = ks[i];
+  if (lane == 0) {  // gnorm exactly as the drivers form it (Optimization3D_multi.h:57,72,750; _admm.h:499)
+    double gsum = 0;
+    for (int u = 0; u < D.U; u++) gsum += D.gn(u);
+    D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : D.gn(0);
+  }
+}
+
+// ---- x-objective and Armijo --------------------------------------------------------------------
+constexpr int LS_THREADS = 256;
+__host__ __device__ inline size_t ls_lds_doubles(int S, int T, int P) { return (size_t)S * 18 + 3 * (size_t)T + LS_THREADS + 8 + (S + 2) / 2 + 1; }
+
+// block-wide deterministic sum (fixed tree); result valid in all threads
+__device__ inline double block_sum(double v, double* red, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  for (int s = LS_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = red[tid] + red[tid + s]; __syncthreads(); }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// Energy_admm::spline_energy for robot u on control net `net` (LDS) and piece time pt
+__device__ inline double x_energy(const Dev& D, int u, const double* net, double pt, double* hulls, double* red, const int* pref, int* bad, int tid) {
+  const int S = D.S;
+  for (int idx = tid; idx < S * 18; idx += LS_THREADS) {
+    const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
+    const double* B = D.basis + (size_t)tr * 36 + j * 6;
+    const double* col = net + (tr / D.res) * 3 + D.T * a;
+    double acc = 0;
+    for (int k = 0; k < 6; k++) acc += B[k] * col[k];
+    hulls[idx] = acc;
+  }
+  if (tid == 0) *bad = 0;
+  __syncthreads();
+  const double m = D.margin;
+  // plane barrier (Energy_admm.h:46-96)
+  double part = 0; int mybad = 0;
+  const int M = pref[S];
+  for (int it = tid; it < M; it += LS_THREADS) {
+    int tr = 0;
+    { int lo = 0, hi = S; while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; } tr = lo; }
+    const int k = it - pref[tr];
+    const int no = D.ocount[u * S + tr];
+    const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
+    const double c0 = pl[0], c1 = pl[1], c2 = pl[2], dk = pl[3];
+    const double w = seg_weight(D, tr);
+    const double* Pp = hulls + tr * 18;
+    for (int j = 0; j < 6; j++) {
+      const double d = Pp[3 * j] * c0 + Pp[3 * j + 1] * c1 + Pp[3 * j + 2] * c2 + dk;
+      if (d <= 0) mybad = 1;
+      else if (d < m) part += barrier(w, d, m);
+    }
+  }
+  // velocity / acceleration barriers (Energy_admm.h:98-170)
+  double partb = 0;
+  for (int it = tid; it < S * 9; it += LS_THREADS) {
+    const int tr = it / 9, b = it % 9;
+    const double w = seg_weight(D, tr);
+    const double* Pp = hulls + tr * 18;
+    double d;
+    if (b < 5) {
+      const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
+      d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
+    } else {
+      const int j = b - 5;
+      const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
+                   az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
+      d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
+    }
+    if (d <= 0) mybad = 1;
+    else if (d < m) partb += barrier(w, d, m);
+  }
+  if (mybad) atomicOr(bad, 1);
+  const double eplane = block_sum(part, red, tid);
+  const double ebound = block_sum(partb, red, tid);
+  double e = D.lambda * eplane + D.lambda * ebound;
+  // augmented-Lagrangian terms, in the reference's statement order (Energy_admm.h:24-41)
+  const int P6 = 6 * D.P;
+  for (int sp = 0; sp < D.P; sp++) {
+    const double* C = D.convert + (size_t)sp * 36;
+    double delta[18], prod[18];
+    for (int a = 0; a < 3; a++)
+      for (int j = 0; j < 6; j++) {
+        double acc = 0;
+        for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + D.T * a];
+        delta[j + 6 * a] = acc - D.p_slack[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
+      }
+    for (int i = 0; i < 18; i++) prod[i] = delta[i] * delta[i];
+    e += D.mu / 2.0 * esum(prod, 18);
+    const double dt = pt - D.t_slack[u * D.P + sp];
+    e += D.mu / 2.0 * (dt * dt);
+    for (int a = 0; a < 3; a++) {
+      double pr[6];
+      for (int j = 0; j < 6; j++) pr[j] = D.p_lambda[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a] * delta[j + 6 * a];
+      e += esum(pr, 6);
+    }
+    e += D.t_lambda[u * D.P + sp] * (pt - D.t_slack[u * D.P + sp]);
+  }
+  __syncthreads();
+  if (*bad) e = INFINITY;
+  __syncthreads();
+  return e;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D) {
+  if (D.ctl->done) return;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T;
+  double* hulls = sm;                // [S*18]
+  double* trial = hulls + S * 18;    // [3T]
+  double* red = trial + 3 * T;       // [LS_THREADS]
+  int* bad = (int*)(red + LS_THREADS);
+  int* pref = bad + 2;               // [S+1]
+  double* net = D.spline + (size_t)u * 3 * T;
+  const double* dir = D.dirp(u);
+  if (tid == 0) {
+    int acc = 0;
+    for (int tr = 0; tr < S; tr++) { pref[tr] = acc; acc += D.ocount[u * S + tr] + (D.mode == 1 ? D.scount[u * S + tr] : 0); }
+    pref[S] = acc;
+  }
+  for (int i = tid; i < 3 * T; i += LS_THREADS) trial[i] = net[i];
+  __syncthreads();
+  const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
+  const double t_dir = D.tdir(u), t0 = D.piece_time[u];
+  double step = D.pow08[min(LOOP_CAP, max(D.k_obs[u], D.k_self[u]))];
+  if (t0 + step * t_dir <= 0) step = -0.95 * t0 / t_dir;
+  const double e = x_energy(D, u, trial, t0, hulls, red, pref, bad, tid);
+  double pt = t0 + step * t_dir;
+  int evals = 1, guard = 0;
+  for (;;) {
+    for (int i = tid; i < 3 * T; i += LS_THREADS) trial[i] = net[i] + step * dir[i];
+    __syncthreads();
+    const double en = x_energy(D, u, trial, pt, hulls, red, pref, bad, tid);
+    evals++;
+    if (!(e - 1e-4 * wolfe * step < en)) break;
+    if (++guard >= LOOP_CAP) { if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP); break; }
+    step *= 0.8;
+    pt = t0 + step * t_dir;
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * T; i += LS_THREADS) net[i] = trial[i];
+  if (tid == 0) { D.piece_time[u] = pt; D.step_out[u] = step; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
+}
+
+// ---- slack (z) and dual update -------------------------------------------------------------------
+__device__ inline double z_energy(const Dev& D, const double* cx, double pt, const double* z, double t, const double* lam, double tl) {
+  // Energy_admm::slack_energy / dynamic_energy (Energy_admm.h:172-215)
+  double e = 0;
+  const double s = D.ks / pow(t, 5.0) * 0.5;
+  for (int a = 0; a < 3; a++) {
+    double rrow[6], y[6];
+    for (int k = 0; k < 6; k++) rrow[k] = s * z[k + 6 * a];
+    for (int j = 0; j < 6; j++) { double acc = 0; for (int k = 0; k < 6; k++) acc += rrow[k] * D.mdyn[k * 6 + j]; y[j] = acc; }
+    double q = 0; for (int j = 0; j < 6; j++) q += y[j] * z[j + 6 * a];
+    e += q;
+  }
+  e = e + D.kt * pow(t, 1.1);
+  double delta[18], prod[18];
+  for (int i = 0; i < 18; i++) { delta[i] = cx[i] - z[i]; prod[i] = delta[i] * delta[i]; }
+  e += D.mu / 2.0 * esum(prod, 18);
+  e += D.mu / 2.0 * (pt - t) * (pt - t);
+  for (int a = 0; a < 3; a++) { double pr[6]; for (int j = 0; j < 6; j++) pr[j] = lam[j + 6 * a] * delta[j + 6 * a]; e += esum(pr, 6); }
+  e += tl * (pt - t);
+  return e;
+}
+
+__global__ __launch_bounds__(64) void k_slack(Dev D) {
+  if (D.ctl->done) return;
+  const int tid = threadIdx.x;
+  const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
+  const int P6 = 6 * D.P, T = D.T;
+  __shared__ double cx[18], z[18], lam[18], zt[18], dirz[18], g[19], H[361], L[361], g0[19], x0[19], scr[4 * 19];
+  __shared__ double s_t, s_step;
+  const double* net = D.spline + (size_t)u * 3 * T;
+  const double* C = D.convert + (size_t)sp * 36;
+  const double pt = D.piece_time[u];
+  double t = D.t_slack[u * D.P + sp];
+  const double tl = D.t_lambda[u * D.P + sp];
+  if (tid < 18) {
+    const int j = tid % 6, a = tid / 6;
+    double acc = 0;
+    for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + T * a];
+    cx[tid] = acc;
+    z[tid] = D.p_slack[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
+    lam[tid] = D.p_lambda[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
+  }
+  for (int i = tid; i < 361; i += 64) H[i] = 0;
+  __syncthreads();
+  // Gradient_admm::slack_gradient / dynamic_gradient (Gradient_admm.h:574-671)
+  const double sc = D.ks / pow(t, 5.0);
+  if (tid < 18) {
+    const int k = tid / 3, a = tid % 3;
+    double mz = 0;
+    for (int j = 0; j < 6; j++) mz += D.mdyn[k * 6 + j] * z[j + 6 * a];
+    const double g1 = sc * mz;
+    const double g2 = D.mu * (z[k + 6 * a] - cx[k + 6 * a]) - lam[k + 6 * a];
+    g[tid] = g1 + g2;
+    const double pg = -5 * g1 / t;
+    H[tid * 19 + 18] = pg; H[18 * 19 + tid] = pg;
+    for (int b = 0; b < 6; b++) H[tid * 19 + 3 * b + a] = sc * D.mdyn[k * 6 + b] + (k == b ? D.mu : 0.0);
+  }
+  if (tid == 32) {
+    double dyn = 0;
+    const double s = sc * 0.5;
+    for (int a = 0; a < 3; a++) {
+      double rrow[6], y[6];
+      for (int k = 0; k < 6; k++) rrow[k] = s * z[k + 6 * a];
+      for (int j = 0; j < 6; j++) { double acc = 0; for (int k = 0; k < 6; k++) acc += rrow[k] * D.mdyn[k * 6 + j]; y[j] = acc; }
+      double q = 0; for (int j = 0; j < 6; j++) q += y[j] * z[j + 6 * a];
+      dyn += q;
+    }
+    double g_t = -5 * dyn / t;
+    g_t += D.kt * 1.1 * pow(t, 0.1);
+    double h_t = 30 * dyn / (t * t);
+    h_t += D.kt * 0.11 * pow(t, -0.9);
+    g_t += D.mu * (t - pt) - tl;
+    h_t += D.mu;
+    g[18] = g_t; H[18 * 19 + 18] = h_t;
+  }
+  __syncthreads();
+  // boundary pieces keep two control points fixed (Optimization3D_multi.h:374-420)
+  int lo = 0, tn = 6;
+  if (sp == 0) { lo = 2; tn = 4; } else if (sp == D.P - 1) { lo = 0; tn = 4; }
+  const int n = 3 * tn + 1;
+  auto mapi = [&](int i) { return i < 3 * tn ? 3 * lo + i : 18; };
+  for (int idx = tid; idx < n * n; idx += 64) { const int i = idx / n, j = idx % n; L[idx] = H[mapi(i) * 19 + mapi(j)]; }
+  if (tid < n) g0[tid] = g[mapi(tid)];
+  __syncthreads();
+  for (int idx = tid; idx < n * n; idx += 64) H[idx] = L[idx];  // H now holds the reduced system (n x n)
+  __syncthreads();
+  if (!chol_lds(L, n, tid, 64)) {
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += 64) L[idx] = H[idx];
+    __syncthreads();
+    const double ev = min_eig_lds(L, n, scr, scr + 19, scr + 38, scr + 57, tid, 64);
+    if (ev < 0 && tid < n) H[tid * n + tid] = H[tid * n + tid] - ev * 1.0 + 0.01 * 1.0;
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += 64) L[idx] = H[idx];
+    __syncthreads();
+    chol_lds(L, n, tid, 64);
+    __syncthreads();
+  }
+  chol_solve_lds(L, n, g0, x0, tid, 64);
+  if (tid < n) x0[tid] = -x0[tid];
+  if (tid < 18) dirz[tid] = 0;
+  __syncthreads();
+  if (tid < 3 * tn) { const int i = tid / 3, a = tid % 3; dirz[(lo + i) + 6 * a] = x0[tid]; }
+  __syncthreads();
+  if (tid == 0) {  // scalar Armijo loop: the objective is ~300 flops
+    double pr[19];
+    for (int i = 0; i < n; i++) pr[i] = x0[i] * g0[i];
+    const double wolfe = -esum(pr, n);
+    const double t_dir = x0[3 * tn];
+    double step = 1.0;
+    if (t + step * t_dir <= 0) step = -0.95 * t / t_dir;
+    const double e = z_energy(D, cx, pt, z, t, lam, tl);
+    const double t_init = t;
+    double tt = t_init + step * t_dir;
+    int guard = 0;
+    for (;;) {
+      for (int i = 0; i < 18; i++) zt[i] = z[i] + step * dirz[i];
+      const double en = z_energy(D, cx, pt, zt, tt, lam, tl);
+      if (!(e - 1e-4 * wolfe * step < en)) break;
+      if (++guard >= LOOP_CAP) { atomicOr(&D.ctl->error, ERR_LOOP_CAP); break; }
+      step *= 0.8;
+      tt = t_init + step * t_dir;
+    }
+    s_t = tt; s_step = step;
+  }
+  __syncthreads();
+  if (tid < 18) {
+    const int j = tid % 6, a = tid / 6;
+    const size_t o = (size_t)u * 3 * P6 + sp * 6 + j + P6 * a;
+    D.p_slack[o] = zt[tid];
+    D.p_lambda[o] += D.mu * (cx[tid] - zt[tid]);
+  }
+  if (tid == 0) {
+    D.t_slack[u * D.P + sp] = s_t;
+    D.t_lambda[u * D.P + sp] += D.mu * (pt - s_t);
+  }
+}
+
+// ---- iteration bookkeeping ---------------------------------------------------------------------
+__global__ void k_begin(Dev D) {
+  // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
+  __shared__ int done;
+  if (threadIdx.x == 0) {
+    if (!D.ctl->done && D.stop > 0 && D.ctl->iter > 1 && D.ctl->gnorm < D.stop) D.ctl->done = 1;
+    done = D.ctl->done;
+  }
+  __syncthreads();
+  if (done) return;
+  for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
+}
+__global__ void k_end(Dev D) {
+  if (!D.ctl->done) D.ctl->iter++;
+}
+
+}  // namespace tj

@@ -1,0 +1,471 @@
+// tj_api.hip -- host side of libtrajadmm.so: context, device memory, launch sequence of one ADMM
+// iteration, and the C ABI declared in include/trajadmm.h.
+//
+// One iteration = the stage sequence of Optimization3D_multi::optimization_decouple
+// (Optimization3D_multi.h:29-118) / Optimization3D_admm::optimization (Optimization3D_admm.h:29-67),
+// enqueued on one HIP stream with no host synchronisation inside or between iterations; a batch
+// of iterations is captured once into a hipGraph and replayed.  The stop test of the mains runs on
+// the device (k_begin), so a converged problem turns the remaining replays into early-exit kernels.
+//
+// There is deliberately no CPU path in this file: every entry point either runs HIP kernels or
+// fails with TJ_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/trajadmm.h"
+#include "dev_common.h"
+#include "host_tables.h"
+#include "kernels_sep.h"
+#include "kernels_newton.h"
+#include "kernels_step.h"
+
+using namespace tj;
+
+struct tj_ctx {
+  tj_params prm;
+  Dev d;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  std::string err;
+  bool have_cloud = false, have_state = false;
+  // graph of one full iteration
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  bool graph_ok = false;
+  size_t lds_grad = 0, lds_xs = 0, lds_ls = 0, lds_seq = 0;
+  // cloud-dependent allocations (rebuilt by tj_set_cloud)
+  std::vector<void*> cloud_allocs;
+};
+
+namespace {
+
+#define HIPCHK(c, call)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return TJ_ERR_DEVICE;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+template <class T>
+int dalloc(tj_ctx* c, T** p, size_t n, std::vector<void*>* list = nullptr) {
+  void* q = nullptr;
+  HIPCHK(c, hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+  HIPCHK(c, hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  (list ? *list : c->allocs).push_back(q);
+  *p = (T*)q;
+  return TJ_OK;
+}
+
+int upload(tj_ctx* c, const void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return TJ_OK;
+  HIPCHK(c, hipMemcpy((void*)dst, src, bytes, hipMemcpyHostToDevice));
+  return TJ_OK;
+}
+
+void drop_graph(tj_ctx* c) {
+  if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+  if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+  c->graph_ok = false;
+}
+
+// enqueue one stage on the context's stream
+int enqueue_stage(tj_ctx* c, int stage) {
+  const Dev& d = c->d;
+  const int owned = d.u1 - d.u0;
+  hipStream_t s = c->stream;
+  switch (stage) {
+    case TJ_STAGE_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); break;
+    case TJ_STAGE_PLANES_OBS: hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); break;
+    case TJ_STAGE_PLANES_SELF: if (d.mode == 1) hipLaunchKernelGGL(k_sep_self, dim3(owned * d.S), dim3(64), 0, s, d); break;
+    case TJ_STAGE_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); break;
+    case TJ_STAGE_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_THREADS), c->lds_xs, s, d); break;
+    case TJ_STAGE_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); break;
+    case TJ_STAGE_CCD_OBS: hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); break;
+    case TJ_STAGE_CCD_SELF:
+      if (d.mode == 1) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S), dim3(64), 0, s, d);
+      hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d);
+      break;
+    case TJ_STAGE_LINESEARCH: hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d); break;
+    case TJ_STAGE_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d); break;
+    case TJ_STAGE_END: hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, d); break;
+    default: c->err = "unknown stage"; return TJ_ERR_INVALID;
+  }
+  HIPCHK(c, hipGetLastError());
+  return TJ_OK;
+}
+
+int enqueue_iteration(tj_ctx* c) {
+  for (int st = TJ_STAGE_BEGIN; st <= TJ_STAGE_END; st++) { int r = enqueue_stage(c, st); if (r) return r; }
+  return TJ_OK;
+}
+
+int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
+  Ctl h;
+  HIPCHK(c, hipMemcpyAsync(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (out) *out = h;
+  if (h.error & (ERR_PLANE_OVERFLOW | ERR_FRONT_OVERFLOW | ERR_PAIR_OVERFLOW)) {
+    c->err = "device list overflow (error bits " + std::to_string(h.error) + "): raise cap_obs/cap_self/cap_pairs";
+    return TJ_ERR_CAPACITY;
+  }
+  if (h.error & ERR_LOOP_CAP) { c->err = "a device back-off/Newton/Armijo loop hit its cap (infeasible state)"; return TJ_ERR_NO_PROGRESS; }
+  return TJ_OK;
+}
+
+bool ready(tj_ctx* c) {
+  if (!c->have_cloud) { c->err = "tj_set_cloud has not been called"; return false; }
+  if (!c->have_state) { c->err = "tj_init_state has not been called"; return false; }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void tj_default_params(tj_params* p, int mode, int uav_num, int piece_num) {
+  memset(p, 0, sizeof(*p));
+  p->mode = mode; p->uav_num = uav_num; p->piece_num = piece_num; p->res = 8;
+  p->lambda = 10.0; p->margin = 0.1; p->offset = 0.1; p->mu = 0.1; p->vel_limit = 2.0; p->acc_limit = 2.0;
+  p->ks = mode == TJ_MODE_SINGLE ? 1e-8 : 1e-3; p->kt = 1.0; p->stop = 1e-2;
+  p->device = 0; p->rank = 0; p->world = 1;
+}
+
+const char* tj_last_error(const tj_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int tj_create(const tj_params* p, tj_ctx** out) {
+  if (!p || !out) return TJ_ERR_INVALID;
+  *out = nullptr;
+  tj_ctx* c = new tj_ctx();
+  *out = c;  // returned even on failure so the caller can read tj_last_error()
+  c->prm = *p;
+  if (p->uav_num < 1 || p->piece_num < 2 || p->res < 1 || (p->mode != 0 && p->mode != 1) || p->world < 1 || p->rank < 0 || p->rank >= p->world) {
+    c->err = "invalid tj_params (need uav_num>=1, piece_num>=2, res>=1, mode 0/1, 0<=rank<world)";
+    return TJ_ERR_INVALID;
+  }
+  if (p->mode == TJ_MODE_SINGLE && p->uav_num != 1) { c->err = "TJ_MODE_SINGLE requires uav_num == 1"; return TJ_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device available (this library has no CPU fallback)"; return TJ_ERR_DEVICE; }
+  HIPCHK(c, hipSetDevice(p->device));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  Dev& d = c->d;
+  memset(&d, 0, sizeof(d));
+  d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0;
+  d.u0 = (int)((long long)p->rank * d.U / p->world); d.u1 = (int)((long long)(p->rank + 1) * d.U / p->world);
+  d.lambda = p->lambda; d.margin = p->margin; d.offset = p->offset; d.mu = p->mu; d.vel_limit = p->vel_limit; d.acc_limit = p->acc_limit;
+  d.ks = p->ks; d.kt = p->kt; d.stop = p->stop;
+  d.cap_obs = p->cap_obs > 0 ? p->cap_obs : 256;
+  d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, d.U - 1);
+  d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : std::min(4096, std::max(64, d.U * (d.U - 1) / 2));
+  d.xs = 3 * d.T + 4;
+  const int n = 9 * d.P - 2;
+  c->lds_grad = grad_lds_doubles(d.cap_obs + d.cap_self) * sizeof(double);
+  c->lds_xs = xsolve_lds_doubles(n) * sizeof(double);
+  c->lds_ls = ls_lds_doubles(d.S, d.T, d.P) * sizeof(double);
+  c->lds_seq = 2 * (size_t)d.U * sizeof(int);
+  const size_t lds_max = 160 * 1024 - 1024;
+  if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max) {
+    c->err = "problem does not fit the 160 KB LDS of one CU (piece_num <= 10 and cap_obs+cap_self <= ~1100 supported in this version)";
+    return TJ_ERR_UNSUPPORTED;
+  }
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_linesearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
+
+  HostTables t;
+  build_tables(d.P, d.res, LOOP_CAP, t);
+  double *basis, *convert, *mdyn, *kdop, *pow08;
+  int r;
+  if ((r = dalloc(c, &basis, t.basis.size())) || (r = dalloc(c, &convert, t.convert.size())) || (r = dalloc(c, &mdyn, 36)) ||
+      (r = dalloc(c, &kdop, 147)) || (r = dalloc(c, &pow08, t.pow08.size()))) return r;
+  if ((r = upload(c, basis, t.basis.data(), t.basis.size() * 8)) || (r = upload(c, convert, t.convert.data(), t.convert.size() * 8)) ||
+      (r = upload(c, mdyn, t.mdyn, 36 * 8)) || (r = upload(c, kdop, t.kdop, 147 * 8)) || (r = upload(c, pow08, t.pow08.data(), t.pow08.size() * 8))) return r;
+  d.basis = basis; d.convert = convert; d.mdyn = mdyn; d.kdop = kdop; d.pow08 = pow08;
+  const size_t U = d.U, S = d.S, P = d.P, T = d.T;
+  if ((r = dalloc(c, &d.spline, U * 3 * T)) || (r = dalloc(c, &d.p_slack, U * 18 * P)) || (r = dalloc(c, &d.p_lambda, U * 18 * P)) ||
+      (r = dalloc(c, &d.t_slack, U * P)) || (r = dalloc(c, &d.t_lambda, U * P)) || (r = dalloc(c, &d.piece_time, U)) ||
+      (r = dalloc(c, &d.oplanes, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ocount, U * S)) ||
+      (r = dalloc(c, &d.splanes, U * S * d.cap_self * 4)) || (r = dalloc(c, &d.scount, U * S)) ||
+      (r = dalloc(c, &d.lg, U * P * 19)) || (r = dalloc(c, &d.lh, U * P * 361)) || (r = dalloc(c, &d.xdir, U * d.xs)) ||
+      (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) ||
+      (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, S * (size_t)d.cap_pairs * 2)) ||
+      (r = dalloc(c, &d.pair_count, S)) || (r = dalloc(c, &d.ctl, 1))) return r;
+  return TJ_OK;
+}
+
+void tj_destroy(tj_ctx* c) {
+  if (!c) return;
+  drop_graph(c);
+  for (void* p : c->allocs) hipFree(p);
+  for (void* p : c->cloud_allocs) hipFree(p);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int tj_set_cloud(tj_ctx* c, const double* xyz, int n) {
+  if (!c || n < 0 || (n > 0 && !xyz)) return TJ_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drop_graph(c);
+  for (void* p : c->cloud_allocs) hipFree(p);
+  c->cloud_allocs.clear();
+  Dev& d = c->d;
+  d.N = n; d.nlevels = 0; d.px = d.py = d.pz = d.boxes = nullptr;
+  if (n > 0) {
+    HostBvh b;
+    build_bvh(xyz, n, b);
+    if ((int)b.lvl_n.size() > MAX_LEVELS) { c->err = "cloud too large for MAX_LEVELS"; return TJ_ERR_UNSUPPORTED; }
+    double *px, *py, *pz, *boxes;
+    int r;
+    if ((r = dalloc(c, &px, n, &c->cloud_allocs)) || (r = dalloc(c, &py, n, &c->cloud_allocs)) || (r = dalloc(c, &pz, n, &c->cloud_allocs)) ||
+        (r = dalloc(c, &boxes, b.boxes.size(), &c->cloud_allocs))) return r;
+    if ((r = upload(c, px, b.px.data(), (size_t)n * 8)) || (r = upload(c, py, b.py.data(), (size_t)n * 8)) || (r = upload(c, pz, b.pz.data(), (size_t)n * 8)) ||
+        (r = upload(c, boxes, b.boxes.data(), b.boxes.size() * 8))) return r;
+    d.px = px; d.py = py; d.pz = pz; d.boxes = boxes;
+    d.nlevels = (int)b.lvl_n.size();
+    for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = b.lvl_off[i]; d.lvl_n[i] = b.lvl_n[i]; }
+  }
+  c->have_cloud = true;
+  return TJ_OK;
+}
+
+int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
+  if (!c || !wp) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  const int U = d.U, P = d.P, T = d.T;
+  HostTables t;
+  build_tables(P, d.res, 1, t);
+  std::vector<double> spline((size_t)U * 3 * T), p_slack((size_t)U * 18 * P), zeros((size_t)U * 18 * P, 0.0), ts((size_t)U * P, pt0), tz((size_t)U * P, 0.0), ptv(U, pt0);
+  for (int u = 0; u < U; u++) {
+    double* s = &spline[(size_t)u * 3 * T];
+    for (int a = 0; a < 3; a++) {
+      auto W = [&](int k) { return wp[((size_t)u * (P + 1) + k) * 3 + a]; };
+      double* col = s + T * a;
+      col[0] = W(0);
+      if (d.mode == TJ_MODE_SINGLE) {  // Main/admmPathPlanning3D.cpp:258-275
+        for (int i = 0; i < P; i++) {
+          const double head = 0.9 * W(i) + 0.1 * W(i + 1), tail = 0.9 * W(i + 1) + 0.1 * W(i);
+          col[3 * i + 1] = W(i);
+          for (int j = 1; j < 3; j++) col[j + 3 * i + 1] = double(2 - j) / 1 * head + (double)(j - 1) / 1 * tail;
+          col[3 * (i + 1) + 1] = W(i + 1);
+        }
+      } else {  // Main/multiPathPlanning3D.cpp:363-375
+        for (int k = 0; k < P; k++)
+          for (int j = 0; j <= 3; j++) col[j + 3 * k + 1] = double(3 - j) / 3 * W(k) + (double)j / 3 * W(k + 1);
+      }
+      col[T - 1] = W(P);
+      col[1] = col[0];
+      col[T - 2] = col[T - 1];
+    }
+    for (int sp = 0; sp < P; sp++)
+      for (int a = 0; a < 3; a++)
+        for (int j = 0; j < 6; j++) {
+          double acc = 0;
+          for (int k = 0; k < 6; k++) acc += t.convert[sp * 36 + j * 6 + k] * s[sp * 3 + k + T * a];
+          p_slack[(size_t)u * 18 * P + sp * 6 + j + 6 * P * a] = acc;
+        }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int r;
+  if ((r = upload(c, d.spline, spline.data(), spline.size() * 8)) || (r = upload(c, d.p_slack, p_slack.data(), p_slack.size() * 8)) ||
+      (r = upload(c, d.p_lambda, zeros.data(), zeros.size() * 8)) || (r = upload(c, d.t_slack, ts.data(), ts.size() * 8)) ||
+      (r = upload(c, d.t_lambda, tz.data(), tz.size() * 8)) || (r = upload(c, d.piece_time, ptv.data(), ptv.size() * 8))) return r;
+  Ctl h;
+  memset(&h, 0, sizeof(h));
+  h.gnorm = 1.0;  // Main/multiPathPlanning3D.cpp:594
+  if ((r = upload(c, d.ctl, &h, sizeof(h)))) return r;
+  HIPCHK(c, hipMemset(d.xdir, 0, (size_t)U * d.xs * 8));
+  HIPCHK(c, hipMemset(d.ocount, 0, (size_t)U * d.S * 4));
+  HIPCHK(c, hipMemset(d.scount, 0, (size_t)U * d.S * 4));
+  c->have_state = true;
+  return TJ_OK;
+}
+
+int tj_get_state(tj_ctx* c, int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time) {
+  if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (spline) HIPCHK(c, hipMemcpy(spline, d.spline + (size_t)u * 3 * d.T, 3 * d.T * 8, hipMemcpyDeviceToHost));
+  if (p_slack) HIPCHK(c, hipMemcpy(p_slack, d.p_slack + (size_t)u * 18 * d.P, 18 * d.P * 8, hipMemcpyDeviceToHost));
+  if (p_lambda) HIPCHK(c, hipMemcpy(p_lambda, d.p_lambda + (size_t)u * 18 * d.P, 18 * d.P * 8, hipMemcpyDeviceToHost));
+  if (t_slack) HIPCHK(c, hipMemcpy(t_slack, d.t_slack + (size_t)u * d.P, d.P * 8, hipMemcpyDeviceToHost));
+  if (t_lambda) HIPCHK(c, hipMemcpy(t_lambda, d.t_lambda + (size_t)u * d.P, d.P * 8, hipMemcpyDeviceToHost));
+  if (piece_time) HIPCHK(c, hipMemcpy(piece_time, d.piece_time + u, 8, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_set_state(tj_ctx* c, int u, const double* spline, const double* p_slack, const double* p_lambda, const double* t_slack, const double* t_lambda, double piece_time) {
+  if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int r;
+  if (spline && (r = upload(c, d.spline + (size_t)u * 3 * d.T, spline, 3 * d.T * 8))) return r;
+  if (p_slack && (r = upload(c, d.p_slack + (size_t)u * 18 * d.P, p_slack, 18 * d.P * 8))) return r;
+  if (p_lambda && (r = upload(c, d.p_lambda + (size_t)u * 18 * d.P, p_lambda, 18 * d.P * 8))) return r;
+  if (t_slack && (r = upload(c, d.t_slack + (size_t)u * d.P, t_slack, d.P * 8))) return r;
+  if (t_lambda && (r = upload(c, d.t_lambda + (size_t)u * d.P, t_lambda, d.P * 8))) return r;
+  if ((r = upload(c, d.piece_time + u, &piece_time, 8))) return r;
+  c->have_state = true;
+  return TJ_OK;
+}
+
+int tj_iterate_async(tj_ctx* c, int n_iters) {
+  if (!c || n_iters < 0) return TJ_ERR_INVALID;
+  if (!ready(c)) return TJ_ERR_INVALID;
+  if (!c->graph_ok) {  // capture one iteration once; replay it n times
+    drop_graph(c);
+    hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      int r = enqueue_iteration(c);
+      hipGraph_t g = nullptr;
+      e = hipStreamEndCapture(c->stream, &g);
+      if (r == TJ_OK && e == hipSuccess && g && hipGraphInstantiate(&c->gexec, g, nullptr, nullptr, 0) == hipSuccess) { c->graph = g; c->graph_ok = true; }
+      else { if (g) hipGraphDestroy(g); (void)hipGetLastError(); }
+    } else (void)hipGetLastError();
+  }
+  for (int i = 0; i < n_iters; i++) {
+    if (c->graph_ok) HIPCHK(c, hipGraphLaunch(c->gexec, c->stream));
+    else { int r = enqueue_iteration(c); if (r) return r; }
+  }
+  return TJ_OK;
+}
+
+int tj_sync(tj_ctx* c) {
+  if (!c) return TJ_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TJ_OK;
+}
+
+void* tj_stream(tj_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int tj_iterate(tj_ctx* c, int n_iters, double* gnorm, int* iters_total, int* converged) {
+  int r = tj_iterate_async(c, n_iters);
+  if (r) return r;
+  Ctl h;
+  r = check_device_errors(c, &h);
+  if (gnorm) *gnorm = h.gnorm;
+  if (iters_total) *iters_total = h.iter;
+  if (converged) *converged = h.done;
+  return r;
+}
+
+int tj_run_stage(tj_ctx* c, int stage) {
+  if (!c) return TJ_ERR_INVALID;
+  if (!ready(c)) return TJ_ERR_INVALID;
+  int r = enqueue_stage(c, stage);
+  if (r) return r;
+  return check_device_errors(c);
+}
+
+int tj_iterate_phase(tj_ctx* c, int phase) {
+  if (!c) return TJ_ERR_INVALID;
+  if (!ready(c)) return TJ_ERR_INVALID;
+  static const int ph0[] = {TJ_STAGE_BEGIN, TJ_STAGE_PLANES_OBS};
+  static const int ph1[] = {TJ_STAGE_PLANES_SELF, TJ_STAGE_GRAD, TJ_STAGE_XSOLVE};
+  static const int ph2[] = {TJ_STAGE_CCD_PREP, TJ_STAGE_CCD_OBS, TJ_STAGE_CCD_SELF, TJ_STAGE_LINESEARCH, TJ_STAGE_SLACK, TJ_STAGE_END};
+  const int* lst = phase == 0 ? ph0 : phase == 1 ? ph1 : ph2;
+  const int cnt = phase == 0 ? 2 : phase == 1 ? 3 : 6;
+  if (phase < 0 || phase > 2) return TJ_ERR_INVALID;
+  for (int i = 0; i < cnt; i++) { int r = enqueue_stage(c, lst[i]); if (r) return r; }
+  return TJ_OK;
+}
+
+int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_robot, int* first_owned, int* n_owned) {
+  if (!c || what < 0 || what > 1) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  if (dev_ptr) *dev_ptr = what == 0 ? (void*)d.spline : (void*)d.xdir;
+  if (doubles_per_robot) *doubles_per_robot = what == 0 ? 3 * d.T : d.xs;
+  if (first_owned) *first_owned = d.u0;
+  if (n_owned) *n_owned = d.u1 - d.u0;
+  return TJ_OK;
+}
+
+int tj_get_planes(tj_ctx* c, int u, int* counts_obs, int* counts_self, double* planes, int cap) {
+  if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int> co(d.S), cs(d.S, 0);
+  HIPCHK(c, hipMemcpy(co.data(), d.ocount + (size_t)u * d.S, d.S * 4, hipMemcpyDeviceToHost));
+  if (d.mode == 1) HIPCHK(c, hipMemcpy(cs.data(), d.scount + (size_t)u * d.S, d.S * 4, hipMemcpyDeviceToHost));
+  int total = 0;
+  for (int tr = 0; tr < d.S; tr++) total += co[tr] + cs[tr];
+  if (counts_obs) memcpy(counts_obs, co.data(), d.S * 4);
+  if (counts_self) memcpy(counts_self, cs.data(), d.S * 4);
+  if (planes) {
+    if (cap < total) { c->err = "tj_get_planes: buffer too small"; return TJ_ERR_INVALID; }
+    size_t w = 0;
+    for (int tr = 0; tr < d.S; tr++) {
+      if (co[tr]) HIPCHK(c, hipMemcpy(planes + 4 * w, d.oplanes + ((size_t)u * d.S + tr) * d.cap_obs * 4, (size_t)co[tr] * 32, hipMemcpyDeviceToHost));
+      w += co[tr];
+      if (cs[tr]) HIPCHK(c, hipMemcpy(planes + 4 * w, d.splanes + ((size_t)u * d.S + tr) * d.cap_self * 4, (size_t)cs[tr] * 32, hipMemcpyDeviceToHost));
+      w += cs[tr];
+    }
+  }
+  return total;
+}
+
+int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes) {
+  if (!c || u < 0 || u >= c->d.U || !counts) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  size_t w = 0;
+  std::vector<int> zero(d.S, 0);
+  for (int tr = 0; tr < d.S; tr++) {
+    if (counts[tr] > d.cap_obs) { c->err = "tj_set_planes: more planes than cap_obs"; return TJ_ERR_CAPACITY; }
+    if (counts[tr]) HIPCHK(c, hipMemcpy(d.oplanes + ((size_t)u * d.S + tr) * d.cap_obs * 4, planes + 4 * w, (size_t)counts[tr] * 32, hipMemcpyHostToDevice));
+    w += counts[tr];
+  }
+  HIPCHK(c, hipMemcpy(d.ocount + (size_t)u * d.S, counts, d.S * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(d.scount + (size_t)u * d.S, zero.data(), d.S * 4, hipMemcpyHostToDevice));
+  return TJ_OK;
+}
+
+int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, double* wolfe, double* gn) {
+  if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<double> rec(d.xs);
+  HIPCHK(c, hipMemcpy(rec.data(), d.xdir + (size_t)u * d.xs, d.xs * 8, hipMemcpyDeviceToHost));
+  if (direction) memcpy(direction, rec.data(), 3 * d.T * 8);
+  if (t_direction) *t_direction = rec[3 * d.T];
+  if (wolfe) *wolfe = rec[3 * d.T + 1];
+  if (gn) *gn = rec[3 * d.T + 2];
+  return TJ_OK;
+}
+
+int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361) {
+  if (!c || u < 0 || u >= c->d.U || piece < 0 || piece >= c->d.P) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (g19) HIPCHK(c, hipMemcpy(g19, d.lg + ((size_t)u * d.P + piece) * 19, 19 * 8, hipMemcpyDeviceToHost));
+  if (h361) HIPCHK(c, hipMemcpy(h361, d.lh + ((size_t)u * d.P + piece) * 361, 361 * 8, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_armijo) {
+  if (!c) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int> ko(d.U), ks(d.U);
+  HIPCHK(c, hipMemcpy(ko.data(), d.k_obs, d.U * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(ks.data(), d.k_self, d.U * 4, hipMemcpyDeviceToHost));
+  auto p = [](int k) { double s = 1.0; for (int i = 0; i < k; i++) s *= 0.8; return s; };
+  for (int u = 0; u < d.U; u++) { if (step_self) step_self[u] = p(ks[u]); if (step_obs) step_obs[u] = p(ko[u]); }
+  if (step_armijo) HIPCHK(c, hipMemcpy(step_armijo, d.step_out, d.U * 8, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_get_stats(tj_ctx* c, tj_stats* s) {
+  if (!c || !s) return TJ_ERR_INVALID;
+  Ctl h;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+  s->iters = h.iter; s->nodes_dcd = h.nodes_dcd; s->nodes_ccd = h.nodes_ccd; s->cand_dcd = h.cand_dcd; s->cand_ccd = h.cand_ccd;
+  s->planes_obs = h.planes_obs; s->planes_self = h.planes_self; s->energy_evals = h.energy_evals; s->pair_tests = h.pair_tests;
+  s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error;
+  return TJ_OK;
+}
+
+}  // extern "C"

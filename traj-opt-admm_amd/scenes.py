@@ -93,3 +93,29 @@ def write_reference_files(scene, root, mesh_name):
         wp = scene["waypoints"] * scale
         for k in range(wp.shape[1]):
             f.write(" ".join("%.17g" % v for u in range(wp.shape[0]) for v in wp[u, k]) + "\n")
+
+
+def hard(U=4, n_points=4000, seed=3, pieces=5, radius=4.0, dz=0.13, clear=0.13):
+    """Stress scene for tests: robots cross almost in one plane (offset < dz < offset+2*margin, so the start is feasible but tight) and the
+    cloud fills the volume around the straight-line initial paths (kept `clear` away from them),
+    so obstacle planes, inter-robot planes and both CCD step clamps become active."""
+    rng = np.random.default_rng(seed)
+    wp = np.zeros((U, pieces + 1, 3))
+    for u in range(U):
+        th = np.pi * u / U + 0.1
+        a = np.array([radius * np.cos(th), radius * np.sin(th), dz * u])
+        b = -a.copy(); b[2] = dz * u
+        for k in range(pieces + 1):
+            wp[u, k] = a + (b - a) * (k / pieces)
+    pts = np.empty((0, 3))
+    while pts.shape[0] < n_points:
+        c = rng.uniform([-radius, -radius, -0.6], [radius, radius, 0.6 + dz * U], size=(4 * n_points, 3))
+        keep = np.ones(len(c), dtype=bool)
+        for u in range(U):
+            a, b = wp[u, 0], wp[u, -1]
+            ab = b - a
+            t = np.clip(((c - a) @ ab) / (ab @ ab), 0, 1)
+            dist = np.linalg.norm(c - (a + t[:, None] * ab), axis=1)
+            keep &= dist > clear
+        pts = np.concatenate([pts, c[keep]], axis=0)
+    return dict(name=f"hard-U{U}", mode=1, U=U, P=pieces, waypoints=wp, cloud=np.ascontiguousarray(pts[:n_points]), ks=1e-3)
