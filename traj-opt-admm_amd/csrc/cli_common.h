@@ -1,0 +1,92 @@
+// cli_common.h -- file formats of the reference's two command-line tools, kept verbatim so the
+// binaries are drop-ins on the same working directory layout:
+//   Config_File/3D.json          16 flat numeric keys (Main/admmPathPlanning3D.cpp:368-397)
+//   model/{single,multiple}/<m>  OBJ, only `v` lines are used, reading stops at the first other
+//                                line once more than 10 vertices were seen (CCDUtils.h:317-391)
+//   init/<m>_init_file.txt       way points (admmPathPlanning3D.cpp:79-112, multiPathPlanning3D.cpp:78-121)
+//   result/<m>_result_file_*.txt iter / running time / point cloud size (admmPathPlanning3D.cpp:507-510)
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace tjcli {
+
+// flat JSON object with numeric values
+inline std::map<std::string, double> read_flat_json(const std::string& path) {
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  std::stringstream ss; ss << f.rdbuf();
+  const std::string s = ss.str();
+  std::map<std::string, double> out;
+  size_t i = 0;
+  while ((i = s.find('"', i)) != std::string::npos) {
+    size_t j = s.find('"', i + 1);
+    if (j == std::string::npos) break;
+    std::string key = s.substr(i + 1, j - i - 1);
+    size_t c = s.find(':', j);
+    if (c == std::string::npos) break;
+    char* end = nullptr;
+    double v = std::strtod(s.c_str() + c + 1, &end);
+    if (end == s.c_str() + c + 1) throw std::runtime_error("bad value for key " + key + " in " + path);
+    out[key] = v;
+    i = (size_t)(end - s.c_str());
+  }
+  return out;
+}
+
+inline double need(const std::map<std::string, double>& j, const char* key) {
+  auto it = j.find(key);
+  if (it == j.end()) throw std::runtime_error(std::string("3D.json: missing key \"") + key + "\"");  // all 16 keys are mandatory in the reference
+  return it->second;
+}
+
+inline std::vector<double> read_obj_vertices(const std::string& path) {
+  FILE* fp = fopen(path.c_str(), "r");
+  if (!fp) throw std::runtime_error("cannot open " + path);
+  std::vector<double> v;
+  char line[2048], type[2048];
+  int count = 0;
+  while (fgets(line, sizeof(line), fp)) {
+    if (sscanf(line, "%s", type) != 1) continue;
+    if (strcmp(type, "v") == 0) {
+      std::istringstream ls(line + 1);
+      double x, y, z;
+      if (ls >> x >> y >> z) { v.push_back(x); v.push_back(y); v.push_back(z); count++; }
+    } else if (count > 10) break;
+  }
+  fclose(fp);
+  return v;
+}
+
+// single: one "x y z" per line.  multi: 3*U numbers per line, U from the first line.
+inline void read_waypoints(const std::string& path, bool multi, int& U, int& P, std::vector<double>& wp /*[U][P+1][3]*/) {
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  std::vector<std::vector<double>> rows;
+  std::string line;
+  while (std::getline(f, line)) {
+    std::istringstream is(line);
+    std::vector<double> r; double x;
+    while (is >> x) r.push_back(x);
+    if (!r.empty()) rows.push_back(r);
+  }
+  if (rows.size() < 3) throw std::runtime_error(path + ": need at least 3 way points");
+  U = multi ? (int)rows[0].size() / 3 : 1;
+  if (U < 1) throw std::runtime_error(path + ": first line has fewer than 3 numbers");
+  P = (int)rows.size() - 1;
+  wp.assign((size_t)U * (P + 1) * 3, 0.0);
+  for (int k = 0; k <= P; k++) {
+    if ((int)rows[k].size() < 3 * U) throw std::runtime_error(path + ": short line");
+    for (int u = 0; u < U; u++) for (int a = 0; a < 3; a++) wp[((size_t)u * (P + 1) + k) * 3 + a] = rows[k][3 * u + a];
+  }
+}
+
+}  // namespace tjcli

@@ -1,0 +1,101 @@
+// cli_main.cpp -- `admmPathPlanning3D <mesh>` (-DTJ_CLI_SINGLE) and `multiPathPlanning3D <mesh>`
+// (-DTJ_CLI_MULTI): the headless branches of the reference mains
+// (Main/admmPathPlanning3D.cpp:355-547, Main/multiPathPlanning3D.cpp:470-695) with the per-iteration
+// call replaced by the C ABI of libtrajadmm.so.  Same working-directory layout, same config keys,
+// same result file.  GUI (`gui:1`), OMPL initialisation (`init:2`), `optimal_plane:1` and the
+// coupled multi-robot mode (`decouple:0`) are outside the accelerated path and are rejected with a
+// message instead of being silently ignored.
+//
+// Extras (ours): --max-iter N, --dump-state FILE (the reference never writes the trajectory),
+// --batch N iterations per device batch (the stop test runs on the device before every iteration).
+#include <chrono>
+#include "../../include/trajadmm.h"
+#include "cli_common.h"
+
+#if defined(TJ_CLI_MULTI)
+static const bool kMulti = true;
+#else
+static const bool kMulti = false;
+#endif
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::cerr << "Syntax: " << argv[0] << " <mesh file> [--max-iter N] [--batch N] [--dump-state FILE]" << std::endl; return -1; }
+  const std::string mesh = argv[1];
+  long max_iter = 1000000; int batch = 8; std::string dump;
+  for (int i = 2; i < argc; i++) {
+    std::string a = argv[i];
+    if (a == "--max-iter" && i + 1 < argc) max_iter = atol(argv[++i]);
+    else if (a == "--batch" && i + 1 < argc) batch = atoi(argv[++i]);
+    else if (a == "--dump-state" && i + 1 < argc) dump = argv[++i];
+    else { std::cerr << "unknown argument " << a << std::endl; return -1; }
+  }
+  tj_ctx* ctx = nullptr;
+  try {
+    auto j = tjcli::read_flat_json("Config_File/3D.json");
+    const double lambda = tjcli::need(j, "lambda"), margin = tjcli::need(j, "margin"), offset = tjcli::need(j, "offset");
+    const double mu = tjcli::need(j, "mu"), stop = tjcli::need(j, "stop"), vel = tjcli::need(j, "vel_limit"), acc = tjcli::need(j, "acc_limit");
+    const int res = (int)tjcli::need(j, "res"), init = (int)tjcli::need(j, "init"), gui = (int)tjcli::need(j, "gui");
+    const int optimal_plane = (int)tjcli::need(j, "optimal_plane"), if_exit = (int)tjcli::need(j, "exit"), init_ob = (int)tjcli::need(j, "init_ob");
+    tjcli::need(j, "auto"); tjcli::need(j, "epsilon");
+    const int decouple = (int)tjcli::need(j, "decouple");
+    (void)if_exit;
+    if (gui) throw std::runtime_error("gui:1 is not part of the accelerated path (use gui:0)");
+    if (init != 1) throw std::runtime_error("only init:1 (init/<mesh>_init_file.txt) is supported; init:2 needs OMPL");
+    if (optimal_plane) throw std::runtime_error("optimal_plane:1 is not implemented on the device path yet");
+    if (kMulti && !decouple) throw std::runtime_error("decouple:0 (shared piece_time) is not implemented on the device path yet");
+
+    std::vector<double> V = tjcli::read_obj_vertices(std::string(kMulti ? "model/multiple/" : "model/single/") + mesh);
+    int U = 1, P = 0; std::vector<double> wp;
+    tjcli::read_waypoints("init/" + mesh + "_init_file.txt", kMulti, U, P, wp);
+    if (kMulti) {  // Main/multiPathPlanning3D.cpp:107,536
+      for (double& x : V) x *= 5;
+      for (double& x : wp) x *= 5;
+      std::cout << "uav_num: " << U << "\n";
+    }
+    const int N = init_ob ? (int)(V.size() / 3) : 0;
+    std::cout << "time_obstacle build: " << N << " points" << std::endl;
+
+    tj_params p;
+    tj_default_params(&p, kMulti ? TJ_MODE_MULTI_DECOUPLE : TJ_MODE_SINGLE, U, P);
+    p.res = res; p.lambda = lambda; p.margin = margin; p.offset = offset; p.mu = mu; p.vel_limit = vel; p.acc_limit = acc; p.stop = stop;
+    auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + tj_last_error(ctx)); };
+    chk(tj_create(&p, &ctx), "tj_create");
+    chk(tj_set_cloud(ctx, V.data(), N), "tj_set_cloud");
+    chk(tj_init_state(ctx, wp.data(), 20.0), "tj_init_state");  // piece_time = 20 (admmPathPlanning3D.cpp:482)
+
+    std::ofstream result("result/" + mesh + (kMulti ? "_result_file_multi.txt" : "_result_file_admm.txt"));
+    double whole_ms = 0, gnorm = 1;
+    int iter = 0, converged = 0;
+    while (iter < max_iter && !converged) {
+      const int n = (int)std::min<long>(batch, max_iter - iter);
+      auto t0 = std::chrono::steady_clock::now();
+      chk(tj_iterate(ctx, n, &gnorm, &iter, &converged), "tj_iterate");
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      whole_ms += ms;
+      std::cout << "iter: " << iter << "\n" << "gnorm: " << gnorm << "\n" << "time:" << ms << std::endl;
+    }
+    if (converged) {
+      result << "iter: " << iter << std::endl;
+      result << "running time: " << whole_ms << std::endl;
+      result << "point cloud size: " << V.size() / 3 << std::endl;
+    }
+    if (!dump.empty()) {
+      std::ofstream df(dump);
+      df.precision(17);
+      const int T = 3 * P + 3;
+      std::vector<double> s(3 * T); double pt = 0;
+      df << "uav_num " << U << " piece_num " << P << " iter " << iter << " gnorm " << gnorm << " converged " << converged << "\n";
+      for (int u = 0; u < U; u++) {
+        chk(tj_get_state(ctx, u, s.data(), nullptr, nullptr, nullptr, nullptr, &pt), "tj_get_state");
+        df << "uav " << u << " piece_time " << pt << "\n";
+        for (int r = 0; r < T; r++) df << s[r] << " " << s[r + T] << " " << s[r + 2 * T] << "\n";
+      }
+    }
+    tj_destroy(ctx);
+    return converged ? 0 : 2;
+  } catch (const std::exception& e) {
+    std::cerr << "error: " << e.what() << std::endl;
+    if (ctx) tj_destroy(ctx);
+    return 1;
+  }
+}

@@ -27,6 +27,7 @@ struct tj_ctx {
   tj_params prm;
   Dev d;
   hipStream_t stream = nullptr;
+  bool own_stream = true;
   std::vector<void*> allocs;
   std::string err;
   bool have_cloud = false, have_state = false;
@@ -201,7 +202,7 @@ void tj_destroy(tj_ctx* c) {
   drop_graph(c);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->cloud_allocs) hipFree(p);
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -339,6 +340,48 @@ int tj_sync(tj_ctx* c) {
 }
 
 void* tj_stream(tj_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int tj_set_stream(tj_ctx* c, void* hip_stream) {
+  if (!c) return TJ_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drop_graph(c);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)hip_stream;
+  c->own_stream = false;
+  return TJ_OK;
+}
+
+int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
+  if (!c || !ms || n_iters < 0) return TJ_ERR_INVALID;
+  if (!ready(c)) return TJ_ERR_INVALID;
+  const int NS = TJ_STAGE_END + 1;
+  std::vector<hipEvent_t> ev((size_t)n_iters * (NS + 1));
+  for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+  for (int it = 0; it < n_iters; it++) {
+    hipEvent_t* e = &ev[(size_t)it * (NS + 1)];
+    HIPCHK(c, hipEventRecord(e[0], c->stream));
+    for (int st = 0; st < NS; st++) {
+      int r = enqueue_stage(c, st);
+      if (r) return r;
+      HIPCHK(c, hipEventRecord(e[st + 1], c->stream));
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int st = 0; st < NS; st++) ms[st] = 0;
+  for (int it = 0; it < n_iters; it++)
+    for (int st = 0; st < NS; st++) {
+      float t = 0;
+      HIPCHK(c, hipEventElapsedTime(&t, ev[(size_t)it * (NS + 1) + st], ev[(size_t)it * (NS + 1) + st + 1]));
+      ms[st] += t;
+    }
+  for (auto& e : ev) hipEventDestroy(e);
+  if (launches) {
+    for (int st = 0; st < NS; st++) launches[st] = n_iters;
+    if (c->d.mode != 1) launches[TJ_STAGE_PLANES_SELF] = 0;
+    launches[TJ_STAGE_CCD_SELF] = n_iters * (c->d.mode == 1 ? 2 : 1);
+  }
+  return check_device_errors(c);
+}
 
 int tj_iterate(tj_ctx* c, int n_iters, double* gnorm, int* iters_total, int* converged) {
   int r = tj_iterate_async(c, n_iters);
