@@ -154,10 +154,9 @@ class Prims:
 
     def __init__(self, kind):
         self.lib = C.CDLL(_PATHS[kind]); self.px = _PREFIX[kind]
-        if kind == "ref":  # k-DOP axes are normalised inside ref_setup
-            Engine("ref", _dummy_scene())
-        else:
-            f = getattr(self.lib, "orc_quiet", None)
+        # both libraries keep parameters (offset, margin, k-DOP axes) in process-wide state that a
+        # setup call initialises with the shipped 3D.json values
+        Engine(kind, _dummy_scene())
 
     def _f(self, name, restype=C.c_int):
         f = getattr(self.lib, self.px + name); f.restype = restype; return f

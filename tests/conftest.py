@@ -1,0 +1,74 @@
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module("traj-opt-admm_amd")
+
+
+@pytest.fixture(scope="session")
+def scenes(pkg):
+    return pkg.scenes
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_oracle():
+    """the CPU checker is compiled on demand (g++ only, a few seconds)"""
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "port"], cwd=os.path.join(ROOT, "oracle"), check=True)
+    return so
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def canon(counts, planes):
+    """order-free view of per-(robot, segment) plane lists"""
+    out = []
+    w = 0
+    planes = np.asarray(planes).reshape(-1, 4)
+    for n in np.asarray(counts).ravel():
+        blk = planes[w:w + n]
+        w += n
+        if n:
+            blk = blk[np.lexsort(blk.T[::-1])]
+        out.append(blk)
+    return np.concatenate(out, axis=0) if out else planes
+
+
+def maxdiff(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def rel(a, b):
+    return maxdiff(a, b) / max(1e-300, float(np.max(np.abs(b))))
+
+
+def scene_by_name(scenes, name):
+    return {"tiny_multi": lambda: scenes.tiny(1), "tiny_single": lambda: scenes.tiny(0, n_points=3000), "hard": scenes.hard,
+            "scn_a": scenes.scn_a, "scn_b": scenes.scn_b, "scn_c": scenes.scn_c}[name]()
+
+
+def check_scene_matches_fixture(scene, g):
+    """the fixtures were generated for seeded scenes; make sure numpy still generates the same cloud"""
+    cs = np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()])
+    assert np.allclose(cs, g["cloud_sum"], rtol=1e-13), "seeded scene differs from the one the golden file was made for"

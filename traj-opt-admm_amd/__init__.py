@@ -25,7 +25,7 @@ EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
     "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_set_stream", "tj_profile_iterations",
+    "tj_iterate_phase", "tj_set_stream", "tj_profile_iterations", "tj_kat_gjk", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
 ]
 
 STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
@@ -236,6 +236,31 @@ class Solver:
     def stage_slack(self):
         self.run_stage("slack")
         self.run_stage("end")
+
+    # ---- known-answer hooks (device primitives on caller batches) -------------------------------
+    def kat_gjk(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        n = a.shape[0]; v = np.zeros((n, 3))
+        self._check(self.lib.tj_kat_gjk(self._ctx, C.c_int(n), C.c_int(a.shape[1]), _d(a), C.c_int(b.shape[1]), _d(b), _d(v)))
+        return v
+
+    def kat_planes(self, what, P, Q, dist):
+        P = np.ascontiguousarray(P, dtype=np.float64); Q = np.ascontiguousarray(Q, dtype=np.float64)
+        n = P.shape[0]; out = np.zeros((n, 5))
+        self._check(self.lib.tj_kat_planes(self._ctx, C.c_int(what), C.c_int(n), _d(P), _d(Q), C.c_double(dist), _d(out)))
+        return out
+
+    def kat_ccd(self, P, D, Q, E, q, tu, d):
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (P, D, Q, E, q, tu)]
+        n = arrs[0].shape[0]; out = np.zeros((n, 2))
+        self._check(self.lib.tj_kat_ccd(self._ctx, C.c_int(n), *[_d(x) for x in arrs], C.c_double(d), _d(out)))
+        return out
+
+    def kat_linalg(self, mats):
+        mats = np.ascontiguousarray(mats, dtype=np.float64)
+        out = np.zeros((mats.shape[0], 2))
+        self._check(self.lib.tj_kat_linalg(self._ctx, C.c_int(mats.shape[0]), C.c_int(mats.shape[1]), _d(mats), _d(out)))
+        return out
 
     def stats(self):
         s = TjStats()

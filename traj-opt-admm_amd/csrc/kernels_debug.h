@@ -1,0 +1,83 @@
+// kernels_debug.h -- known-answer entry points: run the SAME device functions the hot-path kernels
+// use (gjk, plane_obstacle, plane_pair, k-DOP tests, swept-hull CCD predicates, chol / min-eig) on
+// caller-supplied batches, one case per lane (or per workgroup for the LDS linear algebra), so the
+// parity tests can compare them bit-for-bit against vectors produced by the reference
+// (tests/golden/gjk_kat.npz, prims_kat.npz).
+#pragma once
+#include "dev_common.h"
+#include "dev_linalg.h"
+#include "kernels_sep.h"
+
+namespace tj {
+
+template <int K>
+struct BodyPts {  // K explicit points, row-major [K][3]
+  const double* p;
+  static constexpr int N = K;
+  __device__ __forceinline__ V3 get(int i) const { return V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+};
+
+template <int K1, int K2>
+__global__ void k_dbg_gjk(int n, const double* a, const double* b, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 v = gjk(BodyPts<K1>{a + (size_t)i * 3 * K1}, BodyPts<K2>{b + (size_t)i * 3 * K2});
+  out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+}
+
+// what: 0 plane_obstacle(P,q) -> out[5] = ok,c,d ; 1 plane_pair(P,Q) with Newton refine -> ok,c,d ;
+//       2 k-DOP hull/point ; 3 k-DOP hull/hull   (out[0] = pass)
+__global__ void k_dbg_planes(Dev D, int what, int n, const double* P, const double* Q, double dist, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* p = P + (size_t)i * 18;
+  double* o = out + (size_t)i * 5;
+  if (what == 0) {
+    const V3 q{Q[3 * i], Q[3 * i + 1], Q[3 * i + 2]};
+    double c0 = 0, c1 = 0, c2 = 0, dd = 0;
+    const bool ok = plane_obstacle(p, q, dist, D.offset, c0, c1, c2, dd);
+    o[0] = ok; o[1] = c0; o[2] = c1; o[3] = c2; o[4] = dd;
+  } else if (what == 1) {
+    double e0 = 0, e1 = 0, e2 = 0, dpl = 0; bool capped;
+    const bool ok = plane_pair(p, Q + (size_t)i * 18, dist, D.margin, D.offset, true, e0, e1, e2, dpl, capped);
+    o[0] = ok; o[1] = e0; o[2] = e1; o[3] = e2; o[4] = dpl;
+  } else if (what == 2) {
+    double klo[49], khi[49];
+    for (int k = 0; k < 49; k++) {
+      const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+      double up = -INFINITY, lo = INFINITY;
+      for (int j = 0; j < 6; j++) { const double lv = x * p[3 * j] + y * p[3 * j + 1] + z * p[3 * j + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+      klo[k] = lo; khi[k] = up;
+    }
+    o[0] = kdop_point_pass(D, klo, khi, V3{Q[3 * i], Q[3 * i + 1], Q[3 * i + 2]}, dist);
+  } else {
+    o[0] = kdop_hulls_pass(D, p, Q + (size_t)i * 18, dist);
+  }
+}
+
+// swept-hull CCD predicates at steps (t1,u1): out[0] = GJKCCD(P,D,q), out[1] = SelfGJKCCD(P,D,Q,E)
+__global__ void k_dbg_ccd(int n, const double* P, const double* Dd, const double* Q, const double* E, const double* q, const double* tu, double d, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double t1 = tu[2 * i], u1 = tu[2 * i + 1];
+  const V3 v = gjk(BodySwept{P + (size_t)i * 18, Dd + (size_t)i * 18, t1}, BodyPoint{V3{q[3 * i], q[3 * i + 1], q[3 * i + 2]}});
+  out[2 * i] = (v.x * v.x + v.y * v.y + v.z * v.z <= d * d);
+  const V3 w = gjk(BodySwept{P + (size_t)i * 18, Dd + (size_t)i * 18, t1}, BodySwept{Q + (size_t)i * 18, E + (size_t)i * 18, u1});
+  out[2 * i + 1] = (w.x * w.x + w.y * w.y + w.z * w.z <= d * d);
+}
+
+// one workgroup per matrix: out[2*i] = LLT fails, out[2*i+1] = smallest eigenvalue
+__global__ __launch_bounds__(64) void k_dbg_linalg(int nmat, int n, const double* mats, double* out) {
+  extern __shared__ double sm[];
+  double* A = sm; double* W = A + n * n; double* scr = W + n * n;
+  const int tid = threadIdx.x;
+  const double* src = mats + (size_t)blockIdx.x * n * n;
+  for (int i = tid; i < n * n; i += 64) { A[i] = src[i]; W[i] = src[i]; }
+  __syncthreads();
+  const bool ok = chol_lds(W, n, tid, 64);
+  __syncthreads();
+  const double ev = min_eig_lds(A, n, scr, scr + n, scr + 2 * n, scr + 3 * n, tid, 64);
+  if (tid == 0) { out[2 * blockIdx.x] = ok ? 0.0 : 1.0; out[2 * blockIdx.x + 1] = ev; }
+}
+
+}  // namespace tj

@@ -127,6 +127,76 @@ __device__ __forceinline__ bool kdop_point_pass(const Dev& D, const double* klo,
   return true;
 }
 
+// Separate::opengjk (Separate.h:18-163): plane (c,d) between a 6-point hull and one cloud point
+__device__ __forceinline__ bool plane_obstacle(const double* P, const V3& qp, double dist, double offset, double& c0, double& c1, double& c2, double& dd) {
+  const V3 v = gjk(BodyHull{P}, BodyPoint{qp});
+  const double cn = norm3(v.x, v.y, v.z);
+  if (cn > dist) return false;
+  c0 = v.x / cn; c1 = v.y / cn; c2 = v.z / cn;
+  const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
+  dd = d0 - offset;
+  return true;
+}
+
+__device__ __forceinline__ double dot_fixed3(double c0, double c1, double c2, const double* r) { return c0 * r[0] + (c1 * r[1] + c2 * r[2]); }  // Eigen unrolled 3-term order (Separate.h:268,276)
+
+// 49-axis test between two 6-point hulls (CCD::SelfKDOPDCD, CCD.h:535-587)
+__device__ inline bool kdop_hulls_pass(const Dev& D, const double* A, const double* Bq, double dist) {
+  for (int k = 0; k < 49; k++) {
+    const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+    double upA = -INFINITY, loA = INFINITY, upB = -INFINITY, loB = INFINITY;
+    for (int i = 0; i < 6; i++) {
+      const double la = x * A[3 * i] + y * A[3 * i + 1] + z * A[3 * i + 2];
+      if (la < loA) loA = la; if (la > upA) upA = la;
+      const double lb = x * Bq[3 * i] + y * Bq[3 * i + 1] + z * Bq[3 * i + 2];
+      if (lb < loB) loB = lb; if (lb > upB) upB = lb;
+    }
+    if (upB < loA - dist || upA < loB - dist) return false;
+  }
+  return true;
+}
+
+// Separate::selfgjk (Separate.h:165-304) + Optimal_plane::optimal_d (Optimal_plane.h:13-71).
+// A is the hull of the lower robot index.  Returns false if the hulls are farther than dist.
+// capped = true when the Newton loop hit LOOP_CAP.
+__device__ inline bool plane_pair(const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped) {
+  capped = false;
+  const V3 v = gjk(BodyHull{A}, BodyHull{Bq});
+  const double cn = norm3(v.x, v.y, v.z);
+  if (cn > dist) return false;
+  e0 = v.x / cn; e1c = v.y / cn; e2c = v.z / cn;
+  double d0 = INFINITY, d1 = -INFINITY;
+  for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, Bq + 3 * i); if (d0 > t) d0 = t; }
+  for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, A + 3 * i); if (d1 < t) d1 = t; }
+  dpl = 0.5 * (d0 + d1);
+  if (!refine) return true;
+  int it = 0;
+  for (; it < LOOP_CAP; it++) {  // Newton on the offset until |grad| < 1e-2
+    double grad = 0, hess = 0;
+    for (int j = 0; j < 6; j++) {
+      const double ds = (A[3 * j] * e0 + A[3 * j + 1] * e1c + A[3 * j + 2] * e2c) + dpl - 0.5 * off;
+      if (ds < m) {
+        const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
+        const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+        grad += g1; hess += g2;
+      }
+    }
+    for (int j = 0; j < 6; j++) {
+      const double ds = -(Bq[3 * j] * e0 + Bq[3 * j + 1] * e1c + Bq[3 * j + 2] * e2c) - dpl - 0.5 * off;
+      if (ds < m) {
+        const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
+        const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+        grad += -g1; hess += g2;
+      }
+    }
+    const double dir = -grad / hess;
+    dpl = dpl + 1.0 * dir;
+    if (fabs(grad) < 1e-2) break;
+  }
+  capped = it == LOOP_CAP;
+  return true;
+}
+
 __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
   if (D.ctl->done) return;
   const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
@@ -155,16 +225,7 @@ __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
     double c0 = 0, c1 = 0, c2 = 0, dd = 0;
     if (pt >= 0) {
       const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
-      if (kdop_point_pass(D, klo, khi, qp, dist)) {
-        const V3 v = gjk(BodyHull{P}, BodyPoint{qp});
-        const double cn = norm3(v.x, v.y, v.z);
-        if (!(cn > dist)) {
-          c0 = v.x / cn; c1 = v.y / cn; c2 = v.z / cn;
-          const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
-          dd = d0 - D.offset;
-          ok = true;
-        }
-      }
+      if (kdop_point_pass(D, klo, khi, qp, dist)) ok = plane_obstacle(P, qp, dist, D.offset, c0, c1, c2, dd);
     }
     const unsigned long long mask = ballot(ok);
     const int idx = base + prefix_count(mask);
@@ -183,8 +244,6 @@ __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
 }
 
 // ---- inter-robot planes ------------------------------------------------------------------------
-__device__ __forceinline__ double dot_fixed3(double c0, double c1, double c2, const double* r) { return c0 * r[0] + (c1 * r[1] + c2 * r[2]); }  // Eigen unrolled 3-term order (Separate.h:268,276)
-
 __global__ __launch_bounds__(64) void k_sep_self(Dev D) {
   if (D.ctl->done) return;
   const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
@@ -225,52 +284,10 @@ __global__ __launch_bounds__(64) void k_sep_self(Dev D) {
       if (hit) {
         const double* A = (u < q) ? myP : Q;  // body 1 is always the lower robot index
         const double* Bq = (u < q) ? Q : myP;
-        bool pass = true;
-        for (int k = 0; k < 49 && pass; k++) {
-          const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
-          double upA = -INFINITY, loA = INFINITY, upB = -INFINITY, loB = INFINITY;
-          for (int i = 0; i < 6; i++) {
-            const double la = x * A[3 * i] + y * A[3 * i + 1] + z * A[3 * i + 2];
-            if (la < loA) loA = la; if (la > upA) upA = la;
-            const double lb = x * Bq[3 * i] + y * Bq[3 * i + 1] + z * Bq[3 * i + 2];
-            if (lb < loB) loB = lb; if (lb > upB) upB = lb;
-          }
-          if (upB < loA - dist || upA < loB - dist) pass = false;
-        }
-        if (pass) {
-          const V3 v = gjk(BodyHull{A}, BodyHull{Bq});
-          const double cn = norm3(v.x, v.y, v.z);
-          if (!(cn > dist)) {
-            const double e0 = v.x / cn, e1c = v.y / cn, e2c = v.z / cn;
-            double d0 = INFINITY, d1 = -INFINITY;
-            for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, Bq + 3 * i); if (d0 > t) d0 = t; }
-            for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, A + 3 * i); if (d1 < t) d1 = t; }
-            double dpl = 0.5 * (d0 + d1);
-            // Optimal_plane::optimal_d: Newton on the offset until |grad| < 1e-2
-            int it = 0;
-            for (; it < LOOP_CAP; it++) {
-              double grad = 0, hess = 0;
-              for (int j = 0; j < 6; j++) {
-                const double ds = (A[3 * j] * e0 + A[3 * j + 1] * e1c + A[3 * j + 2] * e2c) + dpl - 0.5 * off;
-                if (ds < m) {
-                  const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
-                  const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
-                  grad += g1; hess += g2;
-                }
-              }
-              for (int j = 0; j < 6; j++) {
-                const double ds = -(Bq[3 * j] * e0 + Bq[3 * j + 1] * e1c + Bq[3 * j + 2] * e2c) - dpl - 0.5 * off;
-                if (ds < m) {
-                  const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
-                  const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
-                  grad += -g1; hess += g2;
-                }
-              }
-              const double dir = -grad / hess;
-              dpl = dpl + 1.0 * dir;
-              if (fabs(grad) < 1e-2) break;
-            }
-            if (it == LOOP_CAP) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+        if (kdop_hulls_pass(D, A, Bq, dist)) {
+          double e0, e1c, e2c, dpl; bool capped;
+          if (plane_pair(A, Bq, dist, m, off, true, e0, e1c, e2c, dpl, capped)) {
+            if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
             if (u < q) { c0 = e0; c1 = e1c; c2 = e2c; dd = dpl - 0.5 * off; }
             else { c0 = -e0; c1 = -e1c; c2 = -e2c; dd = -dpl - 0.5 * off; }
             ok = true;

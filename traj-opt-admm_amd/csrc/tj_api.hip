@@ -20,6 +20,7 @@
 #include "kernels_sep.h"
 #include "kernels_newton.h"
 #include "kernels_step.h"
+#include "kernels_debug.h"
 
 using namespace tj;
 
@@ -497,6 +498,76 @@ int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_ar
   auto p = [](int k) { double s = 1.0; for (int i = 0; i < k; i++) s *= 0.8; return s; };
   for (int u = 0; u < d.U; u++) { if (step_self) step_self[u] = p(ks[u]); if (step_obs) step_obs[u] = p(ko[u]); }
   if (step_armijo) HIPCHK(c, hipMemcpy(step_armijo, d.step_out, d.U * 8, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+// ---- known-answer hooks ------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+};
+int to_dev(tj_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+  HIPCHK(c, hipMalloc(&b.p, std::max<size_t>(bytes, 8)));
+  if (src && bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return TJ_OK;
+}
+}  // namespace
+
+int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v) {
+  if (!c || n < 0 || !a || !b || !v) return TJ_ERR_INVALID;
+  DevBuf da, db, dv; int r;
+  if ((r = to_dev(c, da, a, (size_t)n * n1 * 24)) || (r = to_dev(c, db, b, (size_t)n * n2 * 24)) || (r = to_dev(c, dv, nullptr, (size_t)n * 24))) return r;
+  dim3 g((n + 63) / 64), t(64);
+  const double *A = (const double*)da.p, *B = (const double*)db.p; double* V = (double*)dv.p;
+  if (n1 == 6 && n2 == 1) hipLaunchKernelGGL((k_dbg_gjk<6, 1>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 6 && n2 == 6) hipLaunchKernelGGL((k_dbg_gjk<6, 6>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 12 && n2 == 1) hipLaunchKernelGGL((k_dbg_gjk<12, 1>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 12 && n2 == 12) hipLaunchKernelGGL((k_dbg_gjk<12, 12>), g, t, 0, c->stream, n, A, B, V);
+  else { c->err = "tj_kat_gjk: body sizes must be 6v1, 6v6, 12v1 or 12v12"; return TJ_ERR_INVALID; }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(v, dv.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out) {
+  if (!c || n < 0 || what < 0 || what > 3 || !P || !Q || !out) return TJ_ERR_INVALID;
+  const size_t qbytes = (what == 0 || what == 2) ? (size_t)n * 24 : (size_t)n * 144;
+  DevBuf dp, dq, dout; int r;
+  if ((r = to_dev(c, dp, P, (size_t)n * 144)) || (r = to_dev(c, dq, Q, qbytes)) || (r = to_dev(c, dout, nullptr, (size_t)n * 40))) return r;
+  HIPCHK(c, hipMemset(dout.p, 0, std::max<size_t>((size_t)n * 40, 8)));
+  hipLaunchKernelGGL(k_dbg_planes, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, what, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 40, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double* Q, const double* E, const double* q, const double* tu, double d, double* out) {
+  if (!c || n < 0 || !P || !D || !Q || !E || !q || !tu || !out) return TJ_ERR_INVALID;
+  DevBuf b[6], dout; int r;
+  const void* src[6] = {P, D, Q, E, q, tu};
+  const size_t sz[6] = {(size_t)n * 144, (size_t)n * 144, (size_t)n * 144, (size_t)n * 144, (size_t)n * 24, (size_t)n * 16};
+  for (int i = 0; i < 6; i++) if ((r = to_dev(c, b[i], src[i], sz[i]))) return r;
+  if ((r = to_dev(c, dout, nullptr, (size_t)n * 16))) return r;
+  hipLaunchKernelGGL(k_dbg_ccd, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, (const double*)b[0].p, (const double*)b[1].p, (const double*)b[2].p,
+                     (const double*)b[3].p, (const double*)b[4].p, (const double*)b[5].p, d, (double*)dout.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out) {
+  if (!c || nmat < 0 || n < 1 || n > 64 || !mats || !out) return TJ_ERR_INVALID;
+  DevBuf dm, dout; int r;
+  if ((r = to_dev(c, dm, mats, (size_t)nmat * n * n * 8)) || (r = to_dev(c, dout, nullptr, (size_t)nmat * 16))) return r;
+  const size_t lds = (2 * (size_t)n * n + 4 * n) * 8;
+  hipLaunchKernelGGL(k_dbg_linalg, dim3(nmat), dim3(64), lds, c->stream, nmat, n, (const double*)dm.p, (double*)dout.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, dout.p, (size_t)nmat * 16, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
 
