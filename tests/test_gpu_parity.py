@@ -191,23 +191,16 @@ def test_sharded_equals_unsharded(pkg, scenes):
     ref = pkg.Solver(scene, stop=0.0)
     r0 = pkg.Solver(scene, stop=0.0, rank=0, world=2)
     r1 = pkg.Solver(scene, stop=0.0, rank=1, world=2)
-    import torch
-    hip = C.CDLL(pkg.LIB_PATH)  # hipMemcpy is resolved through the already loaded runtime
-
-    class View:
-        def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-    def views(s, what):
-        ptr, per, first, n = s.exchange_buffer(what)
-        full = torch.as_tensor(View(ptr, per * s.U), device="cuda:0")
-        return full, slice(first * per, (first + n) * per)
+    hip = C.CDLL("libamdhip64.so")  # the runtime libtrajadmm.so already loaded
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
     def exchange(what):
-        f0, s0 = views(r0, what); f1, s1 = views(r1, what)
+        p0, per, f0, n0 = r0.exchange_buffer(what)
+        p1, _, f1, n1 = r1.exchange_buffer(what)
         r0.sync(); r1.sync()
-        f0[s1] = f1[s1]; f1[s0] = f0[s0]
-        torch.cuda.synchronize()
+        # rank 1's slice -> rank 0's copy, rank 0's slice -> rank 1's copy (device to device)
+        assert hip.hipMemcpy(p0 + f1 * per * 8, p1 + f1 * per * 8, n1 * per * 8, 3) == 0
+        assert hip.hipMemcpy(p1 + f0 * per * 8, p0 + f0 * per * 8, n0 * per * 8, 3) == 0
 
     for it in range(8):
         ref.iterate(1)
