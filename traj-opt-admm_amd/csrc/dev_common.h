@@ -25,9 +25,12 @@ struct Ctl {
   int done;            // stop test fired: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
   int error;           // ERR_* bits
   int order_ambiguous; // segments whose inter-robot CCD result depended on pair order (see k_ccd_self_seq)
+  int pending;         // an iteration was started by k_begin and is not yet counted in `iter`
+  int epoch;           // bumped by every k_begin: stamp that marks this iteration's pair-plane slots as valid
   double gnorm;        // reference global `gnorm`
   // statistics for the algorithmic-byte model; accumulated over iterations
-  unsigned long long nodes_dcd, nodes_ccd, cand_dcd, cand_ccd, planes_obs, planes_self, energy_evals, pair_tests;
+  unsigned long long llt_fail_piece, llt_fail_robot;  // PSD repairs taken (per-piece 19x19, per-robot reduced system)
+  unsigned long long energy_evals;
 };
 
 struct Dev {
@@ -57,6 +60,8 @@ struct Dev {
   // ---- per-iteration intermediates ----
   double *oplanes; int *ocount;   // obstacle planes  [U][S][cap_obs][4], [U][S]
   double *splanes; int *scount;   // inter-robot planes [U][S][cap_self][4], [U][S]
+  double *hullinfo;               // [U][S][HULL_STRIDE] hull, AABB, k-DOP intervals of the current control net
+  double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
   double *lg, *lh;                // per-piece gradient [U][P][19] and Hessian [U][P][361] (after PSD repair)
   // search direction record per robot, robot-major so a rank's robots are one slice for the
   // all-gather: [U][xs], xs = 3T+4 : direction (T x 3 col-major), t_direction, wolfe, |g|, pad
@@ -68,7 +73,12 @@ struct Dev {
   int *k_obs, *k_self;            // [U] exponents: step = 0.8^k
   double *step_out;               // [U] accepted Armijo step (diagnostics)
   double *ccdinfo;                // [U][S][CCD_STRIDE] swept-hull cache of the current direction
-  int *pair_list; int *pair_count;   // [S][cap_pairs][2], [S]
+  int *pair_list; int *pair_count;   // [S][U][cap_row] partner indices per (segment, lower robot), [S][U]
+  int cap_row;
+  // per-(robot, segment) statistics slots {nodes_dcd, cand_dcd, nodes_ccd, cand_ccd, planes_obs, planes_self}:
+  // each slot is only ever touched by the one wave that owns (robot, segment), so plain += suffices
+  // (a shared counter would serialise ~10^4 atomics per iteration on one L2 word)
+  unsigned long long* seg_stats;
   Ctl* ctl;
 };
 constexpr int CCD_STRIDE = 18 + 18 + 6 + 6 + 98;  // P, D, obstacle box, pair box, 49 k-DOP intervals (lo,hi)

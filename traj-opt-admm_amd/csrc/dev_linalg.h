@@ -13,7 +13,11 @@ namespace tj {
 // Returns false as soon as a pivot is <= 0 (Eigen LLT.h:320-323).  Subtractions happen in
 // column order, i.e. the same association as the left-looking scalar loop of the CPU oracle.
 // Must be called by all `nth` threads of the block; contains barriers.
+constexpr int CHOL_R = 19;  // max rows touched per pivot by the row-per-thread kernel (bw <= 18, dense n <= 20)
+__device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth);
+
 __device__ inline bool chol_lds(double* A, int n, int tid, int nth) {
+  if (n <= CHOL_R + 1 && nth >= CHOL_R) return chol_arrow_lds(A, n, n, tid, nth);  // the 19x19 / 13x13 piece systems
   for (int k = 0; k < n; k++) {
     __syncthreads();
     const double x = A[k * n + k];
@@ -23,14 +27,76 @@ __device__ inline bool chol_lds(double* A, int n, int tid, int nth) {
     if (tid == 0) A[k * n + k] = sx;
     for (int i = k + 1 + tid; i < n; i += nth) A[i * n + k] = A[i * n + k] / sx;
     __syncthreads();
-    const int m = n - k - 1;
-    for (int idx = tid; idx < m * m; idx += nth) {
-      const int i = k + 1 + idx / m, j = k + 1 + idx % m;
-      if (j <= i) A[i * n + j] -= A[i * n + k] * A[j * n + k];
+    for (int i = k + 1 + tid; i < n; i += nth) {  // one thread per row: no div/mod, two barriers per pivot
+      const double lik = A[i * n + k];
+      for (int j = k + 1; j <= i; j++) A[i * n + j] -= lik * A[j * n + k];
     }
   }
   __syncthreads();
   return true;
+}
+
+// Same factorisation for the x-update's reduced Hessian, whose sparsity is known: pieces couple
+// control points at most 17 coordinates apart (half-bandwidth bw) and only the last row/column
+// (piece time) is dense ("arrowhead").  Cholesky creates no fill outside that pattern, so every
+// skipped update would subtract an exact 0: results are bit-identical to chol_lds at ~1/6 of the work.
+__device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth) {
+  const int last = n - 1;
+  for (int k = 0; k < n; k++) {
+    __syncthreads();
+    const double x = A[k * n + k];
+    if (x <= 0) return false;
+    const double sx = sqrt(x);
+    __syncthreads();
+    const int mb = max(0, min(bw, last - 1 - k));            // band rows below k (arrow row excluded)
+    const int nrows = mb + ((k < last) ? 1 : 0);              // + the arrow row; <= CHOL_R
+    if (tid == 0) A[k * n + k] = sx;
+    // one thread per affected row: no index arithmetic, two barriers per pivot; the row and the
+    // scaled pivot column are pulled into registers with back-to-back LDS loads so the update is
+    // not a chain of dependent LDS round trips
+    if (tid < nrows) { const int i = tid < mb ? k + 1 + tid : last; A[i * n + k] = A[i * n + k] / sx; }
+    __syncthreads();
+    if (tid < nrows) {
+      const int i = tid < mb ? k + 1 + tid : last;
+      double lk[CHOL_R], ar[CHOL_R];
+#pragma unroll
+      for (int c = 0; c < CHOL_R; c++) {
+        const int j = c < mb ? k + 1 + c : last;
+        lk[c] = A[j * n + k];
+        ar[c] = A[i * n + j];
+      }
+      const double lik = A[i * n + k];
+#pragma unroll
+      for (int c = 0; c < CHOL_R; c++) {
+        const int j = c < mb ? k + 1 + c : last;
+        if (c <= tid && c < nrows) A[i * n + j] = ar[c] - lik * lk[c];
+      }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+__device__ inline void chol_arrow_solve_lds(const double* L, int n, int bw, const double* b, double* y, int tid, int nth) {
+  const int last = n - 1;
+  for (int i = tid; i < n; i += nth) y[i] = b[i];
+  __syncthreads();
+  for (int j = 0; j < n; j++) {
+    if (tid == 0) y[j] = y[j] / L[j * n + j];
+    __syncthreads();
+    const double yj = y[j];
+    const int mb = max(0, min(bw, last - 1 - j));
+    const int nrows = mb + ((j < last) ? 1 : 0);
+    for (int r = tid; r < nrows; r += nth) { const int i = r < mb ? j + 1 + r : last; y[i] -= yj * L[i * n + j]; }
+    __syncthreads();
+  }
+  for (int j = n - 1; j >= 0; j--) {
+    if (tid == 0) y[j] = y[j] / L[j * n + j];
+    __syncthreads();
+    const double yj = y[j];
+    const int lo = (j == last) ? 0 : max(0, j - bw);          // row j of L is dense only for the arrow row
+    for (int i = lo + tid; i < j; i += nth) y[i] -= yj * L[j * n + i];
+    __syncthreads();
+  }
 }
 
 // x = L^-T L^-1 b, column-oriented substitutions (same order as oracle chol_solve).  y is LDS scratch[n].

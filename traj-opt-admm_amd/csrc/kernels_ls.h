@@ -1,0 +1,241 @@
+// kernels_ls.h -- Armijo line search on the x-objective, one workgroup per robot.
+//
+// Replaces spline_line_search (Optimization3D_multi.h:754-811, Optimization3D_admm.h:505-557) and
+// Energy_admm::spline_energy / plane_barrier_energy / bound_energy (Energy_admm.h:16-170).
+//
+// The reference evaluates E(x), then E(x + s d) for s = s0, 0.8 s0, 0.8^2 s0, ... one after the other
+// and stops at the first s that satisfies the Armijo test.  Each evaluation is tiny (a few hundred
+// barrier terms) but strictly sequential -- on a GPU that is a chain of ~10 us latencies.  Here the
+// 256-thread workgroup is split into 8 groups of 32 lanes and each group evaluates ONE candidate:
+// round 0 covers E(x) and the first 7 trial steps, later rounds 8 steps each.  The accepted step is
+// the first one in the reference's order that passes the test, so the result is the one the
+// sequential loop would produce; E(.) is a pure function of its inputs here (fixed reduction tree
+// inside a group), i.e. it does not depend on which group or round evaluates it.
+// Everything an evaluation reads more than once (basis, this robot's planes, slack/dual blocks)
+// is staged in LDS once per launch.
+#pragma once
+#include "dev_common.h"
+
+namespace tj {
+
+constexpr int LS_THREADS = 256;
+constexpr int LS_GROUPS = 8;
+constexpr int LS_GSIZE = 32;
+
+struct LsLayout {  // offsets in doubles into dynamic LDS
+  size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, res, planes, pltr, total;
+  int plane_cap;
+};
+__host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_budget_bytes) {
+  LsLayout L;
+  size_t o = 0;
+  L.basis = o; o += (size_t)S * 36;
+  L.convert = o; o += (size_t)P * 36;
+  L.slack = o; o += (size_t)18 * P;
+  L.lambda = o; o += (size_t)18 * P;
+  L.tsl = o; o += P;
+  L.tla = o; o += P;
+  L.net = o; o += 3 * (size_t)T;
+  L.dir = o; o += 3 * (size_t)T;
+  L.gnet = o; o += (size_t)LS_GROUPS * 3 * T;
+  L.ghull = o; o += (size_t)LS_GROUPS * S * 18;
+  L.res = o; o += 2 * LS_GROUPS + 8;
+  L.planes = o;
+  const size_t used = o * 8;
+  size_t room = lds_budget_bytes > used ? (lds_budget_bytes - used) / 36 : 0;  // 32 B plane + 4 B segment id
+  if (room > 4096) room = 4096;
+  L.plane_cap = (int)room;
+  o += (size_t)L.plane_cap * 4;
+  L.pltr = o; o += ((size_t)L.plane_cap + 1) / 2;
+  L.total = o;
+  return L;
+}
+
+// E(net, pt) for robot u, evaluated by ONE group of 32 lanes (gl = lane within the group).
+// Returns the value in every lane of the group.  Must be called by the whole workgroup (contains a
+// block barrier); width-32 shuffles keep the two halves of a wave independent.
+__device__ inline double x_energy_group(const Dev& D, int u, const double* sm, const LsLayout& L, const double* net, double pt, double* hulls,
+                                        int M, bool planes_in_lds, const int* pref, int gl) {
+  const int S = D.S, T = D.T;
+  const double* basis = sm + L.basis;
+  for (int idx = gl; idx < S * 18; idx += LS_GSIZE) {
+    const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
+    const double* B = basis + (size_t)tr * 36 + j * 6;
+    const double* col = net + (tr / D.res) * 3 + T * a;
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc += B[k] * col[k];
+    hulls[idx] = acc;
+  }
+  __syncthreads();  // all 8 groups run this function in lock step (uniform trip counts)
+  const double m = D.margin;
+  double part = 0, partb = 0;
+  int bad = 0;
+  // plane barrier (Energy_admm.h:46-96)
+  const double* pl_lds = sm + L.planes;
+  const int* pltr = (const int*)(sm + L.pltr);
+  for (int it = gl; it < M; it += LS_GSIZE) {
+    int tr; double c0, c1, c2, dk;
+    if (planes_in_lds) { tr = pltr[it]; c0 = pl_lds[4 * it]; c1 = pl_lds[4 * it + 1]; c2 = pl_lds[4 * it + 2]; dk = pl_lds[4 * it + 3]; }
+    else {
+      int lo = 0, hi = S;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
+      tr = lo;
+      const int k = it - pref[tr], no = D.ocount[u * S + tr];
+      const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
+      c0 = pl[0]; c1 = pl[1]; c2 = pl[2]; dk = pl[3];
+    }
+    const double w = seg_weight(D, tr);
+    const double* Pp = hulls + tr * 18;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const double d = Pp[3 * j] * c0 + Pp[3 * j + 1] * c1 + Pp[3 * j + 2] * c2 + dk;
+      if (d <= 0) bad = 1;
+      else if (d < m) part += barrier(w, d, m);
+    }
+  }
+  // velocity / acceleration barriers (Energy_admm.h:98-170)
+  for (int it = gl; it < S * 9; it += LS_GSIZE) {
+    const int tr = it / 9, b = it % 9;
+    const double w = seg_weight(D, tr);
+    const double* Pp = hulls + tr * 18;
+    double d;
+    if (b < 5) {
+      const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
+      d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
+    } else {
+      const int j = b - 5;
+      const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
+                   az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
+      d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
+    }
+    if (d <= 0) bad = 1;
+    else if (d < m) partb += barrier(w, d, m);
+  }
+  // fixed butterfly inside the 32-lane group
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    part += __shfl_xor(part, off, LS_GSIZE);
+    partb += __shfl_xor(partb, off, LS_GSIZE);
+    bad |= __shfl_xor(bad, off, LS_GSIZE);
+  }
+  double e = D.lambda * part + D.lambda * partb;
+  // augmented-Lagrangian terms in the reference's statement order (Energy_admm.h:24-41); every lane
+  // of the group computes them redundantly from LDS (no divergence, no broadcast needed)
+  const int P6 = 6 * D.P;
+  const double* cv = sm + L.convert; const double* sl = sm + L.slack; const double* la = sm + L.lambda;
+  for (int sp = 0; sp < D.P; sp++) {
+    const double* C = cv + (size_t)sp * 36;
+    double delta[18], prod[18];
+    for (int a = 0; a < 3; a++)
+      for (int j = 0; j < 6; j++) {
+        double acc = 0;
+        for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + T * a];
+        delta[j + 6 * a] = acc - sl[sp * 6 + j + P6 * a];
+      }
+    for (int i = 0; i < 18; i++) prod[i] = delta[i] * delta[i];
+    e += D.mu / 2.0 * esum(prod, 18);
+    const double dt = pt - sm[L.tsl + sp];
+    e += D.mu / 2.0 * (dt * dt);
+    for (int a = 0; a < 3; a++) {
+      double pr[6];
+      for (int j = 0; j < 6; j++) pr[j] = la[sp * 6 + j + P6 * a] * delta[j + 6 * a];
+      e += esum(pr, 6);
+    }
+    e += sm[L.tla + sp] * (pt - sm[L.tsl + sp]);
+  }
+  if (bad) e = INFINITY;
+  return e;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
+  if (D.ctl->done) return;
+  extern __shared__ double sm[];
+  __shared__ int pref[512];   // plane prefix per segment (S <= 511 checked on the host)
+  __shared__ int s_accept;
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
+  const int g = tid / LS_GSIZE, gl = tid % LS_GSIZE;
+  double* net = sm + L.net; double* dir = sm + L.dir;
+  double* gnet = sm + L.gnet + (size_t)g * 3 * T;
+  double* ghull = sm + L.ghull + (size_t)g * S * 18;
+  double* res = sm + L.res;
+  double* gspline = D.spline + (size_t)u * 3 * T;
+  const int P6 = 6 * P;
+  // ---- stage everything that is reused ----
+  for (int i = tid; i < S * 36; i += LS_THREADS) sm[L.basis + i] = D.basis[i];
+  for (int i = tid; i < P * 36; i += LS_THREADS) sm[L.convert + i] = D.convert[i];
+  for (int i = tid; i < 18 * P; i += LS_THREADS) { sm[L.slack + i] = D.p_slack[(size_t)u * 3 * P6 + i]; sm[L.lambda + i] = D.p_lambda[(size_t)u * 3 * P6 + i]; }
+  for (int i = tid; i < P; i += LS_THREADS) { sm[L.tsl + i] = D.t_slack[u * P + i]; sm[L.tla + i] = D.t_lambda[u * P + i]; }
+  for (int i = tid; i < 3 * T; i += LS_THREADS) { net[i] = gspline[i]; dir[i] = D.dirp(u)[i]; }
+  if (tid == 0) {
+    int acc = 0;
+    for (int tr = 0; tr < S; tr++) { pref[tr] = acc; acc += D.ocount[u * S + tr] + (D.mode == 1 ? D.scount[u * S + tr] : 0); }
+    pref[S] = acc;
+  }
+  __syncthreads();
+  const int M = pref[S];
+  const bool in_lds = M <= L.plane_cap;
+  if (in_lds) {
+    int* pltr = (int*)(sm + L.pltr);
+    for (int it = tid; it < M; it += LS_THREADS) {
+      int lo = 0, hi = S;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
+      const int tr = lo, k = it - pref[tr], no = D.ocount[u * S + tr];
+      const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
+      pltr[it] = tr;
+      sm[L.planes + 4 * it] = pl[0]; sm[L.planes + 4 * it + 1] = pl[1]; sm[L.planes + 4 * it + 2] = pl[2]; sm[L.planes + 4 * it + 3] = pl[3];
+    }
+  }
+  __syncthreads();
+  const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
+  const double t_dir = D.tdir(u), t0 = D.piece_time[u];
+  double step0 = D.pow08[min(LOOP_CAP, max(D.k_obs[u], D.k_self[u]))];
+  if (t0 + step0 * t_dir <= 0) step0 = -0.95 * t0 / t_dir;
+
+  double e_base = 0, step_acc = step0, pt_acc = t0;
+  int k_acc = -1, evals = 0;
+  for (int round = 0; k_acc < 0; round++) {
+    // candidate of this group: -1 = E(x) (round 0, group 0), otherwise trial index k >= 0
+    const int k = round == 0 ? g - 1 : 7 + (round - 1) * LS_GROUPS + g;
+    double step = step0;
+    for (int i = 0; i < k; i++) step *= 0.8;           // same rounding as the reference's repeated step *= 0.8
+    const double pt = k < 0 ? t0 : t0 + step * t_dir;
+    for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
+    __syncthreads();
+    const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, M, in_lds, pref, gl);
+    if (gl == 0) { res[g] = e; res[LS_GROUPS + g] = step; }
+    if (tid == 0) s_accept = -1;
+    __syncthreads();
+    if (round == 0) e_base = res[0];
+    if (tid == 0) {
+      for (int c = (round == 0 ? 1 : 0); c < LS_GROUPS; c++) {
+        const double st = res[LS_GROUPS + c];
+        if (!(e_base - 1e-4 * wolfe * st < res[c])) { s_accept = c; break; }
+      }
+    }
+    __syncthreads();
+    const int acc = s_accept;
+    if (acc >= 0) {
+      k_acc = round == 0 ? acc - 1 : 7 + (round - 1) * LS_GROUPS + acc;
+      step_acc = res[LS_GROUPS + acc];
+      pt_acc = t0 + step_acc * t_dir;
+      evals = 2 + k_acc;
+      // commit: the accepting group's trial net is the new control net
+      const double* win = sm + L.gnet + (size_t)acc * 3 * T;
+      for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+    } else if (7 + round * LS_GROUPS >= LOOP_CAP) {
+      // no acceptable step: behave like the capped sequential loop (take the last candidate)
+      if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+      k_acc = 7 + (round - 1) * LS_GROUPS + LS_GROUPS - 1;
+      step_acc = res[2 * LS_GROUPS - 1];
+      pt_acc = t0 + step_acc * t_dir;
+      evals = 2 + k_acc;
+      const double* win = sm + L.gnet + (size_t)(LS_GROUPS - 1) * 3 * T;
+      for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
+}
+
+}  // namespace tj

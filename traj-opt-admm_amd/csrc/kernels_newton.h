@@ -221,6 +221,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   for (int idx = tid; idx < 361; idx += GRAD_THREADS) W[idx] = H[idx];
   __syncthreads();
   if (!chol_lds(W, 19, tid, GRAD_THREADS)) {
+    if (tid == 0) atomicAdd(&D.ctl->llt_fail_piece, 1ull);
     __syncthreads();
     for (int idx = tid; idx < 361; idx += GRAD_THREADS) W[idx] = H[idx];
     __syncthreads();
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
 }
 
 // ---- per-robot reduced Newton solve -------------------------------------------------------------
-constexpr int XS_THREADS = 256;
+constexpr int XS_THREADS = 64;   // one wave per robot: every barrier is a single-wave barrier
+constexpr int XS_BAND = 17;      // pieces couple reduced coordinates at most 17 apart
 __host__ __device__ inline size_t xsolve_lds_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16; }
 
 __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
@@ -252,29 +254,36 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
 
   // overlap-add of piece blocks; global index of local (sp, a) is 9*sp + a, time is 3T.
   // Reduced index r = global - 6 for 6 <= global < 3T-6, time -> m.
-  for (int idx = tid; idx < n * n; idx += XS_THREADS) H[idx] = 0;
-  for (int i = tid; i < n; i += XS_THREADS) g0[i] = 0;
-  __syncthreads();
-  for (int sp = 0; sp < D.P; sp++) {  // pieces in order: each entry receives its (at most two) block terms in piece order
-    const double* lg = D.lg + ((size_t)u * D.P + sp) * 19;
-    const double* lh = D.lh + ((size_t)u * D.P + sp) * 361;
-    for (int idx = tid; idx < 361; idx += XS_THREADS) {
-      const int a = idx / 19, b = idx % 19;
-      const int ga = a < 18 ? 9 * sp + a : 3 * T, gb = b < 18 ? 9 * sp + b : 3 * T;
-      const int ra = ga == 3 * T ? m : ga - 6, rb = gb == 3 * T ? m : gb - 6;
-      if (ra < 0 || rb < 0 || (ga != 3 * T && ga >= 3 * T - 6) || (gb != 3 * T && gb >= 3 * T - 6)) continue;
-      H[ra * n + rb] += lh[idx];
+  // Gather form of the overlap-add: every reduced entry sums the (at most two, or P for the
+  // time-time entry) piece blocks that cover it, in piece order like the reference's += sequence.
+  // No read-modify-write, so all global loads of a pass are in flight together.
+  const double* lgu = D.lg + (size_t)u * D.P * 19;
+  const double* lhu = D.lh + (size_t)u * D.P * 361;
+  for (int idx = tid; idx < n * n; idx += XS_THREADS) {
+    const int ra = idx / n, rb = idx % n;
+    const int ga = ra == m ? -1 : ra + 6, gb = rb == m ? -1 : rb + 6;  // -1 = time
+    // pieces covering a coordinate g: 9sp <= g <= 9sp+17
+    int lo = 0, hi = D.P - 1;
+    if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
+    if (gb >= 0) { lo = max(lo, (gb - 17 + 8) / 9); hi = min(hi, gb / 9); }
+    double acc = 0;
+    for (int sp = max(lo, 0); sp <= hi; sp++) {
+      const int a = ga < 0 ? 18 : ga - 9 * sp, b = gb < 0 ? 18 : gb - 9 * sp;
+      acc += lhu[(size_t)sp * 361 + a * 19 + b];
     }
-    if (tid < 19) {
-      const int ga = tid < 18 ? 9 * sp + tid : 3 * T;
-      const int ra = ga == 3 * T ? m : ga - 6;
-      if (!(ra < 0 || (ga != 3 * T && ga >= 3 * T - 6))) g0[ra] += lg[tid];
-    }
-    __syncthreads();
+    H[idx] = acc; L[idx] = acc;
   }
-  for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
+  for (int ra = tid; ra < n; ra += XS_THREADS) {
+    const int ga = ra == m ? -1 : ra + 6;
+    int lo = 0, hi = D.P - 1;
+    if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
+    double acc = 0;
+    for (int sp = max(lo, 0); sp <= hi; sp++) acc += lgu[sp * 19 + (ga < 0 ? 18 : ga - 9 * sp)];
+    g0[ra] = acc;
+  }
   __syncthreads();
-  if (!chol_lds(L, n, tid, XS_THREADS)) {
+  if (!chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS)) {
+    if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
     __syncthreads();
     if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
       for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
@@ -285,10 +294,10 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
     }
     for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
     __syncthreads();
-    chol_lds(L, n, tid, XS_THREADS);  // like the reference, the second factorisation is not re-checked
+    chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS);  // like the reference, the second factorisation is not re-checked
     __syncthreads();
   }
-  chol_solve_lds(L, n, g0, x0, tid, XS_THREADS);
+  chol_arrow_solve_lds(L, n, XS_BAND, g0, x0, tid, XS_THREADS);
   for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
   __syncthreads();
   for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }

@@ -6,11 +6,8 @@
 //               aabb::Tree::query (AABB.cc:608-667), CCD::KDOPDCD (CCD.h:354-413) and
 //               Separate::opengjk (Separate.h:18-163) as sequenced by separate_plane
 //               (Optimization3D_multi.h:176-235 / Optimization3D_admm.h:69-197).
-//   k_sep_self  one wavefront per (robot, segment), lanes over the other robots: box test,
-//               k-DOP, hull-hull GJK, 1-D Newton on the offset.  Replaces separate_self
-//               (Optimization3D_multi.h:237-342), BVH::SelfDCDCollision (BVH.cpp:252-287),
-//               CCD::SelfKDOPDCD (CCD.h:535-587), Separate::selfgjk (Separate.h:165-304) and
-//               Optimal_plane::optimal_d (Optimal_plane.h:13-71).
+//   plane_pair  device function for one robot pair (hull-hull GJK + 1-D Newton on the offset),
+//               used by kernels_pairs.h which replaces separate_self (Optimization3D_multi.h:237-342).
 //
 // The BVH is an implicit 8-ary box hierarchy over Morton-sorted points.  A wave walks it level
 // by level: 64 lanes test 8 frontier nodes x 8 children per step (coalesced 48-B boxes, 384 B per
@@ -237,77 +234,8 @@ __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
   });
   if (lane == 0) {
     D.ocount[u * D.S + tr] = min(base, D.cap_obs);
-    atomicAdd(&D.ctl->nodes_dcd, visits);
-    atomicAdd(&D.ctl->cand_dcd, (unsigned long long)found);
-    atomicAdd(&D.ctl->planes_obs, (unsigned long long)base);
-  }
-}
-
-// ---- inter-robot planes ------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sep_self(Dev D) {
-  if (D.ctl->done) return;
-  const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
-  const int lane = lane_id();
-  __shared__ double myP[18];
-  __shared__ double oth[64 * 18];
-  if (lane < 18) myP[lane] = hull_entry(D, D.spline + (size_t)u * 3 * D.T, tr, lane / 3, lane % 3);
-  __syncthreads();
-  double mlo[3], mhi[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double lo = INFINITY, hi = -INFINITY;
-    for (int j = 0; j < 6; j++) { const double v = myP[3 * j + k]; if (v < lo) lo = v; if (v > hi) hi = v; }
-    mlo[k] = lo; mhi[k] = hi;
-  }
-  const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
-  double* out = D.splanes + ((size_t)u * D.S + tr) * D.cap_self * 4;
-  int base = 0;
-  unsigned long long tests = 0;
-  for (int q0 = 0; q0 < D.U; q0 += 64) {
-    const int q = q0 + lane;
-    bool ok = false;
-    double c0 = 0, c1 = 0, c2 = 0, dd = 0;
-    if (q < D.U && q != u) {
-      double* Q = oth + lane * 18;
-      const double* netq = D.spline + (size_t)q * 3 * D.T;
-      double qlo[3] = {INFINITY, INFINITY, INFINITY}, qhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-      for (int j = 0; j < 6; j++)
-        for (int a = 0; a < 3; a++) {
-          const double v = hull_entry(D, netq, tr, j, a);
-          Q[3 * j + a] = v;
-          if (v < qlo[a]) qlo[a] = v;
-          if (v > qhi[a]) qhi[a] = v;
-        }
-      bool hit = true;
-#pragma unroll
-      for (int k = 0; k < 3; k++) hit = hit && !(qhi[k] + dist < mlo[k] || qlo[k] > mhi[k] + dist);
-      if (hit) {
-        const double* A = (u < q) ? myP : Q;  // body 1 is always the lower robot index
-        const double* Bq = (u < q) ? Q : myP;
-        if (kdop_hulls_pass(D, A, Bq, dist)) {
-          double e0, e1c, e2c, dpl; bool capped;
-          if (plane_pair(A, Bq, dist, m, off, true, e0, e1c, e2c, dpl, capped)) {
-            if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
-            if (u < q) { c0 = e0; c1 = e1c; c2 = e2c; dd = dpl - 0.5 * off; }
-            else { c0 = -e0; c1 = -e1c; c2 = -e2c; dd = -dpl - 0.5 * off; }
-            ok = true;
-          }
-        }
-      }
-    }
-    const unsigned long long mask = ballot(ok);
-    const int idx = base + prefix_count(mask);
-    if (ok) {
-      if (idx < D.cap_self) { out[4 * idx] = c0; out[4 * idx + 1] = c1; out[4 * idx + 2] = c2; out[4 * idx + 3] = dd; }
-      else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
-    }
-    base += __popcll(mask);
-    tests += min(64, D.U - q0);
-  }
-  if (lane == 0) {
-    D.scount[u * D.S + tr] = min(base, D.cap_self);
-    atomicAdd(&D.ctl->planes_self, (unsigned long long)base);
-    atomicAdd(&D.ctl->pair_tests, tests);
+    unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;
+    st[0] += visits; st[1] += (unsigned long long)found; st[4] += (unsigned long long)base;
   }
 }
 

@@ -22,6 +22,7 @@
 #include "dev_common.h"
 #include "dev_linalg.h"
 #include "kernels_sep.h"
+#include "kernels_ls.h"
 
 namespace tj {
 
@@ -95,32 +96,26 @@ __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
       }
     }
   });
-  if (lane == 0) { atomicAdd(&D.ctl->nodes_ccd, visits); atomicAdd(&D.ctl->cand_ccd, (unsigned long long)found); }
+  if (lane == 0) {
+    unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;
+    st[2] += visits; st[3] += (unsigned long long)found;
+  }
 }
 
-// Phase A: one wave per segment; pairs in lexicographic order, 64 per step.
+// Phase A: one wave per (segment, lower robot p0); lanes over the partners p1 > p0.  Survivors are
+// written in ascending p1, so (segment, p0, p1) is a lexicographic, deterministic pair order.
 __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
   if (D.ctl->done) return;
-  const int tr = blockIdx.x, lane = lane_id();
+  const int tr = blockIdx.x / D.U, p0 = blockIdx.x % D.U, lane = lane_id();
   const int U = D.U;
-  const long long npairs = (long long)U * (U - 1) / 2;
-  int base = 0;
-  int* out = D.pair_list + (size_t)tr * D.cap_pairs * 2;
   const double off = D.offset;
-  for (long long c0 = 0; c0 < npairs; c0 += 64) {
-    const long long idx = c0 + lane;
-    bool ok = false; int p0 = 0, p1 = 0;
-    if (idx < npairs) {
-      // idx -> (p0,p1), p0<p1, row-major over the strict upper triangle
-      long long rem = idx; p0 = 0;
-      // closed form with a correction step
-      double fp = ((2.0 * U - 1.0) - sqrt((2.0 * U - 1.0) * (2.0 * U - 1.0) - 8.0 * (double)idx)) * 0.5;
-      p0 = (int)fp; if (p0 < 0) p0 = 0; if (p0 > U - 2) p0 = U - 2;
-      while (p0 > 0 && (long long)p0 * (2 * U - p0 - 1) / 2 > idx) p0--;
-      while ((long long)(p0 + 1) * (2 * U - p0 - 2) / 2 <= idx) p0++;
-      rem = idx - (long long)p0 * (2 * U - p0 - 1) / 2;
-      p1 = p0 + 1 + (int)rem;
-      const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
+  const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
+  int* out = D.pair_list + ((size_t)tr * U + p0) * D.cap_row;
+  int base = 0;
+  for (int c0 = p0 + 1; c0 < U; c0 += 64) {
+    const int p1 = c0 + lane;
+    bool ok = false;
+    if (p1 < U) {
       const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
       bool hit = true;
       for (int k = 0; k < 3; k++) hit = hit && !(a[45 + k] + off < b[42 + k] || a[42 + k] > b[45 + k] + off);
@@ -133,12 +128,12 @@ __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
     const unsigned long long mask = ballot(ok);
     const int w = base + prefix_count(mask);
     if (ok) {
-      if (w < D.cap_pairs) { out[2 * w] = p0; out[2 * w + 1] = p1; }
+      if (w < D.cap_row) out[w] = p1;
       else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
     }
     base += __popcll(mask);
   }
-  if (lane == 0) D.pair_count[tr] = min(base, D.cap_pairs);
+  if (lane == 0) D.pair_count[tr * U + p0] = min(base, D.cap_row);
 }
 
 // Phase B + gnorm.  One workgroup of one wave; control flow is wave uniform.
@@ -147,16 +142,23 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   const int lane = lane_id();
   extern __shared__ int ks[];  // [U] exponents, [U] last segment in which the robot appeared
   int* seen = ks + D.U;
+  int* cnt = seen + D.U;  // [S*U] survivor counts, staged once so the segment loop never waits on HBM
   for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
+  if (D.mode == 1) for (int i = lane; i < D.S * D.U; i += 64) cnt[i] = D.pair_count[i];
   __syncthreads();
   if (D.mode == 1) {
     const double off2 = D.offset * D.offset;
     int ambiguous = 0;
     for (int tr = 0; tr < D.S; tr++) {
-      const int n = D.pair_count[tr];
       bool seg_hit = false, seg_share = false;
+      for (int r0 = 0; r0 < D.U; r0 += 64) {  // rows with survivors, found 64 at a time
+      unsigned long long rows = ballot(r0 + lane < D.U && cnt[tr * D.U + min(r0 + lane, D.U - 1)] > 0);
+      while (rows) {
+      const int p0 = r0 + __ffsll((long long)rows) - 1;
+      rows &= rows - 1;
+      const int n = cnt[tr * D.U + p0];
       for (int i = 0; i < n; i++) {
-        const int p0 = D.pair_list[((size_t)tr * D.cap_pairs + i) * 2], p1 = D.pair_list[((size_t)tr * D.cap_pairs + i) * 2 + 1];
+        const int p1 = D.pair_list[((size_t)tr * D.U + p0) * D.cap_row + i];
         const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
         const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
         int k0 = ks[p0], k1 = ks[p1];
@@ -174,6 +176,8 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
         if (lane == 0) { ks[p0] = k0; ks[p1] = k1; }
         __syncthreads();
       }
+      }
+      }
       if (seg_hit && seg_share) ambiguous++;
     }
     if (lane == 0 && ambiguous) atomicAdd(&D.ctl->order_ambiguous, ambiguous);
@@ -185,143 +189,6 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     for (int u = 0; u < D.U; u++) gsum += D.gn(u);
     D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : D.gn(0);
   }
-}
-
-// ---- x-objective and Armijo --------------------------------------------------------------------
-constexpr int LS_THREADS = 256;
-__host__ __device__ inline size_t ls_lds_doubles(int S, int T, int P) { return (size_t)S * 18 + 3 * (size_t)T + LS_THREADS + 8 + (S + 2) / 2 + 1; }
-
-// block-wide deterministic sum (fixed tree); result valid in all threads
-__device__ inline double block_sum(double v, double* red, int tid) {
-  red[tid] = v;
-  __syncthreads();
-  for (int s = LS_THREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = red[tid] + red[tid + s]; __syncthreads(); }
-  const double r = red[0];
-  __syncthreads();
-  return r;
-}
-
-// Energy_admm::spline_energy for robot u on control net `net` (LDS) and piece time pt
-__device__ inline double x_energy(const Dev& D, int u, const double* net, double pt, double* hulls, double* red, const int* pref, int* bad, int tid) {
-  const int S = D.S;
-  for (int idx = tid; idx < S * 18; idx += LS_THREADS) {
-    const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
-    const double* B = D.basis + (size_t)tr * 36 + j * 6;
-    const double* col = net + (tr / D.res) * 3 + D.T * a;
-    double acc = 0;
-    for (int k = 0; k < 6; k++) acc += B[k] * col[k];
-    hulls[idx] = acc;
-  }
-  if (tid == 0) *bad = 0;
-  __syncthreads();
-  const double m = D.margin;
-  // plane barrier (Energy_admm.h:46-96)
-  double part = 0; int mybad = 0;
-  const int M = pref[S];
-  for (int it = tid; it < M; it += LS_THREADS) {
-    int tr = 0;
-    { int lo = 0, hi = S; while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; } tr = lo; }
-    const int k = it - pref[tr];
-    const int no = D.ocount[u * S + tr];
-    const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
-    const double c0 = pl[0], c1 = pl[1], c2 = pl[2], dk = pl[3];
-    const double w = seg_weight(D, tr);
-    const double* Pp = hulls + tr * 18;
-    for (int j = 0; j < 6; j++) {
-      const double d = Pp[3 * j] * c0 + Pp[3 * j + 1] * c1 + Pp[3 * j + 2] * c2 + dk;
-      if (d <= 0) mybad = 1;
-      else if (d < m) part += barrier(w, d, m);
-    }
-  }
-  // velocity / acceleration barriers (Energy_admm.h:98-170)
-  double partb = 0;
-  for (int it = tid; it < S * 9; it += LS_THREADS) {
-    const int tr = it / 9, b = it % 9;
-    const double w = seg_weight(D, tr);
-    const double* Pp = hulls + tr * 18;
-    double d;
-    if (b < 5) {
-      const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
-      d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
-    } else {
-      const int j = b - 5;
-      const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
-                   az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
-      d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
-    }
-    if (d <= 0) mybad = 1;
-    else if (d < m) partb += barrier(w, d, m);
-  }
-  if (mybad) atomicOr(bad, 1);
-  const double eplane = block_sum(part, red, tid);
-  const double ebound = block_sum(partb, red, tid);
-  double e = D.lambda * eplane + D.lambda * ebound;
-  // augmented-Lagrangian terms, in the reference's statement order (Energy_admm.h:24-41)
-  const int P6 = 6 * D.P;
-  for (int sp = 0; sp < D.P; sp++) {
-    const double* C = D.convert + (size_t)sp * 36;
-    double delta[18], prod[18];
-    for (int a = 0; a < 3; a++)
-      for (int j = 0; j < 6; j++) {
-        double acc = 0;
-        for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + D.T * a];
-        delta[j + 6 * a] = acc - D.p_slack[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
-      }
-    for (int i = 0; i < 18; i++) prod[i] = delta[i] * delta[i];
-    e += D.mu / 2.0 * esum(prod, 18);
-    const double dt = pt - D.t_slack[u * D.P + sp];
-    e += D.mu / 2.0 * (dt * dt);
-    for (int a = 0; a < 3; a++) {
-      double pr[6];
-      for (int j = 0; j < 6; j++) pr[j] = D.p_lambda[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a] * delta[j + 6 * a];
-      e += esum(pr, 6);
-    }
-    e += D.t_lambda[u * D.P + sp] * (pt - D.t_slack[u * D.P + sp]);
-  }
-  __syncthreads();
-  if (*bad) e = INFINITY;
-  __syncthreads();
-  return e;
-}
-
-__global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D) {
-  if (D.ctl->done) return;
-  extern __shared__ double sm[];
-  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T;
-  double* hulls = sm;                // [S*18]
-  double* trial = hulls + S * 18;    // [3T]
-  double* red = trial + 3 * T;       // [LS_THREADS]
-  int* bad = (int*)(red + LS_THREADS);
-  int* pref = bad + 2;               // [S+1]
-  double* net = D.spline + (size_t)u * 3 * T;
-  const double* dir = D.dirp(u);
-  if (tid == 0) {
-    int acc = 0;
-    for (int tr = 0; tr < S; tr++) { pref[tr] = acc; acc += D.ocount[u * S + tr] + (D.mode == 1 ? D.scount[u * S + tr] : 0); }
-    pref[S] = acc;
-  }
-  for (int i = tid; i < 3 * T; i += LS_THREADS) trial[i] = net[i];
-  __syncthreads();
-  const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
-  const double t_dir = D.tdir(u), t0 = D.piece_time[u];
-  double step = D.pow08[min(LOOP_CAP, max(D.k_obs[u], D.k_self[u]))];
-  if (t0 + step * t_dir <= 0) step = -0.95 * t0 / t_dir;
-  const double e = x_energy(D, u, trial, t0, hulls, red, pref, bad, tid);
-  double pt = t0 + step * t_dir;
-  int evals = 1, guard = 0;
-  for (;;) {
-    for (int i = tid; i < 3 * T; i += LS_THREADS) trial[i] = net[i] + step * dir[i];
-    __syncthreads();
-    const double en = x_energy(D, u, trial, pt, hulls, red, pref, bad, tid);
-    evals++;
-    if (!(e - 1e-4 * wolfe * step < en)) break;
-    if (++guard >= LOOP_CAP) { if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP); break; }
-    step *= 0.8;
-    pt = t0 + step * t_dir;
-  }
-  __syncthreads();
-  for (int i = tid; i < 3 * T; i += LS_THREADS) net[i] = trial[i];
-  if (tid == 0) { D.piece_time[u] = pt; D.step_out[u] = step; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
 }
 
 // ---- slack (z) and dual update -------------------------------------------------------------------
@@ -467,15 +334,18 @@ __global__ void k_begin(Dev D) {
   // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
   __shared__ int done;
   if (threadIdx.x == 0) {
+    if (D.ctl->pending) { D.ctl->iter++; D.ctl->pending = 0; }  // count the previous iteration (saves a launch)
     if (!D.ctl->done && D.stop > 0 && D.ctl->iter > 1 && D.ctl->gnorm < D.stop) D.ctl->done = 1;
     done = D.ctl->done;
+    if (!done) { D.ctl->pending = 1; D.ctl->epoch++; }
   }
   __syncthreads();
   if (done) return;
   for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
 }
+// only used by the stage API: commit the iteration counter explicitly
 __global__ void k_end(Dev D) {
-  if (!D.ctl->done) D.ctl->iter++;
+  if (D.ctl->pending) { D.ctl->iter++; D.ctl->pending = 0; }
 }
 
 }  // namespace tj

@@ -18,6 +18,7 @@
 #include "dev_common.h"
 #include "host_tables.h"
 #include "kernels_sep.h"
+#include "kernels_pairs.h"
 #include "kernels_newton.h"
 #include "kernels_step.h"
 #include "kernels_debug.h"
@@ -29,6 +30,8 @@ struct tj_ctx {
   Dev d;
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  hipStream_t side = nullptr;                 // second branch of the per-iteration graph
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fork/join markers
   std::vector<void*> allocs;
   std::string err;
   bool have_cloud = false, have_state = false;
@@ -37,6 +40,7 @@ struct tj_ctx {
   hipGraphExec_t gexec = nullptr;
   bool graph_ok = false;
   size_t lds_grad = 0, lds_xs = 0, lds_ls = 0, lds_seq = 0;
+  LsLayout lsl;
   // cloud-dependent allocations (rebuilt by tj_set_cloud)
   std::vector<void*> cloud_allocs;
 };
@@ -75,23 +79,29 @@ void drop_graph(tj_ctx* c) {
 }
 
 // enqueue one stage on the context's stream
-int enqueue_stage(tj_ctx* c, int stage) {
+int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
-  hipStream_t s = c->stream;
+  if (!s) s = c->stream;
   switch (stage) {
     case TJ_STAGE_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); break;
     case TJ_STAGE_PLANES_OBS: hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); break;
-    case TJ_STAGE_PLANES_SELF: if (d.mode == 1) hipLaunchKernelGGL(k_sep_self, dim3(owned * d.S), dim3(64), 0, s, d); break;
+    case TJ_STAGE_PLANES_SELF:
+      if (d.mode == 1) {
+        hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d);
+      }
+      break;
     case TJ_STAGE_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); break;
     case TJ_STAGE_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_THREADS), c->lds_xs, s, d); break;
     case TJ_STAGE_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); break;
     case TJ_STAGE_CCD_OBS: hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); break;
     case TJ_STAGE_CCD_SELF:
-      if (d.mode == 1) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S), dim3(64), 0, s, d);
+      if (d.mode == 1) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d);
       hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d);
       break;
-    case TJ_STAGE_LINESEARCH: hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d); break;
+    case TJ_STAGE_LINESEARCH: hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); break;
     case TJ_STAGE_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d); break;
     case TJ_STAGE_END: hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, d); break;
     default: c->err = "unknown stage"; return TJ_ERR_INVALID;
@@ -100,8 +110,27 @@ int enqueue_stage(tj_ctx* c, int stage) {
   return TJ_OK;
 }
 
+// One iteration as a small DAG on two streams (captured into the hipGraph as parallel branches):
+//   begin -> { obstacle planes | robot-pair planes } -> grad -> xsolve -> ccd_prep
+//         -> { obstacle CCD | pair CCD (select, replay) } -> line search -> slack + dual
+// The two plane builders and the two CCD clamps are independent of each other, so their
+// latencies overlap instead of adding.  The iteration counter is committed by the next k_begin.
 int enqueue_iteration(tj_ctx* c) {
-  for (int st = TJ_STAGE_BEGIN; st <= TJ_STAGE_END; st++) { int r = enqueue_stage(c, st); if (r) return r; }
+  hipStream_t m = c->stream, s2 = c->side;
+  int r;
+#define STG(st, str) if ((r = enqueue_stage(c, st, str))) return r
+  STG(TJ_STAGE_BEGIN, m);
+  HIPCHK(c, hipEventRecord(c->ev[0], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[0], 0));
+  STG(TJ_STAGE_PLANES_OBS, m);
+  STG(TJ_STAGE_PLANES_SELF, s2);
+  HIPCHK(c, hipEventRecord(c->ev[1], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[1], 0));
+  STG(TJ_STAGE_GRAD, m); STG(TJ_STAGE_XSOLVE, m); STG(TJ_STAGE_CCD_PREP, m);
+  HIPCHK(c, hipEventRecord(c->ev[2], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));
+  STG(TJ_STAGE_CCD_OBS, m);
+  STG(TJ_STAGE_CCD_SELF, s2);
+  HIPCHK(c, hipEventRecord(c->ev[3], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[3], 0));
+  STG(TJ_STAGE_LINESEARCH, m); STG(TJ_STAGE_SLACK, m);
+#undef STG
   return TJ_OK;
 }
 
@@ -153,6 +182,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device available (this library has no CPU fallback)"; return TJ_ERR_DEVICE; }
   HIPCHK(c, hipSetDevice(p->device));
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (auto& e : c->ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   Dev& d = c->d;
   memset(&d, 0, sizeof(d));
   d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0;
@@ -161,13 +192,16 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.ks = p->ks; d.kt = p->kt; d.stop = p->stop;
   d.cap_obs = p->cap_obs > 0 ? p->cap_obs : 256;
   d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, d.U - 1);
-  d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : std::min(4096, std::max(64, d.U * (d.U - 1) / 2));
+  d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
+  d.cap_row = std::max(1, std::min(d.cap_pairs, d.U));  // partners per (segment, lower robot)
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
   c->lds_grad = grad_lds_doubles(d.cap_obs + d.cap_self) * sizeof(double);
   c->lds_xs = xsolve_lds_doubles(n) * sizeof(double);
-  c->lds_ls = ls_lds_doubles(d.S, d.T, d.P) * sizeof(double);
-  c->lds_seq = 2 * (size_t)d.U * sizeof(int);
+  c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
+  c->lds_ls = c->lsl.total * sizeof(double);
+  if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
+  c->lds_seq = (2 * (size_t)d.U + (size_t)d.S * d.U) * sizeof(int);
   const size_t lds_max = 160 * 1024 - 1024;
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (piece_num <= 10 and cap_obs+cap_self <= ~1100 supported in this version)";
@@ -176,6 +210,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_linesearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_ccd_self_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_seq));
 
   HostTables t;
   build_tables(d.P, d.res, LOOP_CAP, t);
@@ -193,8 +228,10 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.splanes, U * S * d.cap_self * 4)) || (r = dalloc(c, &d.scount, U * S)) ||
       (r = dalloc(c, &d.lg, U * P * 19)) || (r = dalloc(c, &d.lh, U * P * 361)) || (r = dalloc(c, &d.xdir, U * d.xs)) ||
       (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) ||
-      (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, S * (size_t)d.cap_pairs * 2)) ||
-      (r = dalloc(c, &d.pair_count, S)) || (r = dalloc(c, &d.ctl, 1))) return r;
+      (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, S * U * (size_t)d.cap_row)) ||
+      (r = dalloc(c, &d.pair_count, S * U)) || (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
+      (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.pairplane, d.mode == 1 ? S * U * U * 4 : 1)) ||
+      (r = dalloc(c, &d.pairstamp, d.mode == 1 ? S * U * U : 1)) || (r = dalloc(c, &d.ctl, 1))) return r;
   return TJ_OK;
 }
 
@@ -204,6 +241,8 @@ void tj_destroy(tj_ctx* c) {
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->cloud_allocs) hipFree(p);
   if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
+  if (c->side) hipStreamDestroy(c->side);
+  for (auto& e : c->ev) if (e) hipEventDestroy(e);
   delete c;
 }
 
@@ -281,6 +320,8 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemset(d.xdir, 0, (size_t)U * d.xs * 8));
   HIPCHK(c, hipMemset(d.ocount, 0, (size_t)U * d.S * 4));
   HIPCHK(c, hipMemset(d.scount, 0, (size_t)U * d.S * 4));
+  HIPCHK(c, hipMemset(d.seg_stats, 0, (size_t)U * d.S * 6 * 8));
+  if (d.mode == 1) HIPCHK(c, hipMemset(d.pairstamp, 0, (size_t)d.S * U * U * 4));  // epochs restart at 1
   c->have_state = true;
   return TJ_OK;
 }
@@ -362,8 +403,10 @@ int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
     hipEvent_t* e = &ev[(size_t)it * (NS + 1)];
     HIPCHK(c, hipEventRecord(e[0], c->stream));
     for (int st = 0; st < NS; st++) {
-      int r = enqueue_stage(c, st);
-      if (r) return r;
+      if (st != TJ_STAGE_END) {  // the counter commit is folded into the next k_begin on the hot path
+        int r = enqueue_stage(c, st);
+        if (r) return r;
+      }
       HIPCHK(c, hipEventRecord(e[st + 1], c->stream));
     }
   }
@@ -380,6 +423,8 @@ int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
     for (int st = 0; st < NS; st++) launches[st] = n_iters;
     if (c->d.mode != 1) launches[TJ_STAGE_PLANES_SELF] = 0;
     launches[TJ_STAGE_CCD_SELF] = n_iters * (c->d.mode == 1 ? 2 : 1);
+    if (c->d.mode == 1) launches[TJ_STAGE_PLANES_SELF] = 3 * n_iters;
+    launches[TJ_STAGE_END] = 0;
   }
   return check_device_errors(c);
 }
@@ -389,9 +434,11 @@ int tj_iterate(tj_ctx* c, int n_iters, double* gnorm, int* iters_total, int* con
   if (r) return r;
   Ctl h;
   r = check_device_errors(c, &h);
+  // the iteration counter of the last started iteration is committed by the next k_begin
+  const int it = h.iter + h.pending;
   if (gnorm) *gnorm = h.gnorm;
-  if (iters_total) *iters_total = h.iter;
-  if (converged) *converged = h.done;
+  if (iters_total) *iters_total = it;
+  if (converged) *converged = h.done || (c->d.stop > 0 && it > 1 && h.gnorm < c->d.stop);
   return r;
 }
 
@@ -576,8 +623,15 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   Ctl h;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
-  s->iters = h.iter; s->nodes_dcd = h.nodes_dcd; s->nodes_ccd = h.nodes_ccd; s->cand_dcd = h.cand_dcd; s->cand_ccd = h.cand_ccd;
-  s->planes_obs = h.planes_obs; s->planes_self = h.planes_self; s->energy_evals = h.energy_evals; s->pair_tests = h.pair_tests;
+  const Dev& d = c->d;
+  std::vector<unsigned long long> seg((size_t)d.U * d.S * 6);
+  HIPCHK(c, hipMemcpy(seg.data(), d.seg_stats, seg.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
+  for (size_t i = 0; i < seg.size(); i++) tot[i % 6] += seg[i];
+  s->iters = (unsigned long long)(h.iter + h.pending);
+  s->nodes_dcd = tot[0]; s->cand_dcd = tot[1]; s->nodes_ccd = tot[2]; s->cand_ccd = tot[3]; s->planes_obs = tot[4]; s->planes_self = tot[5];
+  s->energy_evals = h.energy_evals; s->llt_fail_piece = h.llt_fail_piece; s->llt_fail_robot = h.llt_fail_robot;
+  s->pair_tests = d.mode == 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
   s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error;
   return TJ_OK;
 }
