@@ -4,119 +4,114 @@
 // 64-way Sturm multisection).  These replace Eigen::LLT / SelfAdjointEigenSolver as used in
 // Gradient_admm.h:38-53, Optimization3D_multi.h:697-722 and :423-446.  No MFMA: n is tiny and
 // the work is latency bound; the matrix never leaves LDS.
+//
+// The systems on the hot path are all "arrowhead + band": unknowns are control-point coordinates
+// that couple at most `bw` positions apart, plus one dense last row/column (piece time).  A
+// factorisation is a chain of n dependent pivots executed by ONE wavefront, so what matters is the
+// instruction count per pivot, not parallel width: each lane owns a fixed handful of positions of
+// the (bw+1)^2/2 update window, the scaled pivot column is exchanged through a 19-word LDS vector,
+// and the right-hand side rides along as one more row so that the forward substitution costs no
+// extra dependent steps.  Every entry sees exactly the subtraction sequence of the scalar
+// left-looking loop (CPU oracle / Eigen's unblocked LLT), i.e. results are bit-identical to it.
 #pragma once
 #include "dev_common.h"
 
 namespace tj {
 
-// In-place lower Cholesky of the row-major n x n matrix A (only the lower triangle is read).
-// Returns false as soon as a pivot is <= 0 (Eigen LLT.h:320-323).  Subtractions happen in
-// column order, i.e. the same association as the left-looking scalar loop of the CPU oracle.
-// Must be called by all `nth` threads of the block; contains barriers.
-constexpr int CHOL_R = 19;  // max rows touched per pivot by the row-per-thread kernel (bw <= 18, dense n <= 20)
-__device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth);
+constexpr int CHOL_MB = 18;  // max band rows below a pivot handled by the wave kernel (bw <= 18, dense n <= 20)
 
-__device__ inline bool chol_lds(double* A, int n, int tid, int nth) {
-  if (n <= CHOL_R + 1 && nth >= CHOL_R) return chol_arrow_lds(A, n, n, tid, nth);  // the 19x19 / 13x13 piece systems
+// In-place lower Cholesky of the row-major n x n matrix A (lower triangle is read and written).
+// Pattern: half-bandwidth bw (bw >= n-1 means dense) plus a dense last row.  Returns false as soon as
+// a pivot is <= 0 (Eigen LLT.h:320-323; NaN pivots pass, like Eigen).  If y != nullptr, y <- L^-1 y.
+// Must be called by all `nth` threads of the block (contains barriers); the first wave does the work.
+__device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth, double* y = nullptr) {
+  __shared__ double s_col[CHOL_MB + 2];  // scaled pivot column: [0..mb) band rows, [CHOL_MB] arrow row
+  const int last = n - 1;
+  // fixed ownership of the lower-triangular update window (r,c), c <= r < CHOL_MB: 171 positions over 64 lanes
+  int er[3], ec[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int e = tid + 64 * t;
+    er[t] = -1; ec[t] = 0;
+    if (tid < 64 && e < CHOL_MB * (CHOL_MB + 1) / 2) {
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= e) r++;
+      er[t] = r; ec[t] = e - r * (r + 1) / 2;
+    }
+  }
   for (int k = 0; k < n; k++) {
     __syncthreads();
     const double x = A[k * n + k];
     if (x <= 0) return false;  // uniform: every thread reads the same LDS word
     const double sx = sqrt(x);
+    const int mb = max(0, min(min(bw, CHOL_MB), last - 1 - k));  // band rows below the pivot (arrow row excluded)
+    const bool arrow = k < last;
+    double yk = 0;
+    if (y) yk = y[k] / sx;
     __syncthreads();
     if (tid == 0) A[k * n + k] = sx;
-    for (int i = k + 1 + tid; i < n; i += nth) A[i * n + k] = A[i * n + k] / sx;
+    if (tid < mb) { const double v = A[(k + 1 + tid) * n + k] / sx; A[(k + 1 + tid) * n + k] = v; s_col[tid] = v; }
+    else if (tid == mb && arrow) { const double v = A[last * n + k] / sx; A[last * n + k] = v; s_col[CHOL_MB] = v; }
     __syncthreads();
-    for (int i = k + 1 + tid; i < n; i += nth) {  // one thread per row: no div/mod, two barriers per pivot
-      const double lik = A[i * n + k];
-      for (int j = k + 1; j <= i; j++) A[i * n + j] -= lik * A[j * n + k];
+    if (tid < 64) {
+      double* base = A + (size_t)(k + 1) * n + (k + 1);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int r = er[t], c = ec[t];
+        if (r >= 0 && r < mb) base[r * n + c] = base[r * n + c] - s_col[r] * s_col[c];
+      }
+      if (arrow) {
+        const double la = s_col[CHOL_MB];
+        if (tid < mb) A[last * n + k + 1 + tid] = A[last * n + k + 1 + tid] - la * s_col[tid];
+        if (tid == CHOL_MB + 1) A[last * n + last] = A[last * n + last] - la * la;
+      }
+      if (y) {
+        if (tid < mb) y[k + 1 + tid] = y[k + 1 + tid] - yk * s_col[tid];
+        else if (tid == mb && arrow) y[last] = y[last] - yk * s_col[CHOL_MB];
+        if (tid == 63) y[k] = yk;
+      }
     }
   }
   __syncthreads();
   return true;
 }
 
-// Same factorisation for the x-update's reduced Hessian, whose sparsity is known: pieces couple
-// control points at most 17 coordinates apart (half-bandwidth bw) and only the last row/column
-// (piece time) is dense ("arrowhead").  Cholesky creates no fill outside that pattern, so every
-// skipped update would subtract an exact 0: results are bit-identical to chol_lds at ~1/6 of the work.
-__device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth) {
-  const int last = n - 1;
+// Generic dense variant for larger matrices (only the known-answer hook uses n > 20).
+__device__ inline bool chol_lds(double* A, int n, int tid, int nth, double* y = nullptr) {
+  if (n <= CHOL_MB + 2) return chol_arrow_lds(A, n, n, tid, nth, y);  // the 19x19 / 13x13 piece systems
   for (int k = 0; k < n; k++) {
     __syncthreads();
     const double x = A[k * n + k];
     if (x <= 0) return false;
     const double sx = sqrt(x);
+    double yk = 0;
+    if (y) yk = y[k] / sx;
     __syncthreads();
-    const int mb = max(0, min(bw, last - 1 - k));            // band rows below k (arrow row excluded)
-    const int nrows = mb + ((k < last) ? 1 : 0);              // + the arrow row; <= CHOL_R
-    if (tid == 0) A[k * n + k] = sx;
-    // one thread per affected row: no index arithmetic, two barriers per pivot; the row and the
-    // scaled pivot column are pulled into registers with back-to-back LDS loads so the update is
-    // not a chain of dependent LDS round trips
-    if (tid < nrows) { const int i = tid < mb ? k + 1 + tid : last; A[i * n + k] = A[i * n + k] / sx; }
+    if (tid == 0) { A[k * n + k] = sx; if (y) y[k] = yk; }
+    for (int i = k + 1 + tid; i < n; i += nth) A[i * n + k] = A[i * n + k] / sx;
     __syncthreads();
-    if (tid < nrows) {
-      const int i = tid < mb ? k + 1 + tid : last;
-      double lk[CHOL_R], ar[CHOL_R];
-#pragma unroll
-      for (int c = 0; c < CHOL_R; c++) {
-        const int j = c < mb ? k + 1 + c : last;
-        lk[c] = A[j * n + k];
-        ar[c] = A[i * n + j];
-      }
+    for (int i = k + 1 + tid; i < n; i += nth) {
       const double lik = A[i * n + k];
-#pragma unroll
-      for (int c = 0; c < CHOL_R; c++) {
-        const int j = c < mb ? k + 1 + c : last;
-        if (c <= tid && c < nrows) A[i * n + j] = ar[c] - lik * lk[c];
-      }
+      for (int j = k + 1; j <= i; j++) A[i * n + j] -= lik * A[j * n + k];
+      if (y) y[i] -= yk * lik;
     }
   }
   __syncthreads();
   return true;
 }
-__device__ inline void chol_arrow_solve_lds(const double* L, int n, int bw, const double* b, double* y, int tid, int nth) {
-  const int last = n - 1;
-  for (int i = tid; i < n; i += nth) y[i] = b[i];
-  __syncthreads();
-  for (int j = 0; j < n; j++) {
-    if (tid == 0) y[j] = y[j] / L[j * n + j];
-    __syncthreads();
-    const double yj = y[j];
-    const int mb = max(0, min(bw, last - 1 - j));
-    const int nrows = mb + ((j < last) ? 1 : 0);
-    for (int r = tid; r < nrows; r += nth) { const int i = r < mb ? j + 1 + r : last; y[i] -= yj * L[i * n + j]; }
-    __syncthreads();
-  }
-  for (int j = n - 1; j >= 0; j--) {
-    if (tid == 0) y[j] = y[j] / L[j * n + j];
-    __syncthreads();
-    const double yj = y[j];
-    const int lo = (j == last) ? 0 : max(0, j - bw);          // row j of L is dense only for the arrow row
-    for (int i = lo + tid; i < j; i += nth) y[i] -= yj * L[j * n + i];
-    __syncthreads();
-  }
-}
 
-// x = L^-T L^-1 b, column-oriented substitutions (same order as oracle chol_solve).  y is LDS scratch[n].
-__device__ inline void chol_solve_lds(const double* L, int n, const double* b, double* y, int tid, int nth) {
-  for (int i = tid; i < n; i += nth) y[i] = b[i];
-  __syncthreads();
-  for (int j = 0; j < n; j++) {
-    if (tid == 0) y[j] = y[j] / L[j * n + j];
-    __syncthreads();
-    const double yj = y[j];
-    for (int i = j + 1 + tid; i < n; i += nth) y[i] -= yj * L[i * n + j];
-    __syncthreads();
-  }
+// x = L^-T y in place (column oriented; row j of L is dense only for the arrow row)
+__device__ inline void chol_arrow_backsolve_lds(const double* L, int n, int bw, double* y, int tid, int nth) {
+  const int last = n - 1;
   for (int j = n - 1; j >= 0; j--) {
-    if (tid == 0) y[j] = y[j] / L[j * n + j];
     __syncthreads();
-    const double yj = y[j];
-    for (int i = tid; i < j; i += nth) y[i] -= yj * L[j * n + i];
+    const double yj = y[j] / L[j * n + j];   // every thread computes it; one publishes it
     __syncthreads();
+    if (tid == 0) y[j] = yj;
+    const int lo = (j == last) ? 0 : max(0, j - bw);
+    for (int i = lo + tid; i < j; i += nth) y[i] -= yj * L[j * n + i];
   }
+  __syncthreads();
 }
 
 // Smallest eigenvalue of the symmetric row-major n x n matrix A (lower triangle authoritative;

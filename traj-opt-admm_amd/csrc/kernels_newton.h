@@ -238,7 +238,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
 // ---- per-robot reduced Newton solve -------------------------------------------------------------
 constexpr int XS_THREADS = 64;   // one wave per robot: every barrier is a single-wave barrier
 constexpr int XS_BAND = 17;      // pieces couple reduced coordinates at most 17 apart
-__host__ __device__ inline size_t xsolve_lds_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16; }
+__host__ __device__ inline size_t xsolve_lds_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16 + ((size_t)(n + 2) / 9) * 380; }
 
 __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
   if (D.ctl->done) return;
@@ -257,8 +257,17 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
   // Gather form of the overlap-add: every reduced entry sums the (at most two, or P for the
   // time-time entry) piece blocks that cover it, in piece order like the reference's += sequence.
   // No read-modify-write, so all global loads of a pass are in flight together.
-  const double* lgu = D.lg + (size_t)u * D.P * 19;
-  const double* lhu = D.lh + (size_t)u * D.P * 361;
+  // piece blocks first go to LDS with one streaming copy (independent loads, many in flight); the
+  // scatter below then never waits on HBM/L2
+  double* lhu = scr + 6 * n;          // [P*361]
+  double* lgu = lhu + D.P * 361;      // [P*19]
+  {
+    const double* gh = D.lh + (size_t)u * D.P * 361;
+    const double* gg = D.lg + (size_t)u * D.P * 19;
+    for (int i = tid; i < D.P * 361; i += XS_THREADS) lhu[i] = gh[i];
+    for (int i = tid; i < D.P * 19; i += XS_THREADS) lgu[i] = gg[i];
+  }
+  __syncthreads();
   for (int idx = tid; idx < n * n; idx += XS_THREADS) {
     const int ra = idx / n, rb = idx % n;
     const int ga = ra == m ? -1 : ra + 6, gb = rb == m ? -1 : rb + 6;  // -1 = time
@@ -279,10 +288,10 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
     if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
     double acc = 0;
     for (int sp = max(lo, 0); sp <= hi; sp++) acc += lgu[sp * 19 + (ga < 0 ? 18 : ga - 9 * sp)];
-    g0[ra] = acc;
+    g0[ra] = acc; x0[ra] = acc;
   }
   __syncthreads();
-  if (!chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS)) {
+  if (!chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS, x0)) {  // forward substitution fused: x0 <- L^-1 g0
     if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
     __syncthreads();
     if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
@@ -293,11 +302,12 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
       __syncthreads();
     }
     for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
+    for (int i = tid; i < n; i += XS_THREADS) x0[i] = g0[i];
     __syncthreads();
-    chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS);  // like the reference, the second factorisation is not re-checked
+    chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS, x0);  // like the reference, the second factorisation is not re-checked
     __syncthreads();
   }
-  chol_arrow_solve_lds(L, n, XS_BAND, g0, x0, tid, XS_THREADS);
+  chol_arrow_backsolve_lds(L, n, XS_BAND, x0, tid, XS_THREADS);
   for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
   __syncthreads();
   for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }

@@ -183,11 +183,17 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     if (lane == 0 && ambiguous) atomicAdd(&D.ctl->order_ambiguous, ambiguous);
   }
   __syncthreads();
-  for (int i = lane; i < D.U; i += 64) D.k_self[i] = ks[i];
-  if (lane == 0) {  // gnorm exactly as the drivers form it (Optimization3D_multi.h:57,72,750; _admm.h:499)
+  for (int i = lane; i < D.U; i += 64) { D.k_self[i] = ks[i]; seen[i] = 0; }
+  // gnorm exactly as the drivers form it (Optimization3D_multi.h:57,72,750; _admm.h:499): a
+  // sequential sum in robot order; the values are first pulled into LDS by all lanes
+  double* gns = reinterpret_cast<double*>(cnt);  // reuse the staging area (S*U ints >= U doubles for S >= 2)
+  __syncthreads();
+  for (int i = lane; i < D.U; i += 64) gns[i] = D.gn(i);
+  __syncthreads();
+  if (lane == 0) {
     double gsum = 0;
-    for (int u = 0; u < D.U; u++) gsum += D.gn(u);
-    D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : D.gn(0);
+    for (int u = 0; u < D.U; u++) gsum += gns[u];
+    D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : gns[0];
   }
 }
 
@@ -273,11 +279,11 @@ __global__ __launch_bounds__(64) void k_slack(Dev D) {
   const int n = 3 * tn + 1;
   auto mapi = [&](int i) { return i < 3 * tn ? 3 * lo + i : 18; };
   for (int idx = tid; idx < n * n; idx += 64) { const int i = idx / n, j = idx % n; L[idx] = H[mapi(i) * 19 + mapi(j)]; }
-  if (tid < n) g0[tid] = g[mapi(tid)];
+  if (tid < n) { g0[tid] = g[mapi(tid)]; x0[tid] = g[mapi(tid)]; }
   __syncthreads();
   for (int idx = tid; idx < n * n; idx += 64) H[idx] = L[idx];  // H now holds the reduced system (n x n)
   __syncthreads();
-  if (!chol_lds(L, n, tid, 64)) {
+  if (!chol_lds(L, n, tid, 64, x0)) {  // forward substitution fused: x0 <- L^-1 g0
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += 64) L[idx] = H[idx];
     __syncthreads();
@@ -285,11 +291,12 @@ __global__ __launch_bounds__(64) void k_slack(Dev D) {
     if (ev < 0 && tid < n) H[tid * n + tid] = H[tid * n + tid] - ev * 1.0 + 0.01 * 1.0;
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += 64) L[idx] = H[idx];
+    if (tid < n) x0[tid] = g0[tid];
     __syncthreads();
-    chol_lds(L, n, tid, 64);
+    chol_lds(L, n, tid, 64, x0);
     __syncthreads();
   }
-  chol_solve_lds(L, n, g0, x0, tid, 64);
+  chol_arrow_backsolve_lds(L, n, n, x0, tid, 64);
   if (tid < n) x0[tid] = -x0[tid];
   if (tid < 18) dirz[tid] = 0;
   __syncthreads();
