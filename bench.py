@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "H8"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
     args = ap.parse_args()
 
     pkg = importlib.import_module("traj-opt-admm_amd")
@@ -88,34 +89,44 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_dist
+    torch.cuda.set_device(local)   # torch initialises the HIP runtime first; the library then shares it
+    if sharded:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
+        if "TJ_KEEP_NCCL_DEBUG" not in os.environ:
+            os.environ["NCCL_DEBUG"] = "WARN"   # no version banner on stdout next to the JSON line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
 
     if scene["U"] % world != 0:
         raise SystemExit("robot count must divide evenly over the ranks")
     slv = pkg.Solver(scene, device=local, rank=rank, world=world, stop=0.0)  # stop test off: time exactly K iterations
     K, W = args.steps, args.warmup
 
-    if world > 1:
-        # order kernels and collectives on torch's current stream
-        slv.set_stream(torch.cuda.current_stream().cuda_stream)
+    if sharded:
+        # kernels and collectives are ordered on one dedicated torch stream
+        tstream = torch.cuda.Stream(device=local)
+        torch.cuda.set_stream(tstream)
+        slv.set_stream(tstream.cuda_stream)
         views = []
         for what in (0, 1):
             ptr, per, first, n = slv.exchange_buffer(what)
             full = torch.as_tensor(_DevView(ptr, per * slv.U), device=f"cuda:{local}")
             views.append((full, full[first * per:(first + n) * per]))
 
+        sharding = importlib.import_module("traj-opt-admm_amd.sharding")
+
+        class _Eng:
+            @staticmethod
+            def phase(k):
+                slv.iterate_phase(k)
+
+        def _gather(what):  # RCCL all-gather straight on the library's device buffers (in place)
+            dist.all_gather_into_tensor(views[what][0], views[what][1])
+
         def run(n_it):
-            for _ in range(n_it):
-                slv.iterate_phase(0)                              # obstacle planes of owned robots
-                dist.all_gather_into_tensor(views[0][0], views[0][1])   # control points of all robots
-                slv.iterate_phase(1)                              # robot-pair planes, Newton direction
-                dist.all_gather_into_tensor(views[1][0], views[1][1])   # directions + wolfe + |g|
-                slv.iterate_phase(2)                              # CCD clamps, line search, slack + dual
+            sharding.run_sharded(_Eng, _gather, n_it)
     else:
         def run(n_it):
             slv.iterate_async(n_it)
@@ -173,10 +184,19 @@ def main():
         out["stats_per_iter"] = {k: (v / K if k not in ("error_bits", "order_ambiguous", "iters") else v) for k, v in st2.items()}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(scene, K)
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    # make the JSON line the LAST thing on stdout: flush whatever native libraries (RCCL banner ...)
+    # still hold in C stdio buffers first
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -115,6 +115,10 @@ class Engine:
             out["t_direction"][u], out["wolfe"][u], out["gn"][u] = a.value, b.value, c.value
         return out
 
+    def set_direction(self, u, direction, t_direction, wolfe, gn):
+        d = np.ascontiguousarray(direction, dtype=np.float64)
+        self._f("set_direction")(C.c_int(u), _d(d), C.c_double(t_direction), C.c_double(wolfe), C.c_double(gn))
+
     def local_grad(self, u, sp):
         g = np.zeros(19); h = np.zeros((19, 19))
         self._f("local_grad")(C.c_int(u), C.c_int(sp), _d(g), _d(h))

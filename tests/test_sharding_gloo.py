@@ -1,0 +1,107 @@
+"""CPU, world_size 2, gloo: the robot-sharding schedule (traj-opt-admm_amd/sharding.py -- the same
+function bench.py drives over RCCL) gives bit-identical results to the unsharded run.  Compute is
+done by the CPU oracle here (tests may use it; the product never does); every quantity a rank does
+not own is poisoned with NaN before each exchange, so only data that really travelled through the
+all-gathers can make the owned robots' results come out right."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_iters, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scenes = importlib.import_module("traj-opt-admm_amd.scenes")
+    sharding = importlib.import_module("traj-opt-admm_amd.sharding")
+    from oracle.pyoracle import Engine
+    scene = scenes.hard(4, 4000)
+    e = Engine("port", scene)
+    U, T = e.U, e.T
+    u0, u1 = sharding.owned_range(U, rank, world)
+    own = np.zeros(U, dtype=bool); own[u0:u1] = True
+    rec = {}
+
+    def poison_foreign_state(keys):
+        st = e.get_state()
+        for k in keys:
+            st[k][~own] = np.nan
+        e.set_state(st)
+
+    class Eng:
+        @staticmethod
+        def phase(k):
+            if k == 0:
+                # slack / dual blocks of foreign robots are never exchanged: they must not matter
+                poison_foreign_state(("p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time"))
+            elif k == 1:
+                e.stage_planes()
+                rec["d"] = e.stage_direction()
+            else:
+                e.stage_steps(); e.stage_linesearch(); e.stage_slack()
+
+    def all_gather_rows(local):  # local: [U, ...] with valid rows u0:u1 -> every rank's rows
+        t = torch.from_numpy(np.ascontiguousarray(local[u0:u1]))
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return np.concatenate([p.numpy() for p in parts], axis=0)
+
+    def gather(what):
+        if what == 0:
+            st = e.get_state()
+            st["spline"][~own] = np.nan                         # only the gathered copy may be used
+            st["spline"] = all_gather_rows(st["spline"])
+            e.set_state(st)
+        else:
+            d = rec["d"]
+            packed = np.concatenate([d["direction"].reshape(U, -1), d["t_direction"][:, None], d["wolfe"][:, None], d["gn"][:, None]], axis=1)
+            packed[~own] = np.nan
+            packed = all_gather_rows(packed)
+            for u in range(U):
+                e.set_direction(u, packed[u, :3 * T].reshape(3, T), packed[u, 3 * T], packed[u, 3 * T + 1], packed[u, 3 * T + 2])
+
+    sharding.run_sharded(Eng, gather, n_iters)
+    st = e.get_state()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u0=u0, u1=u1, **st)
+    dist.destroy_process_group()
+
+
+def test_two_rank_schedule_matches_unsharded(scenes, tmp_path):
+    from oracle.pyoracle import Engine
+    n_iters = 6
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_iters, str(tmp_path)), nprocs=2, join=True)
+    ref = Engine("port", scenes.hard(4, 4000))
+    for _ in range(n_iters):
+        ref.iterate()
+    want = ref.get_state()
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        u0, u1 = int(got["u0"]), int(got["u1"])
+        assert (u0, u1) == ((0, 2), (2, 4))[r]
+        for k in ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time"):
+            assert np.array_equal(got[k][u0:u1], want[k][u0:u1]), (r, k)
+
+
+def test_owned_range_is_a_partition(pkg):
+    sharding = importlib.import_module("traj-opt-admm_amd.sharding")
+    for U in (1, 7, 64, 256):
+        for world in (1, 2, 3, 4, 8):
+            if world > U:
+                continue
+            r = [sharding.owned_range(U, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == U
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))

@@ -1,0 +1,34 @@
+"""Robot sharding across ranks: who owns which robots and the per-iteration exchange schedule.
+
+The reference is single-process.  Cross-robot data dependencies of one decoupled ADMM iteration
+(SURVEY 3.3): `separate_self` needs every robot's control points (Optimization3D_multi.h:246-259),
+`Step::self_step` needs every robot's control points AND search directions (Step.h:196-208), the
+line search uses the LAST robot's `wolfe` (Optimization3D_multi.h:730 vs :792) and `gnorm` is the mean
+of all |g| (:57,72).  Everything else is per robot.  Hence two all-gathers per iteration:
+
+    phase 0   stop test, obstacle planes of owned robots
+    gather 0  control points of all robots
+    phase 1   robot-pair planes, gradient/Hessian, Newton direction (owned robots)
+    gather 1  direction records (direction, t_direction, wolfe, |g|) of all robots
+    phase 2   CCD clamps (pair clamp replicated on every rank), line search, slack + dual (owned)
+
+`run_sharded` is the one schedule used both by bench.py (HIP engine, RCCL all-gather on device
+buffers) and by the CPU test (oracle engine, gloo all-gather), so the N>1 path is covered without
+a multi-GPU box.
+"""
+
+
+def owned_range(n_robots, rank, world):
+    """Block partition: rank r owns robots [r*U/world, (r+1)*U/world) -- same formula as tj_create."""
+    return (rank * n_robots) // world, ((rank + 1) * n_robots) // world
+
+
+def run_sharded(engine, gather, n_iters):
+    """engine.phase(k) runs phase k for the robots this rank owns; gather(what) all-gathers buffer
+    `what` (0 = control points, 1 = direction records) in place."""
+    for _ in range(n_iters):
+        engine.phase(0)
+        gather(0)
+        engine.phase(1)
+        gather(1)
+        engine.phase(2)
