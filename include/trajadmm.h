@@ -115,6 +115,7 @@ int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_ar
 typedef struct tj_stats {
   unsigned long long iters, nodes_dcd, nodes_ccd, cand_dcd, cand_ccd, planes_obs, planes_self, energy_evals, pair_tests;
   unsigned long long llt_fail_piece, llt_fail_robot; /* PSD repairs taken: per-piece 19x19 blocks, per-robot reduced systems */
+  unsigned long long newton_iters, pair_solves;      /* Optimal_plane::optimal_d iterations, robot pairs solved */
   int order_ambiguous; /* segments whose inter-robot clamp could depend on pair order (diagnostic) */
   int error_bits;
 } tj_stats;

@@ -31,6 +31,7 @@ struct Ctl {
   // statistics for the algorithmic-byte model; accumulated over iterations
   unsigned long long llt_fail_piece, llt_fail_robot;  // PSD repairs taken (per-piece 19x19, per-robot reduced system)
   unsigned long long energy_evals;
+  unsigned long long newton_iters, pair_solves;  // Optimal_plane::optimal_d iterations / robot pairs solved
 };
 
 struct Dev {
@@ -62,6 +63,7 @@ struct Dev {
   double *splanes; int *scount;   // inter-robot planes [U][S][cap_self][4], [U][S]
   double *hullinfo;               // [U][S][HULL_STRIDE] hull, AABB, k-DOP intervals of the current control net
   double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
+  int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
   double *lg, *lh;                // per-piece gradient [U][P][19] and Hessian [U][P][361] (after PSD repair)
   // search direction record per robot, robot-major so a rank's robots are one slice for the
   // all-gather: [U][xs], xs = 3T+4 : direction (T x 3 col-major), t_direction, wolfe, |g|, pad

@@ -54,11 +54,14 @@ struct Simplex {
   double l0, l1, l2, l3;
 };
 __device__ __forceinline__ V3 sx_v(const Simplex& s, int i) { return i == 0 ? s.v0 : (i == 1 ? s.v1 : (i == 2 ? s.v2 : s.v3)); }
-__device__ __forceinline__ void sx_set_v(Simplex& s, int i, const V3& p) { if (i == 0) s.v0 = p; else if (i == 1) s.v1 = p; else if (i == 2) s.v2 = p; else s.v3 = p; }
+__device__ __forceinline__ V3 sel3(bool c, const V3& a, const V3& b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+// writes are value selects on every slot (never a store through a selected address), so the
+// simplex can stay in registers
+__device__ __forceinline__ void sx_set_v(Simplex& s, int i, const V3& p) { s.v0 = sel3(i == 0, p, s.v0); s.v1 = sel3(i == 1, p, s.v1); s.v2 = sel3(i == 2, p, s.v2); s.v3 = sel3(i == 3, p, s.v3); }
 __device__ __forceinline__ int sx_w(const Simplex& s, int i) { return i == 0 ? s.w0 : (i == 1 ? s.w1 : (i == 2 ? s.w2 : s.w3)); }
-__device__ __forceinline__ void sx_set_w(Simplex& s, int i, int w) { if (i == 0) s.w0 = w; else if (i == 1) s.w1 = w; else if (i == 2) s.w2 = w; else s.w3 = w; }
+__device__ __forceinline__ void sx_set_w(Simplex& s, int i, int w) { s.w0 = i == 0 ? w : s.w0; s.w1 = i == 1 ? w : s.w1; s.w2 = i == 2 ? w : s.w2; s.w3 = i == 3 ? w : s.w3; }
 __device__ __forceinline__ double sx_l(const Simplex& s, int i) { return i == 0 ? s.l0 : (i == 1 ? s.l1 : (i == 2 ? s.l2 : s.l3)); }
-__device__ __forceinline__ void sx_set_l(Simplex& s, int i, double l) { if (i == 0) s.l0 = l; else if (i == 1) s.l1 = l; else if (i == 2) s.l2 = l; else s.l3 = l; }
+__device__ __forceinline__ void sx_set_l(Simplex& s, int i, double l) { s.l0 = i == 0 ? l : s.l0; s.l1 = i == 1 ? l : s.l1; s.l2 = i == 2 ? l : s.l2; s.l3 = i == 3 ? l : s.l3; }
 
 // sum_i lambda_i v_i, accumulated from zero in vertex order (openGJK.c:157-162)
 __device__ __forceinline__ V3 sx_point(const Simplex& s) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ V3 sx_point(const Simplex& s) {
 }
 
 // segment {v0 = B, v1 = A} (openGJK.c:82-163)
-__device__ __noinline__ void gjk_seg(Simplex& s) {
+__device__ __forceinline__ void gjk_seg(Simplex& s) {
   const V3 b = s.v0, a = s.v1;
   const V3 t{b.x - a.x, b.y - a.y, b.z - a.z};
   const double f0 = fabs(t.x), f1 = fabs(t.y), f2 = fabs(t.z);
@@ -94,7 +97,7 @@ __device__ __noinline__ void gjk_seg(Simplex& s) {
 }
 
 // triangle {v0 = C, v1 = B, v2 = A} (openGJK.c:168-393)
-__device__ __noinline__ void gjk_tri(Simplex& s) {
+__device__ __forceinline__ void gjk_tri(Simplex& s) {
   const V3 c = s.v0, b = s.v1, a = s.v2;
   const V3 s21{b.x - a.x, b.y - a.y, b.z - a.z}, s31{c.x - a.x, c.y - a.y, c.z - a.z};
   // cofactors of the projected triangle, cyclic (k,l) = (1,2),(2,0),(0,1); sign (-1)^i
@@ -162,7 +165,7 @@ __device__ __forceinline__ double det3x(const V3& p, const V3& q, const V3& r) {
 }
 
 // tetrahedron {v0 = D, v1 = C, v2 = B, v3 = A} (openGJK.c:398-711)
-__device__ __noinline__ void gjk_tet(Simplex& s) {
+__device__ __forceinline__ void gjk_tet(Simplex& s) {
   const V3 d = s.v0, c = s.v1, b = s.v2, a = s.v3;
   const double B0 = -1 * det3x(b, c, d);
   const double B1 = +1 * det3x(a, c, d);
@@ -285,7 +288,7 @@ __device__ __forceinline__ void support(const Body& body, const V3& dir, V3& cur
 
 // witness vector of conv(b1) - conv(b2) (openGJK.c:754-852)
 template <class B1, class B2>
-__device__ V3 gjk(const B1& b1, const B2& b2) {
+__device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2) {
   const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
   Simplex s;
   V3 s1 = b1.get(0), s2 = b2.get(0);

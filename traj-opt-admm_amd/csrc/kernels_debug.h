@@ -18,7 +18,7 @@ struct BodyPts {  // K explicit points, row-major [K][3]
 };
 
 template <int K1, int K2>
-__global__ void k_dbg_gjk(int n, const double* a, const double* b, double* out) {
+__global__ __launch_bounds__(64) void k_dbg_gjk(int n, const double* a, const double* b, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const V3 v = gjk(BodyPts<K1>{a + (size_t)i * 3 * K1}, BodyPts<K2>{b + (size_t)i * 3 * K2});
@@ -27,7 +27,7 @@ __global__ void k_dbg_gjk(int n, const double* a, const double* b, double* out) 
 
 // what: 0 plane_obstacle(P,q) -> out[5] = ok,c,d ; 1 plane_pair(P,Q) with Newton refine -> ok,c,d ;
 //       2 k-DOP hull/point ; 3 k-DOP hull/hull   (out[0] = pass)
-__global__ void k_dbg_planes(Dev D, int what, int n, const double* P, const double* Q, double dist, double* out) {
+__global__ __launch_bounds__(64) void k_dbg_planes(Dev D, int what, int n, const double* P, const double* Q, double dist, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double* p = P + (size_t)i * 18;
@@ -56,7 +56,7 @@ __global__ void k_dbg_planes(Dev D, int what, int n, const double* P, const doub
 }
 
 // swept-hull CCD predicates at steps (t1,u1): out[0] = GJKCCD(P,D,q), out[1] = SelfGJKCCD(P,D,Q,E)
-__global__ void k_dbg_ccd(int n, const double* P, const double* Dd, const double* Q, const double* E, const double* q, const double* tu, double d, double* out) {
+__global__ __launch_bounds__(64) void k_dbg_ccd(int n, const double* P, const double* Dd, const double* Q, const double* E, const double* q, const double* tu, double d, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double t1 = tu[2 * i], u1 = tu[2 * i + 1];

@@ -5,10 +5,13 @@
 // (Separate.h:165-304) and Optimal_plane::optimal_d (Optimal_plane.h:13-71).
 //
 //   k_hullinfo          per (robot, segment): hull, its AABB and its 49 k-DOP intervals, once.
-//   k_sep_self_rows     one wavefront per (segment, lower robot p0), lanes over partners p1 > p0:
-//                       box test and 49 interval comparisons straight from the cache (no dot
-//                       products), then -- for the few survivors only -- hull-hull GJK and the
-//                       Newton refinement of the offset.  Each unordered pair is solved ONCE and
+//   k_sep_self_rows     one wavefront per (segment, lower robot p0): lanes over partners p1 > p0 for
+//                       the box test; lanes over the 49 AXES for each box survivor (interval
+//                       comparisons straight from the cache, no dot products, two coalesced loads
+//                       per lane); pairs that pass go to a work list.
+//   k_sep_self_solve    one wavefront per listed pair: hull-hull GJK and the Newton refinement of
+//                       the offset (scalar, divergent -- hence one program counter per pair).
+//                       Each unordered pair is solved ONCE and
 //                       the plane is stored for both robots, (c, d - off/2) and (-c, -d - off/2),
 //                       in a dense [segment][robot][partner] slot table stamped with the current
 //                       epoch (no clearing pass).
@@ -50,35 +53,83 @@ __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
   if (D.ctl->done) return;
   const int tr = blockIdx.x / D.U, p0 = blockIdx.x % D.U, lane = lane_id();
   const int U = D.U;
-  __shared__ double A[18];
-  __shared__ double oth[64 * 18];
+  __shared__ double A[HULL_STRIDE];   // hull, box and k-DOP intervals of robot p0
+  __shared__ int todo[64];            // partner ids that passed box + k-DOP
   const double* a = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
-  if (lane < 18) A[lane] = a[lane];
+  for (int i = lane; i < HULL_STRIDE; i += 64) A[i] = a[i];
   __syncthreads();
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
   const bool own0 = p0 >= D.u0 && p0 < D.u1;
   for (int c0 = p0 + 1; c0 < U; c0 += 64) {
+    // 1. lanes over partners: AABB test (12 independent loads per lane)
     const int p1 = c0 + lane;
-    if (p1 >= U) continue;
-    if (!own0 && !(p1 >= D.u0 && p1 < D.u1)) continue;  // neither robot belongs to this rank
-    const double* b = D.hullinfo + ((size_t)p1 * D.S + tr) * HULL_STRIDE;
-    bool hit = true;
-    for (int k = 0; k < 3; k++) hit = hit && !(b[21 + k] + dist < a[18 + k] || b[18 + k] > a[21 + k] + dist);
-    if (!hit) continue;
-    bool pass = true;
-    for (int k = 0; k < 49 && pass; k++) if (b[73 + k] < a[24 + k] - dist || a[73 + k] < b[24 + k] - dist) pass = false;
-    if (!pass) continue;
-    double* Bq = oth + lane * 18;
-    for (int i = 0; i < 18; i++) Bq[i] = b[i];
-    double e0, e1c, e2c, dpl; bool capped;
-    if (!plane_pair(A, Bq, dist, m, off, true, e0, e1c, e2c, dpl, capped)) continue;
-    if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
-    const size_t s0 = ((size_t)tr * U + p0) * U + p1, s1 = ((size_t)tr * U + p1) * U + p0;
-    double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
-    q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
-    q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
-    D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+    bool hit = false;
+    if (p1 < U && (own0 || (p1 >= D.u0 && p1 < D.u1))) {  // at least one robot of the pair belongs to this rank
+      const double* b = D.hullinfo + ((size_t)p1 * D.S + tr) * HULL_STRIDE;
+      hit = true;
+#pragma unroll
+      for (int k = 0; k < 3; k++) hit = hit && !(b[21 + k] + dist < A[18 + k] || b[18 + k] > A[21 + k] + dist);
+    }
+    unsigned long long box = ballot(hit);
+    // 2. per box survivor, wave-cooperative 49-axis interval test: lanes over AXES, two coalesced
+    //    loads per lane instead of a 49-step dependent chain per pair
+    int ntodo = 0;
+    while (box) {
+      const int l = __ffsll((long long)box) - 1;
+      box &= box - 1;
+      const int q = c0 + l;
+      const double* b = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
+      bool sep = false;
+      if (lane < 49) { const double lob = b[24 + lane], hib = b[73 + lane]; sep = hib < A[24 + lane] - dist || A[73 + lane] < lob - dist; }
+      if (ballot(sep) == 0ull) {
+        if (lane == 0) todo[ntodo] = q;
+        ntodo++;
+      }
+    }
+    __syncthreads();
+    // 3. hand the remaining pairs to k_sep_self_solve: one work item per pair.  Solving them here,
+    //    one lane per pair, serialises up to 63 divergent GJK paths in one wave where many robots
+    //    meet (measured: 87 us); one pair per wave keeps every path on its own program counter.
+    if (ntodo > 0) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(D.pair_work_n, ntodo);
+      base = __shfl(base, 0);
+      if (lane < ntodo) {
+        const int w = base + lane;
+        if (w < D.cap_work) { D.pair_work[3 * w] = tr; D.pair_work[3 * w + 1] = p0; D.pair_work[3 * w + 2] = todo[lane]; }
+        else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// one wavefront per robot pair (grid-stride over the work list); lane 0 runs the scalar GJK + Newton
+__global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
+  if (D.ctl->done) return;
+  const int lane = lane_id();
+  __shared__ double A[18], B[18];
+  const int n = min(*D.pair_work_n, D.cap_work), U = D.U;
+  const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
+  const int epoch = D.ctl->epoch;
+  for (int w = blockIdx.x; w < n; w += gridDim.x) {
+    const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+    __syncthreads();
+    if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
+    __syncthreads();
+    if (lane == 0) {
+      double e0, e1c, e2c, dpl; bool capped; int nit = 0;
+      if (plane_pair(A, B, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
+        atomicAdd(&D.ctl->newton_iters, (unsigned long long)nit); atomicAdd(&D.ctl->pair_solves, 1ull);
+        if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+        const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
+        double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
+        q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
+        q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
+        D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+      }
+    }
   }
 }
 

@@ -349,6 +349,7 @@ __global__ void k_begin(Dev D) {
   __syncthreads();
   if (done) return;
   for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
+  if (threadIdx.x == 0) *D.pair_work_n = 0;
 }
 // only used by the stage API: commit the iteration counter explicitly
 __global__ void k_end(Dev D) {

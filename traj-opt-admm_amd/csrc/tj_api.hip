@@ -94,6 +94,7 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
       if (d.mode == 1) {
         hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d);
         hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(k_sep_self_solve, dim3(std::min(d.cap_work, 4096)), dim3(64), 0, s, d);
         hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d);
       }
       break;
@@ -236,6 +237,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, d.U - 1);
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
   d.cap_row = std::max(1, std::min(d.cap_pairs, d.U));  // partners per (segment, lower robot)
+  d.cap_work = d.mode == 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
   c->lds_grad = grad_lds_doubles(d.cap_obs + d.cap_self) * sizeof(double);
@@ -273,7 +275,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, S * U * (size_t)d.cap_row)) ||
       (r = dalloc(c, &d.pair_count, S * U)) || (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.pairplane, d.mode == 1 ? S * U * U * 4 : 1)) ||
-      (r = dalloc(c, &d.pairstamp, d.mode == 1 ? S * U * U : 1)) || (r = dalloc(c, &d.ctl, 1))) return r;
+      (r = dalloc(c, &d.pairstamp, d.mode == 1 ? S * U * U : 1)) ||
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 1)) || (r = dalloc(c, &d.ctl, 1))) return r;
   return TJ_OK;
 }
 
@@ -451,7 +454,7 @@ int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
     for (int st = 0; st < NS; st++) launches[st] = n_iters;
     if (c->d.mode != 1) launches[TJ_STAGE_PLANES_SELF] = 0;
     launches[TJ_STAGE_CCD_SELF] = n_iters * (c->d.mode == 1 ? 2 : 1);
-    if (c->d.mode == 1) launches[TJ_STAGE_PLANES_SELF] = 3 * n_iters;
+    if (c->d.mode == 1) launches[TJ_STAGE_PLANES_SELF] = 4 * n_iters;
     launches[TJ_STAGE_END] = 0;
   }
   return check_device_errors(c);
@@ -653,7 +656,7 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   for (size_t i = 0; i < seg.size(); i++) tot[i % 6] += seg[i];
   s->iters = (unsigned long long)(h.iter + h.pending);
   s->nodes_dcd = tot[0]; s->cand_dcd = tot[1]; s->nodes_ccd = tot[2]; s->cand_ccd = tot[3]; s->planes_obs = tot[4]; s->planes_self = tot[5];
-  s->energy_evals = h.energy_evals; s->llt_fail_piece = h.llt_fail_piece; s->llt_fail_robot = h.llt_fail_robot;
+  s->energy_evals = h.energy_evals; s->llt_fail_piece = h.llt_fail_piece; s->llt_fail_robot = h.llt_fail_robot; s->newton_iters = h.newton_iters; s->pair_solves = h.pair_solves;
   s->pair_tests = d.mode == 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
   s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error;
   return TJ_OK;
