@@ -27,6 +27,9 @@ struct Ctl {
   int order_ambiguous; // segments whose inter-robot CCD result depended on pair order (see k_ccd_self_seq)
   int pending;         // an iteration was started by k_begin and is not yet counted in `iter`
   int epoch;           // bumped by every k_begin: stamp that marks this iteration's pair-plane slots as valid
+  int slack_now;       // the slack/dual update of the PREVIOUS iteration is due (deferred so it overlaps the next planes)
+  int slack_next;      // the iteration that k_begin just started still owes its slack/dual update
+
   double gnorm;        // reference global `gnorm`
   // statistics for the algorithmic-byte model; accumulated over iterations
   unsigned long long llt_fail_piece, llt_fail_robot;  // PSD repairs taken (per-piece 19x19, per-robot reduced system)

@@ -219,8 +219,11 @@ __device__ inline double z_energy(const Dev& D, const double* cx, double pt, con
   return e;
 }
 
-__global__ __launch_bounds__(64) void k_slack(Dev D) {
-  if (D.ctl->done) return;
+// deferred = 1: this launch belongs to the NEXT iteration's graph (or to a flush) and performs the
+// update the previous iteration still owes, concurrently with the next iteration's plane kernels
+// (they only read the control points).  deferred = 0: stage API, update of the current iteration.
+__global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
+  if (deferred ? !D.ctl->slack_now : D.ctl->done) return;
   const int tid = threadIdx.x;
   const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
   const int P6 = 6 * D.P, T = D.T;
@@ -333,6 +336,7 @@ __global__ __launch_bounds__(64) void k_slack(Dev D) {
   if (tid == 0) {
     D.t_slack[u * D.P + sp] = s_t;
     D.t_lambda[u * D.P + sp] += D.mu * (pt - s_t);
+    if (!deferred && blockIdx.x == 0) D.ctl->slack_next = 0;  // paid
   }
 }
 
@@ -342,9 +346,10 @@ __global__ void k_begin(Dev D) {
   __shared__ int done;
   if (threadIdx.x == 0) {
     if (D.ctl->pending) { D.ctl->iter++; D.ctl->pending = 0; }  // count the previous iteration (saves a launch)
+    D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0;
     if (!D.ctl->done && D.stop > 0 && D.ctl->iter > 1 && D.ctl->gnorm < D.stop) D.ctl->done = 1;
     done = D.ctl->done;
-    if (!done) { D.ctl->pending = 1; D.ctl->epoch++; }
+    if (!done) { D.ctl->pending = 1; D.ctl->epoch++; D.ctl->slack_next = 1; }
   }
   __syncthreads();
   if (done) return;
@@ -352,6 +357,10 @@ __global__ void k_begin(Dev D) {
   if (threadIdx.x == 0) *D.pair_work_n = 0;
 }
 // only used by the stage API: commit the iteration counter explicitly
+// hand a still-owed slack/dual update to the next k_slack(deferred) launch without starting an iteration
+__global__ void k_flush(Dev D) {
+  D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0;
+}
 __global__ void k_end(Dev D) {
   if (D.ctl->pending) { D.ctl->iter++; D.ctl->pending = 0; }
 }

@@ -30,8 +30,9 @@ struct tj_ctx {
   Dev d;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  hipStream_t side = nullptr;                 // second branch of the per-iteration graph
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fork/join markers
+  hipStream_t side = nullptr, side2 = nullptr;   // further branches of the per-iteration graph
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fork/join markers
+  bool maybe_deferred = false;                    // a graph iteration ran since the last flush
   std::vector<void*> allocs;
   std::string err;
   bool have_cloud = false, have_state = false;
@@ -107,7 +108,7 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
       hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d);
       break;
     case TJ_STAGE_LINESEARCH: hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); break;
-    case TJ_STAGE_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d); break;
+    case TJ_STAGE_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, 0); break;
     case TJ_STAGE_END: hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, d); break;
     default: c->err = "unknown stage"; return TJ_ERR_INVALID;
   }
@@ -115,29 +116,56 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
   return TJ_OK;
 }
 
-// One iteration as a small DAG on two streams (captured into the hipGraph as parallel branches):
-//   begin -> { obstacle planes | robot-pair planes } -> grad -> xsolve -> ccd_prep
-//         -> { obstacle CCD | pair CCD (select, replay) } -> line search -> slack + dual
-// The two plane builders and the two CCD clamps are independent of each other, so their
-// latencies overlap instead of adding.  The iteration counter is committed by the next k_begin.
+// One iteration as a small DAG on three streams (captured into the hipGraph as parallel branches):
+//   begin -> { obstacle planes | robot-pair planes | slack+dual of the PREVIOUS iteration }
+//         -> grad -> xsolve -> ccd_prep -> { obstacle CCD | pair CCD (select, replay) } -> line search
+// The plane builders only read control points, which the line search of the previous iteration
+// already committed, so that iteration's slack/dual update (which touches z, Lambda, t_z, tau only)
+// is deferred into this graph and runs beside them; grad waits for all three.  flush_deferred()
+// pays the last one before anything on the host looks at the state.  The iteration counter is
+// committed by the next k_begin.
 int enqueue_iteration(tj_ctx* c) {
-  hipStream_t m = c->stream, s2 = c->side;
+  hipStream_t m = c->stream, s2 = c->side, s3 = c->side2;
+  const Dev& d = c->d;
   int r;
 #define STG(st, str) if ((r = enqueue_stage(c, st, str))) return r
   STG(TJ_STAGE_BEGIN, m);
-  HIPCHK(c, hipEventRecord(c->ev[0], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[0], 0));
+  HIPCHK(c, hipEventRecord(c->ev[0], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[0], 0)); HIPCHK(c, hipStreamWaitEvent(s3, c->ev[0], 0));
   STG(TJ_STAGE_PLANES_OBS, m);
   STG(TJ_STAGE_PLANES_SELF, s2);
+  hipLaunchKernelGGL(k_slack, dim3((d.u1 - d.u0) * d.P), dim3(64), 0, s3, d, 1);
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[1], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[1], 0));
+  HIPCHK(c, hipEventRecord(c->ev[4], s3)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[4], 0));
   STG(TJ_STAGE_GRAD, m); STG(TJ_STAGE_XSOLVE, m); STG(TJ_STAGE_CCD_PREP, m);
   HIPCHK(c, hipEventRecord(c->ev[2], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));
   STG(TJ_STAGE_CCD_OBS, m);
   STG(TJ_STAGE_CCD_SELF, s2);
   HIPCHK(c, hipEventRecord(c->ev[3], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[3], 0));
-  STG(TJ_STAGE_LINESEARCH, m); STG(TJ_STAGE_SLACK, m);
+  STG(TJ_STAGE_LINESEARCH, m);
 #undef STG
+  c->maybe_deferred = true;
   return TJ_OK;
 }
+
+// Pay a deferred slack/dual update (no-op kernels if nothing is owed).
+int flush_deferred(tj_ctx* c) {
+  if (!c->maybe_deferred) return TJ_OK;
+  const Dev& d = c->d;
+  hipLaunchKernelGGL(k_flush, dim3(1), dim3(1), 0, c->stream, d);
+  hipLaunchKernelGGL(k_slack, dim3((d.u1 - d.u0) * d.P), dim3(64), 0, c->stream, d, 1);
+  HIPCHK(c, hipGetLastError());
+  c->maybe_deferred = false;
+  return TJ_OK;
+}
+
+// every host-visible read or write of solver state first pays a deferred slack/dual update
+#define QUIESCE(c)                                              \
+  do {                                                          \
+    int qr_ = flush_deferred(c);                                \
+    if (qr_) return qr_;                                        \
+    HIPCHK(c, hipStreamSynchronize((c)->stream));               \
+  } while (0)
 
 // Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two
 // all-gathers), 3 = one full iteration.  Independent stages go to the side stream.
@@ -173,14 +201,18 @@ int launch_graph_or_eager(tj_ctx* c, int which) {
       else { if (g) hipGraphDestroy(g); (void)hipGetLastError(); c->graph_failed[which] = true; }
     } else { (void)hipGetLastError(); c->graph_failed[which] = true; }
   }
-  if (c->graph_ok[which]) { HIPCHK(c, hipGraphLaunch(c->gexec[which], c->stream)); return TJ_OK; }
+  if (c->graph_ok[which]) {
+    HIPCHK(c, hipGraphLaunch(c->gexec[which], c->stream));
+    if (which == 3) c->maybe_deferred = true;  // a replayed iteration leaves its slack/dual update owed
+    return TJ_OK;
+  }
   return enqueue_body(c, which);
 }
 
 int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
   Ctl h;
   HIPCHK(c, hipMemcpyAsync(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   if (out) *out = h;
   if (h.error & (ERR_PLANE_OVERFLOW | ERR_FRONT_OVERFLOW | ERR_PAIR_OVERFLOW)) {
     c->err = "device list overflow (error bits " + std::to_string(h.error) + "): raise cap_obs/cap_self/cap_pairs";
@@ -226,6 +258,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   HIPCHK(c, hipSetDevice(p->device));
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
   for (auto& e : c->ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   Dev& d = c->d;
   memset(&d, 0, sizeof(d));
@@ -287,13 +320,14 @@ void tj_destroy(tj_ctx* c) {
   for (void* p : c->cloud_allocs) hipFree(p);
   if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
   if (c->side) hipStreamDestroy(c->side);
+  if (c->side2) hipStreamDestroy(c->side2);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   delete c;
 }
 
 int tj_set_cloud(tj_ctx* c, const double* xyz, int n) {
   if (!c || n < 0 || (n > 0 && !xyz)) return TJ_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   drop_graph(c);
   for (void* p : c->cloud_allocs) hipFree(p);
   c->cloud_allocs.clear();
@@ -353,7 +387,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
           p_slack[(size_t)u * 18 * P + sp * 6 + j + 6 * P * a] = acc;
         }
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   int r;
   if ((r = upload(c, d.spline, spline.data(), spline.size() * 8)) || (r = upload(c, d.p_slack, p_slack.data(), p_slack.size() * 8)) ||
       (r = upload(c, d.p_lambda, zeros.data(), zeros.size() * 8)) || (r = upload(c, d.t_slack, ts.data(), ts.size() * 8)) ||
@@ -374,7 +408,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
 int tj_get_state(tj_ctx* c, int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time) {
   if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   if (spline) HIPCHK(c, hipMemcpy(spline, d.spline + (size_t)u * 3 * d.T, 3 * d.T * 8, hipMemcpyDeviceToHost));
   if (p_slack) HIPCHK(c, hipMemcpy(p_slack, d.p_slack + (size_t)u * 18 * d.P, 18 * d.P * 8, hipMemcpyDeviceToHost));
   if (p_lambda) HIPCHK(c, hipMemcpy(p_lambda, d.p_lambda + (size_t)u * 18 * d.P, 18 * d.P * 8, hipMemcpyDeviceToHost));
@@ -387,7 +421,7 @@ int tj_get_state(tj_ctx* c, int u, double* spline, double* p_slack, double* p_la
 int tj_set_state(tj_ctx* c, int u, const double* spline, const double* p_slack, const double* p_lambda, const double* t_slack, const double* t_lambda, double piece_time) {
   if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   int r;
   if (spline && (r = upload(c, d.spline + (size_t)u * 3 * d.T, spline, 3 * d.T * 8))) return r;
   if (p_slack && (r = upload(c, d.p_slack + (size_t)u * 18 * d.P, p_slack, 18 * d.P * 8))) return r;
@@ -408,7 +442,8 @@ int tj_iterate_async(tj_ctx* c, int n_iters) {
 
 int tj_sync(tj_ctx* c) {
   if (!c) return TJ_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  { int r = flush_deferred(c); if (r) return r; }
+  QUIESCE(c);
   return TJ_OK;
 }
 
@@ -416,7 +451,7 @@ void* tj_stream(tj_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int tj_set_stream(tj_ctx* c, void* hip_stream) {
   if (!c) return TJ_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   drop_graph(c);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   c->stream = (hipStream_t)hip_stream;
@@ -427,6 +462,7 @@ int tj_set_stream(tj_ctx* c, void* hip_stream) {
 int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
   if (!c || !ms || n_iters < 0) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
+  { int fr = flush_deferred(c); if (fr) return fr; }
   const int NS = TJ_STAGE_END + 1;
   std::vector<hipEvent_t> ev((size_t)n_iters * (NS + 1));
   for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
@@ -441,7 +477,7 @@ int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
       HIPCHK(c, hipEventRecord(e[st + 1], c->stream));
     }
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   for (int st = 0; st < NS; st++) ms[st] = 0;
   for (int it = 0; it < n_iters; it++)
     for (int st = 0; st < NS; st++) {
@@ -463,6 +499,7 @@ int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
 int tj_iterate(tj_ctx* c, int n_iters, double* gnorm, int* iters_total, int* converged) {
   int r = tj_iterate_async(c, n_iters);
   if (r) return r;
+  if ((r = flush_deferred(c))) return r;
   Ctl h;
   r = check_device_errors(c, &h);
   // the iteration counter of the last started iteration is committed by the next k_begin
@@ -476,14 +513,16 @@ int tj_iterate(tj_ctx* c, int n_iters, double* gnorm, int* iters_total, int* con
 int tj_run_stage(tj_ctx* c, int stage) {
   if (!c) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
-  int r = enqueue_stage(c, stage);
+  int r = flush_deferred(c);
   if (r) return r;
+  if ((r = enqueue_stage(c, stage))) return r;
   return check_device_errors(c);
 }
 
 int tj_iterate_phase(tj_ctx* c, int phase) {
   if (!c || phase < 0 || phase > 2) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
+  { int fr = flush_deferred(c); if (fr) return fr; }
   // eager launches: measured faster than three graph replays per iteration (a replay costs
   // ~10-16 us of host time, a plain launch ~3.5 us, and a phase has only 2-7 kernels)
   return enqueue_body(c, phase);
@@ -502,7 +541,7 @@ int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_rob
 int tj_get_planes(tj_ctx* c, int u, int* counts_obs, int* counts_self, double* planes, int cap) {
   if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   std::vector<int> co(d.S), cs(d.S, 0);
   HIPCHK(c, hipMemcpy(co.data(), d.ocount + (size_t)u * d.S, d.S * 4, hipMemcpyDeviceToHost));
   if (d.mode == 1) HIPCHK(c, hipMemcpy(cs.data(), d.scount + (size_t)u * d.S, d.S * 4, hipMemcpyDeviceToHost));
@@ -526,7 +565,7 @@ int tj_get_planes(tj_ctx* c, int u, int* counts_obs, int* counts_self, double* p
 int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes) {
   if (!c || u < 0 || u >= c->d.U || !counts) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   size_t w = 0;
   std::vector<int> zero(d.S, 0);
   for (int tr = 0; tr < d.S; tr++) {
@@ -542,7 +581,7 @@ int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes) {
 int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, double* wolfe, double* gn) {
   if (!c || u < 0 || u >= c->d.U) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   std::vector<double> rec(d.xs);
   HIPCHK(c, hipMemcpy(rec.data(), d.xdir + (size_t)u * d.xs, d.xs * 8, hipMemcpyDeviceToHost));
   if (direction) memcpy(direction, rec.data(), 3 * d.T * 8);
@@ -555,7 +594,7 @@ int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, d
 int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361) {
   if (!c || u < 0 || u >= c->d.U || piece < 0 || piece >= c->d.P) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   if (g19) HIPCHK(c, hipMemcpy(g19, d.lg + ((size_t)u * d.P + piece) * 19, 19 * 8, hipMemcpyDeviceToHost));
   if (h361) HIPCHK(c, hipMemcpy(h361, d.lh + ((size_t)u * d.P + piece) * 361, 361 * 8, hipMemcpyDeviceToHost));
   return TJ_OK;
@@ -564,7 +603,7 @@ int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361) {
 int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_armijo) {
   if (!c) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   std::vector<int> ko(d.U), ks(d.U);
   HIPCHK(c, hipMemcpy(ko.data(), d.k_obs, d.U * 4, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(ks.data(), d.k_self, d.U * 4, hipMemcpyDeviceToHost));
@@ -599,7 +638,7 @@ int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* 
   else if (n1 == 12 && n2 == 12) hipLaunchKernelGGL((k_dbg_gjk<12, 12>), g, t, 0, c->stream, n, A, B, V);
   else { c->err = "tj_kat_gjk: body sizes must be 6v1, 6v6, 12v1 or 12v12"; return TJ_ERR_INVALID; }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   HIPCHK(c, hipMemcpy(v, dv.p, (size_t)n * 24, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
@@ -612,7 +651,7 @@ int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, 
   HIPCHK(c, hipMemset(dout.p, 0, std::max<size_t>((size_t)n * 40, 8)));
   hipLaunchKernelGGL(k_dbg_planes, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, what, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 40, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
@@ -627,7 +666,7 @@ int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double*
   hipLaunchKernelGGL(k_dbg_ccd, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, (const double*)b[0].p, (const double*)b[1].p, (const double*)b[2].p,
                      (const double*)b[3].p, (const double*)b[4].p, (const double*)b[5].p, d, (double*)dout.p);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
@@ -639,7 +678,7 @@ int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out) {
   const size_t lds = (2 * (size_t)n * n + 4 * n) * 8;
   hipLaunchKernelGGL(k_dbg_linalg, dim3(nmat), dim3(64), lds, c->stream, nmat, n, (const double*)dm.p, (double*)dout.p);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)nmat * 16, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
@@ -647,7 +686,7 @@ int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out) {
 int tj_get_stats(tj_ctx* c, tj_stats* s) {
   if (!c || !s) return TJ_ERR_INVALID;
   Ctl h;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  QUIESCE(c);
   HIPCHK(c, hipMemcpy(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
   const Dev& d = c->d;
   std::vector<unsigned long long> seg((size_t)d.U * d.S * 6);
