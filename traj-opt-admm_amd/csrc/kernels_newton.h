@@ -24,29 +24,35 @@ namespace tj {
 
 constexpr int GRAD_THREADS = 192;
 
-// dynamic LDS layout of k_grad, in doubles; npl = cap_obs + cap_self
-__host__ __device__ inline size_t grad_lds_doubles(int npl) { return 18 + 36 + 4 * (size_t)npl + 12 * (size_t)npl + 9 * (3 + 3 + 9 + 6 + 2) + 9 + 361 + 361 + 19 + 4 * 19 + 8; }
+// dynamic LDS layout of k_grad, in doubles; npl = cap_obs + cap_self (capacity of one plane batch)
+constexpr int GRAD_MAXRES = 16;  // segments per piece staged at once ("res" of 3D.json, shipped value 8)
+__host__ __device__ inline size_t grad_lds_doubles(int npl, int res) {  // sized by the actual res: 2 blocks must fit one CU
+  return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 23 + (size_t)res * 9 + 361 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
+}
 
 __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   if (D.ctl->done) return;
   extern __shared__ double sm[];
   const int npl = D.cap_obs + D.cap_self;
-  double* P = sm;                 // [18] hull of the current segment, row-major [6][3]
-  double* Bs = P + 18;            // [36] its basis
-  double* pc = Bs + 36;           // [npl][4] planes
-  double* E1 = pc + 4 * npl;      // [6][npl]
-  double* E2 = E1 + 6 * npl;      // [6][npl]  (0 when inactive)
-  double* bt = E2 + 6 * npl;      // 9 bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
-  double* bact = bt + 9 * 23;     // [9] active flags
-  double* H = bact + 9;           // [361]
-  double* W = H + 361;            // [361] scratch copy for Cholesky / eigenvalue
-  double* g = W + 361;            // [19]
-  double* scr = g + 19;           // [4*19] d,e,v,p
+  double* Pall = sm;                          // [res][18] hulls of the piece's segments, row-major [6][3]
+  double* Ball = Pall + D.res * 18;           // [res][36] their bases
+  double* pc = Ball + D.res * 36;             // [npl][4] planes of the current batch of segments
+  double* E1 = pc + 4 * npl;                  // [6 * planes] barrier derivatives (0 when inactive)
+  double* E2 = E1 + 6 * npl;
+  double* bt = E2 + 6 * npl;                  // [res][9] bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
+  double* bact = bt + D.res * 9 * 23;         // [res][9] active flags
+  double* H = bact + D.res * 9;               // [361]
+  double* W = H + 361;                        // [361] scratch copy for Cholesky / eigenvalue
+  double* g = W + 361;                        // [19]
+  double* scr = g + 19;                       // [4*19] d,e,v,p
+  int* segn = (int*)(scr + 4 * 19);           // [res] planes per segment, [res+1] offsets inside the batch
+  int* sego = segn + GRAD_MAXRES;
 
   const int tid = threadIdx.x;
   const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
   const double* net = D.spline + (size_t)u * 3 * D.T;
   const double m = D.margin, pt = D.piece_time[u];
+  const int res = D.res;
 
   // role of this thread
   int hi_ = -1, hk_ = -1;  // Hessian entry (row >= col) for tid < 171
@@ -57,111 +63,125 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   const int av = vr >= 0 ? vr / 3 : 0, qv = vr >= 0 ? vr % 3 : 0;
   double Hacc = 0, gacc = 0, pacc = 0, gt = 0, ht = 0;
 
-  // ---- plane barrier terms, segment by segment (Gradient_admm.h:85-105, :331-407) ----
-  for (int i = 0; i < D.res; i++) {
-    const int tr = sp * D.res + i;
-    const int no = D.ocount[u * D.S + tr], ns = (D.mode == 1) ? D.scount[u * D.S + tr] : 0;
-    const int n = no + ns;
-    if (n == 0) continue;
-    const double w = seg_weight(D, tr);
-    __syncthreads();
-    if (tid < 18) P[tid] = hull_entry(D, net, tr, tid / 3, tid % 3);
-    if (tid >= 64 && tid < 100) Bs[tid - 64] = D.basis[(size_t)tr * 36 + tid - 64];
-    for (int k = tid; k < 4 * n; k += GRAD_THREADS) {
-      const int pl = k / 4, c = k % 4;
-      pc[k] = pl < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + pl) * 4 + c]
-                      : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (pl - no)) * 4 + c];
-    }
-    __syncthreads();
-    for (int it = tid; it < 6 * n; it += GRAD_THREADS) {
-      const int j = it / n, k = it % n;
-      const double d = P[3 * j] * pc[4 * k] + P[3 * j + 1] * pc[4 * k + 1] + P[3 * j + 2] * pc[4 * k + 2] + pc[4 * k + 3];
-      double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
-      if (d < m) barrier_d(w, d, m, e1, e2);
-      E1[j * n + k] = e1; E2[j * n + k] = e2;
-    }
-    __syncthreads();
-    if (hi_ >= 0) {
-      double seg = 0;
-      for (int j = 0; j < 6; j++) {
-        const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
-        for (int k = 0; k < n; k++) {
-          const double dxi = bi * pc[4 * k + qi], dxk = bk * pc[4 * k + qk];
-          seg += (E2[j * n + k] * dxi) * dxk;
+  // ---- stage every segment of the piece once: hull, basis, plane counts ----
+  for (int idx = tid; idx < res * 18; idx += GRAD_THREADS) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
+  for (int idx = tid; idx < res * 36; idx += GRAD_THREADS) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
+  if (tid < res) segn[tid] = D.ocount[u * D.S + sp * res + tid] + (D.mode == 1 ? D.scount[u * D.S + sp * res + tid] : 0);
+  __syncthreads();
+
+  // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
+  for (int sb = 0; sb < res;) {
+    int se = sb, tot = 0;
+    while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
+    if (tot > 0) {
+      __syncthreads();
+      if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
+      __syncthreads();
+      // planes of the batch: obstacle list first, then inter-robot list, per segment
+      for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
+        const int w = it >> 2, c = it & 3;
+        int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
+        const int tr = sp * res + i, k = w - sego[i], no = D.ocount[u * D.S + tr];
+        pc[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
+                        : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
+      }
+      __syncthreads();
+      // barrier derivatives for every (plane, control point) of the batch, stored [segment][j][k]
+      for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
+        int i = sb; while (i + 1 < se && 6 * sego[i + 1] <= it) i++;
+        const int n = segn[i], loc = it - 6 * sego[i], j = loc / n, k = loc % n;
+        const double* P = Pall + i * 18; const double* pl = pc + 4 * (sego[i] + k);
+        const double d = P[3 * j] * pl[0] + P[3 * j + 1] * pl[1] + P[3 * j + 2] * pl[2] + pl[3];
+        double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
+        if (d < m) barrier_d(seg_weight(D, sp * res + i), d, m, e1, e2);
+        E1[it] = e1; E2[it] = e2;
+      }
+      __syncthreads();
+      for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
+        const int n = segn[i];
+        if (n == 0) continue;
+        const double* Bs = Ball + i * 36; const double* pls = pc + 4 * sego[i];
+        const double* e1s = E1 + 6 * sego[i]; const double* e2s = E2 + 6 * sego[i];
+        if (hi_ >= 0) {
+          double seg = 0;
+          for (int j = 0; j < 6; j++) {
+            const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
+            for (int k = 0; k < n; k++) {
+              const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
+              seg += (e2s[j * n + k] * dxi) * dxk;
+            }
+          }
+          Hacc += seg;
+        } else if (vr >= 0) {
+          double seg = 0;
+          for (int j = 0; j < 6; j++) {
+            const double bv = Bs[j * 6 + av];
+            for (int k = 0; k < n; k++) seg += e1s[j * n + k] * (bv * pls[4 * k + qv]);
+          }
+          gacc += seg;
         }
       }
-      Hacc += seg;
-    } else if (vr >= 0) {
-      double seg = 0;
-      for (int j = 0; j < 6; j++) {
-        const double bv = Bs[j * 6 + av];
-        for (int k = 0; k < n; k++) {
-          seg += E1[j * n + k] * (bv * pc[4 * k + qv]);
-        }
-      }
-      gacc += seg;
     }
+    sb = se;
   }
 
-  // ---- velocity / acceleration barrier terms (Gradient_admm.h:107-129, :409-572) ----
-  for (int i = 0; i < D.res; i++) {
-    const int tr = sp * D.res + i;
-    const double w = seg_weight(D, tr);
-    __syncthreads();
-    if (tid < 18) P[tid] = hull_entry(D, net, tr, tid / 3, tid % 3);
-    if (tid >= 64 && tid < 100) Bs[tid - 64] = D.basis[(size_t)tr * 36 + tid - 64];
-    __syncthreads();
-    if (tid < 9) {
-      double* t = bt + tid * 23;
-      double Dv[3], len, d, coef, e1 = 0, e2 = 0, e3 = 0, tg = 0, th = 0;
-      bool act;
-      if (tid < 5) {
-        const int j = tid;
-        for (int a = 0; a < 3; a++) Dv[a] = P[3 * (j + 1) + a] - P[3 * j + a];
-        len = norm3(Dv[0], Dv[1], Dv[2]);
-        const double v = 5 * len / w;
-        d = D.vel_limit - v / pt;
-        act = d < m;
-        if (act) {
-          barrier_d(w, d, m, e1, e2);
-          tg = e1 * v / (pt * pt);
-          th = -2 * e1 * v / pow(pt, 3.0) + e2 * v * v / pow(pt, 4.0);
-          coef = -5 / (w * pt);
-          e3 = -e1 / pt + e2 * (D.vel_limit - d) / pt;
-          for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 1) * 6 + a] - Bs[j * 6 + a];
-        }
-      } else {
-        const int j = tid - 5;
-        for (int a = 0; a < 3; a++) Dv[a] = P[3 * (j + 2) + a] - 2 * P[3 * (j + 1) + a] + P[3 * j + a];
-        len = norm3(Dv[0], Dv[1], Dv[2]);
-        const double acc = 20 * len / (w * w);
-        d = D.acc_limit - acc / (pt * pt);
-        act = d < m;
-        if (act) {
-          barrier_d(w, d, m, e1, e2);
-          tg = 2 * e1 * acc / pow(pt, 3.0);
-          th = -6 * e1 * acc / pow(pt, 4.0) + 4 * e2 * acc * acc / pow(pt, 6.0);
-          const double wp = w * pt;
-          coef = -20 / (wp * wp);
-          e3 = -2 * e1 / pt + 2 * e2 * (D.acc_limit - d) / pt;
-          for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 2) * 6 + a] - 2 * Bs[(j + 1) * 6 + a] + Bs[j * 6 + a];
-        }
-      }
-      bact[tid] = act ? 1.0 : 0.0;
+  // ---- velocity / acceleration barrier terms (Gradient_admm.h:107-129, :409-572): all res*9 records at once ----
+  if (tid < res * 9) {
+    const int i = tid / 9, b = tid % 9;
+    const double w = seg_weight(D, sp * res + i);
+    const double* P = Pall + i * 18; const double* Bs = Ball + i * 36;
+    double* t = bt + tid * 23;
+    double Dv[3], len, d, coef = 0, e1 = 0, e2 = 0, e3 = 0, tg = 0, th = 0;
+    bool act;
+    if (b < 5) {
+      const int j = b;
+      for (int a = 0; a < 3; a++) Dv[a] = P[3 * (j + 1) + a] - P[3 * j + a];
+      len = norm3(Dv[0], Dv[1], Dv[2]);
+      const double v = 5 * len / w;
+      d = D.vel_limit - v / pt;
+      act = d < m;
       if (act) {
-        const double len3 = pow(len, 3.0);
-        t[0] = e1; t[1] = e2; t[2] = e3;
-        for (int q = 0; q < 3; q++) t[3 + q] = coef * Dv[q] / len;
-        for (int q = 0; q < 3; q++) for (int s = 0; s < 3; s++) t[6 + 3 * q + s] = coef * ((q == s ? 1.0 : 0.0) / len - Dv[q] * Dv[s] / len3);
-        t[21] = tg; t[22] = th;
+        barrier_d(w, d, m, e1, e2);
+        tg = e1 * v / (pt * pt);
+        th = -2 * e1 * v / pow(pt, 3.0) + e2 * v * v / pow(pt, 4.0);
+        coef = -5 / (w * pt);
+        e3 = -e1 / pt + e2 * (D.vel_limit - d) / pt;
+        for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 1) * 6 + a] - Bs[j * 6 + a];
+      }
+    } else {
+      const int j = b - 5;
+      for (int a = 0; a < 3; a++) Dv[a] = P[3 * (j + 2) + a] - 2 * P[3 * (j + 1) + a] + P[3 * j + a];
+      len = norm3(Dv[0], Dv[1], Dv[2]);
+      const double acc = 20 * len / (w * w);
+      d = D.acc_limit - acc / (pt * pt);
+      act = d < m;
+      if (act) {
+        barrier_d(w, d, m, e1, e2);
+        tg = 2 * e1 * acc / pow(pt, 3.0);
+        th = -6 * e1 * acc / pow(pt, 4.0) + 4 * e2 * acc * acc / pow(pt, 6.0);
+        const double wp = w * pt;
+        coef = -20 / (wp * wp);
+        e3 = -2 * e1 / pt + 2 * e2 * (D.acc_limit - d) / pt;
+        for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 2) * 6 + a] - 2 * Bs[(j + 1) * 6 + a] + Bs[j * 6 + a];
       }
     }
-    __syncthreads();
+    bact[tid] = act ? 1.0 : 0.0;
+    if (act) {
+      const double len3 = pow(len, 3.0);
+      t[0] = e1; t[1] = e2; t[2] = e3;
+      for (int q = 0; q < 3; q++) t[3 + q] = coef * Dv[q] / len;
+      for (int q = 0; q < 3; q++) for (int s = 0; s < 3; s++) t[6 + 3 * q + s] = coef * ((q == s ? 1.0 : 0.0) / len - Dv[q] * Dv[s] / len3);
+      t[21] = tg; t[22] = th;
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < res; i++) {  // per segment partial sums, added in segment order
+    const double* bts = bt + i * 9 * 23; const double* acts = bact + i * 9;
     if (hi_ >= 0) {
       double seg = 0;
       for (int b = 0; b < 9; b++) {
-        if (bact[b] == 0.0) continue;
-        const double* t = bt + b * 23;
+        if (acts[b] == 0.0) continue;
+        const double* t = bts + b * 23;
         const double dxi = t[3 + qi] * t[15 + ai], dxk = t[3 + qk] * t[15 + ak];
         const double s = t[1] * dxi, lft = t[0] * t[15 + ai];
         seg = (seg + s * dxk) + (lft * t[6 + 3 * qi + qk]) * t[15 + ak];
@@ -170,15 +190,15 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
     } else if (vr >= 0) {
       double sg = 0, spp = 0;
       for (int b = 0; b < 9; b++) {
-        if (bact[b] == 0.0) continue;
-        const double* t = bt + b * 23;
+        if (acts[b] == 0.0) continue;
+        const double* t = bts + b * 23;
         const double dx = t[3 + qv] * t[15 + av];
         sg += t[0] * dx; spp += t[2] * dx;
       }
       gacc += sg; pacc += spp;
     } else if (scal) {
       double sg = 0, sh = 0;
-      for (int b = 0; b < 9; b++) { if (bact[b] == 0.0) continue; sg += bt[b * 23 + 21]; sh += bt[b * 23 + 22]; }
+      for (int b = 0; b < 9; b++) { if (acts[b] == 0.0) continue; sg += bts[b * 23 + 21]; sh += bts[b * 23 + 22]; }
       gt += sg; ht += sh;
     }
   }

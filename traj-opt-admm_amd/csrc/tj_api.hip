@@ -273,11 +273,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_work = d.mode == 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
-  c->lds_grad = grad_lds_doubles(d.cap_obs + d.cap_self) * sizeof(double);
+  c->lds_grad = grad_lds_doubles(d.cap_obs + d.cap_self, d.res) * sizeof(double);
   c->lds_xs = xsolve_lds_doubles(n) * sizeof(double);
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
   c->lds_ls = c->lsl.total * sizeof(double);
   if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
+  if (d.res > GRAD_MAXRES) { c->err = "res > 16 segments per piece is not supported by the gradient kernel"; return TJ_ERR_UNSUPPORTED; }
   c->lds_seq = (2 * (size_t)d.U + (size_t)d.S * d.U) * sizeof(int);
   const size_t lds_max = 160 * 1024 - 1024;
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max) {
