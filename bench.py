@@ -30,25 +30,32 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def stage_bytes(st, slv, iters):
-    """Algorithmic HBM bytes per iteration of each stage (SURVEY 8d terms, device-counted where data
-    dependent; this implementation's record sizes: BVH box 48 B, point 24 B, plane 32 B)."""
+def kernel_bytes(st, slv, iters):
+    """Algorithmic (compulsory) HBM bytes per iteration of every kernel: inputs read once + outputs
+    written once, device-counted where data dependent.  Record sizes of this
+    implementation: BVH box 48 B, cloud point 24 B, plane 32 B, hull cache 976 B, swept-hull cache 1168 B."""
     U, S, P, T = slv.U, slv.S, slv.P, slv.T
     it = max(1, iters)
-    hull_in = U * S * (18 * 8 + 36 * 8)            # 6 control points x 3 + 6x6 basis per (robot, segment)
-    planes = (st["planes_obs"] + st["planes_self"]) / it
-    b = {}
-    b["planes_obs"] = st["nodes_dcd"] / it * 48 + st["cand_dcd"] / it * 24 + st["planes_obs"] / it * 32 + hull_in
-    b["planes_self"] = st["pair_tests"] / it * 144 + st["planes_self"] / it * 32 + hull_in
-    b["grad"] = planes * 32 + hull_in * 2 + U * P * (19 + 361) * 8 + U * P * (36 + 2 * 18) * 8
-    b["xsolve"] = U * P * (19 + 361) * 8 + U * (3 * T + 4) * 8
-    b["ccd_prep"] = U * S * (2 * 18 * 8 + 36 * 8) + U * S * 146 * 8
-    b["ccd_obs"] = st["nodes_ccd"] / it * 48 + st["cand_ccd"] / it * 24 + U * S * 146 * 8
-    b["ccd_self"] = S * (U * (U - 1) / 2) * 2 * (6 + 98) * 8 / 8  # boxes always, k-DOP intervals for ~1/8 of the pairs
-    b["linesearch"] = st["energy_evals"] / it * (planes / U * 32 + 3 * T * 8 + S * 36 * 8) + U * 2 * 3 * T * 8
-    b["slack"] = U * P * (3 * 18 * 8 * 2 + 36 * 8 * 2)
-    b["begin"] = 64
-    b["end"] = 8
+    per = {k: st[k] / it for k in ("nodes_dcd", "cand_dcd", "nodes_ccd", "cand_ccd", "planes_obs", "planes_self", "pair_solves", "energy_evals")}
+    planes = per["planes_obs"] + per["planes_self"]
+    seg_in = U * S * (18 * 8 + 36 * 8)                 # 6 control points x 3 + 6x6 basis per (robot, segment)
+    half_pairs = S * U * (U - 1) / 2
+    b = {
+        "k_begin": 64,
+        "k_sep_obs": per["nodes_dcd"] * 48 + per["cand_dcd"] * 24 + per["planes_obs"] * 32 + seg_in,
+        "k_hullinfo": seg_in + U * S * 976,
+        "k_sep_self_rows": U * S * 976 + half_pairs * 48 + per["pair_solves"] * 12,
+        "k_sep_self_solve": per["pair_solves"] * (2 * 144 + 2 * 32 + 2 * 4 + 12),
+        "k_sep_self_compact": U * S * U * 4 + per["planes_self"] * 64,
+        "k_grad": planes * 32 + seg_in + U * P * (19 + 361) * 8 + U * P * (36 + 2 * 18) * 8,
+        "k_xsolve": U * P * (19 + 361) * 8 + U * (3 * T + 4) * 8,
+        "k_ccd_prep": U * S * (2 * 18 * 8 + 36 * 8) + U * S * 1168,
+        "k_ccd_obs": per["nodes_ccd"] * 48 + per["cand_ccd"] * 24 + U * S * 1168,
+        "k_ccd_self_pairs": U * S * 1168 + half_pairs * 48,
+        "k_ccd_self_seq": S * U * 4 + U * 16,
+        "k_linesearch": U * (S * 36 * 8 + 2 * 3 * T * 8 + P * (36 + 2 * 18 + 2) * 8) + planes * 32 + U * 3 * T * 8,
+        "k_slack": U * P * ((18 + 36) * 8 + 2 * 18 * 8 * 2 + 4 * 8),
+    }
     return b
 
 
@@ -166,21 +173,26 @@ def main():
     if world == 1:
         # per-kernel device time with hipEvents on the solver's stream, same K iterations
         slv.reset()
-        prof = slv.profile_iterations(K)
+        prof = slv.profile_kernels(K)
         st2 = slv.stats()
-        bytes_it = stage_bytes(st2, slv, K)
-        launches = {k: v[1] for k, v in prof.items()}
-        per_launch_ms = {k: (v[0] / max(1, v[1])) for k, v in prof.items()}
-        dom = max(prof, key=lambda k: prof[k][0])
-        kern_ms = prof[dom][0] / K
-        ach = bytes_it[dom] / (kern_ms * 1e-3) / 1e9
-        total_bytes = sum(bytes_it.values())
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                           "traffic": None, "algorithmic_bytes_per_launch": bytes_it[dom] / max(1, launches[dom] // K),
-                           "avg_launch_ms": per_launch_ms[dom],
+        bytes_it = kernel_bytes(st2, slv, K)
+        per_launch_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+        dom = max(per_launch_ms, key=per_launch_ms.get)
+        ach = bytes_it[dom] / (per_launch_ms[dom] * 1e-3) / 1e9
+        total_bytes = sum(bytes_it[k] for k, v in prof.items() if v[1])
+        pmc = None
+        try:  # PMC traffic of the same command, measured with rocprofv3 --pmc in separate passes (profiles/)
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if pj.get("scene") == scene["name"]:
+                pmc = pj["kernels"].get(dom)
+        except Exception:
+            pass
+        out["roofline"] = {"bound": "hbm", "kernel": "tj::" + dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                           "traffic": pmc, "algorithmic_bytes_per_launch": bytes_it[dom], "avg_launch_ms": per_launch_ms[dom],
+                           "note": "latency-bound at this size: the 35 MB working set is Infinity-Cache resident (DESIGN.md 5)",
                            "whole_iteration": {"algorithmic_bytes": total_bytes, "achieved_GBps": total_bytes / (dt / K) / 1e9,
                                                "frac": total_bytes / (dt / K) / 1e9 / 8000.0},
-                           "stage_ms_per_iter": {k: v[0] / K for k, v in prof.items()}}
+                           "kernel_ms_per_launch": per_launch_ms}
         out["stats_per_iter"] = {k: (v / K if k not in ("error_bits", "order_ambiguous", "iters") else v) for k, v in st2.items()}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(scene, K)

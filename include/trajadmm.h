@@ -93,10 +93,13 @@ int tj_sync(tj_ctx* c);
 void* tj_stream(tj_ctx* c);
 /* Enqueue on a caller-owned stream instead (e.g. the stream a collective library orders against). */
 int tj_set_stream(tj_ctx* c, void* hip_stream);
-/* Runs n_iters iterations with a hipEvent pair around every stage ON THE CONTEXT'S STREAM and
- * returns the summed device time per stage in milliseconds (ms[TJ_STAGE_END+1]) and, per stage,
- * the number of kernel launches (launches[...], may be NULL).  Same work as tj_iterate. */
-int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches);
+/* Runs n_iters iterations with a hipEvent pair around EVERY KERNEL on the context's stream and
+ * returns the summed device time per kernel in milliseconds (ms[tj_kernel_count()]) and how often each
+ * kernel was launched (launches[...], may be NULL).  Same work as tj_iterate; kernel i is tj_kernel_name(i),
+ * the name rocprofv3 reports (tj::<name>). */
+int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches);
+int tj_kernel_count(void);
+const char* tj_kernel_name(int i);
 
 /* ---- stage-level access (teacher-forced parity tests, profiling) ---------------------------- */
 enum { TJ_STAGE_BEGIN = 0, TJ_STAGE_PLANES_OBS = 1, TJ_STAGE_PLANES_SELF = 2, TJ_STAGE_GRAD = 3, TJ_STAGE_XSOLVE = 4,

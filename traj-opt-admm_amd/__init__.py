@@ -25,7 +25,7 @@ EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
     "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_set_stream", "tj_profile_iterations", "tj_kat_gjk", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
+    "tj_iterate_phase", "tj_set_stream", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
 ]
 
 STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
@@ -161,12 +161,13 @@ class Solver:
     def set_stream(self, hip_stream):
         self._check(self.lib.tj_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
-    def profile_iterations(self, n):
-        """per-stage device time (ms, summed over n iterations) measured with hipEvents on the solver's stream"""
-        ms = np.zeros(len(STAGES)); ln = np.zeros(len(STAGES), dtype=np.int32)
-        self._check(self.lib.tj_profile_iterations(self._ctx, C.c_int(n), _d(ms), _i(ln)))
-        names = sorted(STAGES, key=STAGES.get)
-        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(names)}
+    def profile_kernels(self, n):
+        """{kernel name: (device ms summed over n iterations, launches)} measured with hipEvents on the solver's stream"""
+        self.lib.tj_kernel_name.restype = C.c_char_p
+        nk = self.lib.tj_kernel_count()
+        ms = np.zeros(nk); ln = np.zeros(nk, dtype=np.int32)
+        self._check(self.lib.tj_profile_kernels(self._ctx, C.c_int(n), _d(ms), _i(ln)))
+        return {self.lib.tj_kernel_name(i).decode(): (float(ms[i]), int(ln[i])) for i in range(nk)}
 
     def run_stage(self, name):
         self._check(self.lib.tj_run_stage(self._ctx, C.c_int(STAGES[name])))

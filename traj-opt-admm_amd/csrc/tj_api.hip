@@ -83,33 +83,52 @@ void drop_graph(tj_ctx* c) {
   }
 }
 
-// enqueue one stage on the context's stream
-int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
+// ---- kernels of one iteration, in stream order (also the unit of tj_profile_kernels) ----
+enum { K_BEGIN = 0, K_SEP_OBS, K_HULLINFO, K_SEP_SELF_ROWS, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_CCD_PREP,
+       K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH, K_SLACK, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_begin", "k_sep_obs", "k_hullinfo", "k_sep_self_rows", "k_sep_self_solve", "k_sep_self_compact",
+                                           "k_grad", "k_xsolve", "k_ccd_prep", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
+                                           "k_linesearch", "k_slack"};
+
+// launch exactly one kernel (returns false for kernels that do not exist in this mode)
+bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
+  const bool multi = d.mode == 1;
+  switch (kid) {
+    case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
+    case K_SEP_OBS: hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_HULLINFO: if (multi) hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return multi;
+    case K_SEP_SELF_ROWS: if (multi) hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return multi;
+    case K_SEP_SELF_SOLVE: if (multi) hipLaunchKernelGGL(k_sep_self_solve, dim3(std::min(d.cap_work, 4096)), dim3(64), 0, s, d); return multi;
+    case K_SEP_SELF_COMPACT: if (multi) hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return multi;
+    case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
+    case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_THREADS), c->lds_xs, s, d); return true;
+    case K_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
+    case K_CCD_OBS: hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_CCD_SELF_PAIRS: if (multi) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return multi;
+    case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
+    case K_LINESEARCH: hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); return true;
+    case K_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
+  }
+  return false;
+}
+
+// enqueue one stage (= one or more kernels) on a stream
+int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
   if (!s) s = c->stream;
   switch (stage) {
-    case TJ_STAGE_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); break;
-    case TJ_STAGE_PLANES_OBS: hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); break;
-    case TJ_STAGE_PLANES_SELF:
-      if (d.mode == 1) {
-        hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d);
-        hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d);
-        hipLaunchKernelGGL(k_sep_self_solve, dim3(std::min(d.cap_work, 4096)), dim3(64), 0, s, d);
-        hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d);
-      }
-      break;
-    case TJ_STAGE_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); break;
-    case TJ_STAGE_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_THREADS), c->lds_xs, s, d); break;
-    case TJ_STAGE_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); break;
-    case TJ_STAGE_CCD_OBS: hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); break;
-    case TJ_STAGE_CCD_SELF:
-      if (d.mode == 1) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d);
-      hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d);
-      break;
-    case TJ_STAGE_LINESEARCH: hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); break;
-    case TJ_STAGE_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, 0); break;
-    case TJ_STAGE_END: hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, d); break;
+    case TJ_STAGE_BEGIN: launch_kernel(c, K_BEGIN, s); break;
+    case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); break;
+    case TJ_STAGE_PLANES_SELF: for (int k = K_HULLINFO; k <= K_SEP_SELF_COMPACT; k++) launch_kernel(c, k, s); break;
+    case TJ_STAGE_GRAD: launch_kernel(c, K_GRAD, s); break;
+    case TJ_STAGE_XSOLVE: launch_kernel(c, K_XSOLVE, s); break;
+    case TJ_STAGE_CCD_PREP: launch_kernel(c, K_CCD_PREP, s); break;
+    case TJ_STAGE_CCD_OBS: launch_kernel(c, K_CCD_OBS, s); break;
+    case TJ_STAGE_CCD_SELF: launch_kernel(c, K_CCD_SELF_PAIRS, s); launch_kernel(c, K_CCD_SELF_SEQ, s); break;
+    case TJ_STAGE_LINESEARCH: launch_kernel(c, K_LINESEARCH, s); break;
+    case TJ_STAGE_SLACK: launch_kernel(c, K_SLACK, s, 0); break;
+    case TJ_STAGE_END: hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, c->d); break;
     default: c->err = "unknown stage"; return TJ_ERR_INVALID;
   }
   HIPCHK(c, hipGetLastError());
@@ -133,7 +152,7 @@ int enqueue_iteration(tj_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[0], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[0], 0)); HIPCHK(c, hipStreamWaitEvent(s3, c->ev[0], 0));
   STG(TJ_STAGE_PLANES_OBS, m);
   STG(TJ_STAGE_PLANES_SELF, s2);
-  hipLaunchKernelGGL(k_slack, dim3((d.u1 - d.u0) * d.P), dim3(64), 0, s3, d, 1);
+  launch_kernel(c, K_SLACK, s3, 1);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[1], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[1], 0));
   HIPCHK(c, hipEventRecord(c->ev[4], s3)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[4], 0));
@@ -153,7 +172,7 @@ int flush_deferred(tj_ctx* c) {
   if (!c->maybe_deferred) return TJ_OK;
   const Dev& d = c->d;
   hipLaunchKernelGGL(k_flush, dim3(1), dim3(1), 0, c->stream, d);
-  hipLaunchKernelGGL(k_slack, dim3((d.u1 - d.u0) * d.P), dim3(64), 0, c->stream, d, 1);
+  launch_kernel(c, K_SLACK, c->stream, 1);
   HIPCHK(c, hipGetLastError());
   c->maybe_deferred = false;
   return TJ_OK;
@@ -460,42 +479,37 @@ int tj_set_stream(tj_ctx* c, void* hip_stream) {
   return TJ_OK;
 }
 
-int tj_profile_iterations(tj_ctx* c, int n_iters, double* ms, int* launches) {
+int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
   if (!c || !ms || n_iters < 0) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
   { int fr = flush_deferred(c); if (fr) return fr; }
-  const int NS = TJ_STAGE_END + 1;
-  std::vector<hipEvent_t> ev((size_t)n_iters * (NS + 1));
+  std::vector<hipEvent_t> ev((size_t)n_iters * (K_COUNT + 1));
   for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+  std::vector<int> ran(K_COUNT, 0);
   for (int it = 0; it < n_iters; it++) {
-    hipEvent_t* e = &ev[(size_t)it * (NS + 1)];
+    hipEvent_t* e = &ev[(size_t)it * (K_COUNT + 1)];
     HIPCHK(c, hipEventRecord(e[0], c->stream));
-    for (int st = 0; st < NS; st++) {
-      if (st != TJ_STAGE_END) {  // the counter commit is folded into the next k_begin on the hot path
-        int r = enqueue_stage(c, st);
-        if (r) return r;
-      }
-      HIPCHK(c, hipEventRecord(e[st + 1], c->stream));
+    for (int k = 0; k < K_COUNT; k++) {
+      if (launch_kernel(c, k, c->stream, 0)) ran[k]++;
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(e[k + 1], c->stream));
     }
   }
-  QUIESCE(c);
-  for (int st = 0; st < NS; st++) ms[st] = 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < K_COUNT; k++) ms[k] = 0;
   for (int it = 0; it < n_iters; it++)
-    for (int st = 0; st < NS; st++) {
+    for (int k = 0; k < K_COUNT; k++) {
       float t = 0;
-      HIPCHK(c, hipEventElapsedTime(&t, ev[(size_t)it * (NS + 1) + st], ev[(size_t)it * (NS + 1) + st + 1]));
-      ms[st] += t;
+      HIPCHK(c, hipEventElapsedTime(&t, ev[(size_t)it * (K_COUNT + 1) + k], ev[(size_t)it * (K_COUNT + 1) + k + 1]));
+      if (ran[k]) ms[k] += t;
     }
   for (auto& e : ev) hipEventDestroy(e);
-  if (launches) {
-    for (int st = 0; st < NS; st++) launches[st] = n_iters;
-    if (c->d.mode != 1) launches[TJ_STAGE_PLANES_SELF] = 0;
-    launches[TJ_STAGE_CCD_SELF] = n_iters * (c->d.mode == 1 ? 2 : 1);
-    if (c->d.mode == 1) launches[TJ_STAGE_PLANES_SELF] = 4 * n_iters;
-    launches[TJ_STAGE_END] = 0;
-  }
+  if (launches) for (int k = 0; k < K_COUNT; k++) launches[k] = ran[k];
   return check_device_errors(c);
 }
+
+int tj_kernel_count(void) { return K_COUNT; }
+const char* tj_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? kKernelNames[i] : ""; }
 
 int tj_iterate(tj_ctx* c, int n_iters, double* gnorm, int* iters_total, int* converged) {
   int r = tj_iterate_async(c, n_iters);
