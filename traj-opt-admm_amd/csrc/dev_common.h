@@ -115,6 +115,18 @@ __device__ __forceinline__ void barrier_d(double w, double d, double m, double& 
   e2 = -w * (2 * log(d / m) + 4 * (d - m) / d - (d - m) * (d - m) / (d * d));
 }
 
+// Integer powers x^3 .. x^6 evaluated in double-double and rounded once.  The reference calls
+// std::pow(x, k) (glibc, < 0.53 ulp); a once-rounded product agrees with it except on near-ties,
+// and costs ~10 instructions where the device pow() costs several hundred.
+struct DD { double h, l; };
+__device__ __forceinline__ DD dd_sq(double x) { const double h = x * x; return DD{h, fma(x, x, -h)}; }
+__device__ __forceinline__ DD dd_mul_d(DD a, double x) { const double h = a.h * x; return DD{h, fma(a.h, x, -h) + a.l * x}; }
+__device__ __forceinline__ DD dd_sq(DD a) { const double h = a.h * a.h; return DD{h, fma(a.h, a.h, -h) + 2 * (a.h * a.l)}; }
+__device__ __forceinline__ double pow3(double x) { const DD r = dd_mul_d(dd_sq(x), x); return r.h + r.l; }
+__device__ __forceinline__ double pow4(double x) { const DD r = dd_sq(dd_sq(x)); return r.h + r.l; }
+__device__ __forceinline__ double pow5(double x) { DD q = dd_sq(dd_sq(x)); const double h = q.h + q.l; q = DD{h, (q.h - h) + q.l}; const DD r = dd_mul_d(q, x); return r.h + r.l; }
+__device__ __forceinline__ double pow6(double x) { DD c = dd_mul_d(dd_sq(x), x); const double h = c.h + c.l; c = DD{h, (c.h - h) + c.l}; const DD r = dd_sq(c); return r.h + r.l; }
+
 // Sum in the association order of Eigen's 2-wide vectorised reduction (Redux.h) -- used for the
 // few scalars that feed Armijo / stop decisions (wolfe, |g|, consensus norms).
 __device__ inline double esum(const double* e, int n) {

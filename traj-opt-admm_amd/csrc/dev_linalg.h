@@ -39,40 +39,77 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
       er[t] = r; ec[t] = e - r * (r + 1) / 2;
     }
   }
+  // Each pivot costs three LDS round trips, not one per operand: every lane first issues ALL the
+  // loads it will need (pivot, its column entry, its window positions, arrow and rhs entries, with
+  // clamped indices so that no load sits behind a branch), then the scaled column is exchanged
+  // through s_col, then everything is stored.
   for (int k = 0; k < n; k++) {
     __syncthreads();
-    const double x = A[k * n + k];
-    if (x <= 0) return false;  // uniform: every thread reads the same LDS word
-    const double sx = sqrt(x);
     const int mb = max(0, min(min(bw, CHOL_MB), last - 1 - k));  // band rows below the pivot (arrow row excluded)
     const bool arrow = k < last;
-    double yk = 0;
-    if (y) yk = y[k] / sx;
+    const int myrow = tid < mb ? k + 1 + tid : last;
+    const double x = A[k * n + k];
+    const double ci = A[myrow * n + k];
+    double w[3]; int widx[3]; bool wact[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      wact[t] = er[t] >= 0 && er[t] < mb;
+      widx[t] = wact[t] ? (k + 1 + er[t]) * n + (k + 1 + ec[t]) : k * n + k;
+      w[t] = A[widx[t]];
+    }
+    const int aidx = last * n + min(k + 1 + tid, last);
+    const double ae = A[aidx], add = A[last * n + last];
+    double yk_raw = 0, yi = 0, ylast = 0;
+    if (y) { yk_raw = y[k]; yi = y[min(k + 1 + tid, last)]; ylast = y[last]; }
+    if (x <= 0) return false;  // uniform: every thread read the same LDS word
+    const double sx = sqrt(x);
+    const double v = ci / sx;
+    const double yk = yk_raw / sx;
     __syncthreads();
     if (tid == 0) A[k * n + k] = sx;
-    if (tid < mb) { const double v = A[(k + 1 + tid) * n + k] / sx; A[(k + 1 + tid) * n + k] = v; s_col[tid] = v; }
-    else if (tid == mb && arrow) { const double v = A[last * n + k] / sx; A[last * n + k] = v; s_col[CHOL_MB] = v; }
+    if (tid < mb) { A[myrow * n + k] = v; s_col[tid] = v; }
+    else if (tid == mb && arrow) { A[last * n + k] = v; s_col[CHOL_MB] = v; }
     __syncthreads();
     if (tid < 64) {
-      double* base = A + (size_t)(k + 1) * n + (k + 1);
+      const double la = s_col[CHOL_MB];
+      const double cm = s_col[min(tid, CHOL_MB - 1)];
+      double cr[3], cc[3];
 #pragma unroll
-      for (int t = 0; t < 3; t++) {
-        const int r = er[t], c = ec[t];
-        if (r >= 0 && r < mb) base[r * n + c] = base[r * n + c] - s_col[r] * s_col[c];
-      }
+      for (int t = 0; t < 3; t++) { cr[t] = s_col[max(er[t], 0)]; cc[t] = s_col[ec[t]]; }
+#pragma unroll
+      for (int t = 0; t < 3; t++) if (wact[t]) A[widx[t]] = w[t] - cr[t] * cc[t];
       if (arrow) {
-        const double la = s_col[CHOL_MB];
-        if (tid < mb) A[last * n + k + 1 + tid] = A[last * n + k + 1 + tid] - la * s_col[tid];
-        if (tid == CHOL_MB + 1) A[last * n + last] = A[last * n + last] - la * la;
+        if (tid < mb) A[aidx] = ae - la * cm;
+        if (tid == CHOL_MB + 1) A[last * n + last] = add - la * la;
       }
       if (y) {
-        if (tid < mb) y[k + 1 + tid] = y[k + 1 + tid] - yk * s_col[tid];
-        else if (tid == mb && arrow) y[last] = y[last] - yk * s_col[CHOL_MB];
+        if (tid < mb) y[k + 1 + tid] = yi - yk * cm;
+        else if (tid == mb && arrow) y[last] = ylast - yk * la;
         if (tid == 63) y[k] = yk;
       }
     }
   }
   __syncthreads();
+  return true;
+}
+
+// Dense N x N LLT success test in the registers of ONE wave: lane i holds row i (r[c] = A[i][c]).
+// Same right-looking operation order as chol_arrow_lds (a_ij - l_ik * l_jk, k ascending), so the
+// pivots are bit-identical; pivot and scaled column are broadcast with v_readlane -- no LDS round
+// trip, no barrier.  Fully unrolled (N is the 19 of a piece block).  Lanes >= N carry don't-cares.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <int N>
+__device__ __forceinline__ bool chol_check_wave(double (&r)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const double x = readlane_f64(r[k], k);
+    if (x <= 0) return false;
+    const double lik = r[k] / sqrt(x);
+#pragma unroll
+    for (int j = k + 1; j < N; j++) r[j] = r[j] - lik * readlane_f64(lik, j);
+  }
   return true;
 }
 
@@ -105,11 +142,14 @@ __device__ inline void chol_arrow_backsolve_lds(const double* L, int n, int bw, 
   const int last = n - 1;
   for (int j = n - 1; j >= 0; j--) {
     __syncthreads();
-    const double yj = y[j] / L[j * n + j];   // every thread computes it; one publishes it
+    const int lo = (j == last) ? 0 : max(0, j - bw);
+    const int i0 = min(lo + tid, j);                 // first element of this lane (clamped: load is unconditional)
+    const double yj_raw = y[j], ljj = L[j * n + j], lji = L[j * n + i0], yi = y[i0];
+    const double yj = yj_raw / ljj;                  // every thread computes it; one publishes it
     __syncthreads();
     if (tid == 0) y[j] = yj;
-    const int lo = (j == last) ? 0 : max(0, j - bw);
-    for (int i = lo + tid; i < j; i += nth) y[i] -= yj * L[j * n + i];
+    if (lo + tid < j) y[i0] = yi - yj * lji;
+    for (int i = lo + tid + nth; i < j; i += nth) y[i] -= yj * L[j * n + i];   // only the arrow row of large systems
   }
   __syncthreads();
 }

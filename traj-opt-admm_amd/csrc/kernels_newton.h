@@ -40,13 +40,14 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   double* E1 = pc + 4 * npl;                  // [6 * planes] barrier derivatives (0 when inactive)
   double* E2 = E1 + 6 * npl;
   double* bt = E2 + 6 * npl;                  // [res][9] bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
-  double* bact = bt + D.res * 9 * 23;         // [res][9] active flags
-  double* H = bact + D.res * 9;               // [361]
+  double* H = bt + D.res * 9 * 23;            // [361]
   double* W = H + 361;                        // [361] scratch copy for Cholesky / eigenvalue
   double* g = W + 361;                        // [19]
   double* scr = g + 19;                       // [4*19] d,e,v,p
   int* segn = (int*)(scr + 4 * 19);           // [res] planes per segment, [res+1] offsets inside the batch
   int* sego = segn + GRAD_MAXRES;
+  unsigned long long* amask = (unsigned long long*)(sego + GRAD_MAXRES);  // [3] active vel/acc records, then the LLT flag
+  int* llt_ok = (int*)(amask + 3);
 
   const int tid = threadIdx.x;
   const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
           double seg = 0;
           for (int j = 0; j < 6; j++) {
             const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
+#pragma unroll 4
             for (int k = 0; k < n; k++) {
               const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
               seg += (e2s[j * n + k] * dxi) * dxk;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
           double seg = 0;
           for (int j = 0; j < 6; j++) {
             const double bv = Bs[j * 6 + av];
+#pragma unroll 4
             for (int k = 0; k < n; k++) seg += e1s[j * n + k] * (bv * pls[4 * k + qv]);
           }
           gacc += seg;
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   }
 
   // ---- velocity / acceleration barrier terms (Gradient_admm.h:107-129, :409-572): all res*9 records at once ----
+  bool rec_act = false;
   if (tid < res * 9) {
     const int i = tid / 9, b = tid % 9;
     const double w = seg_weight(D, sp * res + i);
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
       if (act) {
         barrier_d(w, d, m, e1, e2);
         tg = e1 * v / (pt * pt);
-        th = -2 * e1 * v / pow(pt, 3.0) + e2 * v * v / pow(pt, 4.0);
+        th = -2 * e1 * v / pow3(pt) + e2 * v * v / pow4(pt);
         coef = -5 / (w * pt);
         e3 = -e1 / pt + e2 * (D.vel_limit - d) / pt;
         for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 1) * 6 + a] - Bs[j * 6 + a];
@@ -157,30 +161,40 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
       act = d < m;
       if (act) {
         barrier_d(w, d, m, e1, e2);
-        tg = 2 * e1 * acc / pow(pt, 3.0);
-        th = -6 * e1 * acc / pow(pt, 4.0) + 4 * e2 * acc * acc / pow(pt, 6.0);
+        tg = 2 * e1 * acc / pow3(pt);
+        th = -6 * e1 * acc / pow4(pt) + 4 * e2 * acc * acc / pow6(pt);
         const double wp = w * pt;
         coef = -20 / (wp * wp);
         e3 = -2 * e1 / pt + 2 * e2 * (D.acc_limit - d) / pt;
         for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 2) * 6 + a] - 2 * Bs[(j + 1) * 6 + a] + Bs[j * 6 + a];
       }
     }
-    bact[tid] = act ? 1.0 : 0.0;
+    rec_act = act;
     if (act) {
-      const double len3 = pow(len, 3.0);
+      const double len3 = pow3(len);
       t[0] = e1; t[1] = e2; t[2] = e3;
       for (int q = 0; q < 3; q++) t[3 + q] = coef * Dv[q] / len;
       for (int q = 0; q < 3; q++) for (int s = 0; s < 3; s++) t[6 + 3 * q + s] = coef * ((q == s ? 1.0 : 0.0) / len - Dv[q] * Dv[s] / len3);
       t[21] = tg; t[22] = th;
     }
   }
+  {  // bitmask of active records (most are inactive: the limits bind on few segments)
+    const unsigned long long bal = __ballot(rec_act);
+    if ((tid & 63) == 0) amask[tid >> 6] = bal;
+  }
   __syncthreads();
-  for (int i = 0; i < res; i++) {  // per segment partial sums, added in segment order
-    const double* bts = bt + i * 9 * 23; const double* acts = bact + i * 9;
+  const unsigned long long am[3] = {amask[0], amask[1], amask[2]};
+  for (int i = 0; i < res; i++) {  // per segment partial sums, added in segment order; an all-inactive segment adds an exact +0
+    const double* bts = bt + i * 9 * 23;
+    const int base = i * 9, aw = base >> 6, ao = base & 63;
+    unsigned long long av9 = am[aw] >> ao;
+    if (ao > 55 && aw < 2) av9 |= am[aw + 1] << (64 - ao);
+    const unsigned bits0 = (unsigned)av9 & 0x1ffu;
+    if (!bits0) continue;
     if (hi_ >= 0) {
       double seg = 0;
-      for (int b = 0; b < 9; b++) {
-        if (acts[b] == 0.0) continue;
+      for (unsigned bits = bits0; bits; bits &= bits - 1) {
+        const int b = __ffs(bits) - 1;
         const double* t = bts + b * 23;
         const double dxi = t[3 + qi] * t[15 + ai], dxk = t[3 + qk] * t[15 + ak];
         const double s = t[1] * dxi, lft = t[0] * t[15 + ai];
@@ -189,8 +203,8 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
       Hacc += seg;
     } else if (vr >= 0) {
       double sg = 0, spp = 0;
-      for (int b = 0; b < 9; b++) {
-        if (acts[b] == 0.0) continue;
+      for (unsigned bits = bits0; bits; bits &= bits - 1) {
+        const int b = __ffs(bits) - 1;
         const double* t = bts + b * 23;
         const double dx = t[3 + qv] * t[15 + av];
         sg += t[0] * dx; spp += t[2] * dx;
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
       gacc += sg; pacc += spp;
     } else if (scal) {
       double sg = 0, sh = 0;
-      for (int b = 0; b < 9; b++) { if (acts[b] == 0.0) continue; sg += bts[b * 23 + 21]; sh += bts[b * 23 + 22]; }
+      for (unsigned bits = bits0; bits; bits &= bits - 1) { const int b = __ffs(bits) - 1; sg += bts[b * 23 + 21]; sh += bts[b * 23 + 22]; }
       gt += sg; ht += sh;
     }
   }
@@ -238,9 +252,16 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   __syncthreads();
 
   // ---- PSD repair: only if LLT fails and lambda_min < 0 (Gradient_admm.h:38-53) ----
-  for (int idx = tid; idx < 361; idx += GRAD_THREADS) W[idx] = H[idx];
+  if (tid < 64) {  // wave 0 factors the block in registers, one row per lane
+    double r[19];
+    const int row = min(tid, 18);
+#pragma unroll
+    for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
+    const bool ok = chol_check_wave<19>(r);
+    if (tid == 0) *llt_ok = ok;
+  }
   __syncthreads();
-  if (!chol_lds(W, 19, tid, GRAD_THREADS)) {
+  if (!*llt_ok) {
     if (tid == 0) atomicAdd(&D.ctl->llt_fail_piece, 1ull);
     __syncthreads();
     for (int idx = tid; idx < 361; idx += GRAD_THREADS) W[idx] = H[idx];

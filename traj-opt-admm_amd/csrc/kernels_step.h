@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
 __device__ inline double z_energy(const Dev& D, const double* cx, double pt, const double* z, double t, const double* lam, double tl) {
   // Energy_admm::slack_energy / dynamic_energy (Energy_admm.h:172-215)
   double e = 0;
-  const double s = D.ks / pow(t, 5.0) * 0.5;
+  const double s = D.ks / pow5(t) * 0.5;
   for (int a = 0; a < 3; a++) {
     double rrow[6], y[6];
     for (int k = 0; k < 6; k++) rrow[k] = s * z[k + 6 * a];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
   for (int i = tid; i < 361; i += 64) H[i] = 0;
   __syncthreads();
   // Gradient_admm::slack_gradient / dynamic_gradient (Gradient_admm.h:574-671)
-  const double sc = D.ks / pow(t, 5.0);
+  const double sc = D.ks / pow5(t);
   if (tid < 18) {
     const int k = tid / 3, a = tid % 3;
     double mz = 0;
