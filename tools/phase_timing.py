@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Phase breakdown inside the kernels of one iteration (development tool, GPU only).
+
+Builds nothing itself: run `make -C traj-opt-admm_amd/csrc timing` first (compiles the library with
+-DTJ_PHASE_TIMING into libtrajadmm_timing.so; thread 0 of every block stamps the 100 MHz wall clock
+at its phase boundaries).  Usage:  python tools/phase_timing.py [--scene C] [--iter 10]
+Prints, per instrumented kernel, mean / max phase times over blocks and the slowest blocks.
+"""
+import argparse, ctypes as C, importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["TRAJADMM_LIB"] = os.path.join(ROOT, "traj-opt-admm_amd", "libtrajadmm_timing.so")
+
+PHASES = {
+    "k_grad": ["stage", "planes", "vel/acc", "consensus", "psd", "store"],
+    "k_xsolve": ["load", "assemble", "chol+fwd", "backsolve"],
+    "k_linesearch": ["stage", "planes->lds", "setup", "E round0", "later rounds"],
+    "k_sep_self_solve": ["load", "gjk+newton+store"],
+    "k_sep_obs": ["hull+kdop", "bvh+planes"],
+}
+NAMES = ["k_begin", "k_sep_obs", "k_hullinfo", "k_sep_self_rows", "k_sep_self_solve", "k_sep_self_compact", "k_grad", "k_xsolve",
+         "k_ccd_prep", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq", "k_linesearch", "k_slack"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="C")
+    ap.add_argument("--iter", type=int, default=10)
+    a = ap.parse_args()
+    pkg = importlib.import_module("traj-opt-admm_amd")
+    sc = pkg.scenes
+    scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d}[a.scene]()
+    s = pkg.Solver(scene, stop=0.0)
+    s.iterate(a.iter)
+    lib = C.CDLL(os.environ["TRAJADMM_LIB"])
+    out = np.zeros((len(NAMES), 4096, 8), dtype=np.int64)
+    lib.tj_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.tj_debug_phase_times(s._ctx, out.ctypes.data) == len(NAMES)
+    for k, name in enumerate(NAMES):
+        if name not in PHASES:
+            continue
+        t = out[k]
+        live = t[:, 0] != 0
+        if not live.any():
+            continue
+        t = t[live]
+        nph = len(PHASES[name])
+        d = np.diff(t[:, :nph + 1], axis=1) * 0.01   # us
+        tot = d.sum(1)
+        span = (t[:, :nph + 1].max() - t[:, 0].min()) * 0.01
+        print(f"{name}: {live.sum()} blocks, first start -> last stamp {span:.1f} us, block total mean {tot.mean():.1f} max {tot.max():.1f} us")
+        print("   phase        " + " ".join(f"{p:>12s}" for p in PHASES[name]))
+        print("   mean us      " + " ".join(f"{x:12.2f}" for x in d.mean(0)))
+        print("   max us       " + " ".join(f"{x:12.2f}" for x in d.max(0)))
+        worst = np.argsort(-tot)[:3]
+        for w in worst:
+            print(f"   slow block {np.flatnonzero(live)[w]:5d}: " + " ".join(f"{x:12.2f}" for x in d[w]))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ import numpy as np
 from . import scenes  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrajadmm.so")
+LIB_PATH = os.environ.get("TRAJADMM_LIB") or os.path.join(_HERE, "libtrajadmm.so")  # override: another BUILD of this library (e.g. `make timing`)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

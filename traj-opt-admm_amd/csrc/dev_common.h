@@ -37,6 +37,19 @@ struct Ctl {
   unsigned long long newton_iters, pair_solves;  // Optimal_plane::optimal_d iterations / robot pairs solved
 };
 
+// kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
+enum { K_BEGIN = 0, K_SEP_OBS, K_HULLINFO, K_SEP_SELF_ROWS, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_CCD_PREP,
+       K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH, K_SLACK, K_COUNT };
+
+// Phase stamps for kernel tuning: compiled in only by `make timing` (-DTJ_PHASE_TIMING); thread 0 of
+// a block stores the constant-rate wall clock at a phase boundary.  The product build has none.
+constexpr int TJ_TIC_BLOCKS = 4096, TJ_TIC_SLOTS = 8;
+#ifdef TJ_PHASE_TIMING
+#define TJ_TIC(D, kid, slot) do { if (threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
+#else
+#define TJ_TIC(D, kid, slot) do {} while (0)
+#endif
+
 struct Dev {
   // ---- parameters (3D.json + hard-coded constants of the mains) ----
   int mode, U, P, res, S, T, N;
@@ -85,6 +98,7 @@ struct Dev {
   // (a shared counter would serialise ~10^4 atomics per iteration on one L2 word)
   unsigned long long* seg_stats;
   Ctl* ctl;
+  long long* dbg;  // phase stamps (TJ_PHASE_TIMING builds only, else null)
 };
 constexpr int CCD_STRIDE = 18 + 18 + 6 + 6 + 98;  // P, D, obstacle box, pair box, 49 k-DOP intervals (lo,hi)
 

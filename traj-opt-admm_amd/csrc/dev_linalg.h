@@ -154,6 +154,18 @@ __device__ inline void chol_arrow_backsolve_lds(const double* L, int n, int bw, 
   __syncthreads();
 }
 
+// a / q for the Sturm recurrence: reciprocal estimate + two Newton steps (~1 ulp) instead of the
+// IEEE division sequence -- the recurrence is a chain of n dependent divisions per trial shift and
+// only the SIGN of each q is used.  |q| is first kept away from zero (LAPACK dstebz's pivmin).
+__device__ __forceinline__ double sturm_div(double a, double& q) {
+  if (fabs(q) < 1e-300) q = q < 0 ? -1e-300 : 1e-300;
+  double r = __builtin_amdgcn_rcp(q);
+  r = fma(r, fma(-q, r, 1.0), r);
+  r = fma(r, fma(-q, r, 1.0), r);
+  return a * r;
+}
+constexpr int STURM_ROUNDS = 10;  // 64-way multisection: 65^10 > 2^60 subdivisions of the Gershgorin interval
+
 // Smallest eigenvalue of the symmetric row-major n x n matrix A (lower triangle authoritative;
 // A is destroyed).  d,e,v,p are LDS scratch of length n.  Called by the whole block.
 __device__ inline double min_eig_lds(double* A, int n, double* d, double* e, double* v, double* p, int tid, int nth) {
@@ -214,7 +226,7 @@ __device__ inline double min_eig_lds(double* A, int n, double* d, double* e, dou
   }
   __syncthreads();
   // multisection on the Sturm count "#eigenvalues < x >= 1"; lanes 0..63 of the first wave
-  for (int round = 0; round < 13; round++) {
+  for (int round = 0; round < STURM_ROUNDS; round++) {
     const double lo = s_scal[0], hi = s_scal[1];
     __syncthreads();
     if (tid < 64) {
@@ -222,8 +234,7 @@ __device__ inline double min_eig_lds(double* A, int n, double* d, double* e, dou
       double q = d[0] - x;
       int cnt = q < 0;
       for (int i = 1; i < n; i++) {
-        if (q == 0) q = 1e-300;
-        q = d[i] - x - e[i - 1] * e[i - 1] / q;
+        q = d[i] - x - sturm_div(e[i - 1] * e[i - 1], q);
         cnt += q < 0;
       }
       const unsigned long long mask = __ballot(cnt >= 1);
@@ -241,6 +252,69 @@ __device__ inline double min_eig_lds(double* A, int n, double* d, double* e, dou
   const double r = 0.5 * (s_scal[0] + s_scal[1]);
   __syncthreads();
   return r;
+}
+
+// min_eig_lds for an N x N block held one FULL row per lane in the registers of one wave (both
+// triangles).  Identical arithmetic, in the same order (sequential sums via v_readlane), so the
+// two agree bit for bit; no LDS round trips, no barriers, nothing serialised on one thread.
+template <int N>
+__device__ __forceinline__ double min_eig_wave(double (&r)[N], int lane) {
+  double d[N], e[N];  // wave-uniform
+#pragma unroll
+  for (int k = 0; k + 2 < N; k++) {
+    double sig = 0;
+#pragma unroll
+    for (int i = k + 2; i < N; i++) { const double a = readlane_f64(r[k], i); sig += a * a; }
+    const double x0 = readlane_f64(r[k], k + 1);
+    d[k] = readlane_f64(r[k], k);
+    if (sig == 0) { e[k] = x0; continue; }  // nothing to eliminate (uniform)
+    const double nrm = sqrt(x0 * x0 + sig);
+    const double alpha = x0 > 0 ? -nrm : nrm;
+    const double v0 = x0 - alpha;
+    const double beta = 2.0 / (v0 * v0 + sig);
+    e[k] = alpha;
+    const double v = lane == k + 1 ? v0 : (lane > k + 1 ? r[k] : 0.0);
+    double vj[N];
+    double acc = 0;
+#pragma unroll
+    for (int j = k + 1; j < N; j++) { vj[j] = readlane_f64(v, j); acc += r[j] * vj[j]; }
+    const double p = lane > k ? beta * acc : 0.0;
+    const double vp = v * p;
+    double kk = 0;
+#pragma unroll
+    for (int i = k + 1; i < N; i++) kk += readlane_f64(vp, i);
+    const double K = 0.5 * beta * kk;
+    const double q = p - K * v;
+#pragma unroll
+    for (int j = k + 1; j < N; j++) { const double qj = readlane_f64(q, j); r[j] -= v * qj + q * vj[j]; }
+  }
+  d[N - 2] = readlane_f64(r[N - 2], N - 2); e[N - 2] = readlane_f64(r[N - 2], N - 1);
+  d[N - 1] = readlane_f64(r[N - 1], N - 1);
+  double lo = d[0], hi = d[0];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < N ? fabs(e[i]) : 0.0);
+    lo = fmin(lo, d[i] - rad); hi = fmax(hi, d[i] + rad);
+  }
+  double e2[N];
+#pragma unroll
+  for (int i = 1; i < N; i++) e2[i] = e[i - 1] * e[i - 1];
+  for (int round = 0; round < STURM_ROUNDS; round++) {
+    const double x = lo + (hi - lo) * (double(lane + 1) / 65.0);
+    double q = d[0] - x;
+    int cnt = q < 0;
+#pragma unroll
+    for (int i = 1; i < N; i++) { q = d[i] - x - sturm_div(e2[i], q); cnt += q < 0; }
+    const unsigned long long mask = __ballot(cnt >= 1);
+    if (mask == 0) lo = lo + (hi - lo) * (64.0 / 65.0);
+    else {
+      const int f = __ffsll((long long)mask) - 1;
+      const double nhi = lo + (hi - lo) * (double(f + 1) / 65.0);
+      if (f > 0) lo = lo + (hi - lo) * (double(f) / 65.0);
+      hi = nhi;
+    }
+  }
+  return 0.5 * (lo + hi);
 }
 
 }  // namespace tj

@@ -77,14 +77,17 @@ __global__ __launch_bounds__(64) void k_dbg_linalg(int nmat, int n, const double
   bool ok = chol_lds(W, n, tid, 64);
   __syncthreads();
   bool agree = true;
-  if (n == 19) {  // the register variant k_grad uses must give the same verdict
-    double r[19];
-    const int row = min(tid, 18);
+  double r[19];
+  const int row = min(tid, 18);
+  if (n == 19) {  // the register variants k_grad uses must give the same verdict / the same bits
 #pragma unroll
     for (int c = 0; c < 19; c++) r[c] = A[row * 19 + c];
     agree = chol_check_wave<19>(r) == ok;
+#pragma unroll
+    for (int c = 0; c < 19; c++) r[c] = A[row * 19 + c];
   }
   const double ev = min_eig_lds(A, n, scr, scr + n, scr + 2 * n, scr + 3 * n, tid, 64);
+  if (n == 19) agree = agree && min_eig_wave<19>(r, tid) == ev;
   if (tid == 0) { out[2 * blockIdx.x] = !agree ? 2.0 : ok ? 0.0 : 1.0; out[2 * blockIdx.x + 1] = ev; }
 }
 

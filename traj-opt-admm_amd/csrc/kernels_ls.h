@@ -161,6 +161,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
   double* res = sm + L.res;
   double* gspline = D.spline + (size_t)u * 3 * T;
   const int P6 = 6 * P;
+  TJ_TIC(D, K_LINESEARCH, 0);
   // ---- stage everything that is reused ----
   for (int i = tid; i < S * 36; i += LS_THREADS) sm[L.basis + i] = D.basis[i];
   for (int i = tid; i < P * 36; i += LS_THREADS) sm[L.convert + i] = D.convert[i];
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
     pref[S] = acc;
   }
   __syncthreads();
+  TJ_TIC(D, K_LINESEARCH, 1);
   const int M = pref[S];
   const bool in_lds = M <= L.plane_cap;
   if (in_lds) {
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
     }
   }
   __syncthreads();
+  TJ_TIC(D, K_LINESEARCH, 2);
   const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   double step0 = D.pow08[min(LOOP_CAP, max(D.k_obs[u], D.k_self[u]))];
@@ -202,7 +205,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
     const double pt = k < 0 ? t0 : t0 + step * t_dir;
     for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
     __syncthreads();
+    if (round == 0) TJ_TIC(D, K_LINESEARCH, 3);
     const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, M, in_lds, pref, gl);
+    if (round == 0) TJ_TIC(D, K_LINESEARCH, 4);
     if (gl == 0) { res[g] = e; res[LS_GROUPS + g] = step; }
     if (tid == 0) s_accept = -1;
     __syncthreads();
@@ -235,6 +240,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
     }
     __syncthreads();
   }
+  TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
 }
 

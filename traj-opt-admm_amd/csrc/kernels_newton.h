@@ -27,7 +27,7 @@ constexpr int GRAD_THREADS = 192;
 // dynamic LDS layout of k_grad, in doubles; npl = cap_obs + cap_self (capacity of one plane batch)
 constexpr int GRAD_MAXRES = 16;  // segments per piece staged at once ("res" of 3D.json, shipped value 8)
 __host__ __device__ inline size_t grad_lds_doubles(int npl, int res) {  // sized by the actual res: 2 blocks must fit one CU
-  return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 23 + (size_t)res * 9 + 361 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
+  return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 23 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
 }
 
 __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
@@ -41,13 +41,11 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   double* E2 = E1 + 6 * npl;
   double* bt = E2 + 6 * npl;                  // [res][9] bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
   double* H = bt + D.res * 9 * 23;            // [361]
-  double* W = H + 361;                        // [361] scratch copy for Cholesky / eigenvalue
-  double* g = W + 361;                        // [19]
+  double* g = H + 361;                        // [19]
   double* scr = g + 19;                       // [4*19] d,e,v,p
   int* segn = (int*)(scr + 4 * 19);           // [res] planes per segment, [res+1] offsets inside the batch
   int* sego = segn + GRAD_MAXRES;
-  unsigned long long* amask = (unsigned long long*)(sego + GRAD_MAXRES);  // [3] active vel/acc records, then the LLT flag
-  int* llt_ok = (int*)(amask + 3);
+  unsigned long long* amask = (unsigned long long*)(sego + GRAD_MAXRES);  // [3] active vel/acc records
 
   const int tid = threadIdx.x;
   const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
@@ -64,12 +62,14 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   const int av = vr >= 0 ? vr / 3 : 0, qv = vr >= 0 ? vr % 3 : 0;
   double Hacc = 0, gacc = 0, pacc = 0, gt = 0, ht = 0;
 
+  TJ_TIC(D, K_GRAD, 0);
   // ---- stage every segment of the piece once: hull, basis, plane counts ----
   for (int idx = tid; idx < res * 18; idx += GRAD_THREADS) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
   for (int idx = tid; idx < res * 36; idx += GRAD_THREADS) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
   if (tid < res) segn[tid] = D.ocount[u * D.S + sp * res + tid] + (D.mode == 1 ? D.scount[u * D.S + sp * res + tid] : 0);
   __syncthreads();
 
+  TJ_TIC(D, K_GRAD, 1);
   // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
   for (int sb = 0; sb < res;) {
     int se = sb, tot = 0;
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
     sb = se;
   }
 
+  TJ_TIC(D, K_GRAD, 2);
   // ---- velocity / acceleration barrier terms (Gradient_admm.h:107-129, :409-572): all res*9 records at once ----
   bool rec_act = false;
   if (tid < res * 9) {
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   }
   __syncthreads();
 
+  TJ_TIC(D, K_GRAD, 3);
   // ---- scale by lambda, add consensus + dual terms (Gradient_admm.h:132-163) ----
   const double* C = D.convert + (size_t)sp * 36;
   const int P6 = 6 * D.P;
@@ -251,29 +253,28 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   }
   __syncthreads();
 
+  TJ_TIC(D, K_GRAD, 4);
   // ---- PSD repair: only if LLT fails and lambda_min < 0 (Gradient_admm.h:38-53) ----
-  if (tid < 64) {  // wave 0 factors the block in registers, one row per lane
+  if (tid < 64) {  // wave 0 works on the block in registers, one row per lane; the other waves wait
     double r[19];
     const int row = min(tid, 18);
 #pragma unroll
     for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
-    const bool ok = chol_check_wave<19>(r);
-    if (tid == 0) *llt_ok = ok;
+    if (!chol_check_wave<19>(r)) {
+      if (tid == 0) atomicAdd(&D.ctl->llt_fail_piece, 1ull);
+#pragma unroll
+      for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
+      const double ev = min_eig_wave<19>(r, tid);
+      if (ev < 0 && tid < 19) H[tid * 19 + tid] = H[tid * 19 + tid] - ev * 1.0 + 0.01 * 1.0;
+    }
   }
   __syncthreads();
-  if (!*llt_ok) {
-    if (tid == 0) atomicAdd(&D.ctl->llt_fail_piece, 1ull);
-    __syncthreads();
-    for (int idx = tid; idx < 361; idx += GRAD_THREADS) W[idx] = H[idx];
-    __syncthreads();
-    const double ev = min_eig_lds(W, 19, scr, scr + 19, scr + 38, scr + 57, tid, GRAD_THREADS);
-    if (ev < 0 && tid < 19) H[tid * 19 + tid] = H[tid * 19 + tid] - ev * 1.0 + 0.01 * 1.0;
-    __syncthreads();
-  }
+  TJ_TIC(D, K_GRAD, 5);
   double* og = D.lg + ((size_t)u * D.P + sp) * 19;
   double* oh = D.lh + ((size_t)u * D.P + sp) * 361;
   if (tid < 19) og[tid] = g[tid];
   for (int idx = tid; idx < 361; idx += GRAD_THREADS) oh[idx] = H[idx];
+  TJ_TIC(D, K_GRAD, 6);
 }
 
 // ---- per-robot reduced Newton solve -------------------------------------------------------------
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
   // No read-modify-write, so all global loads of a pass are in flight together.
   // piece blocks first go to LDS with one streaming copy (independent loads, many in flight); the
   // scatter below then never waits on HBM/L2
+  TJ_TIC(D, K_XSOLVE, 0);
   double* lhu = scr + 6 * n;          // [P*361]
   double* lgu = lhu + D.P * 361;      // [P*19]
   {
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
     for (int i = tid; i < D.P * 19; i += XS_THREADS) lgu[i] = gg[i];
   }
   __syncthreads();
+  TJ_TIC(D, K_XSOLVE, 1);
   for (int idx = tid; idx < n * n; idx += XS_THREADS) {
     const int ra = idx / n, rb = idx % n;
     const int ga = ra == m ? -1 : ra + 6, gb = rb == m ? -1 : rb + 6;  // -1 = time
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
     g0[ra] = acc; x0[ra] = acc;
   }
   __syncthreads();
+  TJ_TIC(D, K_XSOLVE, 2);
   if (!chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS, x0)) {  // forward substitution fused: x0 <- L^-1 g0
     if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
     __syncthreads();
@@ -348,7 +352,9 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
     chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS, x0);  // like the reference, the second factorisation is not re-checked
     __syncthreads();
   }
+  TJ_TIC(D, K_XSOLVE, 3);
   chol_arrow_backsolve_lds(L, n, XS_BAND, x0, tid, XS_THREADS);
+  TJ_TIC(D, K_XSOLVE, 4);
   for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
   __syncthreads();
   for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }

@@ -114,10 +114,12 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
   for (int w = blockIdx.x; w < n; w += gridDim.x) {
+    if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
     const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
     __syncthreads();
     if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
     __syncthreads();
+    if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
     if (lane == 0) {
       double e0, e1c, e2c, dpl; bool capped; int nit = 0;
       if (plane_pair(A, B, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
         D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
       }
     }
+    if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
   }
 }
 

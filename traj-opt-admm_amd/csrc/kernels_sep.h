@@ -203,6 +203,7 @@ __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
   __shared__ double klo[49], khi[49];
   __shared__ int fa[FRONT_CAP], fb[FRONT_CAP], cand[128];
   const double* net = D.spline + (size_t)u * 3 * D.T;
+  TJ_TIC(D, K_SEP_OBS, 0);
   if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
   __syncthreads();
   kdop_intervals(D, P, 6, klo, khi);
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
     q.lo[k] = lo; q.hi[k] = hi;
   }
   __syncthreads();
+  TJ_TIC(D, K_SEP_OBS, 1);
   const double dist = D.offset + D.margin;
   double* out = D.oplanes + ((size_t)u * D.S + tr) * D.cap_obs * 4;
   int base = 0;
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
     }
     base += __popcll(mask);
   });
+  TJ_TIC(D, K_SEP_OBS, 2);
   if (lane == 0) {
     D.ocount[u * D.S + tr] = min(base, D.cap_obs);
     unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;

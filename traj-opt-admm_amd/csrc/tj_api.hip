@@ -84,8 +84,6 @@ void drop_graph(tj_ctx* c) {
 }
 
 // ---- kernels of one iteration, in stream order (also the unit of tj_profile_kernels) ----
-enum { K_BEGIN = 0, K_SEP_OBS, K_HULLINFO, K_SEP_SELF_ROWS, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_CCD_PREP,
-       K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH, K_SLACK, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_begin", "k_sep_obs", "k_hullinfo", "k_sep_self_rows", "k_sep_self_solve", "k_sep_self_compact",
                                            "k_grad", "k_xsolve", "k_ccd_prep", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
                                            "k_linesearch", "k_slack"};
@@ -259,6 +257,18 @@ void tj_default_params(tj_params* p, int mode, int uav_num, int piece_num) {
   p->device = 0; p->rank = 0; p->world = 1;
 }
 
+#ifdef TJ_PHASE_TIMING
+// development build only (make timing): wall-clock stamps (10 ns ticks) the kernels left at their
+// phase boundaries during the most recent launch; out is [K_COUNT][TJ_TIC_BLOCKS][TJ_TIC_SLOTS]
+int tj_debug_phase_times(tj_ctx* c, long long* out) {
+  if (!c || !out) return TJ_ERR_INVALID;
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(out, c->d.dbg, sizeof(long long) * K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemset(c->d.dbg, 0, sizeof(long long) * K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS));
+  return K_COUNT;
+}
+#endif
+
 const char* tj_last_error(const tj_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int tj_create(const tj_params* p, tj_ctx** out) {
@@ -296,6 +306,9 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   c->lds_xs = xsolve_lds_doubles(n) * sizeof(double);
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
   c->lds_ls = c->lsl.total * sizeof(double);
+#ifdef TJ_PHASE_TIMING
+  { int r_ = dalloc(c, &d.dbg, (size_t)K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS); if (r_) return r_; }
+#endif
   if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
   if (d.res > GRAD_MAXRES) { c->err = "res > 16 segments per piece is not supported by the gradient kernel"; return TJ_ERR_UNSUPPORTED; }
   c->lds_seq = (2 * (size_t)d.U + (size_t)d.S * d.U) * sizeof(int);
