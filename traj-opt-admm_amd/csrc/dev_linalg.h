@@ -18,12 +18,23 @@
 
 namespace tj {
 
+// Block barrier, or -- when the caller guarantees that ONE wave is all that is left of the block --
+// just an ordering point: a wave's LDS operations complete in issue order, so lanes of the same
+// wave only need the compiler (and the LDS counter) not to reorder across it.
+template <bool ONE_WAVE>
+__device__ __forceinline__ void blk_sync() {
+  if constexpr (ONE_WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+  else __syncthreads();
+}
+
+
 constexpr int CHOL_MB = 18;  // max band rows below a pivot handled by the wave kernel (bw <= 18, dense n <= 20)
 
 // In-place lower Cholesky of the row-major n x n matrix A (lower triangle is read and written).
 // Pattern: half-bandwidth bw (bw >= n-1 means dense) plus a dense last row.  Returns false as soon as
 // a pivot is <= 0 (Eigen LLT.h:320-323; NaN pivots pass, like Eigen).  If y != nullptr, y <- L^-1 y.
 // Must be called by all `nth` threads of the block (contains barriers); the first wave does the work.
+template <bool ONE_WAVE = false>
 __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth, double* y = nullptr) {
   __shared__ double s_col[CHOL_MB + 2];  // scaled pivot column: [0..mb) band rows, [CHOL_MB] arrow row
   const int last = n - 1;
@@ -44,7 +55,7 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
   // clamped indices so that no load sits behind a branch), then the scaled column is exchanged
   // through s_col, then everything is stored.
   for (int k = 0; k < n; k++) {
-    __syncthreads();
+    blk_sync<ONE_WAVE>();
     const int mb = max(0, min(min(bw, CHOL_MB), last - 1 - k));  // band rows below the pivot (arrow row excluded)
     const bool arrow = k < last;
     const int myrow = tid < mb ? k + 1 + tid : last;
@@ -65,11 +76,11 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
     const double sx = sqrt(x);
     const double v = ci / sx;
     const double yk = yk_raw / sx;
-    __syncthreads();
+    blk_sync<ONE_WAVE>();
     if (tid == 0) A[k * n + k] = sx;
     if (tid < mb) { A[myrow * n + k] = v; s_col[tid] = v; }
     else if (tid == mb && arrow) { A[last * n + k] = v; s_col[CHOL_MB] = v; }
-    __syncthreads();
+    blk_sync<ONE_WAVE>();
     if (tid < 64) {
       const double la = s_col[CHOL_MB];
       const double cm = s_col[min(tid, CHOL_MB - 1)];
@@ -89,7 +100,7 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
       }
     }
   }
-  __syncthreads();
+  blk_sync<ONE_WAVE>();
   return true;
 }
 
@@ -138,20 +149,21 @@ __device__ inline bool chol_lds(double* A, int n, int tid, int nth, double* y = 
 }
 
 // x = L^-T y in place (column oriented; row j of L is dense only for the arrow row)
+template <bool ONE_WAVE = false>
 __device__ inline void chol_arrow_backsolve_lds(const double* L, int n, int bw, double* y, int tid, int nth) {
   const int last = n - 1;
   for (int j = n - 1; j >= 0; j--) {
-    __syncthreads();
+    blk_sync<ONE_WAVE>();
     const int lo = (j == last) ? 0 : max(0, j - bw);
     const int i0 = min(lo + tid, j);                 // first element of this lane (clamped: load is unconditional)
     const double yj_raw = y[j], ljj = L[j * n + j], lji = L[j * n + i0], yi = y[i0];
     const double yj = yj_raw / ljj;                  // every thread computes it; one publishes it
-    __syncthreads();
+    blk_sync<ONE_WAVE>();
     if (tid == 0) y[j] = yj;
     if (lo + tid < j) y[i0] = yi - yj * lji;
     for (int i = lo + tid + nth; i < j; i += nth) y[i] -= yj * L[j * n + i];   // only the arrow row of large systems
   }
-  __syncthreads();
+  blk_sync<ONE_WAVE>();
 }
 
 // a / q for the Sturm recurrence: reciprocal estimate + two Newton steps (~1 ulp) instead of the

@@ -278,11 +278,12 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
 }
 
 // ---- per-robot reduced Newton solve -------------------------------------------------------------
-constexpr int XS_THREADS = 64;   // one wave per robot: every barrier is a single-wave barrier
+constexpr int XS_THREADS = 64;   // the factorisation runs in one wave per robot: its sync points are wave-local
+constexpr int XS_LOAD_THREADS = 256;  // the whole block streams the piece blocks in and assembles; waves 1..3 then retire
 constexpr int XS_BAND = 17;      // pieces couple reduced coordinates at most 17 apart
 __host__ __device__ inline size_t xsolve_lds_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16 + ((size_t)(n + 2) / 9) * 380; }
 
-__global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
+__global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   if (D.ctl->done) return;
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
@@ -307,26 +308,31 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
   {
     const double* gh = D.lh + (size_t)u * D.P * 361;
     const double* gg = D.lg + (size_t)u * D.P * 19;
-    for (int i = tid; i < D.P * 361; i += XS_THREADS) lhu[i] = gh[i];
-    for (int i = tid; i < D.P * 19; i += XS_THREADS) lgu[i] = gg[i];
+    for (int i = tid; i < D.P * 361; i += XS_LOAD_THREADS) lhu[i] = gh[i];
+    for (int i = tid; i < D.P * 19; i += XS_LOAD_THREADS) lgu[i] = gg[i];
   }
   __syncthreads();
   TJ_TIC(D, K_XSOLVE, 1);
-  for (int idx = tid; idx < n * n; idx += XS_THREADS) {
-    const int ra = idx / n, rb = idx % n;
-    const int ga = ra == m ? -1 : ra + 6, gb = rb == m ? -1 : rb + 6;  // -1 = time
-    // pieces covering a coordinate g: 9sp <= g <= 9sp+17
-    int lo = 0, hi = D.P - 1;
-    if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
-    if (gb >= 0) { lo = max(lo, (gb - 17 + 8) / 9); hi = min(hi, gb / 9); }
-    double acc = 0;
-    for (int sp = max(lo, 0); sp <= hi; sp++) {
-      const int a = ga < 0 ? 18 : ga - 9 * sp, b = gb < 0 ? 18 : gb - 9 * sp;
-      acc += lhu[(size_t)sp * 361 + a * 19 + b];
+  {
+    int ra = tid / n, rb = tid % n;  // (row, column) of entry idx, advanced incrementally
+    const int dra = XS_LOAD_THREADS / n, drb = XS_LOAD_THREADS % n;
+    for (int idx = tid; idx < n * n; idx += XS_LOAD_THREADS) {
+      const int ga = ra == m ? -1 : ra + 6, gb = rb == m ? -1 : rb + 6;  // -1 = time
+      // pieces covering a coordinate g: 9sp <= g <= 9sp+17
+      int lo = 0, hi = D.P - 1;
+      if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
+      if (gb >= 0) { lo = max(lo, (gb - 17 + 8) / 9); hi = min(hi, gb / 9); }
+      double acc = 0;
+      for (int sp = max(lo, 0); sp <= hi; sp++) {
+        const int a = ga < 0 ? 18 : ga - 9 * sp, b = gb < 0 ? 18 : gb - 9 * sp;
+        acc += lhu[(size_t)sp * 361 + a * 19 + b];
+      }
+      H[idx] = acc; L[idx] = acc;
+      ra += dra; rb += drb;
+      if (rb >= n) { rb -= n; ra++; }
     }
-    H[idx] = acc; L[idx] = acc;
   }
-  for (int ra = tid; ra < n; ra += XS_THREADS) {
+  for (int ra = tid; ra < n; ra += XS_LOAD_THREADS) {
     const int ga = ra == m ? -1 : ra + 6;
     int lo = 0, hi = D.P - 1;
     if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
@@ -335,30 +341,31 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve(Dev D) {
     g0[ra] = acc; x0[ra] = acc;
   }
   __syncthreads();
+  if (tid >= XS_THREADS) return;  // from here on the block IS wave 0 (s_barrier counts surviving waves only)
   TJ_TIC(D, K_XSOLVE, 2);
-  if (!chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS, x0)) {  // forward substitution fused: x0 <- L^-1 g0
+  if (!chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0)) {  // forward substitution fused: x0 <- L^-1 g0
     if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
-    __syncthreads();
+    blk_sync<true>();
     if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
       for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
-      __syncthreads();
+      blk_sync<true>();
       const double ev = min_eig_lds(L, n, scr, scr + n, scr + 2 * n, scr + 3 * n, tid, XS_THREADS);
       if (ev < 0) for (int i = tid; i < n; i += XS_THREADS) H[i * n + i] = H[i * n + i] - ev * 1.0 + 0.01 * 1.0;
-      __syncthreads();
+      blk_sync<true>();
     }
     for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
     for (int i = tid; i < n; i += XS_THREADS) x0[i] = g0[i];
-    __syncthreads();
-    chol_arrow_lds(L, n, XS_BAND, tid, XS_THREADS, x0);  // like the reference, the second factorisation is not re-checked
-    __syncthreads();
+    blk_sync<true>();
+    chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0);  // like the reference, the second factorisation is not re-checked
+    blk_sync<true>();
   }
   TJ_TIC(D, K_XSOLVE, 3);
-  chol_arrow_backsolve_lds(L, n, XS_BAND, x0, tid, XS_THREADS);
+  chol_arrow_backsolve_lds<true>(L, n, XS_BAND, x0, tid, XS_THREADS);
   TJ_TIC(D, K_XSOLVE, 4);
   for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
-  __syncthreads();
+  blk_sync<true>();
   for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
-  __syncthreads();
+  blk_sync<true>();
   double* dir = D.dirp(u);
   for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
     const int row = idx % T, a = idx / T;

@@ -101,7 +101,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0) {
     case K_SEP_SELF_SOLVE: if (multi) hipLaunchKernelGGL(k_sep_self_solve, dim3(std::min(d.cap_work, 4096)), dim3(64), 0, s, d); return multi;
     case K_SEP_SELF_COMPACT: if (multi) hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return multi;
     case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
-    case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_THREADS), c->lds_xs, s, d); return true;
+    case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
     case K_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
     case K_CCD_OBS: hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_PAIRS: if (multi) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return multi;
