@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 os.environ["TRAJADMM_LIB"] = os.path.join(ROOT, "traj-opt-admm_amd", "libtrajadmm_timing.so")
 
 PHASES = {
+    "k_begin": ["hull", "planes", "velacc", "reduce", "consensus"],
     "k_grad": ["stage", "planes", "vel/acc", "consensus", "psd", "store"],
     "k_xsolve": ["load", "assemble", "chol+fwd", "backsolve"],
     "k_linesearch": ["stage", "planes->lds", "setup", "E round0", "later rounds"],

@@ -6,7 +6,7 @@
 // The reference evaluates E(x), then E(x + s d) for s = s0, 0.8 s0, 0.8^2 s0, ... one after the other
 // and stops at the first s that satisfies the Armijo test.  Each evaluation is tiny (a few hundred
 // barrier terms) but strictly sequential -- on a GPU that is a chain of ~10 us latencies.  Here the
-// 256-thread workgroup is split into 8 groups of 32 lanes and each group evaluates ONE candidate:
+// 512-thread workgroup is split into 8 groups of 64 lanes (one wave each) and each evaluates ONE candidate:
 // round 0 covers E(x) and the first 7 trial steps, later rounds 8 steps each.  The accepted step is
 // the first one in the reference's order that passes the test, so the result is the one the
 // sequential loop would produce; E(.) is a pure function of its inputs here (fixed reduction tree
@@ -15,15 +15,16 @@
 // is staged in LDS once per launch.
 #pragma once
 #include "dev_common.h"
+#include "dev_linalg.h"
 
 namespace tj {
 
-constexpr int LS_THREADS = 256;
+constexpr int LS_THREADS = 512;
 constexpr int LS_GROUPS = 8;
-constexpr int LS_GSIZE = 32;
+constexpr int LS_GSIZE = 64;   // one wave per candidate: group-private LDS needs only wave-local ordering
 
 struct LsLayout {  // offsets in doubles into dynamic LDS
-  size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, res, planes, pltr, total;
+  size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, gcons, res, planes, pltr, total;
   int plane_cap;
 };
 __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_budget_bytes) {
@@ -39,6 +40,7 @@ __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_bu
   L.dir = o; o += 3 * (size_t)T;
   L.gnet = o; o += (size_t)LS_GROUPS * 3 * T;
   L.ghull = o; o += (size_t)LS_GROUPS * S * 18;
+  L.gcons = o; o += (size_t)LS_GROUPS * 24 * P;   // per group: delta[18P], then 6 consensus/dual terms per piece
   L.res = o; o += 2 * LS_GROUPS + 8;
   L.planes = o;
   const size_t used = o * 8;
@@ -51,13 +53,14 @@ __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_bu
   return L;
 }
 
-// E(net, pt) for robot u, evaluated by ONE group of 32 lanes (gl = lane within the group).
+// E(net, pt) for robot u, evaluated by ONE group = one wave (gl = lane within the group).
 // Returns the value in every lane of the group.  Must be called by the whole workgroup (contains a
-// block barrier); width-32 shuffles keep the two halves of a wave independent.
+// block barrier).
 __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, const LsLayout& L, const double* net, double pt, double* hulls,
-                                        int M, bool planes_in_lds, const int* pref, int gl) {
+                                        double* cons, int M, bool planes_in_lds, const int* pref, int gl) {
   const int S = D.S, T = D.T;
   const double* basis = sm + L.basis;
+  TJ_TIC(D, K_BEGIN, 0);
   for (int idx = gl; idx < S * 18; idx += LS_GSIZE) {
     const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
     const double* B = basis + (size_t)tr * 36 + j * 6;
@@ -68,6 +71,7 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
     hulls[idx] = acc;
   }
   __syncthreads();  // all 8 groups run this function in lock step (uniform trip counts)
+  TJ_TIC(D, K_BEGIN, 1);
   const double m = D.margin;
   double part = 0, partb = 0;
   int bad = 0;
@@ -94,56 +98,75 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
       else if (d < m) part += barrier(w, d, m);
     }
   }
-  // velocity / acceleration barriers (Energy_admm.h:98-170)
-  for (int it = gl; it < S * 9; it += LS_GSIZE) {
-    const int tr = it / 9, b = it % 9;
+  TJ_TIC(D, K_BEGIN, 2);
+  // velocity / acceleration barriers (Energy_admm.h:98-170); two loops so that a wave never runs
+  // both formulas
+  for (int it = gl; it < S * 5; it += LS_GSIZE) {
+    const int tr = it / 5, b = it % 5;
     const double w = seg_weight(D, tr);
     const double* Pp = hulls + tr * 18;
-    double d;
-    if (b < 5) {
-      const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
-      d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
-    } else {
-      const int j = b - 5;
-      const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
-                   az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
-      d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
-    }
+    const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
+    const double d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
     if (d <= 0) bad = 1;
     else if (d < m) partb += barrier(w, d, m);
   }
-  // fixed butterfly inside the 32-lane group
+  for (int it = gl; it < S * 4; it += LS_GSIZE) {
+    const int tr = it / 4, j = it % 4;
+    const double w = seg_weight(D, tr);
+    const double* Pp = hulls + tr * 18;
+    const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
+                 az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
+    const double d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
+    if (d <= 0) bad = 1;
+    else if (d < m) partb += barrier(w, d, m);
+  }
+  TJ_TIC(D, K_BEGIN, 3);
+  // fixed butterfly inside the group
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
+  for (int off = LS_GSIZE / 2; off > 0; off >>= 1) {
     part += __shfl_xor(part, off, LS_GSIZE);
     partb += __shfl_xor(partb, off, LS_GSIZE);
     bad |= __shfl_xor(bad, off, LS_GSIZE);
   }
+  TJ_TIC(D, K_BEGIN, 4);
   double e = D.lambda * part + D.lambda * partb;
-  // augmented-Lagrangian terms in the reference's statement order (Energy_admm.h:24-41); every lane
-  // of the group computes them redundantly from LDS (no divergence, no broadcast needed)
+  // augmented-Lagrangian terms (Energy_admm.h:24-41).  The 18P entries of C x - z are spread over
+  // the lanes, lane sp then forms the six terms of piece sp (Eigen's reduction order inside each),
+  // and every lane adds the 6P terms in the reference's statement order.  cons is private to this
+  // group = this wave, so ordering points suffice.
   const int P6 = 6 * D.P;
   const double* cv = sm + L.convert; const double* sl = sm + L.slack; const double* la = sm + L.lambda;
-  for (int sp = 0; sp < D.P; sp++) {
-    const double* C = cv + (size_t)sp * 36;
-    double delta[18], prod[18];
-    for (int a = 0; a < 3; a++)
-      for (int j = 0; j < 6; j++) {
-        double acc = 0;
-        for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + T * a];
-        delta[j + 6 * a] = acc - sl[sp * 6 + j + P6 * a];
-      }
-    for (int i = 0; i < 18; i++) prod[i] = delta[i] * delta[i];
-    e += D.mu / 2.0 * esum(prod, 18);
+  double* delta = cons; double* terms = cons + 18 * D.P;
+  for (int it = gl; it < 18 * D.P; it += LS_GSIZE) {
+    const int sp = it / 18, r = it % 18, a = r / 6, j = r % 6;
+    const double* C = cv + (size_t)sp * 36 + j * 6;
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc += C[k] * net[sp * 3 + k + T * a];
+    delta[it] = acc - sl[sp * 6 + j + P6 * a];
+  }
+  blk_sync<true>();
+  for (int sp = gl; sp < D.P; sp += LS_GSIZE) {
+    const double* dl = delta + 18 * sp;
+    double prod[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) prod[i] = dl[i] * dl[i];
+    double* t = terms + 6 * sp;
+    t[0] = D.mu / 2.0 * esum(prod, 18);
     const double dt = pt - sm[L.tsl + sp];
-    e += D.mu / 2.0 * (dt * dt);
+    t[1] = D.mu / 2.0 * (dt * dt);
+#pragma unroll
     for (int a = 0; a < 3; a++) {
       double pr[6];
-      for (int j = 0; j < 6; j++) pr[j] = la[sp * 6 + j + P6 * a] * delta[j + 6 * a];
-      e += esum(pr, 6);
+#pragma unroll
+      for (int j = 0; j < 6; j++) pr[j] = la[sp * 6 + j + P6 * a] * dl[j + 6 * a];
+      t[2 + a] = esum(pr, 6);
     }
-    e += sm[L.tla + sp] * (pt - sm[L.tsl + sp]);
+    t[5] = sm[L.tla + sp] * (pt - sm[L.tsl + sp]);
   }
+  blk_sync<true>();
+  for (int i = 0; i < 6 * D.P; i++) e += terms[i];
+  TJ_TIC(D, K_BEGIN, 5);
   if (bad) e = INFINITY;
   return e;
 }
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
     for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
     __syncthreads();
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 3);
-    const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, M, in_lds, pref, gl);
+    const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl);
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 4);
     if (gl == 0) { res[g] = e; res[LS_GROUPS + g] = step; }
     if (tid == 0) s_accept = -1;
