@@ -56,6 +56,12 @@ def kernel_bytes(st, slv, iters):
         "k_linesearch": U * (S * 36 * 8 + 2 * 3 * T * 8 + P * (36 + 2 * 18 + 2) * 8) + planes * 32 + U * 3 * T * 8,
         "k_slack": U * P * ((18 + 36) * 8 + 2 * 18 * 8 * 2 + 4 * 8),
     }
+    n = 9 * P - 2
+    b["k_xsolve_c2"] = U * (n * n + 2 * n + 4) * 8 + U * (3 * T + 4) * 8                  # coupled mode: factor + rhs in, direction out
+    b["k_ls_coupled"] = b["k_linesearch"] + U * 8 * 8                                       # per evaluation round (first round; later rounds exit early)
+    b["k_ls_commit"] = U * (2 * 3 * T * 8 + 3 * T * 8) + 4 * U * 8 * 8
+    if st is not None and slv.mode == 2:
+        b["k_xsolve"] = U * P * (19 + 361) * 8 + U * (n * n + 2 * n + 4) * 8               # writes its factor for k_xsolve_c2
     return b
 
 
@@ -82,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "H8"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--coupled", action="store_true", help='time the coupled mode ("decouple":0, one shared piece_time) instead of the shipped decoupled mode; single GPU only')
     ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
     args = ap.parse_args()
 
@@ -89,6 +96,8 @@ def main():
     sc = pkg.scenes
     scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d, "H8": lambda: sc.hard(8, 20000)}[args.scene]()
 
+    if args.coupled:
+        scene = dict(scene); scene["mode"] = 2; scene["name"] += "-coupled"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,7 +176,7 @@ def main():
                "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['cloud'].shape[0]} obstacle points, "
-                                      f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, decoupled mode (3D.json defaults)",
+                                      f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}",
                           "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else "1 GPU, whole iteration in one hipGraph",
                           "iters_timed_from": "initial trajectory"}}
     if world == 1:

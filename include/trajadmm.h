@@ -31,7 +31,10 @@ enum {
 };
 
 enum { TJ_MODE_SINGLE = 0,      /* Optimization3D_admm::optimization            (Optimization3D_admm.h:29-33)  */
-       TJ_MODE_MULTI_DECOUPLE = 1 /* Optimization3D_multi::optimization_decouple (Optimization3D_multi.h:29-33) */ };
+       TJ_MODE_MULTI_DECOUPLE = 1, /* Optimization3D_multi::optimization_decouple (Optimization3D_multi.h:29-33) */
+       TJ_MODE_MULTI_COUPLED = 2   /* Optimization3D_multi::optimization ("decouple":0, one piece_time shared by all robots;
+                                      Optimization3D_multi.h:120-174, update_spline :508-639, Step::couple_self_step Step.h:112-182);
+                                      tj_get_state returns the shared piece_time for every robot */ };
 
 /* Replaces the parameter globals of CCDUtils.cpp:5-44 that the mains fill from Config_File/3D.json
  * (Main/admmPathPlanning3D.cpp:368-397, Main/multiPathPlanning3D.cpp:478-511) and hard-code
@@ -59,6 +62,12 @@ typedef struct tj_params {
 
 /* Fills *p with the shipped 3D.json values ("Config File/3D.json") and the mode's ks/kt. */
 void tj_default_params(tj_params* p, int mode, int uav_num, int piece_num);
+
+/* The constant tables the mains precompute into globals (init_variable, Main/admmPathPlanning3D.cpp:249-353):
+ * convert[P][36] = convert_list (CCDUtils.h:137-170), mdyn[36] = M_dynamic (:172-227), basis[P*res][36] = the
+ * subdivide_tree bases blossom(k/res,(k+1)/res) * convert_list[i] (:229-315), kdop[49][3] = normalised k-DOP axes
+ * (CCDUtils.cpp:56-119).  Row-major; any pointer may be NULL.  Host only -- needs no context and no GPU. */
+int tj_host_tables(int piece_num, int res, double* convert, double* mdyn, double* basis, double* kdop);
 
 int tj_create(const tj_params* p, tj_ctx** out);
 void tj_destroy(tj_ctx* c);

@@ -143,6 +143,12 @@ class Engine:
     def stage_slack(self):
         self._f("stage_slack")()
 
+    def stage_update_spline(self):
+        """coupled mode (scene mode 2): Optimization3D_multi::update_spline as one stage -> (gnorm, wolfe)"""
+        w = C.c_double()
+        g = self._f("stage_update_spline", C.c_double)(C.byref(w))
+        return g, w.value
+
     def spline_energy(self, u):
         return self._f("spline_energy", C.c_double)(C.c_int(u))
 

@@ -10,6 +10,7 @@
 //
 //   Optimization3D_admm::optimization           (Optimization3D_admm.h:29)
 //   Optimization3D_multi::optimization_decouple (Optimization3D_multi.h:29)
+//   Optimization3D_multi::optimization          (Optimization3D_multi.h:120, coupled: "decouple":0)
 //
 // plus the public static stages of those classes so that intermediates can be
 // dumped for golden fixtures (tests/golden/, made by tests/golden/make_golden.py).
@@ -34,7 +35,7 @@ struct NullBuf : std::streambuf { int overflow(int c) override { return c; } };
 NullBuf g_nullbuf;
 std::streambuf* g_old_cout = nullptr;
 
-int g_mode = 0;  // 0 = single (Optimization3D_admm), 1 = multi decouple
+int g_mode = 0;  // 0 = single (Optimization3D_admm), 1 = multi decouple, 2 = multi coupled (shared piece_time)
 BVH* g_bvh = nullptr;
 std::vector<Eigen::RowVector3d> g_vertex_list;
 std::vector<Data> g_spline, g_p_slack, g_p_lambda;
@@ -194,8 +195,12 @@ void ref_set_state(int u, const double* spline, const double* p_slack, const dou
 double ref_iterate() {
   if (g_mode == 0) {
     Optimization3D_admm::optimization(g_spline[0], g_piece_time[0], g_p_slack[0], g_t_slack[0], g_p_lambda[0], g_t_lambda[0], g_vertex_list, *g_bvh);
-  } else {
+  } else if (g_mode == 1) {
     Optimization3D_multi::optimization_decouple(g_spline, g_piece_time, g_p_slack, g_t_slack, g_p_lambda, g_t_lambda, g_vertex_list, *g_bvh);
+  } else {  // Main/multiPathPlanning3D.cpp:674-677: one piece_time shared by all robots
+    double pt = g_piece_time[0];
+    Optimization3D_multi::optimization(g_spline, pt, g_p_slack, g_t_slack, g_p_lambda, g_t_lambda, g_vertex_list, *g_bvh);
+    for (double& v : g_piece_time) v = pt;
   }
   iter++;
   return gnorm;
@@ -217,7 +222,7 @@ int ref_stage_planes() {
     if (g_mode == 0) Optimization3D_admm::separate_plane(g_spline[i], g_vertex_list, g_c_lists[i], g_d_lists[i], *g_bvh);
     else Optimization3D_multi::separate_plane(g_spline[i], g_vertex_list, g_c_lists[i], g_d_lists[i], *g_bvh);
   }
-  if (g_mode == 1) Optimization3D_multi::separate_self(g_spline, g_c_lists, g_d_lists, *g_bvh);
+  if (g_mode >= 1) Optimization3D_multi::separate_self(g_spline, g_c_lists, g_d_lists, *g_bvh);
   int total = 0;
   for (int i = 0; i < U; i++) for (auto& l : g_d_lists[i]) total += l.size();
   return total;
@@ -321,6 +326,16 @@ void ref_stage_slack() {
     if (g_mode == 0) Optimization3D_admm::update_slack_lambda(g_spline[i], g_piece_time[i], g_p_slack[i], g_t_slack[i], g_p_lambda[i], g_t_lambda[i]);
     else Optimization3D_multi::update_slack_lambda(g_spline[i], g_piece_time[i], g_p_slack[i], g_t_slack[i], g_p_lambda[i], g_t_lambda[i]);
   }
+}
+// Coupled mode ("decouple":0): Newton system, CCD clamps and the Armijo search on the summed energy are ONE
+// reference function (Optimization3D_multi::update_spline, Optimization3D_multi.h:508-639).  Uses the planes of
+// ref_stage_planes / ref_set_planes.  Returns gnorm (= |G| / uav_num, :580); *wolfe_out = global wolfe (:558).
+double ref_stage_update_spline(double* wolfe_out) {
+  double pt = g_piece_time[0];
+  Optimization3D_multi::update_spline(g_spline, pt, g_p_slack, g_t_slack, g_p_lambda, g_t_lambda, g_c_lists, g_d_lists, g_vertex_list, *g_bvh);
+  for (double& v : g_piece_time) v = pt;
+  if (wolfe_out) *wolfe_out = wolfe;
+  return gnorm;
 }
 double ref_spline_energy(int u) {
   return Energy_admm::spline_energy(g_spline[u], g_piece_time[u], g_p_slack[u], g_t_slack[u], g_p_lambda[u], g_t_lambda[u], g_c_lists[u], g_d_lists[u]);

@@ -64,6 +64,10 @@ def rel(a, b):
 
 
 def scene_by_name(scenes, name):
+    if name.endswith("_coupled"):  # the same scene with "decouple":0 (one shared piece_time, mode 2)
+        sc = dict(scene_by_name(scenes, name[:-len("_coupled")]))
+        sc["mode"] = 2
+        return sc
     return {"tiny_multi": lambda: scenes.tiny(1), "tiny_single": lambda: scenes.tiny(0, n_points=3000), "hard": scenes.hard,
             "scn_a": scenes.scn_a, "scn_b": scenes.scn_b, "scn_c": scenes.scn_c}[name]()
 

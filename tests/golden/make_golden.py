@@ -150,6 +150,36 @@ def make_stages(name, scene, iters, keep):
     np.savez_compressed(os.path.join(HERE, f"stages_{name}.npz"), **rec)
 
 
+def coupled(scene):
+    """the same scene run with "decouple":0 (Optimization3D_multi::optimization, one shared piece_time)"""
+    sc = dict(scene); sc["mode"] = 2; sc["name"] = scene["name"] + "-coupled"
+    return sc
+
+
+def make_stages_coupled(name, scene, iters, keep):
+    """Coupled mode: planes, then update_spline (one reference function: arrowhead Newton system, CCD clamps,
+    Armijo on the summed energy), then the slack/dual update."""
+    e = Engine("ref", scene)
+    rec = {"cloud_sum": np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), "waypoints": scene["waypoints"]}
+    for it in range(iters):
+        pre = e.get_state()
+        counts, planes = e.stage_planes()
+        gnorm, wolfe = e.stage_update_spline()
+        mid = e.get_state()
+        e.stage_slack()
+        post = e.get_state()
+        e.iters += 1
+        if it in keep:
+            k = f"it{it}_"
+            for n_, v in pre.items(): rec[k + "pre_" + n_] = v
+            rec[k + "counts"] = counts; rec[k + "planes"] = canon(counts, planes)
+            rec[k + "gnorm"] = np.array(gnorm); rec[k + "wolfe"] = np.array(wolfe)
+            rec[k + "mid_spline"] = mid["spline"]; rec[k + "mid_piece_time"] = mid["piece_time"]
+            for n_, v in post.items(): rec[k + "post_" + n_] = v
+    rec["kept"] = np.array(sorted(keep))
+    np.savez_compressed(os.path.join(HERE, f"stages_{name}.npz"), **rec)
+
+
 def make_e2e(name, scene, max_iter=200, stop=1e-2):
     e = Engine("ref", scene)
     gn = []
@@ -163,6 +193,10 @@ def make_e2e(name, scene, max_iter=200, stop=1e-2):
 
 
 if __name__ == "__main__":
+    if "--coupled-only" in sys.argv:
+        make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
+        make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
+        sys.exit(0)
     make_tables()
     make_prims()
     make_stages("tiny_multi", pkg_scenes.tiny(1), 8, {0, 1, 4, 7})
@@ -170,4 +204,6 @@ if __name__ == "__main__":
     make_stages("hard", pkg_scenes.hard(), 12, {0, 3, 4, 5, 8, 11})
     make_e2e("scn_a", pkg_scenes.scn_a())
     make_e2e("scn_b", pkg_scenes.scn_b())
+    make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
+    make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
     print("golden vectors written to", HERE)

@@ -107,3 +107,28 @@ def test_cli_usage_and_config_errors(name, tmp_path):
     (tmp_path / "Config_File" / "3D.json").write_text(shipped)
     r = subprocess.run([exe, "x.obj"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "optimal_plane" in r.stderr           # unsupported branch is rejected, not ignored
+
+
+@pytest.mark.parametrize("P", [2, 5])
+def test_host_tables_bit_exact_vs_reference(pkg, P):
+    """the library's own host precompute (tj_host_tables, no GPU needed) against the tables the unmodified
+    reference produced: C2 junction maps, jerk Gram matrix, blossom subdivision bases, 49 k-DOP axes"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"tables_P{P}.npz"))
+    conv, M, basis, kdop = pkg.host_tables(P, 8)
+    assert np.array_equal(conv, g["convert"])
+    assert np.array_equal(M, g["mdyn"])
+    assert np.array_equal(basis, g["basis"])
+    assert np.array_equal(kdop, g["kdop"])
+
+
+def test_coupled_mode_params(pkg):
+    lib = C.CDLL(pkg.LIB_PATH)
+    lib.tj_last_error.restype = C.c_char_p
+    p = pkg.TjParams()
+    lib.tj_default_params(C.byref(p), 2, 8, 5)        # TJ_MODE_MULTI_COUPLED keeps the multi main's ks
+    assert p.mode == 2 and p.ks == 1e-3
+    p.world, p.rank = 2, 0                            # coupled mode is single-GPU: rejected before any device work
+    ctx = C.c_void_p()
+    assert lib.tj_create(C.byref(p), C.byref(ctx)) == -5
+    assert b"COUPLED" in lib.tj_last_error(ctx)
+    lib.tj_destroy(ctx)

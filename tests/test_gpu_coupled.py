@@ -1,0 +1,81 @@
+"""GPU (-m gpu): coupled mode ("decouple":0, TJ_MODE_MULTI_COUPLED) through the C ABI, against golden vectors of the
+unmodified reference (Optimization3D_multi::optimization, Optimization3D_multi.h:120-174 / update_spline :508-639 /
+Step::couple_self_step Step.h:112-182) and against the CPU oracle.  Tolerances as in test_gpu_parity.py: planes 1e-13,
+teacher-forced stages 1e-9 abs on control points, slack/dual 1e-12 rel, end-to-end 1e-8 rel (BASELINE.json)."""
+import numpy as np
+import pytest
+
+from conftest import canon, check_scene_matches_fixture, gold, maxdiff, rel, scene_by_name
+
+pytestmark = pytest.mark.gpu
+STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
+
+
+def test_coupled_stages_teacher_forced_vs_reference(pkg, scenes):
+    g = gold("stages_hard_coupled.npz")
+    scene = scene_by_name(scenes, "hard_coupled")
+    check_scene_matches_fixture(scene, g)
+    s = pkg.Solver(scene, stop=0.0)
+    for it in g["kept"]:
+        k = f"it{it}_"
+        s.set_state({n: g[k + "pre_" + n] for n in STATE})
+        counts, planes = s.stage_planes()
+        assert np.array_equal(counts, g[k + "counts"]), f"it{it}: plane counts differ"
+        assert maxdiff(canon(counts, planes), g[k + "planes"]) <= 1e-13
+        gnorm, wolfe = s.stage_update_spline()
+        assert abs(gnorm - g[k + "gnorm"]) <= 1e-11 * max(1.0, float(g[k + "gnorm"]))
+        assert abs(wolfe - g[k + "wolfe"]) <= 1e-9 * max(1.0, abs(float(g[k + "wolfe"])))
+        st = s.get_state()
+        assert maxdiff(st["spline"], g[k + "mid_spline"]) <= 1e-9
+        assert maxdiff(st["piece_time"], g[k + "mid_piece_time"]) <= 1e-9      # same CCD exponent, same Armijo halvings
+        s.set_state({n: (g[k + "mid_" + n] if n in ("spline", "piece_time") else g[k + "pre_" + n]) for n in STATE})
+        s.stage_slack()
+        st = s.get_state()
+        for n in STATE:
+            assert maxdiff(st[n], g[k + "post_" + n]) <= 1e-12 * max(1.0, np.abs(g[k + "post_" + n]).max()), (it, n)
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["hard_coupled", "scn_b_coupled"])
+def test_coupled_iterations_vs_oracle_live(pkg, scenes, name):
+    """every iteration of a longer run, each started from the oracle's state, through the hipGraph path"""
+    from oracle.pyoracle import Engine
+    scene = scene_by_name(scenes, name)
+    o = Engine("port", scene)
+    s = pkg.Solver(scene, stop=0.0)
+    for it in range(14):
+        s.set_state(o.get_state())
+        go = o.iterate()
+        gg, _, _ = s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        assert abs(gg - go) <= 1e-10 * max(1.0, go), (it, gg, go)
+        for n in STATE:
+            tol = 1e-9 if n in ("spline", "piece_time") else 1e-9 * max(1.0, np.abs(b[n]).max())
+            assert maxdiff(a[n], b[n]) <= tol, (it, n, maxdiff(a[n], b[n]))
+        assert np.all(a["piece_time"] == a["piece_time"][0])
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+def test_coupled_end_to_end_vs_reference(pkg, scenes):
+    """free-running with the device-side stop test: same iteration count as the reference, final control points and
+    shared piece_time within fp64 rel-tol 1e-8"""
+    g = gold("e2e_scn_b_coupled.npz")
+    scene = scene_by_name(scenes, "scn_b_coupled")
+    check_scene_matches_fixture(scene, g)
+    s = pkg.Solver(scene)
+    gnorm, iters, conv = s.iterate(200)
+    assert conv and iters == int(g["iters"])
+    st = s.get_state()
+    assert rel(st["spline"], g["final_spline"]) <= 1e-8
+    assert rel(st["piece_time"], g["final_piece_time"]) <= 1e-8
+    assert abs(gnorm - g["gnorm_hist"][-1]) <= 1e-3 * g["gnorm_hist"][-1]
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+def test_coupled_is_single_gpu_only(pkg, scenes):
+    scene = scene_by_name(scenes, "hard_coupled")
+    with pytest.raises(pkg.TrajAdmmError):
+        pkg.Solver(scene, rank=0, world=2)

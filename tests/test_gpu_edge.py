@@ -125,3 +125,49 @@ def test_cli_drop_in(pkg, scenes, tmp_path, multi):
     cli_spline = np.array([[float(x) for x in l.split()] for l in lines if len(l.split()) == 3 and l[0] not in "u"]).reshape(scene["U"], T, 3)
     lib_spline = s.get_state()["spline"].transpose(0, 2, 1)
     assert rel(cli_spline, lib_spline) <= (1e-6 if multi else 1e-9)       # x0.2 / x5 file round trip is not bit exact
+
+
+def test_cli_coupled_mode_and_log_data(pkg, scenes, tmp_path):
+    """multiPathPlanning3D with "decouple":0 (Main/multiPathPlanning3D.cpp:674-677) and the log_data lines
+    ("ccd time:", "ccd len:", Main/multiPathPlanning3D.cpp:33-77), checked against an independent numpy
+    restatement of the sampling loop on the dumped control points"""
+    from math import comb
+    scene = scenes.scn_b()
+    mesh = "y.obj"
+    scenes.write_reference_files(scene, str(tmp_path), mesh)
+    os.makedirs(tmp_path / "Config_File", exist_ok=True)
+    (tmp_path / "Config_File" / "3D.json").write_text(
+        '{"auto":0,"init":1,"gui":0,"optimal_plane":0,"decouple":0,"res":8,"vel_limit":2,"acc_limit":2,"lambda":1e1,'
+        '"epsilon":1e-1,"margin":1e-1,"offset":1e-1,"stop":1e-2,"exit":0,"init_ob":1,"mu":0.1}')
+    exe = os.path.join(ROOT, "traj-opt-admm_amd", "multiPathPlanning3D")
+    r = subprocess.run([exe, mesh, "--dump-state", "state.txt", "--sample-traj", "traj.txt", "--max-iter", "300"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    iters = int(open(tmp_path / "result" / (mesh + "_result_file_multi.txt")).read().split("\n")[0].split()[1])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_scn_b_coupled.npz"))
+    assert abs(iters - int(g["iters"])) <= 1                                # the reference's coupled run of the same scene
+    lines = open(tmp_path / "state.txt").read().strip().split("\n")
+    U, P = scene["U"], scene["P"]
+    T = 3 * P + 3
+    pts = [float(l.split()[3]) for l in lines if l.startswith("uav ")]
+    assert len(set(pts)) == 1                                              # one piece_time for every robot
+    assert abs(pts[0] - float(g["final_piece_time"][0])) <= 1e-5 * pts[0]   # x0.2 / x5 file round trip is not bit exact
+    spl = np.array([[float(x) for x in l.split()] for l in lines if len(l.split()) == 3 and l[0] not in "u"]).reshape(U, T, 3)
+    conv, _, _, _ = pkg.host_tables(P, 8)
+    times = [float(l.split(":")[1]) for l in r.stdout.split("\n") if l.startswith("ccd time:")]
+    lens = [float(l.split(":")[1]) for l in r.stdout.split("\n") if l.startswith("ccd len:")]
+    assert len(times) == U and len(lens) == U
+    smp = np.array([[float(x) for x in l.split()] for l in open(tmp_path / "traj.txt").read().strip().split("\n")])
+    for u in range(U):
+        assert abs(times[u] - P * pts[0]) <= 1e-5 * P * pts[0]                             # stdout prints 6 significant digits
+        coeff = np.stack([conv[i] @ spl[u, 3 * i:3 * i + 6] for i in range(P)])      # [P,6,3] Bezier points of each piece
+        t, out = 0.0, []
+        while t < P:
+            i = int(np.floor(t)); ct = t - i
+            w = np.array([comb(5, j) * ct ** j * (1 - ct) ** (5 - j) for j in range(6)])
+            out.append(w @ coeff[i]); t += 0.1 / pts[0]
+        out = np.array(out)
+        want = np.linalg.norm(np.diff(out, axis=0), axis=1).sum()
+        assert abs(lens[u] - want) <= 1e-6 * want                                      # stdout prints 6 significant digits
+        mine = smp[smp[:, 0] == u][:, 2:]
+        assert mine.shape == out.shape and np.max(np.abs(mine - out)) <= 1e-12

@@ -126,3 +126,50 @@ def test_end_to_end_vs_reference(scenes, name):
     assert rel(st["piece_time"], g["final_piece_time"]) <= 1e-8
     # the residual gradient norm is a difference of nearly cancelling terms: compare loosely
     assert abs(gn[-1] - g["gnorm_hist"][-1]) <= 1e-3 * g["gnorm_hist"][-1]
+
+
+# ---- coupled mode ("decouple":0): Optimization3D_multi::optimization, one shared piece_time ----------------
+STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
+
+
+def test_coupled_stages_teacher_forced(scenes):
+    """planes -> update_spline (arrowhead Newton system, couple_self_step, Armijo on the summed energy) ->
+    slack/dual, each started from the reference's own state"""
+    g = gold("stages_hard_coupled.npz")
+    scene = scene_by_name(scenes, "hard_coupled")
+    check_scene_matches_fixture(scene, g)
+    e = Engine("port", scene)
+    for it in g["kept"]:
+        k = f"it{it}_"
+        e.set_state({n: g[k + "pre_" + n] for n in STATE})
+        counts, planes = e.stage_planes()
+        assert np.array_equal(counts, g[k + "counts"])
+        assert np.array_equal(canon(counts, planes), g[k + "planes"])
+        gnorm, wolfe = e.stage_update_spline()
+        assert abs(gnorm - g[k + "gnorm"]) <= 1e-11 * max(1.0, float(g[k + "gnorm"]))
+        assert abs(wolfe - g[k + "wolfe"]) <= 1e-9 * max(1.0, abs(float(g[k + "wolfe"])))
+        st = e.get_state()
+        assert maxdiff(st["spline"], g[k + "mid_spline"]) <= 1e-10
+        assert maxdiff(st["piece_time"], g[k + "mid_piece_time"]) <= 1e-10
+        e.set_state({n: (g[k + "mid_" + n] if n in ("spline", "piece_time") else g[k + "pre_" + n]) for n in STATE})
+        e.stage_slack()
+        st = e.get_state()
+        for n in st:
+            assert maxdiff(st[n], g[k + "post_" + n]) <= 1e-12 * max(1.0, np.abs(g[k + "post_" + n]).max()), (it, n)
+
+
+def test_coupled_end_to_end_vs_reference(scenes):
+    g = gold("e2e_scn_b_coupled.npz")
+    scene = scene_by_name(scenes, "scn_b_coupled")
+    check_scene_matches_fixture(scene, g)
+    e = Engine("port", scene)
+    gn = []
+    for it in range(200):
+        gn.append(e.iterate())
+        if it > 1 and gn[-1] < 1e-2:
+            break
+    assert len(gn) == int(g["iters"])
+    st = e.get_state()
+    assert rel(st["spline"], g["final_spline"]) <= 1e-8
+    assert rel(st["piece_time"], g["final_piece_time"]) <= 1e-8
+    assert np.all(st["piece_time"] == st["piece_time"][0])   # one piece_time for every robot

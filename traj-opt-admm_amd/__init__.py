@@ -25,7 +25,7 @@ EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
     "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_set_stream", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
+    "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
 ]
 
 STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
@@ -67,6 +67,17 @@ def load_library():
 
 def _d(a):
     return a.ctypes.data_as(_dp)
+
+
+def host_tables(piece_num, res=8):
+    """(convert[P,6,6], mdyn[6,6], basis[P*res,6,6], kdop[49,3]) as the library precomputes them on the host
+    (tj_host_tables; needs no GPU).  Row-major [row, col]."""
+    lib = load_library()
+    conv = np.zeros((piece_num, 6, 6)); M = np.zeros((6, 6)); basis = np.zeros((piece_num * res, 6, 6)); kd = np.zeros((49, 3))
+    rc = lib.tj_host_tables(C.c_int(piece_num), C.c_int(res), _d(conv), _d(M), _d(basis), _d(kd))
+    if rc < 0:
+        raise TrajAdmmError(f"tj_host_tables failed ({rc})")
+    return conv, M, basis, kd
 
 
 def _i(a):
@@ -237,6 +248,15 @@ class Solver:
     def stage_slack(self):
         self.run_stage("slack")
         self.run_stage("end")
+
+    def stage_update_spline(self):
+        """coupled mode (scene mode 2): Optimization3D_multi::update_spline as one stage -- arrowhead Newton
+        system, CCD clamps, Armijo search on the summed energy, commit.  Returns (gnorm, wolfe)."""
+        for st in ("grad", "xsolve", "ccd_prep", "ccd_obs", "ccd_self", "linesearch"):
+            self.run_stage(st)
+        t, w, g = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.tj_get_direction(self._ctx, 0, None, C.byref(t), C.byref(w), C.byref(g)))
+        return g.value, w.value
 
     # ---- known-answer hooks (device primitives on caller batches) -------------------------------
     def kat_gjk(self, a, b):

@@ -6,6 +6,7 @@
 //   init/<m>_init_file.txt       way points (admmPathPlanning3D.cpp:79-112, multiPathPlanning3D.cpp:78-121)
 //   result/<m>_result_file_*.txt iter / running time / point cloud size (admmPathPlanning3D.cpp:507-510)
 #pragma once
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -86,6 +87,40 @@ inline void read_waypoints(const std::string& path, bool multi, int& U, int& P, 
   for (int k = 0; k <= P; k++) {
     if ((int)rows[k].size() < 3 * U) throw std::runtime_error(path + ": short line");
     for (int u = 0; u < U; u++) for (int a = 0; a < 3; a++) wp[((size_t)u * (P + 1) + k) * 3 + a] = rows[k][3 * u + a];
+  }
+}
+
+// log_data (Main/admmPathPlanning3D.cpp:33-77, Main/multiPathPlanning3D.cpp:33-77): duration of a trajectory and
+// the length of its polyline sampled every `dt` seconds of flight time (0.05 single, 0.1 multi), evaluated on the
+// per-piece Bezier control points C_i x_i exactly like getPosFromBezier (:17-31).  spline is T x 3 column-major,
+// convert is [P][36] row-major.  samples (optional) receives the sampled positions, 3 per point.
+inline void log_data(const double* spline, int P, const double* convert, double piece_time, double dt,
+                     double& time_out, double& len_out, std::vector<double>* samples = nullptr) {
+  const int T = 3 * P + 3;
+  static const double binom5[6] = {1, 5, 10, 10, 5, 1};
+  std::vector<double> coeff((size_t)P * 18);  // [piece][axis][6]
+  for (int i = 0; i < P; i++)
+    for (int a = 0; a < 3; a++)
+      for (int j = 0; j < 6; j++) {
+        double acc = 0;
+        for (int k = 0; k < 6; k++) acc += convert[(size_t)i * 36 + j * 6 + k] * spline[3 * i + k + T * a];
+        coeff[(size_t)i * 18 + a * 6 + j] = acc;
+      }
+  time_out = 0;
+  for (int i = 0; i < P; i++) time_out += 1.0 * piece_time;  // time_weight == 1 everywhere
+  len_out = 0;
+  double prev[3] = {0, 0, 0};
+  bool have = false;
+  for (double t = 0.0; t < P; t += dt / piece_time) {
+    const int i = (int)std::floor(t);
+    const double ct = t - i;
+    double cur[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++)
+      for (int j = 0; j < 6; j++) cur[a] += binom5[j] * coeff[(size_t)i * 18 + a * 6 + j] * std::pow(ct, j) * std::pow(1 - ct, 5 - j);
+    if (have) len_out += std::sqrt((cur[0] - prev[0]) * (cur[0] - prev[0]) + (cur[1] - prev[1]) * (cur[1] - prev[1]) + (cur[2] - prev[2]) * (cur[2] - prev[2]));
+    if (samples) { samples->push_back(cur[0]); samples->push_back(cur[1]); samples->push_back(cur[2]); }
+    for (int a = 0; a < 3; a++) prev[a] = cur[a];
+    have = true;
   }
 }
 

@@ -2,11 +2,14 @@
 // (-DTJ_CLI_MULTI): the headless branches of the reference mains
 // (Main/admmPathPlanning3D.cpp:355-547, Main/multiPathPlanning3D.cpp:470-695) with the per-iteration
 // call replaced by the C ABI of libtrajadmm.so.  Same working-directory layout, same config keys,
-// same result file.  GUI (`gui:1`), OMPL initialisation (`init:2`), `optimal_plane:1` and the
-// coupled multi-robot mode (`decouple:0`) are outside the accelerated path and are rejected with a
-// message instead of being silently ignored.
+// same result file.  `decouple:0` selects the coupled multi-robot mode (one shared piece_time,
+// Main/multiPathPlanning3D.cpp:674-677).  GUI (`gui:1`), OMPL initialisation (`init:2`) and
+// `optimal_plane:1` are outside the accelerated path and are rejected with a message instead of
+// being silently ignored.  On convergence the trajectory duration and sampled arc length are printed
+// like the mains' log_data ("ccd time:", "ccd len:").
 //
-// Extras (ours): --max-iter N, --dump-state FILE (the reference never writes the trajectory),
+// Extras (ours): --max-iter N, --dump-state FILE (control points; the reference never writes the
+// trajectory), --sample-traj FILE (positions sampled like log_data, one "uav t x y z" per line),
 // --batch N iterations per device batch (the stop test runs on the device before every iteration).
 #include <chrono>
 #include "../../include/trajadmm.h"
@@ -19,14 +22,15 @@ static const bool kMulti = false;
 #endif
 
 int main(int argc, char** argv) {
-  if (argc < 2) { std::cerr << "Syntax: " << argv[0] << " <mesh file> [--max-iter N] [--batch N] [--dump-state FILE]" << std::endl; return -1; }
+  if (argc < 2) { std::cerr << "Syntax: " << argv[0] << " <mesh file> [--max-iter N] [--batch N] [--dump-state FILE] [--sample-traj FILE]" << std::endl; return -1; }
   const std::string mesh = argv[1];
-  long max_iter = 1000000; int batch = 8; std::string dump;
+  long max_iter = 1000000; int batch = 8; std::string dump, sample_file;
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--max-iter" && i + 1 < argc) max_iter = atol(argv[++i]);
     else if (a == "--batch" && i + 1 < argc) batch = atoi(argv[++i]);
     else if (a == "--dump-state" && i + 1 < argc) dump = argv[++i];
+    else if (a == "--sample-traj" && i + 1 < argc) sample_file = argv[++i];
     else { std::cerr << "unknown argument " << a << std::endl; return -1; }
   }
   tj_ctx* ctx = nullptr;
@@ -42,7 +46,6 @@ int main(int argc, char** argv) {
     if (gui) throw std::runtime_error("gui:1 is not part of the accelerated path (use gui:0)");
     if (init != 1) throw std::runtime_error("only init:1 (init/<mesh>_init_file.txt) is supported; init:2 needs OMPL");
     if (optimal_plane) throw std::runtime_error("optimal_plane:1 is not implemented on the device path yet");
-    if (kMulti && !decouple) throw std::runtime_error("decouple:0 (shared piece_time) is not implemented on the device path yet");
 
     std::vector<double> V = tjcli::read_obj_vertices(std::string(kMulti ? "model/multiple/" : "model/single/") + mesh);
     int U = 1, P = 0; std::vector<double> wp;
@@ -56,7 +59,7 @@ int main(int argc, char** argv) {
     std::cout << "time_obstacle build: " << N << " points" << std::endl;
 
     tj_params p;
-    tj_default_params(&p, kMulti ? TJ_MODE_MULTI_DECOUPLE : TJ_MODE_SINGLE, U, P);
+    tj_default_params(&p, kMulti ? (decouple ? TJ_MODE_MULTI_DECOUPLE : TJ_MODE_MULTI_COUPLED) : TJ_MODE_SINGLE, U, P);
     p.res = res; p.lambda = lambda; p.margin = margin; p.offset = offset; p.mu = mu; p.vel_limit = vel; p.acc_limit = acc; p.stop = stop;
     auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + tj_last_error(ctx)); };
     chk(tj_create(&p, &ctx), "tj_create");
@@ -78,6 +81,28 @@ int main(int argc, char** argv) {
       result << "iter: " << iter << std::endl;
       result << "running time: " << whole_ms << std::endl;
       result << "point cloud size: " << V.size() / 3 << std::endl;
+    }
+    if (converged || !sample_file.empty()) {
+      // log_data (Main/admmPathPlanning3D.cpp:33-77 called at :513; Main/multiPathPlanning3D.cpp:33-77 at :644-648).
+      // Deviation: the multi main passes the never-updated global piece_time (20) in decoupled mode; each robot's
+      // own piece_time is used here.
+      const int T = 3 * P + 3;
+      std::vector<double> conv((size_t)P * 36), s(3 * T);
+      tj_host_tables(P, res, conv.data(), nullptr, nullptr, nullptr);
+      std::ofstream sf;
+      if (!sample_file.empty()) { sf.open(sample_file); sf.precision(17); }
+      const double dt = kMulti ? 0.1 : 0.05;
+      double whole_len = 0;
+      for (int u = 0; u < U; u++) {
+        double pt = 0, tt = 0, len = 0;
+        chk(tj_get_state(ctx, u, s.data(), nullptr, nullptr, nullptr, nullptr, &pt), "tj_get_state");
+        std::vector<double> smp;
+        tjcli::log_data(s.data(), P, conv.data(), pt, dt, tt, len, sample_file.empty() ? nullptr : &smp);
+        std::cout << "ccd time:" << tt << std::endl << "ccd len:" << len << std::endl;
+        whole_len += len;
+        for (size_t k = 0; k + 2 < smp.size(); k += 3) sf << u << " " << (k / 3) * dt << " " << smp[k] << " " << smp[k + 1] << " " << smp[k + 2] << "\n";
+      }
+      (void)whole_len;
     }
     if (!dump.empty()) {
       std::ofstream df(dump);

@@ -18,6 +18,8 @@ enum : int {
   ERR_FRONT_OVERFLOW = 2,    // BVH frontier overflow (query box far larger than expected)
   ERR_LOOP_CAP = 4,          // a back-off / Newton / Armijo loop hit LOOP_CAP (infeasible state)
   ERR_PAIR_OVERFLOW = 8,     // inter-robot CCD survivor list overflow
+  ERR_NOT_SPD = 16,          // coupled mode: the arrowhead Newton system is not positive definite (the reference's
+                             // SimplicialLLT has no fallback there either, Optimization3D_multi.h:553-557)
 };
 
 struct Ctl {
@@ -35,11 +37,16 @@ struct Ctl {
   unsigned long long llt_fail_piece, llt_fail_robot;  // PSD repairs taken (per-piece 19x19, per-robot reduced system)
   unsigned long long energy_evals;
   unsigned long long newton_iters, pair_solves;  // Optimal_plane::optimal_d iterations / robot pairs solved
+  double wolfe_c;      // coupled mode: the global `wolfe` of update_spline (Optimization3D_multi.h:558)
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
-enum { K_BEGIN = 0, K_SEP_OBS, K_HULLINFO, K_SEP_SELF_ROWS, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_CCD_PREP,
-       K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH, K_SLACK, K_COUNT };
+enum { K_BEGIN = 0, K_SEP_OBS, K_HULLINFO, K_SEP_SELF_ROWS, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE,
+       K_XSOLVE_C2,                 // coupled mode only ("decouple":0)
+       K_CCD_PREP, K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH,
+       K_LS_COUPLED, K_LS_COMMIT,   // coupled mode only
+       K_SLACK, K_COUNT };
+constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates evaluated per launch (steps 0.8^0 .. 0.8^30)
 
 // Phase stamps for kernel tuning: compiled in only by `make timing` (-DTJ_PHASE_TIMING); thread 0 of
 // a block stores the constant-rate wall clock at a phase boundary.  The product build has none.
@@ -88,6 +95,12 @@ struct Dev {
   __host__ __device__ double& tdir(int u) const { return xdir[(size_t)u * xs + 3 * T]; }
   __host__ __device__ double& wolfe(int u) const { return xdir[(size_t)u * xs + 3 * T + 1]; }
   __host__ __device__ double& gn(int u) const { return xdir[(size_t)u * xs + 3 * T + 2]; }
+  __host__ __device__ bool multi() const { return mode >= 1; }     // robot-pair stages exist
+  __host__ __device__ bool coupled() const { return mode == 2; }   // one piece_time for all robots
+  // coupled mode (shared piece_time): per-robot Cholesky factor of the reduced block incl. the arrow row, the
+  // forward-substituted right-hand side, the raw gradient, {Schur corner, Schur rhs, g_t} contributions,
+  // and the per-(round, robot, candidate) energies of the Armijo search on the summed objective
+  double *xL, *xy, *xg, *xcorner, *ls_e;
   int *k_obs, *k_self;            // [U] exponents: step = 0.8^k
   double *step_out;               // [U] accepted Armijo step (diagnostics)
   double *ccdinfo;                // [U][S][CCD_STRIDE] swept-hull cache of the current direction

@@ -34,8 +34,12 @@ constexpr int CHOL_MB = 18;  // max band rows below a pivot handled by the wave 
 // Pattern: half-bandwidth bw (bw >= n-1 means dense) plus a dense last row.  Returns false as soon as
 // a pivot is <= 0 (Eigen LLT.h:320-323; NaN pivots pass, like Eigen).  If y != nullptr, y <- L^-1 y.
 // Must be called by all `nth` threads of the block (contains barriers); the first wave does the work.
+// npiv < n stops after npiv pivots: with npiv = n-1 the last diagonal entry is left as the Schur
+// complement a_nn - sum l_nk^2 and y[n-1] as the matching reduced right-hand side (coupled mode:
+// the shared-time corner is completed across robots before its pivot can be taken).
 template <bool ONE_WAVE = false>
-__device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth, double* y = nullptr) {
+__device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth, double* y = nullptr, int npiv = -1) {
+  if (npiv < 0) npiv = n;
   __shared__ double s_col[CHOL_MB + 2];  // scaled pivot column: [0..mb) band rows, [CHOL_MB] arrow row
   const int last = n - 1;
   // fixed ownership of the lower-triangular update window (r,c), c <= r < CHOL_MB: 171 positions over 64 lanes
@@ -54,7 +58,7 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
   // loads it will need (pivot, its column entry, its window positions, arrow and rhs entries, with
   // clamped indices so that no load sits behind a branch), then the scaled column is exchanged
   // through s_col, then everything is stored.
-  for (int k = 0; k < n; k++) {
+  for (int k = 0; k < npiv; k++) {
     blk_sync<ONE_WAVE>();
     const int mb = max(0, min(min(bw, CHOL_MB), last - 1 - k));  // band rows below the pivot (arrow row excluded)
     const bool arrow = k < last;

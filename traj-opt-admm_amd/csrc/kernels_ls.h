@@ -171,6 +171,44 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
   return e;
 }
 
+// Stage everything an evaluation reuses into LDS: tables, this robot's slack/dual blocks, control net,
+// search direction and (if they fit) its planes with their segment ids.  Returns the plane count M and
+// whether the planes are LDS resident.  Called by the whole block (contains barriers).
+__device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double* sm, int* pref, int u, int tid, int nth, bool& in_lds_out) {
+  const int S = D.S, T = D.T, P = D.P, P6 = 6 * D.P;
+  double* net = sm + L.net; double* dir = sm + L.dir;
+  const double* gspline = D.spline + (size_t)u * 3 * T;
+  TJ_TIC(D, K_LINESEARCH, 0);
+  for (int i = tid; i < S * 36; i += nth) sm[L.basis + i] = D.basis[i];
+  for (int i = tid; i < P * 36; i += nth) sm[L.convert + i] = D.convert[i];
+  for (int i = tid; i < 18 * P; i += nth) { sm[L.slack + i] = D.p_slack[(size_t)u * 3 * P6 + i]; sm[L.lambda + i] = D.p_lambda[(size_t)u * 3 * P6 + i]; }
+  for (int i = tid; i < P; i += nth) { sm[L.tsl + i] = D.t_slack[u * P + i]; sm[L.tla + i] = D.t_lambda[u * P + i]; }
+  for (int i = tid; i < 3 * T; i += nth) { net[i] = gspline[i]; dir[i] = D.dirp(u)[i]; }
+  if (tid == 0) {
+    int acc = 0;
+    for (int tr = 0; tr < S; tr++) { pref[tr] = acc; acc += D.ocount[u * S + tr] + (D.multi() ? D.scount[u * S + tr] : 0); }
+    pref[S] = acc;
+  }
+  __syncthreads();
+  TJ_TIC(D, K_LINESEARCH, 1);
+  const int M = pref[S];
+  const bool in_lds = M <= L.plane_cap;
+  if (in_lds) {
+    int* pltr = (int*)(sm + L.pltr);
+    for (int it = tid; it < M; it += nth) {
+      int lo = 0, hi = S;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
+      const int tr = lo, k = it - pref[tr], no = D.ocount[u * S + tr];
+      const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
+      pltr[it] = tr;
+      sm[L.planes + 4 * it] = pl[0]; sm[L.planes + 4 * it + 1] = pl[1]; sm[L.planes + 4 * it + 2] = pl[2]; sm[L.planes + 4 * it + 3] = pl[3];
+    }
+  }
+  __syncthreads();
+  in_lds_out = in_lds;
+  return M;
+}
+
 __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
   if (D.ctl->done) return;
   extern __shared__ double sm[];
@@ -183,35 +221,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
   double* ghull = sm + L.ghull + (size_t)g * S * 18;
   double* res = sm + L.res;
   double* gspline = D.spline + (size_t)u * 3 * T;
-  const int P6 = 6 * P;
-  TJ_TIC(D, K_LINESEARCH, 0);
-  // ---- stage everything that is reused ----
-  for (int i = tid; i < S * 36; i += LS_THREADS) sm[L.basis + i] = D.basis[i];
-  for (int i = tid; i < P * 36; i += LS_THREADS) sm[L.convert + i] = D.convert[i];
-  for (int i = tid; i < 18 * P; i += LS_THREADS) { sm[L.slack + i] = D.p_slack[(size_t)u * 3 * P6 + i]; sm[L.lambda + i] = D.p_lambda[(size_t)u * 3 * P6 + i]; }
-  for (int i = tid; i < P; i += LS_THREADS) { sm[L.tsl + i] = D.t_slack[u * P + i]; sm[L.tla + i] = D.t_lambda[u * P + i]; }
-  for (int i = tid; i < 3 * T; i += LS_THREADS) { net[i] = gspline[i]; dir[i] = D.dirp(u)[i]; }
-  if (tid == 0) {
-    int acc = 0;
-    for (int tr = 0; tr < S; tr++) { pref[tr] = acc; acc += D.ocount[u * S + tr] + (D.mode == 1 ? D.scount[u * S + tr] : 0); }
-    pref[S] = acc;
-  }
-  __syncthreads();
-  TJ_TIC(D, K_LINESEARCH, 1);
-  const int M = pref[S];
-  const bool in_lds = M <= L.plane_cap;
-  if (in_lds) {
-    int* pltr = (int*)(sm + L.pltr);
-    for (int it = tid; it < M; it += LS_THREADS) {
-      int lo = 0, hi = S;
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
-      const int tr = lo, k = it - pref[tr], no = D.ocount[u * S + tr];
-      const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
-      pltr[it] = tr;
-      sm[L.planes + 4 * it] = pl[0]; sm[L.planes + 4 * it + 1] = pl[1]; sm[L.planes + 4 * it + 2] = pl[2]; sm[L.planes + 4 * it + 3] = pl[3];
-    }
-  }
-  __syncthreads();
+  bool in_lds;
+  const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
   TJ_TIC(D, K_LINESEARCH, 2);
   const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
@@ -265,6 +276,105 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
   }
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
+}
+
+// ---- coupled mode ("decouple":0): Armijo search on the SUM of all robots' energies ---------------
+// Optimization3D_multi::update_spline (Optimization3D_multi.h:587-636).  One step and one piece_time for
+// every robot, accepted when e0 - 1e-4*wolfe*step >= sum_u E_u(x_u + step d_u, t + step t_dir).  The sum
+// couples all robots, so a launch only EVALUATES: round r has every robot's block compute its energy at 8
+// candidates (round 0: E(x) and steps 0.8^0..0.8^6, later rounds 8 more steps each) into ls_e; the next
+// launch (or k_ls_commit) first forms the totals in robot order -- every block computes the same bits --
+// and returns at once when an earlier round already holds the accepted step.
+__device__ __forceinline__ int lsc_cand_k(int round, int c) { return round == 0 ? c - 1 : 7 + (round - 1) * LS_GROUPS + c; }
+
+// step after the CCD clamps and the t > 0 guard (Optimization3D_multi.h:586-601); wave 0 computes, all threads get it
+__device__ __forceinline__ double lsc_step0(const Dev& D, int tid, double t0, double t_dir, double* s_val) {
+  if (tid < 64) {
+    int kmax = D.k_self[0];
+    for (int r = tid; r < D.U; r += 64) kmax = max(kmax, D.k_obs[r]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+    double step0 = D.pow08[min(LOOP_CAP, kmax)];
+    if (t0 + step0 * t_dir <= 0) step0 = -0.95 * t0 / t_dir;
+    if (tid == 0) *s_val = step0;
+  }
+  __syncthreads();
+  return *s_val;
+}
+
+// wave 0 only: first acceptable candidate among rounds [0, nrounds), in the reference's order.  acc[0] = round
+// (-1 none), acc[1] = slot, accstep = its step.
+__device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double step0, int lane, int* acc, double* accstep) {
+  const double wolfe = D.ctl->wolfe_c;
+  const int c = lane & 7;
+  double e0 = 0;
+  int found_r = -1, found_c = 0; double found_step = step0;
+  for (int r = 0; r < nrounds && found_r < 0; r++) {
+    double tot = 0, step = step0;
+    if (lane < LS_GROUPS) {
+      for (int u = 0; u < D.U; u++) tot += D.ls_e[((size_t)r * D.U + u) * LS_GROUPS + c];  // e += spline_energy(i), robot order
+      const int k = lsc_cand_k(r, c);
+      for (int i = 0; i < k; i++) step *= 0.8;
+    }
+    if (r == 0) e0 = __shfl(tot, 0);
+    const bool ok = lane < LS_GROUPS && !(r == 0 && c == 0) && !(e0 - 1e-4 * wolfe * step < tot);
+    const unsigned long long mask = __ballot(ok);
+    if (mask) { found_r = r; found_c = __ffsll((long long)mask) - 1; found_step = __shfl(step, found_c); }
+  }
+  if (lane == 0) { acc[0] = found_r; acc[1] = found_c; *accstep = found_step; }
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round) {
+  if (D.ctl->done) return;
+  extern __shared__ double sm[];
+  __shared__ int pref[512];
+  __shared__ int s_acc[2];
+  __shared__ double s_step0, s_accstep;
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
+  const int g = tid / LS_GSIZE, gl = tid % LS_GSIZE;
+  const double t_dir = D.tdir(u), t0 = D.piece_time[u];
+  const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
+  if (round > 0) {
+    if (tid < 64) lsc_decide(D, round, step0, tid, s_acc, &s_accstep);
+    __syncthreads();
+    if (s_acc[0] >= 0) return;  // an earlier round already holds the accepted step
+  }
+  bool in_lds;
+  const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
+  double* net = sm + L.net; double* dir = sm + L.dir;
+  double* gnet = sm + L.gnet + (size_t)g * 3 * T;
+  double* ghull = sm + L.ghull + (size_t)g * S * 18;
+  const int k = lsc_cand_k(round, g);
+  double step = step0;
+  for (int i = 0; i < k; i++) step *= 0.8;
+  const double pt = k < 0 ? t0 : t0 + step * t_dir;
+  for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
+  __syncthreads();
+  const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl);
+  if (gl == 0) D.ls_e[((size_t)round * D.U + u) * LS_GROUPS + g] = e;
+}
+
+// commit: x_u += step d_u for every robot, the shared piece_time advances by step * t_direction
+__global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
+  if (D.ctl->done) return;
+  __shared__ int s_acc[2];
+  __shared__ double s_step0, s_accstep;
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, T = D.T;
+  const double t_dir = D.tdir(u), t0 = D.piece_time[u];
+  const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
+  lsc_decide(D, LSC_ROUNDS, step0, tid, s_acc, &s_accstep);
+  __syncthreads();
+  double step = s_accstep;
+  int kacc = s_acc[0] >= 0 ? lsc_cand_k(s_acc[0], s_acc[1]) : lsc_cand_k(LSC_ROUNDS - 1, LS_GROUPS - 1);
+  if (s_acc[0] < 0) {  // no acceptable step within the evaluated range: take the last candidate and report it
+    step = step0;
+    for (int i = 0; i < kacc; i++) step *= 0.8;
+    if (tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+  }
+  double* gspline = D.spline + (size_t)u * 3 * T;
+  const double* dir = D.dirp(u);
+  for (int i = tid; i < 3 * T; i += 64) gspline[i] = gspline[i] + step * dir[i];
+  if (tid == 0) { D.piece_time[u] = t0 + step * t_dir; D.step_out[u] = step; atomicAdd(&D.ctl->energy_evals, (unsigned long long)(2 + kacc)); }
 }
 
 }  // namespace tj

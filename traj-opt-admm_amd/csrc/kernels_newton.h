@@ -66,7 +66,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   // ---- stage every segment of the piece once: hull, basis, plane counts ----
   for (int idx = tid; idx < res * 18; idx += GRAD_THREADS) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
   for (int idx = tid; idx < res * 36; idx += GRAD_THREADS) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
-  if (tid < res) segn[tid] = D.ocount[u * D.S + sp * res + tid] + (D.mode == 1 ? D.scount[u * D.S + sp * res + tid] : 0);
+  if (tid < res) segn[tid] = D.ocount[u * D.S + sp * res + tid] + (D.multi() ? D.scount[u * D.S + sp * res + tid] : 0);
   __syncthreads();
 
   TJ_TIC(D, K_GRAD, 1);
@@ -343,6 +343,20 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   __syncthreads();
   if (tid >= XS_THREADS) return;  // from here on the block IS wave 0 (s_barrier counts surviving waves only)
   TJ_TIC(D, K_XSOLVE, 2);
+  if (D.coupled()) {
+    // Optimization3D_multi::update_spline (Optimization3D_multi.h:519-557): this robot's block of the
+    // arrowhead system.  Eliminate the m control-point unknowns; what is left of the last row is the
+    // robot's contribution to the shared-time corner (Schur complement) -- k_xsolve_c2 completes it.
+    if (!chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0, n - 1)) {
+      if (tid == 0) { atomicAdd(&D.ctl->llt_fail_robot, 1ull); atomicOr(&D.ctl->error, ERR_NOT_SPD); }
+    }
+    blk_sync<true>();
+    double* oL = D.xL + (size_t)u * n * n; double* oy = D.xy + (size_t)u * n; double* og = D.xg + (size_t)u * n;
+    for (int idx = tid; idx < n * n; idx += XS_THREADS) oL[idx] = L[idx];
+    for (int i = tid; i < n; i += XS_THREADS) { oy[i] = x0[i]; og[i] = g0[i]; }
+    if (tid == 0) { double* oc = D.xcorner + (size_t)u * 4; oc[0] = L[m * n + m]; oc[1] = x0[m]; oc[2] = g0[m]; oc[3] = 0; }
+    return;
+  }
   if (!chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0)) {  // forward substitution fused: x0 <- L^-1 g0
     if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
     blk_sync<true>();
@@ -375,6 +389,50 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     D.wolfe(u) = -esum(scr, n);
     D.gn(u) = sqrt(esum(scr + n, n));
     D.tdir(u) = x0[m];
+  }
+}
+
+// Coupled mode, second half of the arrowhead solve: one wave per robot.  The Schur corner
+// sum_u (h_t,u - y_u.y_u) and its right-hand side are summed in robot order (every block forms the
+// same bits), the corner pivot is taken, and the existing arrow back-substitution finishes the
+// robot's block: x_u = L_u^-T (w_u - y_u t).  Per robot it leaves direction, t_direction and the
+// partial sums of wolfe = -x0.G and |G|^2 (completed by k_ccd_self_seq in robot order).
+__global__ __launch_bounds__(XS_THREADS) void k_xsolve_c2(Dev D) {
+  if (D.ctl->done) return;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x;
+  const int T = D.T, m = 3 * (T - 4), n = m + 1;
+  double* L = sm; double* y = L + n * n; double* g0 = y + n; double* scr = g0 + n;  // scr [2n]
+  __shared__ double s_red[3];
+  const double* gL = D.xL + (size_t)u * n * n;
+  for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = gL[idx];
+  for (int i = tid; i < n; i += XS_THREADS) { y[i] = D.xy[(size_t)u * n + i]; g0[i] = D.xg[(size_t)u * n + i]; }
+  if (tid < 3) {  // lane 0: corner, lane 1: rhs, lane 2: G_t -- sequential sums in robot order
+    double acc = 0;
+    for (int r = 0; r < D.U; r++) acc += D.xcorner[(size_t)r * 4 + tid];
+    s_red[tid] = acc;
+  }
+  blk_sync<true>();
+  const double corner = s_red[0], rhs = s_red[1];
+  if (!(corner > 0) && tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_NOT_SPD);
+  const double lc = sqrt(corner);
+  if (tid == 0) { L[m * n + m] = lc; y[m] = rhs / lc; }
+  blk_sync<true>();
+  chol_arrow_backsolve_lds<true>(L, n, XS_BAND, y, tid, XS_THREADS);
+  for (int i = tid; i < n; i += XS_THREADS) y[i] = -y[i];
+  blk_sync<true>();
+  for (int i = tid; i < m; i += XS_THREADS) { scr[i] = y[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
+  blk_sync<true>();
+  double* dir = D.dirp(u);
+  for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
+    const int row = idx % T, a = idx / T;
+    dir[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0;
+  }
+  if (tid == 0) {
+    D.wolfe(u) = esum(scr, m);          // sum_j x_j g_j over this robot's control-point unknowns
+    D.gn(u) = esum(scr + n, m);         // sum_j g_j^2
+    D.tdir(u) = y[m];                   // shared t_direction (same bits on every robot)
+    D.xdir[(size_t)u * D.xs + 3 * T + 3] = g0[m];  // this robot's share of G_t
   }
 }
 

@@ -144,9 +144,10 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   int* seen = ks + D.U;
   int* cnt = seen + D.U;  // [S*U] survivor counts, staged once so the segment loop never waits on HBM
   for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
-  if (D.mode == 1) for (int i = lane; i < D.S * D.U; i += 64) cnt[i] = D.pair_count[i];
+  if (D.multi()) for (int i = lane; i < D.S * D.U; i += 64) cnt[i] = D.pair_count[i];
   __syncthreads();
-  if (D.mode == 1) {
+  if (D.multi()) {
+    const bool shared = D.coupled();  // Step::couple_self_step (Step.h:112-182): one step for all robots, held in ks[0]
     const double off2 = D.offset * D.offset;
     int ambiguous = 0;
     for (int tr = 0; tr < D.S; tr++) {
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
         const int p1 = D.pair_list[((size_t)tr * D.U + p0) * D.cap_row + i];
         const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
         const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
-        int k0 = ks[p0], k1 = ks[p1];
-        if (seen[p0] == tr || seen[p1] == tr) seg_share = true;
+        int k0 = ks[shared ? 0 : p0], k1 = ks[shared ? 0 : p1];
+        if (!shared && (seen[p0] == tr || seen[p1] == tr)) seg_share = true;
         __syncthreads();
         if (lane == 0) { seen[p0] = tr; seen[p1] = tr; }
         int guard = 0;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
         }
         if (guard > LOOP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
         __syncthreads();
-        if (lane == 0) { ks[p0] = k0; ks[p1] = k1; }
+        if (lane == 0) { if (shared) ks[0] = k0; else { ks[p0] = k0; ks[p1] = k1; } }
         __syncthreads();
       }
       }
@@ -183,7 +184,11 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     if (lane == 0 && ambiguous) atomicAdd(&D.ctl->order_ambiguous, ambiguous);
   }
   __syncthreads();
-  for (int i = lane; i < D.U; i += 64) { D.k_self[i] = ks[i]; seen[i] = 0; }
+  {
+    const int kshared = ks[0];
+    __syncthreads();
+    for (int i = lane; i < D.U; i += 64) { D.k_self[i] = D.coupled() ? kshared : ks[i]; seen[i] = 0; }
+  }
   // gnorm exactly as the drivers form it (Optimization3D_multi.h:57,72,750; _admm.h:499): a
   // sequential sum in robot order; the values are first pulled into LDS by all lanes
   double* gns = reinterpret_cast<double*>(cnt);  // reuse the staging area (S*U ints >= U doubles for S >= 2)
@@ -193,7 +198,14 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   if (lane == 0) {
     double gsum = 0;
     for (int u = 0; u < D.U; u++) gsum += gns[u];
-    D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : gns[0];
+    if (D.coupled()) {
+      // gnorm = |G| / uav_num and wolfe = -x0.G over the whole arrowhead system (Optimization3D_multi.h:558,580);
+      // k_xsolve_c2 left per-robot partial sums, the shared-time entries are added here
+      double gt = 0, xg = 0;
+      for (int u = 0; u < D.U; u++) { gt += D.xdir[(size_t)u * D.xs + 3 * D.T + 3]; xg += D.wolfe(u); }
+      D.ctl->gnorm = sqrt(gsum + gt * gt) / double(D.U);
+      D.ctl->wolfe_c = -(xg + D.tdir(0) * gt);
+    } else D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : gns[0];
   }
 }
 

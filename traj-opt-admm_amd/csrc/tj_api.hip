@@ -42,7 +42,7 @@ struct tj_ctx {
   hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
   bool graph_ok[4] = {false, false, false, false};
   bool graph_failed[4] = {false, false, false, false};
-  size_t lds_grad = 0, lds_xs = 0, lds_ls = 0, lds_seq = 0;
+  size_t lds_grad = 0, lds_xs = 0, lds_xs2 = 0, lds_ls = 0, lds_seq = 0;
   LsLayout lsl;
   // cloud-dependent allocations (rebuilt by tj_set_cloud)
   std::vector<void*> cloud_allocs;
@@ -85,14 +85,14 @@ void drop_graph(tj_ctx* c) {
 
 // ---- kernels of one iteration, in stream order (also the unit of tj_profile_kernels) ----
 const char* const kKernelNames[K_COUNT] = {"k_begin", "k_sep_obs", "k_hullinfo", "k_sep_self_rows", "k_sep_self_solve", "k_sep_self_compact",
-                                           "k_grad", "k_xsolve", "k_ccd_prep", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
-                                           "k_linesearch", "k_slack"};
+                                           "k_grad", "k_xsolve", "k_xsolve_c2", "k_ccd_prep", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
+                                           "k_linesearch", "k_ls_coupled", "k_ls_commit", "k_slack"};
 
 // launch exactly one kernel (returns false for kernels that do not exist in this mode)
 bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
-  const bool multi = d.mode == 1;
+  const bool multi = d.mode >= 1, coupled = d.mode == 2;
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_SEP_OBS: hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
@@ -106,7 +106,11 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0) {
     case K_CCD_OBS: hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_PAIRS: if (multi) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return multi;
     case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
-    case K_LINESEARCH: hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); return true;
+    case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); return !coupled;
+    // coupled mode ("decouple":0): second half of the arrowhead solve, evaluation rounds of the summed-energy Armijo search, commit
+    case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
+    case K_LS_COUPLED: if (coupled) for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r); return coupled;
+    case K_LS_COMMIT: if (coupled) hipLaunchKernelGGL(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;
     case K_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
   }
   return false;
@@ -120,11 +124,11 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
     case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); break;
     case TJ_STAGE_PLANES_SELF: for (int k = K_HULLINFO; k <= K_SEP_SELF_COMPACT; k++) launch_kernel(c, k, s); break;
     case TJ_STAGE_GRAD: launch_kernel(c, K_GRAD, s); break;
-    case TJ_STAGE_XSOLVE: launch_kernel(c, K_XSOLVE, s); break;
+    case TJ_STAGE_XSOLVE: launch_kernel(c, K_XSOLVE, s); launch_kernel(c, K_XSOLVE_C2, s); break;
     case TJ_STAGE_CCD_PREP: launch_kernel(c, K_CCD_PREP, s); break;
     case TJ_STAGE_CCD_OBS: launch_kernel(c, K_CCD_OBS, s); break;
     case TJ_STAGE_CCD_SELF: launch_kernel(c, K_CCD_SELF_PAIRS, s); launch_kernel(c, K_CCD_SELF_SEQ, s); break;
-    case TJ_STAGE_LINESEARCH: launch_kernel(c, K_LINESEARCH, s); break;
+    case TJ_STAGE_LINESEARCH: launch_kernel(c, K_LINESEARCH, s); launch_kernel(c, K_LS_COUPLED, s); launch_kernel(c, K_LS_COMMIT, s); break;
     case TJ_STAGE_SLACK: launch_kernel(c, K_SLACK, s, 0); break;
     case TJ_STAGE_END: hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, c->d); break;
     default: c->err = "unknown stage"; return TJ_ERR_INVALID;
@@ -236,6 +240,7 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
     return TJ_ERR_CAPACITY;
   }
   if (h.error & ERR_LOOP_CAP) { c->err = "a device back-off/Newton/Armijo loop hit its cap (infeasible state)"; return TJ_ERR_NO_PROGRESS; }
+  if (h.error & ERR_NOT_SPD) { c->err = "coupled mode: the arrowhead Newton system is not positive definite (the reference has no fallback either)"; return TJ_ERR_NO_PROGRESS; }
   return TJ_OK;
 }
 
@@ -253,7 +258,7 @@ void tj_default_params(tj_params* p, int mode, int uav_num, int piece_num) {
   memset(p, 0, sizeof(*p));
   p->mode = mode; p->uav_num = uav_num; p->piece_num = piece_num; p->res = 8;
   p->lambda = 10.0; p->margin = 0.1; p->offset = 0.1; p->mu = 0.1; p->vel_limit = 2.0; p->acc_limit = 2.0;
-  p->ks = mode == TJ_MODE_SINGLE ? 1e-8 : 1e-3; p->kt = 1.0; p->stop = 1e-2;
+  p->ks = mode == TJ_MODE_SINGLE ? 1e-8 : 1e-3;  /* Main/admmPathPlanning3D.cpp:477, Main/multiPathPlanning3D.cpp:596 */ p->kt = 1.0; p->stop = 1e-2;
   p->device = 0; p->rank = 0; p->world = 1;
 }
 
@@ -269,6 +274,17 @@ int tj_debug_phase_times(tj_ctx* c, long long* out) {
 }
 #endif
 
+int tj_host_tables(int piece_num, int res, double* convert, double* mdyn, double* basis, double* kdop) {
+  if (piece_num < 1 || res < 1) return TJ_ERR_INVALID;
+  HostTables t;
+  build_tables(piece_num, res, 1, t);
+  if (convert) memcpy(convert, t.convert.data(), t.convert.size() * 8);
+  if (mdyn) memcpy(mdyn, t.mdyn, 36 * 8);
+  if (basis) memcpy(basis, t.basis.data(), t.basis.size() * 8);
+  if (kdop) memcpy(kdop, t.kdop, 147 * 8);
+  return TJ_OK;
+}
+
 const char* tj_last_error(const tj_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int tj_create(const tj_params* p, tj_ctx** out) {
@@ -277,10 +293,11 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   tj_ctx* c = new tj_ctx();
   *out = c;  // returned even on failure so the caller can read tj_last_error()
   c->prm = *p;
-  if (p->uav_num < 1 || p->piece_num < 2 || p->res < 1 || (p->mode != 0 && p->mode != 1) || p->world < 1 || p->rank < 0 || p->rank >= p->world) {
-    c->err = "invalid tj_params (need uav_num>=1, piece_num>=2, res>=1, mode 0/1, 0<=rank<world)";
+  if (p->uav_num < 1 || p->piece_num < 2 || p->res < 1 || p->mode < 0 || p->mode > 2 || p->world < 1 || p->rank < 0 || p->rank >= p->world) {
+    c->err = "invalid tj_params (need uav_num>=1, piece_num>=2, res>=1, mode 0/1/2, 0<=rank<world)";
     return TJ_ERR_INVALID;
   }
+  if (p->mode == TJ_MODE_MULTI_COUPLED && p->world != 1) { c->err = "TJ_MODE_MULTI_COUPLED is single-GPU in this version (world must be 1)"; return TJ_ERR_UNSUPPORTED; }
   if (p->mode == TJ_MODE_SINGLE && p->uav_num != 1) { c->err = "TJ_MODE_SINGLE requires uav_num == 1"; return TJ_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device available (this library has no CPU fallback)"; return TJ_ERR_DEVICE; }
@@ -299,11 +316,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, d.U - 1);
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
   d.cap_row = std::max(1, std::min(d.cap_pairs, d.U));  // partners per (segment, lower robot)
-  d.cap_work = d.mode == 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
+  d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
   c->lds_grad = grad_lds_doubles(d.cap_obs + d.cap_self, d.res) * sizeof(double);
   c->lds_xs = xsolve_lds_doubles(n) * sizeof(double);
+  c->lds_xs2 = ((size_t)n * n + 4 * (size_t)n) * sizeof(double);
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
   c->lds_ls = c->lsl.total * sizeof(double);
 #ifdef TJ_PHASE_TIMING
@@ -320,6 +338,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_linesearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_ls_coupled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_c2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs2));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ccd_self_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_seq));
 
   HostTables t;
@@ -340,9 +360,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) ||
       (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, S * U * (size_t)d.cap_row)) ||
       (r = dalloc(c, &d.pair_count, S * U)) || (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
-      (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.pairplane, d.mode == 1 ? S * U * U * 4 : 1)) ||
-      (r = dalloc(c, &d.pairstamp, d.mode == 1 ? S * U * U : 1)) ||
+      (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
+      (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
       (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 1)) || (r = dalloc(c, &d.ctl, 1))) return r;
+  if (d.mode == TJ_MODE_MULTI_COUPLED &&
+      ((r = dalloc(c, &d.xL, U * (size_t)n * n)) || (r = dalloc(c, &d.xy, U * (size_t)n)) || (r = dalloc(c, &d.xg, U * (size_t)n)) ||
+       (r = dalloc(c, &d.xcorner, U * 4)) || (r = dalloc(c, &d.ls_e, (size_t)LSC_ROUNDS * U * LS_GROUPS)))) return r;
   return TJ_OK;
 }
 
@@ -433,7 +456,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemset(d.ocount, 0, (size_t)U * d.S * 4));
   HIPCHK(c, hipMemset(d.scount, 0, (size_t)U * d.S * 4));
   HIPCHK(c, hipMemset(d.seg_stats, 0, (size_t)U * d.S * 6 * 8));
-  if (d.mode == 1) HIPCHK(c, hipMemset(d.pairstamp, 0, (size_t)d.S * U * U * 4));  // epochs restart at 1
+  if (d.mode >= 1) HIPCHK(c, hipMemset(d.pairstamp, 0, (size_t)d.S * U * U * 4));  // epochs restart at 1
   c->have_state = true;
   return TJ_OK;
 }
@@ -572,7 +595,7 @@ int tj_get_planes(tj_ctx* c, int u, int* counts_obs, int* counts_self, double* p
   QUIESCE(c);
   std::vector<int> co(d.S), cs(d.S, 0);
   HIPCHK(c, hipMemcpy(co.data(), d.ocount + (size_t)u * d.S, d.S * 4, hipMemcpyDeviceToHost));
-  if (d.mode == 1) HIPCHK(c, hipMemcpy(cs.data(), d.scount + (size_t)u * d.S, d.S * 4, hipMemcpyDeviceToHost));
+  if (d.mode >= 1) HIPCHK(c, hipMemcpy(cs.data(), d.scount + (size_t)u * d.S, d.S * 4, hipMemcpyDeviceToHost));
   int total = 0;
   for (int tr = 0; tr < d.S; tr++) total += co[tr] + cs[tr];
   if (counts_obs) memcpy(counts_obs, co.data(), d.S * 4);
@@ -616,6 +639,12 @@ int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, d
   if (t_direction) *t_direction = rec[3 * d.T];
   if (wolfe) *wolfe = rec[3 * d.T + 1];
   if (gn) *gn = rec[3 * d.T + 2];
+  if (d.mode == TJ_MODE_MULTI_COUPLED) {  // one Newton system for all robots: report its global wolfe and gnorm
+    Ctl h;
+    HIPCHK(c, hipMemcpy(&h, d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    if (wolfe) *wolfe = h.wolfe_c;
+    if (gn) *gn = h.gnorm;
+  }
   return TJ_OK;
 }
 
@@ -724,7 +753,7 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   s->iters = (unsigned long long)(h.iter + h.pending);
   s->nodes_dcd = tot[0]; s->cand_dcd = tot[1]; s->nodes_ccd = tot[2]; s->cand_ccd = tot[3]; s->planes_obs = tot[4]; s->planes_self = tot[5];
   s->energy_evals = h.energy_evals; s->llt_fail_piece = h.llt_fail_piece; s->llt_fail_robot = h.llt_fail_robot; s->newton_iters = h.newton_iters; s->pair_solves = h.pair_solves;
-  s->pair_tests = d.mode == 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
+  s->pair_tests = d.mode >= 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
   s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error;
   return TJ_OK;
 }
