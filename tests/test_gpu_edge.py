@@ -168,6 +168,6 @@ def test_cli_coupled_mode_and_log_data(pkg, scenes, tmp_path):
             out.append(w @ coeff[i]); t += 0.1 / pts[0]
         out = np.array(out)
         want = np.linalg.norm(np.diff(out, axis=0), axis=1).sum()
-        assert abs(lens[u] - want) <= 1e-6 * want                                      # stdout prints 6 significant digits
+        assert abs(lens[u] - want) <= 1e-5 * want                                      # stdout prints 6 significant digits
         mine = smp[smp[:, 0] == u][:, 2:]
         assert mine.shape == out.shape and np.max(np.abs(mine - out)) <= 1e-12

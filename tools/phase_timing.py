@@ -54,6 +54,13 @@ def main():
         print("   phase        " + " ".join(f"{p:>12s}" for p in PHASES[name]))
         print("   mean us      " + " ".join(f"{x:12.2f}" for x in d.mean(0)))
         print("   max us       " + " ".join(f"{x:12.2f}" for x in d.max(0)))
+        if name == "k_sep_self_solve":
+            gk, nit = t[:, 6], t[:, 7]
+            print("   GJK iterations: hist", np.bincount(gk.astype(int), minlength=51)[[1,2,3,4,5,6,8,10,15,20,30,40,50]], "(at 1,2,3,4,5,6,8,10,15,20,30,40,50); mean", gk.mean(), "max", gk.max())
+            print("   Newton iterations (accepted pairs): mean", nit[nit >= 0].mean() if (nit >= 0).any() else 0, "max", nit.max(), "rejected", int((nit < 0).sum()))
+            print("   corr(total us, gjk iters) =", np.corrcoef(tot, gk)[0, 1], " corr(total us, newton) =", np.corrcoef(tot, np.maximum(nit, 0))[0, 1])
+            o = np.argsort(-tot)[:8]
+            print("   slowest:", [(round(float(tot[i]), 1), int(gk[i]), int(nit[i])) for i in o])
         worst = np.argsort(-tot)[:3]
         for w in worst:
             print(f"   slow block {np.flatnonzero(live)[w]:5d}: " + " ".join(f"{x:12.2f}" for x in d[w]))

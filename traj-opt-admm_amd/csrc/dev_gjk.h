@@ -96,7 +96,13 @@ __device__ __forceinline__ void gjk_seg(Simplex& s) {
   }
 }
 
-// triangle {v0 = C, v1 = B, v2 = A} (openGJK.c:168-393)
+// triangle {v0 = C, v1 = B, v2 = A} (openGJK.c:168-393).
+// Code-size note: the reference's S2D/S3D call the lower-dimensional routine from many branches.  Inlined
+// naively that is ~50 copies of the segment routine and ~10 of the triangle routine per GJK instance
+// (76 KB of ISA -- more than the instruction cache, and every divergent lane walks its own copy).  Here each
+// routine first DECIDES which sub-simplices to visit, then visits them in a loop with ONE call site, then
+// applies the branch's relabelling: same arithmetic and same results, a tenth of the code, and lanes on
+// different branches reconverge on the shared call.
 __device__ __forceinline__ void gjk_tri(Simplex& s) {
   const V3 c = s.v0, b = s.v1, a = s.v2;
   const V3 s21{b.x - a.x, b.y - a.y, b.z - a.z}, s31{c.x - a.x, c.y - a.y, c.z - a.z};
@@ -127,12 +133,30 @@ __device__ __forceinline__ void gjk_tri(Simplex& s) {
   const double B2 = pp0 * sa1 + pp1 * sb0 + sa0 * sb1 - pp0 * sb1 - pp1 * sa0 - sb0 * sa1;
   const int F0 = same_sign(nu_max, B0), F1 = same_sign(nu_max, B1), F2 = same_sign(nu_max, B2);
 
-  if (F1 + F2 == 0 || isnan(n.x)) {
-    Simplex aux;
-    aux.n = 2; aux.v0 = s.v1; aux.v1 = s.v2;
-    s.n = 2; s.v1 = s.v2;
-    gjk_seg(aux);
-    gjk_seg(s);
+  const bool both = F1 + F2 == 0 || isnan(n.x);  // origin outside two edges: try {B,A} and {C,A}, keep the closer
+  if (!both && F0 + F1 + F2 == 3) {
+    const double inv = 1 / nu_max;
+    s.l0 = B2 * inv; s.l1 = B1 * inv; s.l2 = 1 - s.l0 - s.l1;
+    s.w0 = 0; s.w1 = 1; s.w2 = 2; s.n = 3;
+    return;
+  }
+  // edge visited by job j: kind 0 = {B,A} then {C,A}; 1 = {B,A} (F2 == 0); 2 = {C,A} (F1 == 0); 3 = {C,B}
+  const int kind = both ? 0 : (F2 == 0 ? 1 : (F1 == 0 ? 2 : 3));
+  const int njobs = both ? 2 : 1;
+  Simplex aux, cur;
+  aux.n = 1; aux.l0 = aux.l1 = 0; aux.w0 = aux.w1 = 0; aux.v0 = aux.v1 = c;
+#pragma unroll 1
+  for (int j = 0; j < njobs; ++j) {
+    const bool edgeBA = (kind == 0 && j == 0) || kind == 1;
+    const bool edgeCA = (kind == 0 && j == 1) || kind == 2;
+    cur.n = 2;
+    cur.v0 = edgeBA ? b : c;
+    cur.v1 = (edgeBA || edgeCA) ? a : b;
+    gjk_seg(cur);
+    if (kind == 0 && j == 0) { aux.n = cur.n; aux.v0 = cur.v0; aux.v1 = cur.v1; aux.l0 = cur.l0; aux.l1 = cur.l1; aux.w0 = cur.w0; aux.w1 = cur.w1; }
+  }
+  s.n = cur.n; s.v0 = cur.v0; s.v1 = cur.v1; s.l0 = cur.l0; s.l1 = cur.l1; s.w0 = cur.w0; s.w1 = cur.w1;
+  if (kind == 0) {
     const V3 vt = sx_point(aux), v = sx_point(s);
     if (dot(v, v) < dot(vt, vt)) {
       if (s.n > 1) s.w1 = s.w1 + 1;
@@ -140,20 +164,8 @@ __device__ __forceinline__ void gjk_tri(Simplex& s) {
       s.n = aux.n; s.l0 = aux.l0; s.w0 = aux.w0;
       if (s.n > 1) { s.l1 = aux.l1; s.w1 = aux.w1; }
     }
-  } else if (F0 + F1 + F2 == 3) {
-    const double inv = 1 / nu_max;
-    s.l0 = B2 * inv; s.l1 = B1 * inv; s.l2 = 1 - s.l0 - s.l1;
-    s.w0 = 0; s.w1 = 1; s.w2 = 2; s.n = 3;
-  } else if (F2 == 0) {
-    s.n = 2; s.v0 = s.v1; s.v1 = s.v2;
-    gjk_seg(s);
-  } else if (F1 == 0) {
-    s.n = 2; s.v1 = s.v2;
-    gjk_seg(s);
+  } else if (kind == 2) {
     if (s.n > 1) s.w1 = s.w1 + 1;
-  } else {
-    s.n = 2;
-    gjk_seg(s);
   }
 }
 
@@ -190,58 +202,56 @@ __device__ __forceinline__ void gjk_tet(Simplex& s) {
     const double inv = 1 / detM;
     s.l3 = B0 * inv; s.l2 = B1 * inv; s.l1 = B2 * inv; s.l0 = 1 - s.l1 - s.l2 - s.l3;
     s.w0 = 0; s.w1 = 1; s.w2 = 2; s.w3 = 3; s.n = 4;
-  } else if (facing == 0) {
-    int id0 = 0, id1 = 0, id2 = 0, nbest = 0;
-    double lb0 = 0, lb1 = 0, lb2 = 0, best = 0;
-    for (int i = 0; i < 3; ++i) {
-      Simplex aux;
-      aux.n = 3;
-      aux.v2 = sx_v(s, tri_lut(i));
-      aux.v1 = sx_v(s, tri_lut(i + 3));
-      aux.v0 = sx_v(s, tri_lut(i + 6));
-      gjk_tri(aux);
-      const V3 vt = sx_point(aux);
+    return;
+  }
+  // Faces visited, as vertex triples (v0,v1,v2) of the sub-triangle taken from {D,C,B,A} = indices {0,1,2,3}:
+  //   t0 = (D,C,A) "ACD", t1 = (D,B,A) "ABD", t2 = (C,B,A) "ABC", t3 = (D,C,B)
+  //   facing 0: t0, t1, t2, keep the closest          (openGJK.c:470-520)
+  //   facing 1: two faces; first -> aux, second -> s   (:521-640)
+  //   facing 2: one face in place                      (:641-680)
+  //   facing 3: t3, labels shifted by one              (:681-700)
+  const int njobs = facing == 0 ? 3 : (facing == 1 ? 2 : 1);
+  const int first = F1 == 0 ? 0 : 1;                          // facing 1: face of job 0
+  const int second = (F1 == 0 && F2 == 0) ? 1 : 2;            // facing 1: face of job 1
+  const int single = facing == 3 ? 3 : (F1 == 0 ? 0 : (F2 == 0 ? 1 : 2));  // facing 2 / 3
+  const Simplex keep = s;
+  Simplex aux, cur;
+  aux = s;
+  int id0 = 0, id1 = 0, id2 = 0, nbest = 0;
+  double lb0 = 0, lb1 = 0, lb2 = 0, best = 0;
+#pragma unroll 1
+  for (int j = 0; j < njobs; ++j) {
+    const int t = facing == 0 ? j : (facing == 1 ? (j == 0 ? first : second) : single);
+    const int ia = t == 2 ? 1 : 0, ib = (t == 0 || t == 3) ? 1 : 2, ic = t == 3 ? 2 : 3;
+    cur.n = 3;
+    cur.v0 = sx_v(keep, ia); cur.v1 = sx_v(keep, ib); cur.v2 = sx_v(keep, ic);
+    gjk_tri(cur);
+    if (facing == 0) {
+      const V3 vt = sx_point(cur);
       const double dd = dot(vt, vt);
-      if (i == 0 || dd < best) {
-        best = dd; nbest = aux.n;
-        id0 = tri_lut(i + aux.w0 * 3); lb0 = aux.l0;
-        if (nbest > 1) { id1 = tri_lut(i + aux.w1 * 3); lb1 = aux.l1; }
-        if (nbest > 2) { id2 = tri_lut(i + aux.w2 * 3); lb2 = aux.l2; }
+      if (j == 0 || dd < best) {
+        best = dd; nbest = cur.n;
+        id0 = tri_lut(j + cur.w0 * 3); lb0 = cur.l0;
+        if (nbest > 1) { id1 = tri_lut(j + cur.w1 * 3); lb1 = cur.l1; }
+        if (nbest > 2) { id2 = tri_lut(j + cur.w2 * 3); lb2 = cur.l2; }
       }
+    } else if (facing == 1 && j == 0) {
+      aux.n = cur.n; aux.v0 = cur.v0; aux.v1 = cur.v1; aux.v2 = cur.v2;
+      aux.l0 = cur.l0; aux.l1 = cur.l1; aux.l2 = cur.l2; aux.w0 = cur.w0; aux.w1 = cur.w1; aux.w2 = cur.w2;
+      const V3 vt = sx_point(cur); best = dot(vt, vt);
     }
-    const Simplex keep = s;
+  }
+  if (facing == 0) {
     s.n = nbest;
     sx_set_v(s, nbest - 1, sx_v(keep, id0)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
     if (nbest > 1) { sx_set_v(s, nbest - 2, sx_v(keep, id1)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
     if (nbest > 2) { sx_set_v(s, nbest - 3, sx_v(keep, id2)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
-  } else if (facing == 1) {
-    Simplex aux;
-    aux.n = 3;
-    double best = 0;
-    int used = 0, first = 0, second = 0;
-    if (F1 == 0) {  // ACD
-      aux.v0 = s.v0; aux.v1 = s.v1; aux.v2 = s.v3;
-      gjk_tri(aux);
-      const V3 vt = sx_point(aux); best = dot(vt, vt);
-      used = 1; first = 0;
-    }
-    if (F2 == 0) {  // ABD
-      if (!used) {
-        aux.v0 = s.v0; aux.v1 = s.v2; aux.v2 = s.v3;
-        gjk_tri(aux);
-        const V3 vt = sx_point(aux); best = dot(vt, vt);
-        first = 1;
-      } else {
-        s.n = 3; s.v1 = s.v2; s.v2 = s.v3;
-        gjk_tri(s);
-        second = 1;
-      }
-    }
-    if (F3 == 0) {  // ABC
-      s.n = 3; s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3;
-      gjk_tri(s);
-      second = 2;
-    }
+    return;
+  }
+  // the (last) visited face becomes the simplex
+  s.n = cur.n; s.v0 = cur.v0; s.v1 = cur.v1; s.v2 = cur.v2;
+  s.l0 = cur.l0; s.l1 = cur.l1; s.l2 = cur.l2; s.w0 = cur.w0; s.w1 = cur.w1; s.w2 = cur.w2;
+  if (facing == 1) {
     const V3 v = sx_point(s);
     if (dot(v, v) < best) {
       for (int i = 0; i < s.n; ++i) sx_set_w(s, s.n - 1 - i, tri_lut(second + sx_w(s, i) * 3));  // in place, as the reference
@@ -251,20 +261,8 @@ __device__ __forceinline__ void gjk_tet(Simplex& s) {
       for (int i = 0; i < s.n; ++i) sx_set_w(s, aux.n - 1 - i, tri_lut(first + sx_w(aux, i) * 3));
     }
   } else if (facing == 2) {
-    if (F1 == 0) {
-      s.n = 3; s.v2 = s.v3;
-      gjk_tri(s);
-    } else if (F2 == 0) {
-      s.n = 3; s.v1 = s.v2; s.v2 = s.v3;
-      gjk_tri(s);
-      if (s.n > 2) s.w2 = s.w2 + 1;
-    } else if (F3 == 0) {
-      s.n = 3; s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3;
-      gjk_tri(s);
-    }
+    if (single == 1 && s.n > 2) s.w2 = s.w2 + 1;
   } else {
-    s.n = 3;
-    gjk_tri(s);
     s.w0 = s.w0 + 1;
     if (s.n > 1) s.w1 = s.w1 + 1;
     if (s.n > 2) s.w2 = s.w2 + 1;
@@ -288,7 +286,7 @@ __device__ __forceinline__ void support(const Body& body, const V3& dir, V3& cur
 
 // witness vector of conv(b1) - conv(b2) (openGJK.c:754-852)
 template <class B1, class B2>
-__device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2) {
+__device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2, int* iters_out = nullptr) {
   const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
   Simplex s;
   V3 s1 = b1.get(0), s2 = b2.get(0);
@@ -316,6 +314,7 @@ __device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2) {
     if (s.n > 3) { double t = sq(s.v3); if (t > wmax2) wmax2 = t; }
     if (sq(v) <= (eps_tot * eps_tot * wmax2)) break;
   } while ((s.n != 4) && (k != 50));
+  if (iters_out) *iters_out = k;
   return v;
 }
 
