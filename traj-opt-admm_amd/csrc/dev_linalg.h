@@ -128,6 +128,34 @@ __device__ __forceinline__ bool chol_check_wave(double (&r)[N]) {
   return true;
 }
 
+// Arrowhead-band Cholesky of an N x N system (N <= 64) entirely in the registers of ONE wave: lane i holds
+// the full row i (r[j] = A[i][j], both triangles), the right-hand side rides along in y (lane i = y_i).
+// Same operation order as chol_arrow_lds (a_ij - l_ik * l_jk with k ascending; column scaled by IEEE
+// division), so pivots, factor and forward-substituted rhs are bit-identical to it -- but a pivot is
+// ~150 straight-line instructions (v_readlane broadcasts, no LDS round trip, no barrier) instead of three
+// LDS round trips.  Pattern: half-bandwidth BW plus a dense last row.  npiv = N - 1 leaves the Schur
+// complement of the last diagonal entry in lane N-1 (see chol_arrow_lds).  Returns false on a pivot <= 0.
+template <int N, int BW>
+__device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int lane, int npiv) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    if (k == N - 1 && npiv < N) break;
+    const double x = readlane_f64(r[k], k);
+    if (x <= 0) return false;
+    const double sx = sqrt(x);
+    const double lik = r[k] / sx;
+    const double yk = readlane_f64(y, k) / sx;
+    r[k] = lane == k ? sx : lik;
+    constexpr int LAST = N - 1;
+    const int jhi = (k + BW < LAST - 1) ? k + BW : LAST - 1;
+#pragma unroll
+    for (int j = k + 1; j <= jhi; j++) r[j] = r[j] - lik * readlane_f64(lik, j);
+    if (k < LAST) r[LAST] = r[LAST] - lik * readlane_f64(lik, LAST);
+    y = lane == k ? yk : (lane > k ? y - yk * lik : y);
+  }
+  return true;
+}
+
 // Generic dense variant for larger matrices (only the known-answer hook uses n > 20).
 __device__ inline bool chol_lds(double* A, int n, int tid, int nth, double* y = nullptr) {
   if (n <= CHOL_MB + 2) return chol_arrow_lds(A, n, n, tid, nth, y);  // the 19x19 / 13x13 piece systems

@@ -283,6 +283,45 @@ constexpr int XS_LOAD_THREADS = 256;  // the whole block streams the piece block
 constexpr int XS_BAND = 17;      // pieces couple reduced coordinates at most 17 apart
 __host__ __device__ inline size_t xsolve_lds_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16 + ((size_t)(n + 2) / 9) * 380; }
 
+// Factor the reduced system held in LDS (L, row-major n x n) with the register-resident wave kernel when
+// n = 9P-2 fits one row per lane (P <= 7); the factor's band + arrow row and the forward-substituted
+// right-hand side go back to LDS for the back substitution.  handled = false: caller uses chol_arrow_lds.
+template <int N>
+__device__ __noinline__ bool xs_factor_regs_n(double* L, double* x0, int tid, int npiv) {
+  double r[N];
+  const int row = min(tid, N - 1);
+#pragma unroll
+  for (int j = 0; j < N; j++) r[j] = tid < N ? L[row * N + j] : 0.0;
+  double y = tid < N ? x0[row] : 0.0;
+  if (!chol_arrow_wave<N, XS_BAND>(r, y, tid, npiv)) return false;
+#pragma unroll
+  for (int j = 0; j < N; j++)
+    if (tid < N && j <= tid && (j + XS_BAND >= tid || tid == N - 1)) L[tid * N + j] = r[j];
+  if (tid < N) x0[tid] = y;
+  blk_sync<true>();
+  return true;
+}
+__device__ __forceinline__ bool xs_factor_regs(double* L, double* x0, int n, int tid, int npiv, bool& handled) {
+  handled = true;
+  switch (n) {
+    case 16: return xs_factor_regs_n<16>(L, x0, tid, npiv);
+    case 25: return xs_factor_regs_n<25>(L, x0, tid, npiv);
+    case 34: return xs_factor_regs_n<34>(L, x0, tid, npiv);
+    case 43: return xs_factor_regs_n<43>(L, x0, tid, npiv);
+    case 52: return xs_factor_regs_n<52>(L, x0, tid, npiv);
+    case 61: return xs_factor_regs_n<61>(L, x0, tid, npiv);
+  }
+  handled = false;
+  return false;
+}
+// one factorisation attempt: registers when the size allows, LDS otherwise
+__device__ __forceinline__ bool xs_factor(double* L, double* x0, int n, int tid, int npiv) {
+  bool handled;
+  const bool ok = xs_factor_regs(L, x0, n, tid, npiv, handled);
+  if (handled) return ok;
+  return chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0, npiv);
+}
+
 __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   if (D.ctl->done) return;
   extern __shared__ double sm[];
@@ -347,7 +386,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     // Optimization3D_multi::update_spline (Optimization3D_multi.h:519-557): this robot's block of the
     // arrowhead system.  Eliminate the m control-point unknowns; what is left of the last row is the
     // robot's contribution to the shared-time corner (Schur complement) -- k_xsolve_c2 completes it.
-    if (!chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0, n - 1)) {
+    if (!xs_factor(L, x0, n, tid, n - 1)) {
       if (tid == 0) { atomicAdd(&D.ctl->llt_fail_robot, 1ull); atomicOr(&D.ctl->error, ERR_NOT_SPD); }
     }
     blk_sync<true>();
@@ -357,7 +396,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     if (tid == 0) { double* oc = D.xcorner + (size_t)u * 4; oc[0] = L[m * n + m]; oc[1] = x0[m]; oc[2] = g0[m]; oc[3] = 0; }
     return;
   }
-  if (!chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0)) {  // forward substitution fused: x0 <- L^-1 g0
+  if (!xs_factor(L, x0, n, tid, n)) {  // forward substitution fused: x0 <- L^-1 g0
     if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
     blk_sync<true>();
     if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
@@ -370,7 +409,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
     for (int i = tid; i < n; i += XS_THREADS) x0[i] = g0[i];
     blk_sync<true>();
-    chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0);  // like the reference, the second factorisation is not re-checked
+    xs_factor(L, x0, n, tid, n);  // like the reference, the second factorisation is not re-checked
     blk_sync<true>();
   }
   TJ_TIC(D, K_XSOLVE, 3);
