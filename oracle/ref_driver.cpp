@@ -169,6 +169,24 @@ int ref_init_state(const double* wp, double piece_time0) {
   return 0;
 }
 
+// "optimal_plane":1 -- persistent per-(segment, obstacle) / per-(segment, robot pair) plane caches, allocated
+// the way the mains' init_variable does (Main/admmPathPlanning3D.cpp:343-351, Main/multiPathPlanning3D.cpp:450-464).
+// Call after ref_setup / ref_init_state.
+void ref_set_optimal_plane(int on) {
+  is_optimal_plane = on != 0;
+  const int S = piece_num * res, N = (int)g_vertex_list.size();
+  is_seperate.assign(S, std::vector<bool>()); seperate_c.assign(S, {}); seperate_d.assign(S, {});
+  is_self_seperate.assign(S, {}); self_seperate_c.assign(S, {}); self_seperate_d.assign(S, {});
+  if (!on) return;
+  for (int i = 0; i < S; i++) {
+    is_seperate[i].assign(N, false); seperate_c[i].resize(N); seperate_d[i].resize(N);
+    is_self_seperate[i].resize(uav_num); self_seperate_c[i].resize(uav_num); self_seperate_d[i].resize(uav_num);
+    for (int j = 0; j < uav_num; j++) {
+      is_self_seperate[i][j].assign(uav_num, false); self_seperate_c[i][j].resize(uav_num); self_seperate_d[i][j].resize(uav_num);
+    }
+  }
+}
+
 int ref_T() { return trajectory_num; }
 
 void ref_get_state(int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time) {
