@@ -60,6 +60,8 @@ def kernel_bytes(st, slv, iters):
     b["k_xsolve_c2"] = U * (n * n + 2 * n + 4) * 8 + U * (3 * T + 4) * 8                  # coupled mode: factor + rhs in, direction out
     b["k_ls_coupled"] = b["k_linesearch"] + U * 8 * 8                                       # per evaluation round (first round; later rounds exit early)
     b["k_ls_commit"] = U * (2 * 3 * T * 8 + 3 * T * 8) + 4 * U * 8 * 8
+    if slv.mode != 2:   # single-GPU graph: the hull cache is written by k_linesearch (Dev::fuse)
+        b["k_linesearch"] += U * S * 976 if slv.mode == 1 else 0
     if st is not None and slv.mode == 2:
         b["k_xsolve"] = U * P * (19 + 361) * 8 + U * (n * n + 2 * n + 4) * 8               # writes its factor for k_xsolve_c2
     return b

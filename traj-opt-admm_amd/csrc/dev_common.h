@@ -61,6 +61,9 @@ struct Dev {
   // ---- parameters (3D.json + hard-coded constants of the mains) ----
   int mode, U, P, res, S, T, N;
   int u0, u1;  // robots owned by this rank: [u0,u1)
+  int fuse;    // single-GPU iteration graph: k_linesearch leaves the next iteration's hull cache, so k_hullinfo is not
+               // launched (the sharded schedule needs the cache for ALL robots after its all-gather and keeps the kernel;
+               // folding k_ccd_prep into k_xsolve the same way was measured slower: 10 dependent segments per wave)
   double lambda, margin, offset, mu, vel_limit, acc_limit, ks, kt, stop;
   int cap_obs, cap_self, cap_pairs;
   // ---- tables (row-major 6x6) ----

@@ -209,6 +209,32 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
   return M;
 }
 
+// Hull cache of the NEXT iteration's robot-pair stage (layout of k_hullinfo, kernels_pairs.h: hull 18, AABB 6,
+// 49 k-DOP intervals lo/hi), written from the hulls the accepted Armijo candidate was evaluated on -- they ARE the
+// hulls of the control net just committed, so the separate k_hullinfo launch (and its place on the critical path)
+// disappears from the single-GPU iteration graph.  Same expressions as k_hullinfo => identical bits.
+constexpr int LS_HULL_STRIDE = 18 + 6 + 98;
+__device__ __forceinline__ void ls_publish_hullinfo(const Dev& D, int u, const double* hulls, int tid, int nth) {
+  const int S = D.S;
+  double* o = D.hullinfo + (size_t)u * S * LS_HULL_STRIDE;
+  for (int idx = tid; idx < S * 18; idx += nth) o[(size_t)(idx / 18) * LS_HULL_STRIDE + idx % 18] = hulls[idx];
+  for (int idx = tid; idx < S * 3; idx += nth) {
+    const int tr = idx / 3, a = idx % 3;
+    const double* P = hulls + tr * 18;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int j = 0; j < 6; j++) { const double v = P[3 * j + a]; if (v < lo) lo = v; if (v > hi) hi = v; }
+    o[(size_t)tr * LS_HULL_STRIDE + 18 + a] = lo; o[(size_t)tr * LS_HULL_STRIDE + 21 + a] = hi;
+  }
+  for (int idx = tid; idx < S * 49; idx += nth) {
+    const int tr = idx / 49, ax = idx % 49;
+    const double* P = hulls + tr * 18;
+    const double x = D.kdop[3 * ax], y = D.kdop[3 * ax + 1], z = D.kdop[3 * ax + 2];
+    double up = -INFINITY, lo = INFINITY;
+    for (int i = 0; i < 6; i++) { const double lv = x * P[3 * i] + y * P[3 * i + 1] + z * P[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+    o[(size_t)tr * LS_HULL_STRIDE + 24 + ax] = lo; o[(size_t)tr * LS_HULL_STRIDE + 73 + ax] = up;
+  }
+}
+
 __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
   if (D.ctl->done) return;
   extern __shared__ double sm[];
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
   if (t0 + step0 * t_dir <= 0) step0 = -0.95 * t0 / t_dir;
 
   double e_base = 0, step_acc = step0, pt_acc = t0;
-  int k_acc = -1, evals = 0;
+  int k_acc = -1, evals = 0, wg = 0;
   for (int round = 0; k_acc < 0; round++) {
     // candidate of this group: -1 = E(x) (round 0, group 0), otherwise trial index k >= 0
     const int k = round == 0 ? g - 1 : 7 + (round - 1) * LS_GROUPS + g;
@@ -260,6 +286,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
       pt_acc = t0 + step_acc * t_dir;
       evals = 2 + k_acc;
       // commit: the accepting group's trial net is the new control net
+      wg = acc;
       const double* win = sm + L.gnet + (size_t)acc * 3 * T;
       for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
     } else if (7 + round * LS_GROUPS >= LOOP_CAP) {
@@ -269,11 +296,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
       step_acc = res[2 * LS_GROUPS - 1];
       pt_acc = t0 + step_acc * t_dir;
       evals = 2 + k_acc;
+      wg = LS_GROUPS - 1;
       const double* win = sm + L.gnet + (size_t)(LS_GROUPS - 1) * 3 * T;
       for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
     }
     __syncthreads();
   }
+  if (D.fuse && D.multi()) ls_publish_hullinfo(D, u, sm + L.ghull + (size_t)wg * S * 18, tid, LS_THREADS);
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
 }

@@ -26,14 +26,10 @@
 
 namespace tj {
 
-__global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
-  if (D.ctl->done) return;
-  const int u = blockIdx.x / D.S, tr = blockIdx.x % D.S;  // ALL robots: the pair clamp is replicated per rank
-  const int lane = lane_id();
-  __shared__ double sh[18 * 3 + 18];
+// one (robot, segment) of the swept-hull cache, computed by ONE wave; net / dir are T x 3 column-major control nets
+// (global or LDS), sh is 72 doubles of wave-private LDS
+__device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net, const double* dir, int u, int tr, int lane, double* sh) {
   double* P = sh; double* Dh = sh + 18; double* PD = sh + 36; double* PS = sh + 54;
-  const double* net = D.spline + (size_t)u * 3 * D.T;
-  const double* dir = D.dirp(u);
   if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
   else if (lane < 36) Dh[lane - 18] = hull_entry(D, dir, tr, (lane - 18) / 3, (lane - 18) % 3);
   else if (lane < 54) {  // basis * (bz + bz_d), the box the reference uses for the cloud query
@@ -44,9 +40,9 @@ __global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
     for (int k = 0; k < 6; k++) acc += B[k] * (net[r0 + k] + dir[r0 + k]);
     PD[lane - 36] = acc;
   }
-  __syncthreads();
+  blk_sync<true>();
   if (lane < 18) PS[lane] = P[lane] + Dh[lane];  // (P + D) used by the pair box and by the k-DOP at step 1
-  __syncthreads();
+  blk_sync<true>();
   double* o = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
   if (lane < 18) { o[lane] = P[lane]; o[18 + lane] = Dh[lane]; }
   if (lane < 3) {
@@ -65,6 +61,14 @@ __global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
     for (int i = 0; i < 6; i++) { const double lv = x * PS[3 * i] + y * PS[3 * i + 1] + z * PS[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
     o[48 + lane] = lo; o[97 + lane] = up;
   }
+  blk_sync<true>();  // sh is reused by the caller's next segment
+}
+
+__global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
+  if (D.ctl->done) return;
+  const int u = blockIdx.x / D.S, tr = blockIdx.x % D.S;  // ALL robots: the pair clamp is replicated per rank
+  __shared__ double sh[18 * 3 + 18];
+  ccd_prep_segment(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane_id(), sh);
 }
 
 __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {

@@ -36,6 +36,7 @@ struct tj_ctx {
   std::vector<void*> allocs;
   std::string err;
   bool have_cloud = false, have_state = false;
+  bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
   // graph of one full iteration
   // hipGraphs: [0..2] the three phases of a sharded iteration, [3] one full iteration
   hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -88,15 +89,16 @@ const char* const kKernelNames[K_COUNT] = {"k_begin", "k_sep_obs", "k_hullinfo",
                                            "k_grad", "k_xsolve", "k_xsolve_c2", "k_ccd_prep", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
                                            "k_linesearch", "k_ls_coupled", "k_ls_commit", "k_slack"};
 
-// launch exactly one kernel (returns false for kernels that do not exist in this mode)
-bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0) {
+// launch exactly one kernel (returns false for kernels that do not exist in this mode).  in_graph: the launch is part
+// of the single-GPU iteration graph, where k_hullinfo is folded into k_linesearch (Dev::fuse).
+bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2;
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_SEP_OBS: hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
-    case K_HULLINFO: if (multi) hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return multi;
+    case K_HULLINFO: if (in_graph && d.fuse) return false; if (multi) hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return multi;
     case K_SEP_SELF_ROWS: if (multi) hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return multi;
     case K_SEP_SELF_SOLVE: if (multi) hipLaunchKernelGGL(k_sep_self_solve, dim3(std::min(d.cap_work, 4096)), dim3(64), 0, s, d); return multi;
     case K_SEP_SELF_COMPACT: if (multi) hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return multi;
@@ -117,15 +119,15 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0) {
 }
 
 // enqueue one stage (= one or more kernels) on a stream
-int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr) {
+int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr, bool in_graph = false) {
   if (!s) s = c->stream;
   switch (stage) {
     case TJ_STAGE_BEGIN: launch_kernel(c, K_BEGIN, s); break;
     case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); break;
-    case TJ_STAGE_PLANES_SELF: for (int k = K_HULLINFO; k <= K_SEP_SELF_COMPACT; k++) launch_kernel(c, k, s); break;
+    case TJ_STAGE_PLANES_SELF: for (int k = K_HULLINFO; k <= K_SEP_SELF_COMPACT; k++) launch_kernel(c, k, s, 0, in_graph); break;
     case TJ_STAGE_GRAD: launch_kernel(c, K_GRAD, s); break;
     case TJ_STAGE_XSOLVE: launch_kernel(c, K_XSOLVE, s); launch_kernel(c, K_XSOLVE_C2, s); break;
-    case TJ_STAGE_CCD_PREP: launch_kernel(c, K_CCD_PREP, s); break;
+    case TJ_STAGE_CCD_PREP: launch_kernel(c, K_CCD_PREP, s, 0, in_graph); break;
     case TJ_STAGE_CCD_OBS: launch_kernel(c, K_CCD_OBS, s); break;
     case TJ_STAGE_CCD_SELF: launch_kernel(c, K_CCD_SELF_PAIRS, s); launch_kernel(c, K_CCD_SELF_SEQ, s); break;
     case TJ_STAGE_LINESEARCH: launch_kernel(c, K_LINESEARCH, s); launch_kernel(c, K_LS_COUPLED, s); launch_kernel(c, K_LS_COMMIT, s); break;
@@ -149,7 +151,7 @@ int enqueue_iteration(tj_ctx* c) {
   hipStream_t m = c->stream, s2 = c->side, s3 = c->side2;
   const Dev& d = c->d;
   int r;
-#define STG(st, str) if ((r = enqueue_stage(c, st, str))) return r
+#define STG(st, str) if ((r = enqueue_stage(c, st, str, true))) return r
   STG(TJ_STAGE_BEGIN, m);
   HIPCHK(c, hipEventRecord(c->ev[0], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[0], 0)); HIPCHK(c, hipStreamWaitEvent(s3, c->ev[0], 0));
   STG(TJ_STAGE_PLANES_OBS, m);
@@ -244,6 +246,16 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
   return TJ_OK;
 }
 
+// Dev::fuse: the iteration graph has no k_hullinfo (k_linesearch leaves the next iteration's hull cache); after the
+// control points were set from the host the cache is rebuilt once here.
+int ensure_hull_cache(tj_ctx* c) {
+  if (!c->d.fuse || c->hull_valid) return TJ_OK;
+  launch_kernel(c, K_HULLINFO, c->stream);
+  HIPCHK(c, hipGetLastError());
+  c->hull_valid = true;
+  return TJ_OK;
+}
+
 bool ready(tj_ctx* c) {
   if (!c->have_cloud) { c->err = "tj_set_cloud has not been called"; return false; }
   if (!c->have_state) { c->err = "tj_init_state has not been called"; return false; }
@@ -309,6 +321,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   Dev& d = c->d;
   memset(&d, 0, sizeof(d));
   d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0;
+  d.fuse = (p->world == 1 && p->mode != TJ_MODE_MULTI_COUPLED) ? 1 : 0;
   d.u0 = (int)((long long)p->rank * d.U / p->world); d.u1 = (int)((long long)(p->rank + 1) * d.U / p->world);
   d.lambda = p->lambda; d.margin = p->margin; d.offset = p->offset; d.mu = p->mu; d.vel_limit = p->vel_limit; d.acc_limit = p->acc_limit;
   d.ks = p->ks; d.kt = p->kt; d.stop = p->stop;
@@ -452,6 +465,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   memset(&h, 0, sizeof(h));
   h.gnorm = 1.0;  // Main/multiPathPlanning3D.cpp:594
   if ((r = upload(c, d.ctl, &h, sizeof(h)))) return r;
+  c->hull_valid = false;
   HIPCHK(c, hipMemset(d.xdir, 0, (size_t)U * d.xs * 8));
   HIPCHK(c, hipMemset(d.ocount, 0, (size_t)U * d.S * 4));
   HIPCHK(c, hipMemset(d.scount, 0, (size_t)U * d.S * 4));
@@ -485,6 +499,7 @@ int tj_set_state(tj_ctx* c, int u, const double* spline, const double* p_slack, 
   if (t_slack && (r = upload(c, d.t_slack + (size_t)u * d.P, t_slack, d.P * 8))) return r;
   if (t_lambda && (r = upload(c, d.t_lambda + (size_t)u * d.P, t_lambda, d.P * 8))) return r;
   if ((r = upload(c, d.piece_time + u, &piece_time, 8))) return r;
+  c->hull_valid = false;
   c->have_state = true;
   return TJ_OK;
 }
@@ -492,6 +507,7 @@ int tj_set_state(tj_ctx* c, int u, const double* spline, const double* p_slack, 
 int tj_iterate_async(tj_ctx* c, int n_iters) {
   if (!c || n_iters < 0) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
+  if (n_iters > 0) { int r = ensure_hull_cache(c); if (r) return r; }
   for (int i = 0; i < n_iters; i++) { int r = launch_graph_or_eager(c, 3); if (r) return r; }
   return TJ_OK;
 }
@@ -519,6 +535,7 @@ int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
   if (!c || !ms || n_iters < 0) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
   { int fr = flush_deferred(c); if (fr) return fr; }
+  { int hr = ensure_hull_cache(c); if (hr) return hr; }
   std::vector<hipEvent_t> ev((size_t)n_iters * (K_COUNT + 1));
   for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
   std::vector<int> ran(K_COUNT, 0);
@@ -526,7 +543,7 @@ int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
     hipEvent_t* e = &ev[(size_t)it * (K_COUNT + 1)];
     HIPCHK(c, hipEventRecord(e[0], c->stream));
     for (int k = 0; k < K_COUNT; k++) {
-      if (launch_kernel(c, k, c->stream, 0)) ran[k]++;
+      if (launch_kernel(c, k, c->stream, 0, true)) ran[k]++;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipEventRecord(e[k + 1], c->stream));
     }
