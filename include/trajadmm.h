@@ -137,9 +137,12 @@ int tj_get_stats(tj_ctx* c, tj_stats* s);
  * (host pointers; one case per GPU lane; used by the parity tests against tests/golden/) */
 /* GJK witness vector (replaces gjk(), lib/opengjk/src/openGJK.c:754): n1,n2 in {1,6,12}; a[n][n1][3], b[n][n2][3], v[n][3] */
 int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
+/* the same query solved cooperatively by a whole wavefront (the form the inter-robot kernels use): must give the same bits */
+int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
 /* what: 0 Separate::opengjk (Separate.h:18) P[n][6][3], Q = points [n][3] -> out[n][5] = ok,cx,cy,cz,d
  *       1 Separate::selfgjk + Optimal_plane::optimal_d (Separate.h:165, Optimal_plane.h:13), Q[n][6][3] -> ok,c,d
- *       2 CCD::KDOPDCD (CCD.h:354), 3 CCD::SelfKDOPDCD (CCD.h:535) -> out[n][5], out[.][0] = pass */
+ *       2 CCD::KDOPDCD (CCD.h:354), 3 CCD::SelfKDOPDCD (CCD.h:535) -> out[n][5], out[.][0] = pass
+ *       4 = 1 computed by one wavefront per pair (plane_pair_wave, the form k_sep_self_solve uses) */
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out);
 /* CCD::GJKCCD / SelfGJKCCD (CCD.h:116,227) on swept hulls, tu[n][2] = (tMax, _tMax): out[n][2] booleans */
 int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double* Q, const double* E, const double* q, const double* tu, double d, double* out);

@@ -36,6 +36,24 @@ def test_device_gjk_bit_exact_vs_reference(katsolver, shape):
     assert same.all(), f"{(~same).any(axis=1).sum()} of {len(v)} witness vectors differ"
 
 
+@pytest.mark.parametrize("shape", ["6v1", "6v6", "12v1", "12v12"])
+def test_device_gjk_wave_cooperative_bit_exact(katsolver, shape):
+    """the wave-cooperative GJK (one query per wavefront: parallel support search, faces of a tetrahedron step on
+    separate lanes) must reproduce the reference's witness vectors bit for bit as well"""
+    g = gold("gjk_kat.npz")
+    v = katsolver.kat_gjk_wave(g[f"gjk_{shape}_a"], g[f"gjk_{shape}_b"])
+    want = g[f"gjk_{shape}_v"]
+    same = (v == want) | (np.isnan(v) & np.isnan(want))
+    assert same.all(), f"{(~same).any(axis=1).sum()} of {len(v)} witness vectors differ"
+
+
+def test_device_pair_plane_wave_equals_lane_version(katsolver):
+    g = gold("prims_kat.npz")
+    a = katsolver.kat_planes(1, g["P"], g["Q"], 0.3)
+    b = katsolver.kat_planes(4, g["P"], g["Q"], 0.3)
+    assert np.array_equal(a, b, equal_nan=True)          # same GJK path, same Newton sums: identical bits
+
+
 def test_device_planes_kdop_ccd_vs_reference(katsolver):
     g = gold("prims_kat.npz")
     out = katsolver.kat_planes(0, g["P"], g["q"], 0.2)

@@ -25,7 +25,7 @@ EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
     "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
+    "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
 ]
 
 STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
@@ -263,6 +263,12 @@ class Solver:
         a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
         n = a.shape[0]; v = np.zeros((n, 3))
         self._check(self.lib.tj_kat_gjk(self._ctx, C.c_int(n), C.c_int(a.shape[1]), _d(a), C.c_int(b.shape[1]), _d(b), _d(v)))
+        return v
+
+    def kat_gjk_wave(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        n = a.shape[0]; v = np.zeros((n, 3))
+        self._check(self.lib.tj_kat_gjk_wave(self._ctx, C.c_int(n), C.c_int(a.shape[1]), _d(a), C.c_int(b.shape[1]), _d(b), _d(v)))
         return v
 
     def kat_planes(self, what, P, Q, dist):

@@ -318,4 +318,196 @@ __device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2, int* iters_out = n
   return v;
 }
 
+// ---- wave-cooperative variant -----------------------------------------------------------------
+// One query per WAVEFRONT (the inter-robot kernels: a robot pair per wave).  A single lane walking the whole
+// algorithm issues ~1500 instructions per iteration of the main loop; with 64 lanes available the independent
+// pieces run side by side and the results are broadcast back with v_readlane, so every decision is taken on
+// wave-uniform values:
+//   * both support searches at once: lanes 0..15 hold the vertices of body 1, lanes 16..31 those of body 2;
+//     a 4-step DPP butterfly gives each row its maximum, a ballot picks the FIRST lane that attains it
+//     (openGJK's "first maximum wins"), and the previous support is kept unless the maximum is strictly larger;
+//   * the faces a tetrahedron step has to visit (up to three) are solved by lanes 0..2 in parallel.
+// Every floating-point expression is the one the per-lane version evaluates, on the same operands, so the
+// witness vector is bit-identical (pinned by the same golden vectors, tests/test_gpu_parity.py).
+__device__ __forceinline__ double gjk_rl(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ V3 gjk_rl3(const V3& v, int lane) { return V3{gjk_rl(v.x, lane), gjk_rl(v.y, lane), gjk_rl(v.z, lane)}; }
+template <int CTRL>
+__device__ __forceinline__ double gjk_dpp(double v) {
+  // old = the lane's own value: a lane whose DPP source is disabled sees itself, which is neutral for max
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// maximum over each row of 16 lanes, left in every lane of the row (NaNs are ignored like the `>` test does)
+__device__ __forceinline__ double gjk_row_max(double v) {
+  v = fmax(v, gjk_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = fmax(v, gjk_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = fmax(v, gjk_dpp<0x124>(v));  // row_ror:4
+  v = fmax(v, gjk_dpp<0x128>(v));  // row_ror:8
+  return v;
+}
+
+template <class B1, class B2>
+__device__ __forceinline__ void support_wave(const B1& b1, const B2& b2, const V3& dir1, const V3& dir2, V3& s1, V3& s2, int lane) {
+  static_assert(B1::N <= 16 && B2::N <= 16, "one body per row of 16 lanes");
+  const bool row1 = lane < 16, row2 = lane >= 16 && lane < 32;
+  const int idx = lane & 15;
+  const bool valid = (row1 && idx < B1::N) || (row2 && idx < B2::N);
+  V3 p{0, 0, 0};
+  if (row1 && idx < B1::N) p = b1.get(idx);
+  if (row2 && idx < B2::N) p = b2.get(idx);
+  const V3 dir = row1 ? dir1 : dir2;
+  const double sd = valid ? dot(p, dir) : -INFINITY;
+  const double m = gjk_row_max(sd);
+  const unsigned long long hit = __ballot(valid && sd == m);
+  const double base1 = dot(s1, dir1), base2 = dot(s2, dir2);
+  const unsigned h1 = (unsigned)(hit & 0xFFFFull), h2 = (unsigned)((hit >> 16) & 0xFFFFull);
+  if (h1) {  // uniform
+    const int l = __ffs(h1) - 1;
+    const double best = gjk_rl(m, l);
+    const V3 q = gjk_rl3(p, l);
+    if (best > base1) s1 = q;
+  }
+  if (h2) {
+    const int l = 16 + __ffs(h2) - 1;
+    const double best = gjk_rl(m, l);
+    const V3 q = gjk_rl3(p, l);
+    if (best > base2) s2 = q;
+  }
+}
+
+// gjk_tet with the visited faces solved by lanes 0..2 side by side (see gjk_tet for the case analysis)
+__device__ __forceinline__ void gjk_tet_wave(Simplex& s, int lane) {
+  const V3 d = s.v0, c = s.v1, b = s.v2, a = s.v3;
+  const double B0 = -1 * det3x(b, c, d);
+  const double B1 = +1 * det3x(a, c, d);
+  const double B2 = -1 * det3x(a, b, d);
+  const double B3 = +1 * det3x(a, b, c);
+  const double detM = B0 + B1 + B2 + B3;
+  int F0 = 1, F1 = 1, F2 = 1, F3 = 1;
+  const double eps = 1e-13;
+  if (fabs(detM) < eps) {
+    if (fabs(B2) < eps && fabs(B3) < eps) F1 = 0;
+    else if (fabs(B1) < eps && fabs(B3) < eps) F2 = 0;
+    else if (fabs(B1) < eps && fabs(B2) < eps) F3 = 0;
+    else if (fabs(B0) < eps && fabs(B3) < eps) F1 = 0;
+    else if (fabs(B0) < eps && fabs(B2) < eps) F1 = 0;
+    else if (fabs(B0) < eps && fabs(B1) < eps) F2 = 0;
+    else { F0 = F1 = F2 = F3 = 0; }
+  } else {
+    F0 = same_sign(detM, B0); F1 = same_sign(detM, B1); F2 = same_sign(detM, B2); F3 = same_sign(detM, B3);
+  }
+  const int facing = F1 + F2 + F3;
+  if (F0 + facing == 4) {
+    const double inv = 1 / detM;
+    s.l3 = B0 * inv; s.l2 = B1 * inv; s.l1 = B2 * inv; s.l0 = 1 - s.l1 - s.l2 - s.l3;
+    s.w0 = 0; s.w1 = 1; s.w2 = 2; s.w3 = 3; s.n = 4;
+    return;
+  }
+  const int njobs = facing == 0 ? 3 : (facing == 1 ? 2 : 1);
+  const int first = F1 == 0 ? 0 : 1;
+  const int second = (F1 == 0 && F2 == 0) ? 1 : 2;
+  const int single = facing == 3 ? 3 : (F1 == 0 ? 0 : (F2 == 0 ? 1 : 2));
+  const Simplex keep = s;
+  // this lane's face
+  const int j = lane < njobs ? lane : njobs - 1;
+  const int t = facing == 0 ? j : (facing == 1 ? (j == 0 ? first : second) : single);
+  const int ia = t == 2 ? 1 : 0, ib = (t == 0 || t == 3) ? 1 : 2, ic = t == 3 ? 2 : 3;
+  Simplex mine;
+  mine.n = 3;
+  mine.v0 = sx_v(keep, ia); mine.v1 = sx_v(keep, ib); mine.v2 = sx_v(keep, ic);
+  mine.v3 = V3{0, 0, 0}; mine.l0 = mine.l1 = mine.l2 = mine.l3 = 0; mine.w0 = mine.w1 = mine.w2 = mine.w3 = 0;
+  gjk_tri(mine);
+  // result of job jj, broadcast to the whole wave
+  auto fetch = [&](int jj, Simplex& r) {
+    r.n = __builtin_amdgcn_readlane(mine.n, jj);
+    r.v0 = gjk_rl3(mine.v0, jj); r.v1 = gjk_rl3(mine.v1, jj); r.v2 = gjk_rl3(mine.v2, jj);
+    r.l0 = gjk_rl(mine.l0, jj); r.l1 = gjk_rl(mine.l1, jj); r.l2 = gjk_rl(mine.l2, jj);
+    r.w0 = __builtin_amdgcn_readlane(mine.w0, jj); r.w1 = __builtin_amdgcn_readlane(mine.w1, jj); r.w2 = __builtin_amdgcn_readlane(mine.w2, jj);
+  };
+  Simplex cur;
+  cur.v3 = V3{0, 0, 0}; cur.l3 = 0; cur.w3 = 0;
+  if (facing == 0) {
+    int id0 = 0, id1 = 0, id2 = 0, nbest = 0;
+    double lb0 = 0, lb1 = 0, lb2 = 0, best = 0;
+#pragma unroll 1
+    for (int jj = 0; jj < 3; ++jj) {
+      fetch(jj, cur);
+      const V3 vt = sx_point(cur);
+      const double dd = dot(vt, vt);
+      if (jj == 0 || dd < best) {
+        best = dd; nbest = cur.n;
+        id0 = tri_lut(jj + cur.w0 * 3); lb0 = cur.l0;
+        if (nbest > 1) { id1 = tri_lut(jj + cur.w1 * 3); lb1 = cur.l1; }
+        if (nbest > 2) { id2 = tri_lut(jj + cur.w2 * 3); lb2 = cur.l2; }
+      }
+    }
+    s.n = nbest;
+    sx_set_v(s, nbest - 1, sx_v(keep, id0)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
+    if (nbest > 1) { sx_set_v(s, nbest - 2, sx_v(keep, id1)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
+    if (nbest > 2) { sx_set_v(s, nbest - 3, sx_v(keep, id2)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
+    return;
+  }
+  fetch(njobs - 1, cur);  // the (last) visited face becomes the simplex
+  s.n = cur.n; s.v0 = cur.v0; s.v1 = cur.v1; s.v2 = cur.v2;
+  s.l0 = cur.l0; s.l1 = cur.l1; s.l2 = cur.l2; s.w0 = cur.w0; s.w1 = cur.w1; s.w2 = cur.w2;
+  if (facing == 1) {
+    Simplex aux;
+    aux.v3 = V3{0, 0, 0}; aux.l3 = 0; aux.w3 = 0;
+    fetch(0, aux);
+    const V3 vt = sx_point(aux);
+    const double best = dot(vt, vt);
+    const V3 v = sx_point(s);
+    if (dot(v, v) < best) {
+      for (int i = 0; i < s.n; ++i) sx_set_w(s, s.n - 1 - i, tri_lut(second + sx_w(s, i) * 3));  // in place, as the reference
+    } else {
+      s.n = aux.n; s.v0 = aux.v0; s.v1 = aux.v1; s.v2 = aux.v2;
+      s.l0 = aux.l0; s.l1 = aux.l1; s.l2 = aux.l2;
+      for (int i = 0; i < s.n; ++i) sx_set_w(s, aux.n - 1 - i, tri_lut(first + sx_w(aux, i) * 3));
+    }
+  } else if (facing == 2) {
+    if (single == 1 && s.n > 2) s.w2 = s.w2 + 1;
+  } else {
+    s.w0 = s.w0 + 1;
+    if (s.n > 1) s.w1 = s.w1 + 1;
+    if (s.n > 2) s.w2 = s.w2 + 1;
+  }
+}
+
+// witness vector of conv(b1) - conv(b2), computed by the whole wave; all lanes must call it with the same bodies
+// and all lanes return the same vector
+template <class B1, class B2>
+__device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int* iters_out = nullptr) {
+  const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
+  Simplex s;
+  V3 s1 = b1.get(0), s2 = b2.get(0);
+  V3 v{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
+  s.n = 1; s.v0 = v;
+  s.v1 = s.v2 = s.v3 = V3{0, 0, 0};
+  s.w0 = s.w1 = s.w2 = s.w3 = 0; s.l0 = s.l1 = s.l2 = s.l3 = 0;
+  double wmax2 = 0;
+  int k = 0;
+  do {
+    k++;
+    const V3 vm{-v.x, -v.y, -v.z};
+    support_wave(b1, b2, vm, v, s1, s2, lane);
+    const V3 w{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
+    if ((sq(v) - dot(v, w)) <= eps_rel2 * sq(v)) break;
+    if (sq(v) < eps_rel2) break;
+    sx_set_v(s, s.n, w);
+    s.n++;
+    if (s.n == 4) gjk_tet_wave(s, lane); else if (s.n == 3) gjk_tri(s); else gjk_seg(s);
+    v = sx_point(s);
+    { double t = sq(s.v0); if (t > wmax2) wmax2 = t; }
+    if (s.n > 1) { double t = sq(s.v1); if (t > wmax2) wmax2 = t; }
+    if (s.n > 2) { double t = sq(s.v2); if (t > wmax2) wmax2 = t; }
+    if (s.n > 3) { double t = sq(s.v3); if (t > wmax2) wmax2 = t; }
+    if (sq(v) <= (eps_tot * eps_tot * wmax2)) break;
+  } while ((s.n != 4) && (k != 50));
+  if (iters_out) *iters_out = k;
+  return v;
+}
+
 }  // namespace tj

@@ -25,6 +25,26 @@ __global__ __launch_bounds__(64) void k_dbg_gjk(int n, const double* a, const do
   out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
 }
 
+// wave-cooperative variant (gjk_wave): one case per workgroup = one wavefront
+template <int K1, int K2>
+__global__ __launch_bounds__(64) void k_dbg_gjk_wave(int n, const double* a, const double* b, double* out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const V3 v = gjk_wave(BodyPts<K1>{a + (size_t)i * 3 * K1}, BodyPts<K2>{b + (size_t)i * 3 * K2}, lane_id());
+  if (threadIdx.x == 0) { out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z; }
+}
+// plane_pair_wave: one robot pair per wavefront (the form k_sep_self_solve uses)
+__global__ __launch_bounds__(64) void k_dbg_pair_wave(Dev D, int n, const double* P, const double* Q, double dist, double* out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  __shared__ double A[18], B[18];
+  if (threadIdx.x < 18) { A[threadIdx.x] = P[(size_t)i * 18 + threadIdx.x]; B[threadIdx.x] = Q[(size_t)i * 18 + threadIdx.x]; }
+  __syncthreads();
+  double e0 = 0, e1 = 0, e2 = 0, dpl = 0; bool capped;
+  const bool ok = plane_pair_wave(A, B, dist, D.margin, D.offset, lane_id(), e0, e1, e2, dpl, capped);
+  if (threadIdx.x == 0) { double* o = out + (size_t)i * 5; o[0] = ok; o[1] = e0; o[2] = e1; o[3] = e2; o[4] = dpl; }
+}
+
 // what: 0 plane_obstacle(P,q) -> out[5] = ok,c,d ; 1 plane_pair(P,Q) with Newton refine -> ok,c,d ;
 //       2 k-DOP hull/point ; 3 k-DOP hull/hull   (out[0] = pass)
 __global__ __launch_bounds__(64) void k_dbg_planes(Dev D, int what, int n, const double* P, const double* Q, double dist, double* out) {

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
   }
 }
 
-// one wavefront per robot pair (grid-stride over the work list); lane 0 runs the scalar GJK + Newton
+// one wavefront per robot pair (grid-stride over the work list), solved cooperatively by its lanes (plane_pair_wave)
 __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
   if (D.ctl->done) return;
   const int lane = lane_id();
@@ -120,16 +120,13 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
     if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
     __syncthreads();
     if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
-    if (lane == 0) {
-      double e0, e1c, e2c, dpl; bool capped; int nit = 0;
+    {
+      double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
+      const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk);  // whole wave, uniform result
 #ifdef TJ_PHASE_TIMING
-      int gk = 0;
-      const bool okp = plane_pair(A, B, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit, &gk);
-      if (w == blockIdx.x && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
-      if (okp) {
-#else
-      if (plane_pair(A, B, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
+      if (lane == 0 && w == blockIdx.x && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
 #endif
+      if (okp && lane == 0) {
         atomicAdd(&D.ctl->newton_iters, (unsigned long long)nit); atomicAdd(&D.ctl->pair_solves, 1ull);
         if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
         const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;

@@ -195,6 +195,52 @@ __device__ inline bool plane_pair(const double* A, const double* Bq, double dist
   return true;
 }
 
+// plane_pair computed by a whole wave for ONE robot pair (all 64 lanes call it with the same arguments, A and Bq in
+// LDS): wave-cooperative GJK, then the Newton refinement of the offset with its 12 barrier terms (the only
+// transcendental work) evaluated by 12 lanes and summed in the reference's order.  Same expressions, same
+// summation order as plane_pair => identical results.
+__device__ inline bool plane_pair_wave(const double* A, const double* Bq, double dist, double m, double off, int lane, double& e0, double& e1c, double& e2c, double& dpl,
+                                       bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr) {
+  capped = false;
+  const V3 v = gjk_wave(BodyHull{A}, BodyHull{Bq}, lane, gjk_iters);
+  const double cn = norm3(v.x, v.y, v.z);
+  if (cn > dist) return false;
+  e0 = v.x / cn; e1c = v.y / cn; e2c = v.z / cn;
+  double d0 = INFINITY, d1 = -INFINITY;
+  for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, Bq + 3 * i); if (d0 > t) d0 = t; }
+  for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, A + 3 * i); if (d1 < t) d1 = t; }
+  dpl = 0.5 * (d0 + d1);
+  const int j = lane < 6 ? lane : (lane < 12 ? lane - 6 : 0);
+  const double* pt = lane < 6 ? A + 3 * j : Bq + 3 * j;
+  const double px = pt[0], py = pt[1], pz = pt[2];
+  int it = 0;
+  for (; it < LOOP_CAP; it++) {  // Newton on the offset until |grad| < 1e-2 (Optimal_plane.h:13-71)
+    const double dp = px * e0 + py * e1c + pz * e2c;
+    const double ds = lane < 6 ? dp + dpl - 0.5 * off : -dp - dpl - 0.5 * off;
+    const bool act = lane < 12 && ds < m;
+    double g1 = 0, g2 = 0;
+    if (act) {
+      g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
+      g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+    }
+    const unsigned mask = (unsigned)__ballot(act);
+    double grad = 0, hess = 0;
+#pragma unroll
+    for (int q = 0; q < 12; q++)
+      if (mask & (1u << q)) {  // uniform
+        const double a1 = gjk_rl(g1, q), a2 = gjk_rl(g2, q);
+        if (q < 6) grad += a1; else grad += -a1;
+        hess += a2;
+      }
+    const double dir = -grad / hess;
+    dpl = dpl + 1.0 * dir;
+    if (fabs(grad) < 1e-2) break;
+  }
+  capped = it == LOOP_CAP;
+  if (newton_iters) *newton_iters = it + 1;
+  return true;
+}
+
 __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
   if (D.ctl->done) return;
   const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
         if (lane == 0) { seen[p0] = tr; seen[p1] = tr; }
         int guard = 0;
         while (guard++ < LOOP_CAP) {
-          const V3 v = gjk(BodySwept{a, a + 18, D.pow08[min(k0, LOOP_CAP)]}, BodySwept{b, b + 18, D.pow08[min(k1, LOOP_CAP)]});
+          const V3 v = gjk_wave(BodySwept{a, a + 18, D.pow08[min(k0, LOOP_CAP)]}, BodySwept{b, b + 18, D.pow08[min(k1, LOOP_CAP)]}, lane);  // the wave is uniform here: solve the pair cooperatively
           if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off2)) break;
           k0++; k1++; seg_hit = true;
         }

@@ -717,13 +717,31 @@ int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* 
   return TJ_OK;
 }
 
+int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v) {
+  if (!c || n < 0 || !a || !b || !v) return TJ_ERR_INVALID;
+  DevBuf da, db, dv; int r;
+  if ((r = to_dev(c, da, a, (size_t)n * n1 * 24)) || (r = to_dev(c, db, b, (size_t)n * n2 * 24)) || (r = to_dev(c, dv, nullptr, (size_t)n * 24))) return r;
+  dim3 g(std::max(n, 1)), t(64);
+  const double *A = (const double*)da.p, *B = (const double*)db.p; double* V = (double*)dv.p;
+  if (n1 == 6 && n2 == 6) hipLaunchKernelGGL((k_dbg_gjk_wave<6, 6>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 12 && n2 == 12) hipLaunchKernelGGL((k_dbg_gjk_wave<12, 12>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 6 && n2 == 1) hipLaunchKernelGGL((k_dbg_gjk_wave<6, 1>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 12 && n2 == 1) hipLaunchKernelGGL((k_dbg_gjk_wave<12, 1>), g, t, 0, c->stream, n, A, B, V);
+  else { c->err = "tj_kat_gjk_wave: body sizes must be 6v1, 6v6, 12v1 or 12v12"; return TJ_ERR_INVALID; }
+  HIPCHK(c, hipGetLastError());
+  QUIESCE(c);
+  HIPCHK(c, hipMemcpy(v, dv.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out) {
-  if (!c || n < 0 || what < 0 || what > 3 || !P || !Q || !out) return TJ_ERR_INVALID;
-  const size_t qbytes = (what == 0 || what == 2) ? (size_t)n * 24 : (size_t)n * 144;
+  if (!c || n < 0 || what < 0 || what > 4 || !P || !Q || !out) return TJ_ERR_INVALID;
+  const size_t qbytes = (what == 0 || what == 2) ? (size_t)n * 24 : (size_t)n * 144;  // what 1, 3, 4: hull vs hull
   DevBuf dp, dq, dout; int r;
   if ((r = to_dev(c, dp, P, (size_t)n * 144)) || (r = to_dev(c, dq, Q, qbytes)) || (r = to_dev(c, dout, nullptr, (size_t)n * 40))) return r;
   HIPCHK(c, hipMemset(dout.p, 0, std::max<size_t>((size_t)n * 40, 8)));
-  hipLaunchKernelGGL(k_dbg_planes, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, what, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
+  if (what == 4) hipLaunchKernelGGL(k_dbg_pair_wave, dim3(std::max(n, 1)), dim3(64), 0, c->stream, c->d, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
+  else hipLaunchKernelGGL(k_dbg_planes, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, what, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
   HIPCHK(c, hipGetLastError());
   QUIESCE(c);
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 40, hipMemcpyDeviceToHost));
