@@ -56,6 +56,10 @@ def kernel_bytes(st, slv, iters):
         "k_linesearch": U * (S * 36 * 8 + 2 * 3 * T * 8 + P * (36 + 2 * 18 + 2) * 8) + planes * 32 + U * 3 * T * 8,
         "k_slack": U * P * ((18 + 36) * 8 + 2 * 18 * 8 * 2 + 4 * 8),
     }
+    # union kernels of the single-GPU graph: sums of their constituents
+    b["k_front"] = b["k_sep_obs"] + b["k_sep_self_rows"]
+    b["k_mid"] = b["k_slack"] + b["k_sep_self_solve"]
+    b["k_ccd"] = b["k_ccd_obs"] + b["k_ccd_self_pairs"]
     n = 9 * P - 2
     b["k_xsolve_c2"] = U * (n * n + 2 * n + 4) * 8 + U * (3 * T + 4) * 8                  # coupled mode: factor + rhs in, direction out
     b["k_ls_coupled"] = b["k_linesearch"] + U * 8 * 8                                       # per evaluation round (first round; later rounds exit early)
@@ -179,7 +183,7 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['cloud'].shape[0]} obstacle points, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}",
-                          "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else "1 GPU, whole iteration in one hipGraph",
+                          "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else "1 GPU, whole iteration in one hipGraph (linear chain on one queue, union kernels)",
                           "iters_timed_from": "initial trajectory"}}
     if world == 1:
         # per-kernel device time with hipEvents on the solver's stream, same K iterations

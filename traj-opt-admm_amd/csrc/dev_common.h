@@ -41,9 +41,10 @@ struct Ctl {
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
-enum { K_BEGIN = 0, K_SEP_OBS, K_HULLINFO, K_SEP_SELF_ROWS, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE,
+// Union kernels (K_FRONT, K_MID, K_CCD; kernels_step.h) replace their constituents in the single-GPU iteration graph.
+enum { K_BEGIN = 0, K_HULLINFO, K_FRONT, K_SEP_OBS, K_SEP_SELF_ROWS, K_MID, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE,
        K_XSOLVE_C2,                 // coupled mode only ("decouple":0)
-       K_CCD_PREP, K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH,
+       K_CCD_PREP, K_CCD, K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH,
        K_LS_COUPLED, K_LS_COMMIT,   // coupled mode only
        K_SLACK, K_COUNT };
 constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates evaluated per launch (steps 0.8^0 .. 0.8^30)

@@ -49,9 +49,9 @@ __global__ __launch_bounds__(64) void k_hullinfo(Dev D) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
-  if (D.ctl->done) return;
-  const int tr = blockIdx.x / D.U, p0 = blockIdx.x % D.U, lane = lane_id();
+// one (segment, lower robot) row = one wavefront; bid in [0, S * U)
+__device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid) {
+  const int tr = bid / D.U, p0 = bid % D.U, lane = lane_id();
   const int U = D.U;
   __shared__ double A[HULL_STRIDE];   // hull, box and k-DOP intervals of robot p0
   __shared__ int todo[64];            // partner ids that passed box + k-DOP
@@ -105,15 +105,19 @@ __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
   }
 }
 
-// one wavefront per robot pair (grid-stride over the work list), solved cooperatively by its lanes (plane_pair_wave)
-__global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
+__global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
   if (D.ctl->done) return;
+  sep_self_rows_body(D, blockIdx.x);
+}
+
+// one wavefront per robot pair (stride over the work list: wave bid of nwaves), solved cooperatively by its lanes (plane_pair_wave)
+__device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int nwaves) {
   const int lane = lane_id();
   __shared__ double A[18], B[18];
   const int n = min(*D.pair_work_n, D.cap_work), U = D.U;
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
-  for (int w = blockIdx.x; w < n; w += gridDim.x) {
+  for (int w = bid; w < n; w += nwaves) {
     if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
     const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
     __syncthreads();
@@ -138,6 +142,10 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
     }
     if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
   }
+}
+__global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
+  if (D.ctl->done) return;
+  sep_self_solve_body(D, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {

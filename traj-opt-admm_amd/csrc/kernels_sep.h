@@ -241,9 +241,9 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
   return true;
 }
 
-__global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
-  if (D.ctl->done) return;
-  const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
+// work of one (owned robot, segment) = one wavefront; bid in [0, owned * S)
+__device__ __forceinline__ void sep_obs_body(const Dev& D, int bid) {
+  const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   __shared__ double P[18];
   __shared__ double klo[49], khi[49];
@@ -287,6 +287,11 @@ __global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
     unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;
     st[0] += visits; st[1] += (unsigned long long)found; st[4] += (unsigned long long)base;
   }
+}
+
+__global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
+  if (D.ctl->done) return;
+  sep_obs_body(D, blockIdx.x);
 }
 
 }  // namespace tj

@@ -71,9 +71,8 @@ __global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
   ccd_prep_segment(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane_id(), sh);
 }
 
-__global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
-  if (D.ctl->done) return;
-  const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
+__device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
+  const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   __shared__ double info[CCD_STRIDE];
   __shared__ int fa[FRONT_CAP], fb[FRONT_CAP], cand[128];
@@ -106,11 +105,15 @@ __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
   }
 }
 
+__global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
+  if (D.ctl->done) return;
+  ccd_obs_body(D, blockIdx.x);
+}
+
 // Phase A: one wave per (segment, lower robot p0); lanes over the partners p1 > p0.  Survivors are
 // written in ascending p1, so (segment, p0, p1) is a lexicographic, deterministic pair order.
-__global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
-  if (D.ctl->done) return;
-  const int tr = blockIdx.x / D.U, p0 = blockIdx.x % D.U, lane = lane_id();
+__device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
+  const int tr = bid / D.U, p0 = bid % D.U, lane = lane_id();
   const int U = D.U;
   const double off = D.offset;
   const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
@@ -138,6 +141,11 @@ __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
     base += __popcll(mask);
   }
   if (lane == 0) D.pair_count[tr * U + p0] = min(base, D.cap_row);
+}
+
+__global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
+  if (D.ctl->done) return;
+  ccd_self_pairs_body(D, blockIdx.x);
 }
 
 // Phase B + gnorm.  One workgroup of one wave; control flow is wave uniform.
@@ -238,10 +246,9 @@ __device__ inline double z_energy(const Dev& D, const double* cx, double pt, con
 // deferred = 1: this launch belongs to the NEXT iteration's graph (or to a flush) and performs the
 // update the previous iteration still owes, concurrently with the next iteration's plane kernels
 // (they only read the control points).  deferred = 0: stage API, update of the current iteration.
-__global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
-  if (deferred ? !D.ctl->slack_now : D.ctl->done) return;
+__device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) {
   const int tid = threadIdx.x;
-  const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
+  const int u = D.u0 + bid / D.P, sp = bid % D.P;
   const int P6 = 6 * D.P, T = D.T;
   __shared__ double cx[18], z[18], lam[18], zt[18], dirz[18], g[19], H[361], L[361], g0[19], x0[19], scr[4 * 19];
   __shared__ double s_t, s_step;
@@ -352,8 +359,39 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
   if (tid == 0) {
     D.t_slack[u * D.P + sp] = s_t;
     D.t_lambda[u * D.P + sp] += D.mu * (pt - s_t);
-    if (!deferred && blockIdx.x == 0) D.ctl->slack_next = 0;  // paid
+    if (!deferred && bid == 0) D.ctl->slack_next = 0;  // paid
   }
+}
+__global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
+  if (deferred ? !D.ctl->slack_now : D.ctl->done) return;
+  slack_body(D, blockIdx.x, deferred);
+}
+
+// ---- union kernels of the single-GPU iteration graph ---------------------------------------------------------------
+// Measured with rocprofv3: kernels that follow each other on ONE hardware queue start back to back, while every
+// fork/join between the branches of a multi-stream graph costs 12-25 us of cross-queue signalling -- four of them
+// sat on the critical path of a 260 us iteration.  Independent stages therefore share a launch instead of a
+// stream: a block's index range selects the stage it works for (all of these stages are one-wavefront work items),
+// and the whole iteration is a linear chain on one queue.
+//   k_front  obstacle planes (owned * S)  |  robot-pair rows (S * U)
+//   k_mid    slack + dual update the previous iteration still owes (owned * P)  |  robot-pair solves (work list)
+//   k_ccd    obstacle CCD clamp (owned * S)  |  robot-pair CCD selection (S * U)
+__global__ __launch_bounds__(64) void k_front(Dev D) {
+  if (D.ctl->done) return;
+  const int n_obs = (D.u1 - D.u0) * D.S;
+  if ((int)blockIdx.x < n_obs) sep_obs_body(D, blockIdx.x);
+  else sep_self_rows_body(D, blockIdx.x - n_obs);
+}
+__global__ __launch_bounds__(64) void k_mid(Dev D, int n_solve_waves) {
+  const int n_slack = (D.u1 - D.u0) * D.P;
+  if ((int)blockIdx.x < n_slack) { if (D.ctl->slack_now) slack_body(D, blockIdx.x, 1); }   // long single-wave tasks first
+  else if (!D.ctl->done) sep_self_solve_body(D, blockIdx.x - n_slack, n_solve_waves);
+}
+__global__ __launch_bounds__(64) void k_ccd(Dev D) {
+  if (D.ctl->done) return;
+  const int n_obs = (D.u1 - D.u0) * D.S;
+  if ((int)blockIdx.x < n_obs) ccd_obs_body(D, blockIdx.x);
+  else ccd_self_pairs_body(D, blockIdx.x - n_obs);
 }
 
 // ---- iteration bookkeeping ---------------------------------------------------------------------

@@ -85,35 +85,41 @@ void drop_graph(tj_ctx* c) {
 }
 
 // ---- kernels of one iteration, in stream order (also the unit of tj_profile_kernels) ----
-const char* const kKernelNames[K_COUNT] = {"k_begin", "k_sep_obs", "k_hullinfo", "k_sep_self_rows", "k_sep_self_solve", "k_sep_self_compact",
-                                           "k_grad", "k_xsolve", "k_xsolve_c2", "k_ccd_prep", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
+const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "k_sep_obs", "k_sep_self_rows", "k_mid", "k_sep_self_solve", "k_sep_self_compact",
+                                           "k_grad", "k_xsolve", "k_xsolve_c2", "k_ccd_prep", "k_ccd", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
                                            "k_linesearch", "k_ls_coupled", "k_ls_commit", "k_slack"};
 
-// launch exactly one kernel (returns false for kernels that do not exist in this mode).  in_graph: the launch is part
-// of the single-GPU iteration graph, where k_hullinfo is folded into k_linesearch (Dev::fuse).
+// launch exactly one kernel (returns false for kernels that do not exist in this mode / schedule).
+// in_graph: the launch belongs to the single-GPU iteration graph, a linear chain on one queue in which independent
+// stages share a launch (union kernels k_front / k_mid / k_ccd instead of their constituents), the slack/dual update
+// is the deferred one inside k_mid, and -- except in coupled mode -- the hull cache comes from k_linesearch (Dev::fuse).
 bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2;
+  const int n_solve = multi ? std::min(d.cap_work, 4096) : 0;
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
-    case K_SEP_OBS: hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
-    case K_HULLINFO: if (in_graph && d.fuse) return false; if (multi) hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return multi;
-    case K_SEP_SELF_ROWS: if (multi) hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return multi;
-    case K_SEP_SELF_SOLVE: if (multi) hipLaunchKernelGGL(k_sep_self_solve, dim3(std::min(d.cap_work, 4096)), dim3(64), 0, s, d); return multi;
+    case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
+    case K_FRONT: if (!in_graph) return false; hipLaunchKernelGGL(k_front, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
+    case K_SEP_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_SEP_SELF_ROWS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
+    case K_MID: if (!in_graph) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve), dim3(64), 0, s, d, n_solve); return true;
+    case K_SEP_SELF_SOLVE: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_COMPACT: if (multi) hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return multi;
     case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
     case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
+    case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
     case K_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
-    case K_CCD_OBS: hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
-    case K_CCD_SELF_PAIRS: if (multi) hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return multi;
+    case K_CCD: if (!in_graph) return false; hipLaunchKernelGGL(k_ccd, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
+    case K_CCD_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
     case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); return !coupled;
-    // coupled mode ("decouple":0): second half of the arrowhead solve, evaluation rounds of the summed-energy Armijo search, commit
-    case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
+    // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED: if (coupled) for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r); return coupled;
     case K_LS_COMMIT: if (coupled) hipLaunchKernelGGL(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;
-    case K_SLACK: hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
+    case K_SLACK: if (in_graph) return false; hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
   }
   return false;
 }
@@ -124,10 +130,10 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr, bool in_graph =
   switch (stage) {
     case TJ_STAGE_BEGIN: launch_kernel(c, K_BEGIN, s); break;
     case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); break;
-    case TJ_STAGE_PLANES_SELF: for (int k = K_HULLINFO; k <= K_SEP_SELF_COMPACT; k++) launch_kernel(c, k, s, 0, in_graph); break;
+    case TJ_STAGE_PLANES_SELF: launch_kernel(c, K_HULLINFO, s); launch_kernel(c, K_SEP_SELF_ROWS, s); launch_kernel(c, K_SEP_SELF_SOLVE, s); launch_kernel(c, K_SEP_SELF_COMPACT, s); break;
     case TJ_STAGE_GRAD: launch_kernel(c, K_GRAD, s); break;
     case TJ_STAGE_XSOLVE: launch_kernel(c, K_XSOLVE, s); launch_kernel(c, K_XSOLVE_C2, s); break;
-    case TJ_STAGE_CCD_PREP: launch_kernel(c, K_CCD_PREP, s, 0, in_graph); break;
+    case TJ_STAGE_CCD_PREP: launch_kernel(c, K_CCD_PREP, s); break;
     case TJ_STAGE_CCD_OBS: launch_kernel(c, K_CCD_OBS, s); break;
     case TJ_STAGE_CCD_SELF: launch_kernel(c, K_CCD_SELF_PAIRS, s); launch_kernel(c, K_CCD_SELF_SEQ, s); break;
     case TJ_STAGE_LINESEARCH: launch_kernel(c, K_LINESEARCH, s); launch_kernel(c, K_LS_COUPLED, s); launch_kernel(c, K_LS_COMMIT, s); break;
@@ -139,34 +145,17 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr, bool in_graph =
   return TJ_OK;
 }
 
-// One iteration as a small DAG on three streams (captured into the hipGraph as parallel branches):
-//   begin -> { obstacle planes | robot-pair planes | slack+dual of the PREVIOUS iteration }
-//         -> grad -> xsolve -> ccd_prep -> { obstacle CCD | pair CCD (select, replay) } -> line search
-// The plane builders only read control points, which the line search of the previous iteration
-// already committed, so that iteration's slack/dual update (which touches z, Lambda, t_z, tau only)
-// is deferred into this graph and runs beside them; grad waits for all three.  flush_deferred()
-// pays the last one before anything on the host looks at the state.  The iteration counter is
+// One iteration of the single-GPU schedule: a LINEAR chain on one stream / hardware queue (captured into the hipGraph)
+//   begin -> [hullinfo] -> front{obstacle planes | pair rows} -> mid{slack+dual of the PREVIOUS iteration | pair solves}
+//         -> compact -> grad -> xsolve [-> xsolve_c2] -> ccd_prep -> ccd{obstacle CCD | pair CCD selection} -> seq -> line search
+// Same-queue successors start back to back, so concurrency between independent stages comes from sharing a launch
+// (union kernels), not from parallel streams.  The plane builders only read control points, which the previous line
+// search already committed, so that iteration's slack/dual update (touches z, Lambda, t_z, tau only) is deferred into
+// k_mid; flush_deferred() pays the last one before anything on the host looks at the state.  The iteration counter is
 // committed by the next k_begin.
 int enqueue_iteration(tj_ctx* c) {
-  hipStream_t m = c->stream, s2 = c->side, s3 = c->side2;
-  const Dev& d = c->d;
-  int r;
-#define STG(st, str) if ((r = enqueue_stage(c, st, str, true))) return r
-  STG(TJ_STAGE_BEGIN, m);
-  HIPCHK(c, hipEventRecord(c->ev[0], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[0], 0)); HIPCHK(c, hipStreamWaitEvent(s3, c->ev[0], 0));
-  STG(TJ_STAGE_PLANES_OBS, m);
-  STG(TJ_STAGE_PLANES_SELF, s2);
-  launch_kernel(c, K_SLACK, s3, 1);
+  for (int k = 0; k < K_COUNT; k++) launch_kernel(c, k, c->stream, 0, true);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[1], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[1], 0));
-  HIPCHK(c, hipEventRecord(c->ev[4], s3)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[4], 0));
-  STG(TJ_STAGE_GRAD, m); STG(TJ_STAGE_XSOLVE, m); STG(TJ_STAGE_CCD_PREP, m);
-  HIPCHK(c, hipEventRecord(c->ev[2], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));
-  STG(TJ_STAGE_CCD_OBS, m);
-  STG(TJ_STAGE_CCD_SELF, s2);
-  HIPCHK(c, hipEventRecord(c->ev[3], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[3], 0));
-  STG(TJ_STAGE_LINESEARCH, m);
-#undef STG
   c->maybe_deferred = true;
   return TJ_OK;
 }
@@ -548,6 +537,7 @@ int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
       HIPCHK(c, hipEventRecord(e[k + 1], c->stream));
     }
   }
+  if (n_iters > 0) c->maybe_deferred = true;  // the last iteration's slack/dual update is still owed (paid by the flush below)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int k = 0; k < K_COUNT; k++) ms[k] = 0;
   for (int it = 0; it < n_iters; it++)
