@@ -42,11 +42,12 @@ def kernel_bytes(st, slv, iters):
     half_pairs = S * U * (U - 1) / 2
     b = {
         "k_begin": 64,
-        "k_sep_obs": per["nodes_dcd"] * 48 + per["cand_dcd"] * 24 + per["planes_obs"] * 32 + seg_in,
+        "k_obs_query": per["nodes_dcd"] * 48 + per["cand_dcd"] * 24 + per["cand_dcd"] * 12 + seg_in + U * S * 18 * 8,
+        "k_obs_solve": per["cand_dcd"] * (12 + 4 + 24 + 144) + per["planes_obs"] * 36,
         "k_hullinfo": seg_in + U * S * 976,
         "k_sep_self_rows": U * S * 976 + half_pairs * 48 + per["pair_solves"] * 12,
         "k_sep_self_solve": per["pair_solves"] * (2 * 144 + 2 * 32 + 2 * 4 + 12),
-        "k_sep_self_compact": U * S * U * 4 + per["planes_self"] * 64,
+        "k_sep_self_compact": U * S * U * 4 + per["planes_self"] * 64 + U * S * 4 + per["cand_dcd"] * 4 + per["planes_obs"] * 64,
         "k_grad": planes * 32 + seg_in + U * P * (19 + 361) * 8 + U * P * (36 + 2 * 18) * 8,
         "k_xsolve": U * P * (19 + 361) * 8 + U * (3 * T + 4) * 8,
         "k_ccd_prep": U * S * (2 * 18 * 8 + 36 * 8) + U * S * 1168,
@@ -57,8 +58,8 @@ def kernel_bytes(st, slv, iters):
         "k_slack": U * P * ((18 + 36) * 8 + 2 * 18 * 8 * 2 + 4 * 8),
     }
     # union kernels of the single-GPU graph: sums of their constituents
-    b["k_front"] = b["k_sep_obs"] + b["k_sep_self_rows"]
-    b["k_mid"] = b["k_slack"] + b["k_sep_self_solve"]
+    b["k_front"] = b["k_obs_query"] + b["k_sep_self_rows"]
+    b["k_mid"] = b["k_slack"] + b["k_sep_self_solve"] + b["k_obs_solve"]
     b["k_ccd"] = b["k_ccd_obs"] + b["k_ccd_self_pairs"]
     n = 9 * P - 2
     b["k_xsolve_c2"] = U * (n * n + 2 * n + 4) * 8 + U * (3 * T + 4) * 8                  # coupled mode: factor + rhs in, direction out

@@ -42,7 +42,7 @@ struct Ctl {
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
 // Union kernels (K_FRONT, K_MID, K_CCD; kernels_step.h) replace their constituents in the single-GPU iteration graph.
-enum { K_BEGIN = 0, K_HULLINFO, K_FRONT, K_SEP_OBS, K_SEP_SELF_ROWS, K_MID, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE,
+enum { K_BEGIN = 0, K_HULLINFO, K_FRONT, K_SEP_OBS /* k_obs_query */, K_SEP_SELF_ROWS, K_MID, K_OBS_SOLVE, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE,
        K_XSOLVE_C2,                 // coupled mode only ("decouple":0)
        K_CCD_PREP, K_CCD, K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH,
        K_LS_COUPLED, K_LS_COMMIT,   // coupled mode only
@@ -88,6 +88,12 @@ struct Dev {
   // ---- per-iteration intermediates ----
   double *oplanes; int *ocount;   // obstacle planes  [U][S][cap_obs][4], [U][S]
   double *splanes; int *scount;   // inter-robot planes [U][S][cap_self][4], [U][S]
+  // obstacle-plane pipeline (kernels_sep.h): candidate points per segment after the k-DOP cull, the segment's hull, one
+  // (segment, slot) work item per candidate, and per-slot plane + epoch stamp before compaction into oplanes
+  int *ocand, *ocand_n;           // [U][S][cap_obs], [U][S]
+  double *ohull;                  // [U][S][18]
+  int *obs_work, *obs_work_n;     // [U*S*cap_obs][2], [1]
+  double *oraw; int *ostamp;      // [U][S][cap_obs][4], [U][S][cap_obs]
   double *hullinfo;               // [U][S][HULL_STRIDE] hull, AABB, k-DOP intervals of the current control net
   double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration

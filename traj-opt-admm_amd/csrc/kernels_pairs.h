@@ -148,11 +148,29 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
   sep_self_solve_body(D, blockIdx.x, gridDim.x);
 }
 
+// per (owned robot, segment): obstacle planes from the stamped candidate slots (slot order), then -- multi-robot modes --
+// the robot-pair planes from the stamped partner slots (ascending partner): deterministic lists, no atomics
 __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
   if (D.ctl->done) return;
   const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S, lane = lane_id();
   const int U = D.U, epoch = D.ctl->epoch;
-  double* out = D.splanes + ((size_t)u * D.S + tr) * D.cap_self * 4;
+  const size_t seg = (size_t)u * D.S + tr;
+  {
+    const int n = D.ocand_n[seg];
+    double* out = D.oplanes + seg * D.cap_obs * 4;
+    int base = 0;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+      const int sl = s0 + lane;
+      const bool ok = sl < n && D.ostamp[seg * D.cap_obs + min(sl, n - 1)] == epoch;
+      const unsigned long long mask = ballot(ok);
+      const int idx = base + prefix_count(mask);
+      if (ok) { const double* p = D.oraw + (seg * D.cap_obs + sl) * 4; out[4 * idx] = p[0]; out[4 * idx + 1] = p[1]; out[4 * idx + 2] = p[2]; out[4 * idx + 3] = p[3]; }
+      base += __popcll(mask);
+    }
+    if (lane == 0) { D.ocount[seg] = base; D.seg_stats[seg * 6 + 4] += (unsigned long long)base; }
+  }
+  if (!D.multi()) return;
+  double* out = D.splanes + seg * D.cap_self * 4;
   int base = 0;
   for (int q0 = 0; q0 < U; q0 += 64) {
     const int q = q0 + lane;
@@ -167,8 +185,8 @@ __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
     base += __popcll(mask);
   }
   if (lane == 0) {
-    D.scount[u * D.S + tr] = min(base, D.cap_self);
-    D.seg_stats[((size_t)u * D.S + tr) * 6 + 5] += (unsigned long long)base;
+    D.scount[seg] = min(base, D.cap_self);
+    D.seg_stats[seg * 6 + 5] += (unsigned long long)base;
   }
 }
 

@@ -241,8 +241,16 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
   return true;
 }
 
-// work of one (owned robot, segment) = one wavefront; bid in [0, owned * S)
-__device__ __forceinline__ void sep_obs_body(const Dev& D, int bid) {
+// ---- obstacle planes in three steps --------------------------------------------------------------------------------
+// (1) obs_query_body  one wave per (owned robot, segment): hull, BVH walk, k-DOP cull; the surviving points go to the
+//                     segment's candidate list (traversal order, deterministic) and, one work item each, to a global list.
+// (2) obs_solve_body  one wave per candidate (stride over the work list): wave-cooperative GJK hull-vs-point and the plane
+//                     (c,d), written to the candidate's own slot with an epoch stamp.
+// (3) compaction      kernels_pairs.h: stamped slots of a segment -> its plane list, in slot order.
+// A segment next to an obstacle slab has > 100 candidates; solved inside the segment's own wave (64 divergent GJK paths
+// per round) they made a 45 us tail on a 5 us kernel.  One wave per candidate runs them all at once.
+// Plane order = candidate order = what the fused version produced, so downstream sums see the same sequence.
+__device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   __shared__ double P[18];
@@ -263,35 +271,68 @@ __device__ __forceinline__ void sep_obs_body(const Dev& D, int bid) {
   __syncthreads();
   TJ_TIC(D, K_SEP_OBS, 1);
   const double dist = D.offset + D.margin;
-  double* out = D.oplanes + ((size_t)u * D.S + tr) * D.cap_obs * 4;
+  const size_t seg = (size_t)u * D.S + tr;
+  int* list = D.ocand + seg * D.cap_obs;
   int base = 0;
   unsigned long long visits = 0;
   const int found = bvh_query(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
     bool ok = false;
-    double c0 = 0, c1 = 0, c2 = 0, dd = 0;
-    if (pt >= 0) {
-      const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
-      if (kdop_point_pass(D, klo, khi, qp, dist)) ok = plane_obstacle(P, qp, dist, D.offset, c0, c1, c2, dd);
-    }
+    if (pt >= 0) ok = kdop_point_pass(D, klo, khi, V3{D.px[pt], D.py[pt], D.pz[pt]}, dist);
     const unsigned long long mask = ballot(ok);
     const int idx = base + prefix_count(mask);
     if (ok) {
-      if (idx < D.cap_obs) { out[4 * idx] = c0; out[4 * idx + 1] = c1; out[4 * idx + 2] = c2; out[4 * idx + 3] = dd; }
+      if (idx < D.cap_obs) list[idx] = pt;
       else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
     }
     base += __popcll(mask);
   });
   TJ_TIC(D, K_SEP_OBS, 2);
+  const int cnt = min(base, D.cap_obs);
+  if (lane < 18) D.ohull[seg * 18 + lane] = P[lane];
+  int w0 = 0;
   if (lane == 0) {
-    D.ocount[u * D.S + tr] = min(base, D.cap_obs);
-    unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;
-    st[0] += visits; st[1] += (unsigned long long)found; st[4] += (unsigned long long)base;
+    D.ocand_n[seg] = cnt;
+    if (cnt > 0) w0 = atomicAdd(D.obs_work_n, cnt);
+    unsigned long long* st = D.seg_stats + seg * 6;
+    st[0] += visits; st[1] += (unsigned long long)found;
+  }
+  w0 = __shfl(w0, 0);
+  for (int i = lane; i < cnt; i += 64) { D.obs_work[2 * (size_t)(w0 + i)] = (int)seg; D.obs_work[2 * (size_t)(w0 + i) + 1] = i; }
+}
+
+// Separate::opengjk (Separate.h:18-163) for one candidate, by one wave
+__device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves) {
+  const int lane = lane_id();
+  __shared__ double P[18];
+  const int n = *D.obs_work_n;
+  const double dist = D.offset + D.margin;
+  const int epoch = D.ctl->epoch;
+  for (int w = bid; w < n; w += nwaves) {
+    const int seg = D.obs_work[2 * (size_t)w], slot = D.obs_work[2 * (size_t)w + 1];
+    __syncthreads();
+    if (lane < 18) P[lane] = D.ohull[(size_t)seg * 18 + lane];
+    __syncthreads();
+    const int pt = D.ocand[(size_t)seg * D.cap_obs + slot];
+    const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
+    const V3 v = gjk_wave(BodyHull{P}, BodyPoint{qp}, lane);
+    const double cn = norm3(v.x, v.y, v.z);
+    if (!(cn > dist) && lane == 0) {  // same expressions as plane_obstacle
+      const double c0 = v.x / cn, c1 = v.y / cn, c2 = v.z / cn;
+      const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
+      double* o = D.oraw + ((size_t)seg * D.cap_obs + slot) * 4;
+      o[0] = c0; o[1] = c1; o[2] = c2; o[3] = d0 - D.offset;
+      D.ostamp[(size_t)seg * D.cap_obs + slot] = epoch;
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void k_sep_obs(Dev D) {
+__global__ __launch_bounds__(64) void k_obs_query(Dev D) {
   if (D.ctl->done) return;
-  sep_obs_body(D, blockIdx.x);
+  obs_query_body(D, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_obs_solve(Dev D) {
+  if (D.ctl->done) return;
+  obs_solve_body(D, blockIdx.x, gridDim.x);
 }
 
 }  // namespace tj

@@ -373,19 +373,22 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
 // sat on the critical path of a 260 us iteration.  Independent stages therefore share a launch instead of a
 // stream: a block's index range selects the stage it works for (all of these stages are one-wavefront work items),
 // and the whole iteration is a linear chain on one queue.
-//   k_front  obstacle planes (owned * S)  |  robot-pair rows (S * U)
-//   k_mid    slack + dual update the previous iteration still owes (owned * P)  |  robot-pair solves (work list)
+//   k_front  obstacle candidate query (owned * S)  |  robot-pair rows (S * U)
+//   k_mid    slack + dual update the previous iteration still owes (owned * P)  |  robot-pair solves  |  obstacle-candidate solves
 //   k_ccd    obstacle CCD clamp (owned * S)  |  robot-pair CCD selection (S * U)
 __global__ __launch_bounds__(64) void k_front(Dev D) {
   if (D.ctl->done) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
-  if ((int)blockIdx.x < n_obs) sep_obs_body(D, blockIdx.x);
+  if ((int)blockIdx.x < n_obs) obs_query_body(D, blockIdx.x);
   else sep_self_rows_body(D, blockIdx.x - n_obs);
 }
-__global__ __launch_bounds__(64) void k_mid(Dev D, int n_solve_waves) {
+__global__ __launch_bounds__(64) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
   const int n_slack = (D.u1 - D.u0) * D.P;
-  if ((int)blockIdx.x < n_slack) { if (D.ctl->slack_now) slack_body(D, blockIdx.x, 1); }   // long single-wave tasks first
-  else if (!D.ctl->done) sep_self_solve_body(D, blockIdx.x - n_slack, n_solve_waves);
+  const int b = blockIdx.x;
+  if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1); }   // long single-wave tasks first
+  else if (D.ctl->done) return;
+  else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves);
+  else obs_solve_body(D, b - n_slack - n_pair_waves, n_obs_waves);
 }
 __global__ __launch_bounds__(64) void k_ccd(Dev D) {
   if (D.ctl->done) return;
@@ -408,7 +411,7 @@ __global__ void k_begin(Dev D) {
   __syncthreads();
   if (done) return;
   for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
-  if (threadIdx.x == 0) *D.pair_work_n = 0;
+  if (threadIdx.x == 0) { *D.pair_work_n = 0; *D.obs_work_n = 0; }
 }
 // only used by the stage API: commit the iteration counter explicitly
 // hand a still-owed slack/dual update to the next k_slack(deferred) launch without starting an iteration

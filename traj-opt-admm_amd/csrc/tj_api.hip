@@ -85,7 +85,7 @@ void drop_graph(tj_ctx* c) {
 }
 
 // ---- kernels of one iteration, in stream order (also the unit of tj_profile_kernels) ----
-const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "k_sep_obs", "k_sep_self_rows", "k_mid", "k_sep_self_solve", "k_sep_self_compact",
+const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "k_obs_query", "k_sep_self_rows", "k_mid", "k_obs_solve", "k_sep_self_solve", "k_sep_self_compact",
                                            "k_grad", "k_xsolve", "k_xsolve_c2", "k_ccd_prep", "k_ccd", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
                                            "k_linesearch", "k_ls_coupled", "k_ls_commit", "k_slack"};
 
@@ -98,15 +98,17 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2;
   const int n_solve = multi ? std::min(d.cap_work, 4096) : 0;
+  const int n_obs_solve = d.N > 0 ? 1024 : 0;   // waves striding over the obstacle-candidate work list
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
     case K_FRONT: if (!in_graph) return false; hipLaunchKernelGGL(k_front, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
-    case K_SEP_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_sep_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_SEP_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_obs_query, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false; hipLaunchKernelGGL(k_obs_solve, dim3(n_obs_solve), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_ROWS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
-    case K_MID: if (!in_graph) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve), dim3(64), 0, s, d, n_solve); return true;
+    case K_MID: if (!in_graph) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); return true;
     case K_SEP_SELF_SOLVE: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
-    case K_SEP_SELF_COMPACT: if (multi) hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return multi;
+    case K_SEP_SELF_COMPACT: hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
     case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
     case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
@@ -129,7 +131,7 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr, bool in_graph =
   if (!s) s = c->stream;
   switch (stage) {
     case TJ_STAGE_BEGIN: launch_kernel(c, K_BEGIN, s); break;
-    case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); break;
+    case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); launch_kernel(c, K_OBS_SOLVE, s); launch_kernel(c, K_SEP_SELF_COMPACT, s); break;
     case TJ_STAGE_PLANES_SELF: launch_kernel(c, K_HULLINFO, s); launch_kernel(c, K_SEP_SELF_ROWS, s); launch_kernel(c, K_SEP_SELF_SOLVE, s); launch_kernel(c, K_SEP_SELF_COMPACT, s); break;
     case TJ_STAGE_GRAD: launch_kernel(c, K_GRAD, s); break;
     case TJ_STAGE_XSOLVE: launch_kernel(c, K_XSOLVE, s); launch_kernel(c, K_XSOLVE_C2, s); break;
@@ -364,7 +366,10 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.pair_count, S * U)) || (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
-      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 1)) || (r = dalloc(c, &d.ctl, 1))) return r;
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 1)) || (r = dalloc(c, &d.ctl, 1)) ||
+      (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
+      (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
+      (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs))) return r;
   if (d.mode == TJ_MODE_MULTI_COUPLED &&
       ((r = dalloc(c, &d.xL, U * (size_t)n * n)) || (r = dalloc(c, &d.xy, U * (size_t)n)) || (r = dalloc(c, &d.xg, U * (size_t)n)) ||
        (r = dalloc(c, &d.xcorner, U * 4)) || (r = dalloc(c, &d.ls_e, (size_t)LSC_ROUNDS * U * LS_GROUPS)))) return r;
@@ -458,6 +463,8 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemset(d.xdir, 0, (size_t)U * d.xs * 8));
   HIPCHK(c, hipMemset(d.ocount, 0, (size_t)U * d.S * 4));
   HIPCHK(c, hipMemset(d.scount, 0, (size_t)U * d.S * 4));
+  HIPCHK(c, hipMemset(d.ocand_n, 0, (size_t)U * d.S * 4));
+  HIPCHK(c, hipMemset(d.ostamp, 0, (size_t)U * d.S * d.cap_obs * 4));  // epochs restart at 1
   HIPCHK(c, hipMemset(d.seg_stats, 0, (size_t)U * d.S * 6 * 8));
   if (d.mode >= 1) HIPCHK(c, hipMemset(d.pairstamp, 0, (size_t)d.S * U * U * 4));  // epochs restart at 1
   c->have_state = true;
