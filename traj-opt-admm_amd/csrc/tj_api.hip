@@ -97,8 +97,11 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2;
-  const int n_solve = multi ? std::min(d.cap_work, 4096) : 0;
-  const int n_obs_solve = d.N > 0 ? 1024 : 0;   // waves striding over the obstacle-candidate work list
+  // Waves striding over the two device-built work lists.  k_mid holds ~1 wave per SIMD (VGPR bound), i.e. 1024 resident
+  // waves: a larger grid adds no parallelism, only dispatch time for blocks that find no work (measured: with
+  // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
+  const int n_solve = multi ? std::min(d.cap_work, 1024) : 0;
+  const int n_obs_solve = d.N > 0 ? 256 : 0;
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
