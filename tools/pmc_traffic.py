@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+MI355X_MICROARCH.md "rocprofv3 PMC slots").  Usage:
+    rocprofv3 --pmc FETCH_SIZE -d F -o x -- python3 bench.py ...;  rocprofv3 --pmc WRITE_SIZE -d W -o x -- python3 bench.py ...
+    python tools/pmc_traffic.py F/x_results.db W/x_results.db --scene SCN-C --out profiles/pmc_latest.json
+FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3.  Per the guide, on gfx950 FETCH_SIZE counts a wide coalesced
+streaming read at HALF its bytes (128-B requests tallied at 64 B); the kernels here issue 8-byte scattered reads, which the
+guide lists as uncalibrated, so both the raw and the x2 figure are recorded and `hbm_bytes_per_launch` uses the raw one."""
+import argparse, json, re, sqlite3
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path); cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    t = lambda k: [x for x in tabs if x.startswith(k)][0]
+    pm, ip, kd, ks = t("rocpd_pmc_event"), t("rocpd_info_pmc"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
+    q = (f"select s.kernel_name, count(*), sum(e.value) from {pm} e join {ip} i on e.pmc_id=i.id "
+         f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id where i.name=? group by s.kernel_name")
+    out = {}
+    for name, n, v in cur.execute(q, (counter,)):
+        m = re.search(r"_ZN2tj\d+([a-z_0-9]+?)E", name)
+        out[m.group(1) if m else name] = (n, v)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("fetch_db"); ap.add_argument("write_db"); ap.add_argument("--scene", default="SCN-C")
+    ap.add_argument("--command", default="python3 bench.py --steps 20 --warmup 3 --no-cpu"); ap.add_argument("--out")
+    a = ap.parse_args()
+    f, w = per_kernel(a.fetch_db, "FETCH_SIZE"), per_kernel(a.write_db, "WRITE_SIZE")
+    res = {"scene": a.scene, "command": a.command,
+           "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; KB per launch x 1024; FETCH raw (x2 = wide-streaming-read correction of the guide, shown beside it)",
+           "kernels": {}}
+    for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (1, 0))[1] + w.get(k, (1, 0))[1])):
+        nf, vf = f.get(k, (0, 0.0)); nw, vw = w.get(k, (0, 0.0))
+        fb = 1024.0 * vf / max(nf, 1); wb = 1024.0 * vw / max(nw, 1)
+        res["kernels"][k] = {"launches": max(nf, nw), "fetch_bytes": fb, "fetch_bytes_x2": 2 * fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb,
+                             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes"}
+        print(f"{k:22s} launches {max(nf, nw):4d}  fetch {fb / 1e6:8.3f} MB  write {wb / 1e6:8.3f} MB per launch")
+    if a.out:
+        json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
