@@ -171,3 +171,58 @@ def test_cli_coupled_mode_and_log_data(pkg, scenes, tmp_path):
         assert abs(lens[u] - want) <= 1e-5 * want                                      # stdout prints 6 significant digits
         mine = smp[smp[:, 0] == u][:, 2:]
         assert mine.shape == out.shape and np.max(np.abs(mine - out)) <= 1e-12
+
+
+@pytest.mark.parametrize("P,res,mode", [(3, 8, 1), (4, 4, 1), (7, 8, 1), (8, 8, 1), (9, 8, 2), (3, 8, 2), (6, 8, 0)])
+def test_piece_counts_and_resolutions_vs_oracle(pkg, scenes, P, res, mode):
+    """every size class of the per-robot Newton system: n = 9P-2 in {25,...,61} takes the register-resident
+    factorisation, P >= 8 the LDS one; res != 8 changes the segment tables; all three modes.  Each iteration
+    starts from the oracle's state (teacher-forced), tolerances as in test_gpu_parity.py"""
+    from oracle.pyoracle import Engine
+    if mode == 0:
+        scene = scenes.scn_a(n_points=4000, pieces=P)
+    else:
+        scene = dict(scenes.hard(4, 3000, pieces=P)); scene["mode"] = mode
+    params = {"res": res}
+    o = Engine("port", scene, params)
+    s = pkg.Solver(scene, params, stop=0.0)
+    for it in range(6):
+        s.set_state(o.get_state())
+        go = o.iterate()
+        gg, _, _ = s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        assert abs(gg - go) <= 1e-9 * max(1.0, go), (it, gg, go)
+        for n in STATE:
+            assert maxdiff(a[n], b[n]) <= 1e-9 * max(1.0, np.abs(b[n]).max()), (it, n, maxdiff(a[n], b[n]))
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+def test_many_obstacle_candidates_per_segment(pkg, scenes):
+    """a robot skimming a dense strip of obstacle points: several hundred candidates per segment (many query batches,
+    thousands of per-candidate solves per iteration) must give the oracle's planes and iterates; a candidate capacity
+    that is too small is reported, not silently truncated"""
+    from oracle.pyoracle import Engine
+    from conftest import canon
+    rng = np.random.default_rng(3)
+    scene = dict(scenes.crossing(2, 1000, seed=5, name="dense"))
+    x = rng.uniform(-10, 10, 40000); y = rng.uniform(-0.3, 0.3, 40000); z = rng.uniform(-0.19, -0.125, 40000)
+    scene["cloud"] = np.ascontiguousarray(np.stack([x, y, z], 1))
+    o = Engine("port", scene)
+    s = pkg.Solver(scene, stop=0.0, cap_obs=1024)
+    co, po = o.stage_planes(); cg, pg = s.stage_planes()
+    assert co.max() > 500
+    assert np.array_equal(co, cg)
+    assert maxdiff(canon(co, po), canon(cg, pg)) <= 1e-13
+    s.reset(); o = Engine("port", scene)
+    for it in range(3):
+        s.set_state(o.get_state())
+        o.iterate(); s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        for n in STATE:
+            assert maxdiff(a[n], b[n]) <= 1e-9 * max(1.0, np.abs(b[n]).max()), (it, n)
+    s.close()
+    s2 = pkg.Solver(scene, stop=0.0, cap_obs=64)
+    with pytest.raises(pkg.TrajAdmmError) as ei:
+        s2.iterate(1)
+    assert "-3" in str(ei.value)
