@@ -19,6 +19,7 @@ PHASES = {
     "k_linesearch": ["stage", "planes->lds", "setup", "E round0", "later rounds"],
     "k_sep_self_solve": ["load", "gjk+newton+store"],
     "k_sep_obs": ["hull+kdop", "bvh+planes"],
+    "k_ccd_self_seq": ["stage counts", "segment loop", "k_self + gn stage", "gnorm"],
 }
 NAMES = ["k_begin", "k_hullinfo", "k_front", "k_sep_obs", "k_sep_self_rows", "k_mid", "k_obs_solve", "k_sep_self_solve", "k_sep_self_compact", "k_grad", "k_xsolve", "k_xsolve_c2",
          "k_ccd_prep", "k_ccd", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq", "k_linesearch", "k_ls_coupled", "k_ls_commit", "k_slack"]

@@ -131,6 +131,13 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
         for (int k = 0; k < 49 && pass; k++) if (b[97 + k] < a[48 + k] - off || a[97 + k] < b[48 + k] - off) pass = false;
         ok = pass;
       }
+      // A pair can only ever ACT in the sequential replay if its swept hulls are within `offset` at FULL step: hulls are
+      // nested in the step (conv{P, P+tD} shrinks with t), and the replay evaluates them at steps <= 1.  Deciding that
+      // here, in parallel over all rows, leaves the one-wave replay kernel with the (rare) colliding pairs only.
+      if (ok) {
+        const V3 v = gjk(BodySwept{a, a + 18, D.pow08[0]}, BodySwept{b, b + 18, D.pow08[0]});
+        ok = v.x * v.x + v.y * v.y + v.z * v.z <= off * off;
+      }
     }
     const unsigned long long mask = ballot(ok);
     const int w = base + prefix_count(mask);
@@ -155,10 +162,14 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   extern __shared__ int ks[];  // [U] exponents, [U] last segment in which the robot appeared
   int* seen = ks + D.U;
   int* cnt = seen + D.U;  // [S*U] survivor counts, staged once so the segment loop never waits on HBM
+  TJ_TIC(D, K_CCD_SELF_SEQ, 0);
   for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
-  if (D.multi()) for (int i = lane; i < D.S * D.U; i += 64) cnt[i] = D.pair_count[i];
+  int mine = 0;
+  if (D.multi()) for (int i = lane; i < D.S * D.U; i += 64) { const int v = D.pair_count[i]; cnt[i] = v; mine |= v; }
+  const bool any_pair = ballot(mine != 0) != 0ull;  // usually no pair is within `offset` at full step: skip the segment walk
   __syncthreads();
-  if (D.multi()) {
+  TJ_TIC(D, K_CCD_SELF_SEQ, 1);
+  if (D.multi() && any_pair) {
     const bool shared = D.coupled();  // Step::couple_self_step (Step.h:112-182): one step for all robots, held in ks[0]
     const double off2 = D.offset * D.offset;
     int ambiguous = 0;
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     if (lane == 0 && ambiguous) atomicAdd(&D.ctl->order_ambiguous, ambiguous);
   }
   __syncthreads();
+  TJ_TIC(D, K_CCD_SELF_SEQ, 2);
   {
     const int kshared = ks[0];
     __syncthreads();
@@ -207,6 +219,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   __syncthreads();
   for (int i = lane; i < D.U; i += 64) gns[i] = D.gn(i);
   __syncthreads();
+  TJ_TIC(D, K_CCD_SELF_SEQ, 3);
   if (lane == 0) {
     double gsum = 0;
     for (int u = 0; u < D.U; u++) gsum += gns[u];
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
       D.ctl->wolfe_c = -(xg + D.tdir(0) * gt);
     } else D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : gns[0];
   }
+  TJ_TIC(D, K_CCD_SELF_SEQ, 4);
 }
 
 // ---- slack (z) and dual update -------------------------------------------------------------------
