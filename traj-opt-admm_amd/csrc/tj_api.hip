@@ -93,7 +93,7 @@ const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "
 // in_graph: the launch belongs to the single-GPU iteration graph, a linear chain on one queue in which independent
 // stages share a launch (union kernels k_front / k_mid / k_ccd instead of their constituents), the slack/dual update
 // is the deferred one inside k_mid, and -- except in coupled mode -- the hull cache comes from k_linesearch (Dev::fuse).
-bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false) {
+bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false, bool in_phase = false) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2;
@@ -104,19 +104,19 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_obs_solve = d.N > 0 ? 256 : 0;
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
-    case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
+    case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
     case K_FRONT: if (!in_graph) return false; hipLaunchKernelGGL(k_front, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
-    case K_SEP_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_obs_query, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_SEP_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_obs_query, dim3(owned * d.S), dim3(64), 0, s, d); return true;  // stage API and sharded phase 0
     case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false; hipLaunchKernelGGL(k_obs_solve, dim3(n_obs_solve), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_ROWS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
-    case K_MID: if (!in_graph) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); return true;
+    case K_MID: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); return true;
     case K_SEP_SELF_SOLVE: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_COMPACT: hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
     case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
     case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
     case K_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
-    case K_CCD: if (!in_graph) return false; hipLaunchKernelGGL(k_ccd, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
+    case K_CCD: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_ccd, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
     case K_CCD_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
@@ -184,24 +184,22 @@ int flush_deferred(tj_ctx* c) {
     HIPCHK(c, hipStreamSynchronize((c)->stream));               \
   } while (0)
 
-// Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two
-// all-gathers), 3 = one full iteration.  Independent stages go to the side stream.
+// Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two all-gathers), 3 = one full
+// iteration.  The phases are linear chains on the context's stream as well and reuse the union kernels where the
+// stages they join fall into the same phase (k_mid, k_ccd); the slack/dual update is the deferred one inside k_mid.
+//   phase 0: begin, obstacle candidate query (owned robots)                               -> all-gather control points
+//   phase 1: hull cache (ALL robots), pair rows, k_mid, compaction, gradient, Newton solve -> all-gather directions
+//   phase 2: swept-hull cache (ALL robots), k_ccd, sequential pair clamp + gnorm, line search
 int enqueue_body(tj_ctx* c, int which) {
   if (which == 3) return enqueue_iteration(c);
-  hipStream_t m = c->stream, s2 = c->side;
-  int r;
-#define STG(st, str) if ((r = enqueue_stage(c, st, str))) return r
-  if (which == 0) { STG(TJ_STAGE_BEGIN, m); STG(TJ_STAGE_PLANES_OBS, m); }
-  else if (which == 1) { STG(TJ_STAGE_PLANES_SELF, m); STG(TJ_STAGE_GRAD, m); STG(TJ_STAGE_XSOLVE, m); }
-  else {
-    STG(TJ_STAGE_CCD_PREP, m);
-    HIPCHK(c, hipEventRecord(c->ev[2], m)); HIPCHK(c, hipStreamWaitEvent(s2, c->ev[2], 0));
-    STG(TJ_STAGE_CCD_OBS, m);
-    STG(TJ_STAGE_CCD_SELF, s2);
-    HIPCHK(c, hipEventRecord(c->ev[3], s2)); HIPCHK(c, hipStreamWaitEvent(m, c->ev[3], 0));
-    STG(TJ_STAGE_LINESEARCH, m); STG(TJ_STAGE_SLACK, m);
-  }
-#undef STG
+  hipStream_t m = c->stream;
+  static const int ph0[] = {K_BEGIN, K_SEP_OBS}, ph1[] = {K_HULLINFO, K_SEP_SELF_ROWS, K_MID, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_XSOLVE_C2},
+                   ph2[] = {K_CCD_PREP, K_CCD, K_CCD_SELF_SEQ, K_LINESEARCH, K_LS_COUPLED, K_LS_COMMIT};
+  const int* list = which == 0 ? ph0 : (which == 1 ? ph1 : ph2);
+  const int n = which == 0 ? 2 : (which == 1 ? 7 : 6);
+  for (int i = 0; i < n; i++) launch_kernel(c, list[i], m, 0, false, true);
+  HIPCHK(c, hipGetLastError());
+  if (which == 2) c->maybe_deferred = true;  // this iteration's slack/dual update is owed to the next k_mid (or the flush)
   return TJ_OK;
 }
 
@@ -590,9 +588,9 @@ int tj_run_stage(tj_ctx* c, int stage) {
 int tj_iterate_phase(tj_ctx* c, int phase) {
   if (!c || phase < 0 || phase > 2) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
-  { int fr = flush_deferred(c); if (fr) return fr; }
-  // eager launches: measured faster than three graph replays per iteration (a replay costs
-  // ~10-16 us of host time, a plain launch ~3.5 us, and a phase has only 2-7 kernels)
+  // eager launches: measured faster than three graph replays per iteration (a replay costs ~10-16 us of host time, a
+  // plain launch ~3.5 us, and a phase has only 2-7 kernels).  No flush here: the slack/dual update an iteration owes is
+  // paid by k_mid of the next iteration's phase 1 (or by tj_sync / any state access).
   return enqueue_body(c, phase);
 }
 
