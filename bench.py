@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "H8"])
+    ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "E", "H8"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--coupled", action="store_true", help='time the coupled mode ("decouple":0, one shared piece_time) instead of the shipped decoupled mode; single GPU only')
     ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
@@ -101,7 +101,7 @@ def main():
 
     pkg = importlib.import_module("traj-opt-admm_amd")
     sc = pkg.scenes
-    scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d, "H8": lambda: sc.hard(8, 20000)}[args.scene]()
+    scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d, "E": sc.scn_e, "H8": lambda: sc.hard(8, 20000)}[args.scene]()
 
     if args.coupled:
         scene = dict(scene); scene["mode"] = 2; scene["name"] += "-coupled"

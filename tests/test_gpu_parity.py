@@ -234,3 +234,24 @@ def test_sharded_equals_unsharded(pkg, scenes):
         assert np.array_equal(a[n][h:], b1[n][h:]), n
     for x in (ref, r0, r1):
         x.close()
+
+
+def test_full_size_scn_c_teacher_forced_vs_oracle(pkg, scenes):
+    """BASELINE config 4 size (64 UAVs, 100k points): whole iterations through the hipGraph path, each started from the
+    CPU oracle's state.  (Free-running end-to-end parity is meaningless on this scene: the reference's own 1-ulp
+    envelope is 1e-2)"""
+    from oracle.pyoracle import Engine
+    scene = scenes.scn_c()
+    o = Engine("port", scene)
+    s = pkg.Solver(scene, stop=0.0)
+    for it in range(8):
+        s.set_state(o.get_state())
+        go = o.iterate()
+        gg, _, _ = s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        assert abs(gg - go) <= 1e-10 * max(1.0, go), (it, gg, go)
+        for n in STATE:
+            assert maxdiff(a[n], b[n]) <= 1e-9 * max(1.0, np.abs(b[n]).max()), (it, n, maxdiff(a[n], b[n]))
+    st = s.stats()
+    assert st["error_bits"] == 0 and st["order_ambiguous"] == 0
+    s.close()

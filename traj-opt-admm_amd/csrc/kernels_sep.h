@@ -250,6 +250,7 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
 // A segment next to an obstacle slab has > 100 candidates; solved inside the segment's own wave (64 divergent GJK paths
 // per round) they made a 45 us tail on a 5 us kernel.  One wave per candidate runs them all at once.
 // Plane order = candidate order = what the fused version produced, so downstream sums see the same sequence.
+constexpr int OBS_SINGLE_MAX = 16;  // candidates of a segment that still get a wave each
 __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
@@ -289,15 +290,20 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   TJ_TIC(D, K_SEP_OBS, 2);
   const int cnt = min(base, D.cap_obs);
   if (lane < 18) D.ohull[seg * 18 + lane] = P[lane];
+  // Work items: a segment with few candidates hands each one to its own wave (cooperative GJK, lowest latency); a
+  // segment in a dense part of the cloud hands them over in batches of up to 64, one candidate per lane (per-lane GJK,
+  // highest throughput).  slot >= 0: single candidate; slot < 0: batch starting at candidate -(slot + 1).
+  const bool batched = cnt > OBS_SINGLE_MAX;
+  const int items = batched ? (cnt + 63) / 64 : cnt;
   int w0 = 0;
   if (lane == 0) {
     D.ocand_n[seg] = cnt;
-    if (cnt > 0) w0 = atomicAdd(D.obs_work_n, cnt);
+    if (items > 0) w0 = atomicAdd(D.obs_work_n, items);
     unsigned long long* st = D.seg_stats + seg * 6;
     st[0] += visits; st[1] += (unsigned long long)found;
   }
   w0 = __shfl(w0, 0);
-  for (int i = lane; i < cnt; i += 64) { D.obs_work[2 * (size_t)(w0 + i)] = (int)seg; D.obs_work[2 * (size_t)(w0 + i) + 1] = i; }
+  for (int i = lane; i < items; i += 64) { D.obs_work[2 * (size_t)(w0 + i)] = (int)seg; D.obs_work[2 * (size_t)(w0 + i) + 1] = batched ? -(i * 64) - 1 : i; }
 }
 
 // Separate::opengjk (Separate.h:18-163) for one candidate, by one wave
@@ -312,16 +318,22 @@ __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves
     __syncthreads();
     if (lane < 18) P[lane] = D.ohull[(size_t)seg * 18 + lane];
     __syncthreads();
-    const int pt = D.ocand[(size_t)seg * D.cap_obs + slot];
+    const bool batch = slot < 0;
+    const int first = batch ? -(slot + 1) : slot;
+    const int mine = batch ? first + lane : first;                     // candidate of this lane
+    const bool live = !batch || mine < D.ocand_n[seg];
+    const int pt = D.ocand[(size_t)seg * D.cap_obs + (live ? mine : first)];
     const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
-    const V3 v = gjk_wave(BodyHull{P}, BodyPoint{qp}, lane);
+    V3 v;
+    if (batch) v = gjk(BodyHull{P}, BodyPoint{qp});                    // one candidate per lane
+    else v = gjk_wave(BodyHull{P}, BodyPoint{qp}, lane);               // one candidate for the whole wave
     const double cn = norm3(v.x, v.y, v.z);
-    if (!(cn > dist) && lane == 0) {  // same expressions as plane_obstacle
+    if (!(cn > dist) && live && (batch || lane == 0)) {  // same expressions as plane_obstacle
       const double c0 = v.x / cn, c1 = v.y / cn, c2 = v.z / cn;
       const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
-      double* o = D.oraw + ((size_t)seg * D.cap_obs + slot) * 4;
+      double* o = D.oraw + ((size_t)seg * D.cap_obs + mine) * 4;
       o[0] = c0; o[1] = c1; o[2] = c2; o[3] = d0 - D.offset;
-      D.ostamp[(size_t)seg * D.cap_obs + slot] = epoch;
+      D.ostamp[(size_t)seg * D.cap_obs + mine] = epoch;
     }
   }
 }

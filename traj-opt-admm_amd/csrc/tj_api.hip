@@ -101,7 +101,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   // waves: a larger grid adds no parallelism, only dispatch time for blocks that find no work (measured: with
   // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
   const int n_solve = multi ? std::min(d.cap_work, 1024) : 0;
-  const int n_obs_solve = d.N > 0 ? 256 : 0;
+  const int n_obs_solve = d.N > 0 ? 512 : 0;
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)

@@ -60,6 +60,15 @@ def scn_d():
     return crossing(256, 1000000, seed=777, name="SCN-D")
 
 
+def scn_e():
+    """SCN-E (stress, not a BASELINE config): 64 UAVs crossing THROUGH a cloud of 1M points that fills the flight volume
+    (kept 0.22 away from the straight initial paths): ~10^2 broad-phase candidates per segment, the BVH / k-DOP / GJK
+    front end becomes throughput bound."""
+    s = hard(U=64, n_points=1_000_000, seed=9, radius=10.0, dz=0.25, clear=0.22)
+    s["name"] = "SCN-E"
+    return s
+
+
 def tiny(mode=1, U=3, n_points=600, seed=5):
     """Small scene for fast oracle-vs-HIP unit tests."""
     if mode == 0:
