@@ -255,3 +255,35 @@ def test_full_size_scn_c_teacher_forced_vs_oracle(pkg, scenes):
     st = s.stats()
     assert st["error_bits"] == 0 and st["order_ambiguous"] == 0
     s.close()
+
+
+def test_max_size_scn_d_properties_and_two_iterations_vs_oracle(pkg, scenes):
+    """BASELINE config 5 size in the reference's own arithmetic (fp64, obstacles = points): 256 UAVs, 1M obstacle
+    points.  Two whole iterations against the CPU oracle, then size-independent properties: bitwise run-to-run
+    determinism, no device error, fixed end control points, convergence."""
+    from oracle.pyoracle import Engine
+    scene = scenes.scn_d()
+    o = Engine("port", scene)
+    s = pkg.Solver(scene, stop=0.0)
+    for it in range(2):
+        s.set_state(o.get_state())
+        go = o.iterate()
+        gg, _, _ = s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        assert abs(gg - go) <= 1e-10 * max(1.0, go), (it, gg, go)
+        for n in STATE:
+            assert maxdiff(a[n], b[n]) <= 1e-9 * max(1.0, np.abs(b[n]).max()), (it, n, maxdiff(a[n], b[n]))
+    s.close()
+    r1 = pkg.Solver(scene); r2 = pkg.Solver(scene)
+    init = r1.get_state()
+    r1.iterate(6); r2.iterate(6)
+    a, b = r1.get_state(), r2.get_state()
+    for n in STATE:
+        assert np.array_equal(a[n], b[n]), f"{n} is not bitwise reproducible"
+    gnorm, iters, conv = r1.iterate(60)
+    assert conv and iters <= 45
+    fin = r1.get_state()
+    assert r1.stats()["error_bits"] == 0
+    assert np.isfinite(fin["spline"]).all() and (fin["piece_time"] > 0).all()
+    assert np.array_equal(fin["spline"][:, :, :2], init["spline"][:, :, :2]) and np.array_equal(fin["spline"][:, :, -2:], init["spline"][:, :, -2:])
+    r1.close(); r2.close()

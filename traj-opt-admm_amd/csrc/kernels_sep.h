@@ -1,8 +1,9 @@
 // kernels_sep.h -- separating-plane construction ("z-update: GJK separating-plane projection"
 // in BASELINE.json's vocabulary).
 //
-//   k_sep_obs   one wavefront per (robot, Bezier segment): hull -> static-BVH query -> 49-axis
-//               k-DOP cull -> GJK -> plane (c,d).  Replaces BVH::DCDCollision (BVH.cpp:149-193),
+//   obstacle planes (obs_query_body / obs_solve_body, compaction in kernels_pairs.h): per (robot, Bezier segment)
+//               hull -> static-BVH query -> 49-axis k-DOP cull; per candidate GJK -> plane (c,d).
+//               Replaces BVH::DCDCollision (BVH.cpp:149-193),
 //               aabb::Tree::query (AABB.cc:608-667), CCD::KDOPDCD (CCD.h:354-413) and
 //               Separate::opengjk (Separate.h:18-163) as sequenced by separate_plane
 //               (Optimization3D_multi.h:176-235 / Optimization3D_admm.h:69-197).
@@ -125,14 +126,17 @@ __device__ __forceinline__ bool kdop_point_pass(const Dev& D, const double* klo,
 }
 
 // Separate::opengjk (Separate.h:18-163): plane (c,d) between a 6-point hull and one cloud point
-__device__ __forceinline__ bool plane_obstacle(const double* P, const V3& qp, double dist, double offset, double& c0, double& c1, double& c2, double& dd) {
-  const V3 v = gjk(BodyHull{P}, BodyPoint{qp});
+// plane (c,d) from the GJK witness vector v of hull - point (Separate.h:107-151): rejected if |v| > dist
+__device__ __forceinline__ bool plane_from_witness(const V3& v, const V3& qp, double dist, double offset, double& c0, double& c1, double& c2, double& dd) {
   const double cn = norm3(v.x, v.y, v.z);
   if (cn > dist) return false;
   c0 = v.x / cn; c1 = v.y / cn; c2 = v.z / cn;
   const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
   dd = d0 - offset;
   return true;
+}
+__device__ __forceinline__ bool plane_obstacle(const double* P, const V3& qp, double dist, double offset, double& c0, double& c1, double& c2, double& dd) {
+  return plane_from_witness(gjk(BodyHull{P}, BodyPoint{qp}), qp, dist, offset, c0, c1, c2, dd);
 }
 
 __device__ __forceinline__ double dot_fixed3(double c0, double c1, double c2, const double* r) { return c0 * r[0] + (c1 * r[1] + c2 * r[2]); }  // Eigen unrolled 3-term order (Separate.h:268,276)
@@ -327,12 +331,10 @@ __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves
     V3 v;
     if (batch) v = gjk(BodyHull{P}, BodyPoint{qp});                    // one candidate per lane
     else v = gjk_wave(BodyHull{P}, BodyPoint{qp}, lane);               // one candidate for the whole wave
-    const double cn = norm3(v.x, v.y, v.z);
-    if (!(cn > dist) && live && (batch || lane == 0)) {  // same expressions as plane_obstacle
-      const double c0 = v.x / cn, c1 = v.y / cn, c2 = v.z / cn;
-      const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
+    double c0, c1, c2, dd;
+    if (plane_from_witness(v, qp, dist, D.offset, c0, c1, c2, dd) && live && (batch || lane == 0)) {
       double* o = D.oraw + ((size_t)seg * D.cap_obs + mine) * 4;
-      o[0] = c0; o[1] = c1; o[2] = c2; o[3] = d0 - D.offset;
+      o[0] = c0; o[1] = c1; o[2] = c2; o[3] = dd;
       D.ostamp[(size_t)seg * D.cap_obs + mine] = epoch;
     }
   }

@@ -3,8 +3,8 @@
 //
 // One iteration = the stage sequence of Optimization3D_multi::optimization_decouple
 // (Optimization3D_multi.h:29-118) / Optimization3D_admm::optimization (Optimization3D_admm.h:29-67),
-// enqueued on one HIP stream with no host synchronisation inside or between iterations; a batch
-// of iterations is captured once into a hipGraph and replayed.  The stop test of the mains runs on
+// enqueued as a linear chain on ONE HIP stream with no host synchronisation inside or between iterations; one
+// iteration is captured once into a hipGraph and replayed.  The stop test of the mains runs on
 // the device (k_begin), so a converged problem turns the remaining replays into early-exit kernels.
 //
 // There is deliberately no CPU path in this file: every entry point either runs HIP kernels or
@@ -30,8 +30,6 @@ struct tj_ctx {
   Dev d;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  hipStream_t side = nullptr, side2 = nullptr;   // further branches of the per-iteration graph
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fork/join markers
   bool maybe_deferred = false;                    // a graph iteration ran since the last flush
   std::vector<void*> allocs;
   std::string err;
@@ -307,9 +305,6 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device available (this library has no CPU fallback)"; return TJ_ERR_DEVICE; }
   HIPCHK(c, hipSetDevice(p->device));
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  HIPCHK(c, hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
-  for (auto& e : c->ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   Dev& d = c->d;
   memset(&d, 0, sizeof(d));
   d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0;
@@ -383,9 +378,6 @@ void tj_destroy(tj_ctx* c) {
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->cloud_allocs) hipFree(p);
   if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
-  if (c->side) hipStreamDestroy(c->side);
-  if (c->side2) hipStreamDestroy(c->side2);
-  for (auto& e : c->ev) if (e) hipEventDestroy(e);
   delete c;
 }
 
