@@ -39,6 +39,15 @@ def main():
     out = np.zeros((len(NAMES), 4096, 8), dtype=np.int64)
     lib.tj_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.tj_debug_phase_times(s._ctx, out.ctypes.data) == len(NAMES)
+    kf = NAMES.index("k_front")
+    t = out[kf]; live = t[:, 0] != 0
+    if live.any():
+        t0 = t[live, 0].min(); n_obs = scene["U"] * scene["P"] * 8
+        for lab, lo, hi in (("obstacle query", 0, n_obs), ("pair rows", n_obs, 8192)):
+            sel = live.copy(); sel[:lo] = False; sel[hi:] = False
+            if sel.any():
+                st = (t[sel, 0] - t0) * 0.01; en = (t[sel, 1] - t0) * 0.01; du = en - st
+                print(f"k_front {lab:15s}: {sel.sum():5d} blocks  start {st.min():6.1f}..{st.max():6.1f}  end max {en.max():6.1f}  dur mean {du.mean():6.1f} max {du.max():6.1f} us")
     for k, name in enumerate(NAMES):
         if name not in PHASES:
             continue

@@ -95,6 +95,9 @@ struct Dev {
   int *obs_work, *obs_work_n;     // [U*S*cap_obs][2], [1]
   double *oraw; int *ostamp;      // [U][S][cap_obs][4], [U][S][cap_obs]
   double *hullinfo;               // [U][S][HULL_STRIDE] hull, AABB, k-DOP intervals of the current control net
+  // the same AABBs / the swept pair boxes again, robot-minor [S][6][U] (lo.xyz, hi.xyz): the all-pairs box tests read
+  // one component of 64 partners with one coalesced load instead of 64 strided 8-byte loads
+  double *hbox, *cbox;
   double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
   double *lg, *lh;                // per-piece gradient [U][P][19] and Hessian [U][P][361] (after PSD repair)

@@ -224,6 +224,7 @@ __device__ __forceinline__ void ls_publish_hullinfo(const Dev& D, int u, const d
     double lo = INFINITY, hi = -INFINITY;
     for (int j = 0; j < 6; j++) { const double v = P[3 * j + a]; if (v < lo) lo = v; if (v > hi) hi = v; }
     o[(size_t)tr * LS_HULL_STRIDE + 18 + a] = lo; o[(size_t)tr * LS_HULL_STRIDE + 21 + a] = hi;
+    D.hbox[((size_t)tr * 6 + a) * D.U + u] = lo; D.hbox[((size_t)tr * 6 + 3 + a) * D.U + u] = hi;
   }
   for (int idx = tid; idx < S * 49; idx += nth) {
     const int tr = idx / 49, ax = idx % 49;

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(64) void k_hullinfo(Dev D) {
     double lo = INFINITY, hi = -INFINITY;
     for (int j = 0; j < 6; j++) { const double v = P[3 * j + lane]; if (v < lo) lo = v; if (v > hi) hi = v; }
     o[18 + lane] = lo; o[21 + lane] = hi;
+    D.hbox[((size_t)tr * 6 + lane) * D.U + u] = lo; D.hbox[((size_t)tr * 6 + 3 + lane) * D.U + u] = hi;
   }
   if (lane < 49) {
     const double x = D.kdop[3 * lane], y = D.kdop[3 * lane + 1], z = D.kdop[3 * lane + 2];
@@ -66,10 +67,10 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid) {
     const int p1 = c0 + lane;
     bool hit = false;
     if (p1 < U && (own0 || (p1 >= D.u0 && p1 < D.u1))) {  // at least one robot of the pair belongs to this rank
-      const double* b = D.hullinfo + ((size_t)p1 * D.S + tr) * HULL_STRIDE;
+      const double* b = D.hbox + (size_t)tr * 6 * U + p1;   // component k of partner p1: b[k * U], coalesced over lanes
       hit = true;
 #pragma unroll
-      for (int k = 0; k < 3; k++) hit = hit && !(b[21 + k] + dist < A[18 + k] || b[18 + k] > A[21 + k] + dist);
+      for (int k = 0; k < 3; k++) hit = hit && !(b[(3 + k) * U] + dist < A[18 + k] || b[k * U] > A[21 + k] + dist);
     }
     unsigned long long box = ballot(hit);
     // 2. per box survivor, wave-cooperative 49-axis interval test: lanes over AXES, two coalesced

@@ -53,6 +53,7 @@ __device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net
       v = PS[3 * j + lane]; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
     }
     o[36 + lane] = lo; o[39 + lane] = hi; o[42 + lane] = lo2; o[45 + lane] = hi2;
+    D.cbox[((size_t)tr * 6 + lane) * D.U + u] = lo2; D.cbox[((size_t)tr * 6 + 3 + lane) * D.U + u] = hi2;
   }
   if (lane < 49) {
     const double x = D.kdop[3 * lane], y = D.kdop[3 * lane + 1], z = D.kdop[3 * lane + 2];
@@ -124,8 +125,9 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
     bool ok = false;
     if (p1 < U) {
       const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
+      const double* bb = D.cbox + (size_t)tr * 6 * U + p1;   // swept pair box of partner p1, coalesced over lanes
       bool hit = true;
-      for (int k = 0; k < 3; k++) hit = hit && !(a[45 + k] + off < b[42 + k] || a[42 + k] > b[45 + k] + off);
+      for (int k = 0; k < 3; k++) hit = hit && !(a[45 + k] + off < bb[k * U] || a[42 + k] > bb[(3 + k) * U] + off);
       if (hit) {
         bool pass = true;
         for (int k = 0; k < 49 && pass; k++) if (b[97 + k] < a[48 + k] - off || a[97 + k] < b[48 + k] - off) pass = false;
@@ -393,8 +395,10 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
 __global__ __launch_bounds__(64) void k_front(Dev D) {
   if (D.ctl->done) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
+  TJ_TIC(D, K_FRONT, 0);
   if ((int)blockIdx.x < n_obs) obs_query_body(D, blockIdx.x);
   else sep_self_rows_body(D, blockIdx.x - n_obs);
+  TJ_TIC(D, K_FRONT, 1);
 }
 __global__ __launch_bounds__(64) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
   const int n_slack = (D.u1 - D.u0) * D.P;
