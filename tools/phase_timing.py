@@ -39,6 +39,16 @@ def main():
     out = np.zeros((len(NAMES), 4096, 8), dtype=np.int64)
     lib.tj_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.tj_debug_phase_times(s._ctx, out.ctypes.data) == len(NAMES)
+    km = NAMES.index("k_mid")
+    t = out[km]; live = t[:, 0] != 0
+    if live.any():
+        t0 = t[live, 0].min()
+        n_sl = scene["U"] * scene["P"]; n_pair = 1024 if scene["mode"] >= 1 else 0
+        for lab, lo, hi in (("slack", 0, n_sl), ("pair solve", n_sl, n_sl + n_pair), ("obstacle solve", n_sl + n_pair, 4096)):
+            sel = live.copy(); sel[:lo] = False; sel[hi:] = False
+            if sel.any():
+                st = (t[sel, 0] - t0) * 0.01; en = (t[sel, 1] - t0) * 0.01; du = en - st
+                print(f"k_mid {lab:15s}: {sel.sum():5d} blocks  start {st.min():6.1f}..{st.max():6.1f}  end max {en.max():6.1f}  dur mean {du.mean():6.1f} max {du.max():6.1f} us")
     kf = NAMES.index("k_front")
     t = out[kf]; live = t[:, 0] != 0
     if live.any():

@@ -403,10 +403,12 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
 __global__ __launch_bounds__(64) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
   const int n_slack = (D.u1 - D.u0) * D.P;
   const int b = blockIdx.x;
-  if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1); }   // long single-wave tasks first
+  TJ_TIC(D, K_MID, 0);
+  if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
   else if (D.ctl->done) return;
   else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves);
   else obs_solve_body(D, b - n_slack - n_pair_waves, n_obs_waves);
+  TJ_TIC(D, K_MID, 1);
 }
 __global__ __launch_bounds__(64) void k_ccd(Dev D) {
   if (D.ctl->done) return;
