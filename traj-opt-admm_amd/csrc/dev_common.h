@@ -169,7 +169,7 @@ __device__ __forceinline__ double pow6(double x) { DD c = dd_mul_d(dd_sq(x), x);
 
 // Sum in the association order of Eigen's 2-wide vectorised reduction (Redux.h) -- used for the
 // few scalars that feed Armijo / stop decisions (wolfe, |g|, consensus norms).
-__device__ inline double esum(const double* e, int n) {
+__device__ __forceinline__ double esum(const double* e, int n) {
   if (n == 0) return 0;
   int a2 = (n / 4) * 4, a1 = (n / 2) * 2;
   double r;

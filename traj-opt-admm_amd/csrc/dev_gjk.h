@@ -169,6 +169,11 @@ __device__ __forceinline__ void gjk_tri(Simplex& s) {
   }
 }
 
+// vertex i of {p0,p1,p2,p3} as a chain of value selects on explicit operands: a by-index read of a copied struct is
+// turned into a private-memory (scratch) array by the compiler, i.e. a ~0.5 us round trip per tetrahedron step
+__device__ __forceinline__ V3 pick4(int i, const V3& p0, const V3& p1, const V3& p2, const V3& p3) {
+  return sel3(i == 0, p0, sel3(i == 1, p1, sel3(i == 2, p2, p3)));
+}
 __device__ __forceinline__ int tri_lut(int i) {  // {3,3,3, 1,2,2, 0,0,1}
   return (0x100221333 >> (4 * i)) & 0xF;
 }
@@ -214,7 +219,6 @@ __device__ __forceinline__ void gjk_tet(Simplex& s) {
   const int first = F1 == 0 ? 0 : 1;                          // facing 1: face of job 0
   const int second = (F1 == 0 && F2 == 0) ? 1 : 2;            // facing 1: face of job 1
   const int single = facing == 3 ? 3 : (F1 == 0 ? 0 : (F2 == 0 ? 1 : 2));  // facing 2 / 3
-  const Simplex keep = s;
   Simplex aux, cur;
   aux = s;
   int id0 = 0, id1 = 0, id2 = 0, nbest = 0;
@@ -222,9 +226,8 @@ __device__ __forceinline__ void gjk_tet(Simplex& s) {
 #pragma unroll 1
   for (int j = 0; j < njobs; ++j) {
     const int t = facing == 0 ? j : (facing == 1 ? (j == 0 ? first : second) : single);
-    const int ia = t == 2 ? 1 : 0, ib = (t == 0 || t == 3) ? 1 : 2, ic = t == 3 ? 2 : 3;
     cur.n = 3;
-    cur.v0 = sx_v(keep, ia); cur.v1 = sx_v(keep, ib); cur.v2 = sx_v(keep, ic);
+    cur.v0 = sel3(t == 2, c, d); cur.v1 = sel3(t == 0 || t == 3, c, b); cur.v2 = sel3(t == 3, b, a);   // vertices (ia, ib, ic) of {d,c,b,a}
     gjk_tri(cur);
     if (facing == 0) {
       const V3 vt = sx_point(cur);
@@ -243,9 +246,9 @@ __device__ __forceinline__ void gjk_tet(Simplex& s) {
   }
   if (facing == 0) {
     s.n = nbest;
-    sx_set_v(s, nbest - 1, sx_v(keep, id0)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
-    if (nbest > 1) { sx_set_v(s, nbest - 2, sx_v(keep, id1)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
-    if (nbest > 2) { sx_set_v(s, nbest - 3, sx_v(keep, id2)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
+    sx_set_v(s, nbest - 1, pick4(id0, d, c, b, a)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
+    if (nbest > 1) { sx_set_v(s, nbest - 2, pick4(id1, d, c, b, a)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
+    if (nbest > 2) { sx_set_v(s, nbest - 3, pick4(id2, d, c, b, a)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
     return;
   }
   // the (last) visited face becomes the simplex
@@ -410,14 +413,12 @@ __device__ __forceinline__ void gjk_tet_wave(Simplex& s, int lane) {
   const int first = F1 == 0 ? 0 : 1;
   const int second = (F1 == 0 && F2 == 0) ? 1 : 2;
   const int single = facing == 3 ? 3 : (F1 == 0 ? 0 : (F2 == 0 ? 1 : 2));
-  const Simplex keep = s;
   // this lane's face
   const int j = lane < njobs ? lane : njobs - 1;
   const int t = facing == 0 ? j : (facing == 1 ? (j == 0 ? first : second) : single);
-  const int ia = t == 2 ? 1 : 0, ib = (t == 0 || t == 3) ? 1 : 2, ic = t == 3 ? 2 : 3;
   Simplex mine;
   mine.n = 3;
-  mine.v0 = sx_v(keep, ia); mine.v1 = sx_v(keep, ib); mine.v2 = sx_v(keep, ic);
+  mine.v0 = sel3(t == 2, c, d); mine.v1 = sel3(t == 0 || t == 3, c, b); mine.v2 = sel3(t == 3, b, a);   // vertices (ia, ib, ic) of {d,c,b,a}
   mine.v3 = V3{0, 0, 0}; mine.l0 = mine.l1 = mine.l2 = mine.l3 = 0; mine.w0 = mine.w1 = mine.w2 = mine.w3 = 0;
   gjk_tri(mine);
   // result of job jj, broadcast to the whole wave
@@ -445,9 +446,9 @@ __device__ __forceinline__ void gjk_tet_wave(Simplex& s, int lane) {
       }
     }
     s.n = nbest;
-    sx_set_v(s, nbest - 1, sx_v(keep, id0)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
-    if (nbest > 1) { sx_set_v(s, nbest - 2, sx_v(keep, id1)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
-    if (nbest > 2) { sx_set_v(s, nbest - 3, sx_v(keep, id2)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
+    sx_set_v(s, nbest - 1, pick4(id0, d, c, b, a)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
+    if (nbest > 1) { sx_set_v(s, nbest - 2, pick4(id1, d, c, b, a)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
+    if (nbest > 2) { sx_set_v(s, nbest - 3, pick4(id2, d, c, b, a)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
     return;
   }
   fetch(njobs - 1, cur);  // the (last) visited face becomes the simplex

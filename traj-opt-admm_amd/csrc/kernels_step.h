@@ -345,9 +345,10 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
   if (tid < 3 * tn) { const int i = tid / 3, a = tid % 3; dirz[(lo + i) + 6 * a] = x0[tid]; }
   __syncthreads();
   if (tid == 0) {  // scalar Armijo loop: the objective is ~300 flops
-    double pr[19];
-    for (int i = 0; i < n; i++) pr[i] = x0[i] * g0[i];
-    const double wolfe = -esum(pr, n);
+    double pr[19];  // constant trip counts below: the array stays in registers (a run-time n sends it to scratch memory)
+#pragma unroll
+    for (int i = 0; i < 19; i++) pr[i] = i < n ? x0[i] * g0[i] : 0.0;
+    const double wolfe = -(n == 19 ? esum(pr, 19) : esum(pr, 13));
     const double t_dir = x0[3 * tn];
     double step = 1.0;
     if (t + step * t_dir <= 0) step = -0.95 * t / t_dir;
@@ -400,7 +401,9 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   else sep_self_rows_body(D, blockIdx.x - n_obs);
   TJ_TIC(D, K_FRONT, 1);
 }
-__global__ __launch_bounds__(64) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
+// two waves per SIMD (<= 256 VGPRs): all 320 + 1024 + 512 blocks of SCN-C are resident at once; at the natural 340 VGPRs a
+// third of them started only when an earlier block had finished, 18-33 us into the kernel
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
   const int n_slack = (D.u1 - D.u0) * D.P;
   const int b = blockIdx.x;
   TJ_TIC(D, K_MID, 0);
