@@ -287,3 +287,32 @@ def test_max_size_scn_d_properties_and_two_iterations_vs_oracle(pkg, scenes):
     assert np.isfinite(fin["spline"]).all() and (fin["piece_time"] > 0).all()
     assert np.array_equal(fin["spline"][:, :, :2], init["spline"][:, :, :2]) and np.array_equal(fin["spline"][:, :, -2:], init["spline"][:, :, -2:])
     r1.close(); r2.close()
+
+
+@pytest.mark.parametrize("which", ["cross16", "cross12_coupled", "scn_a_seed7"])
+def test_more_scenes_end_to_end_vs_oracle(pkg, scenes, which):
+    """free-running to the mains' stop test on further seeded scenes (not golden-pinned; the CPU oracle, itself pinned
+    against the reference, is the checker): same iteration count, final control points within 1e-7 relative.  Scenes are
+    ones on which the reference reproduces ITSELF to 1e-9 under a 1-ulp input change (tools/ref_sensitivity.py); the
+    `hard` family does not converge and moves by 1e-2 there.  Note for the single-UAV mode (ks = 1e-8): the reference
+    factors with an AMD-ordered SimplicialLLT, this library and the oracle in natural band order -- on SCN-A that costs
+    2.5e-11, on the seed used here the ORACLE is 3e-8 from the reference (elimination-order rounding times 1e8
+    conditioning), which is why this test checks against the oracle at 1e-7 and the golden SCN-A run at 1e-8."""
+    from oracle.pyoracle import Engine
+    scene = {"cross16": lambda: scenes.crossing(16, 30000, seed=4, name="cross16"),
+             "cross12_coupled": lambda: dict(scenes.crossing(12, 20000, seed=6, name="cross12"), mode=2),
+             "scn_a_seed7": lambda: scenes.scn_a(n_points=20000, seed=7)}[which]()
+    o = Engine("port", scene)
+    gn = []
+    for it in range(150):
+        gn.append(o.iterate())
+        if it > 1 and gn[-1] < 1e-2:
+            break
+    assert gn[-1] < 1e-2, "scene does not converge in the oracle"
+    s = pkg.Solver(scene)
+    gnorm, iters, conv = s.iterate(150)
+    assert conv and iters == len(gn), (iters, len(gn))
+    a, b = s.get_state(), o.get_state()
+    assert rel(a["spline"], b["spline"]) <= 1e-7 and rel(a["piece_time"], b["piece_time"]) <= 1e-7
+    assert s.stats()["error_bits"] == 0
+    s.close()
