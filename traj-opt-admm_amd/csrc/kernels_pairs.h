@@ -9,14 +9,15 @@
 //                       the box test; lanes over the 49 AXES for each box survivor (interval
 //                       comparisons straight from the cache, no dot products, two coalesced loads
 //                       per lane); pairs that pass go to a work list.
-//   k_sep_self_solve    one wavefront per listed pair: hull-hull GJK and the Newton refinement of
-//                       the offset (scalar, divergent -- hence one program counter per pair).
+//   k_sep_self_solve    one wavefront per listed pair, solved cooperatively by its lanes (wave-cooperative
+//                       GJK, the 12 barrier terms of the offset Newton on 12 lanes: plane_pair_wave).
 //                       Each unordered pair is solved ONCE and
 //                       the plane is stored for both robots, (c, d - off/2) and (-c, -d - off/2),
 //                       in a dense [segment][robot][partner] slot table stamped with the current
 //                       epoch (no clearing pass).
-//   k_sep_self_compact  per (robot, segment): gathers the stamped slots in ascending partner order
-//                       into the robot's plane list -- deterministic order, no atomics.
+//   k_sep_self_compact  per (robot, segment): the obstacle planes from the stamped candidate slots (slot order), then
+//                       the stamped partner slots in ascending partner order into the robot's plane lists --
+//                       deterministic order, no atomics.
 // The per-segment tree of the reference is replaced by the all-pairs box test (U <= a few hundred):
 // the pair SET is what matters, and it is defined by the same inclusive overlap predicate
 // (AABB.cc:131-148).

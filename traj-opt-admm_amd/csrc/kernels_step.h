@@ -1,23 +1,23 @@
-// kernels_step.h -- CCD step clamps, the Armijo line search on the x-objective, and the slack (z)
-// + dual update.
+// kernels_step.h -- CCD step clamps, the slack (z) + dual update, iteration bookkeeping, and the union kernels of the
+// single-GPU iteration graph.  (The Armijo line search on the x-objective lives in kernels_ls.h.)
 //
 //   k_ccd_prep      per (robot, segment): hull P, direction hull D, query boxes and the 49-axis
-//                   intervals of the swept hull at step 1, cached for the two CCD kernels
+//                   intervals of the swept hull at step 1, cached for the two CCD stages
 //                   (BVH::CCDCollision BVH.cpp:195-250, SelfCCDCollision :289-330, CCD::KDOPCCD
 //                   CCD.h:416-473, SelfKDOPCCD :475-533)
-//   k_ccd_obs       Step::position_step (Step.h:21-110): per candidate cloud point the smallest
+//   ccd_obs_body    Step::position_step (Step.h:21-110): per candidate cloud point the smallest
 //                   exponent k with conv{P, P+0.8^k D} farther than `offset`; atomicMax per robot.
 //                   The reference's running-step loop yields max_k over candidates because swept
 //                   hulls are nested in k, so the result is order independent.
-//   k_ccd_self_*    Step::self_step (Step.h:184-256).  Phase A (parallel, per segment) keeps the
-//                   robot pairs whose swept boxes and k-DOPs overlap at full step -- a superset of
-//                   every pair the reference can act on, since k-DOP separation implies GJK
-//                   separation.  Phase B (one wave, sequential) replays the reference's ORDER
-//                   DEPENDENT joint back-off over those few pairs, segment by segment.
-//   k_linesearch    spline_line_search (Optimization3D_multi.h:754-811, _admm.h:505-557) with
-//                   Energy_admm::spline_energy (Energy_admm.h:16-170) evaluated by the whole block.
-//   k_slack         update_slack_lambda (Optimization3D_multi.h:344-506): per piece Newton step on
+//   ccd_self_pairs_body / k_ccd_self_seq
+//                   Step::self_step (Step.h:184-256).  Phase A (parallel, per segment) keeps the robot pairs whose
+//                   swept boxes and k-DOPs overlap and whose swept hulls are within `offset` at FULL step -- no
+//                   other pair can ever act, hulls being nested in the step.  Phase B (one wave, sequential)
+//                   replays the reference's ORDER DEPENDENT joint back-off over those (rare) pairs, segment by
+//                   segment; it also forms gnorm.
+//   slack_body      update_slack_lambda (Optimization3D_multi.h:344-506): per piece Newton step on
 //                   (z, t_z) with Armijo, then the dual ascent on (Lambda, tau).
+//   k_front / k_mid / k_ccd   union kernels: independent one-wavefront stages sharing a launch (see below).
 #pragma once
 #include "dev_common.h"
 #include "dev_linalg.h"
