@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Dev-container tool (needs oracle/_ref/libref.so): how far does the UNMODIFIED reference move its own final control
 points when its input way points are perturbed by one ulp?  That envelope bounds the end-to-end parity any other
-implementation can reach.  Usage: python tools/ref_sensitivity.py [--optimal-plane] [--coupled] scene ...   (scene: A B C tiny hard)"""
+implementation can reach.  Usage: python tests/devtools/ref_sensitivity.py [--optimal-plane] [--coupled] scene ...   (scene: A B C tiny hard)"""
 import argparse, ctypes as C, importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("traj-opt-admm_amd")
 from oracle.pyoracle import Engine

@@ -293,7 +293,7 @@ def test_max_size_scn_d_properties_and_two_iterations_vs_oracle(pkg, scenes):
 def test_more_scenes_end_to_end_vs_oracle(pkg, scenes, which):
     """free-running to the mains' stop test on further seeded scenes (not golden-pinned; the CPU oracle, itself pinned
     against the reference, is the checker): same iteration count, final control points within 1e-7 relative.  Scenes are
-    ones on which the reference reproduces ITSELF to 1e-9 under a 1-ulp input change (tools/ref_sensitivity.py); the
+    ones on which the reference reproduces ITSELF to 1e-9 under a 1-ulp input change (tests/devtools/ref_sensitivity.py); the
     `hard` family does not converge and moves by 1e-2 there.  Note for the single-UAV mode (ks = 1e-8): the reference
     factors with an AMD-ordered SimplicialLLT, this library and the oracle in natural band order -- on SCN-A that costs
     2.5e-11, on the seed used here the ORACLE is 3e-8 from the reference (elimination-order rounding times 1e8
