@@ -1,6 +1,6 @@
 """Free-running end-to-end comparison HIP path vs CPU oracle (diagnostic). Usage: gpu_e2e.py <scene> <max_iters> [port|ref]"""
 import sys, os, importlib, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 pkg = importlib.import_module("traj-opt-admm_amd")
 sc = pkg.scenes

@@ -1,7 +1,7 @@
 """Teacher-forced, stage-by-stage comparison of the HIP path against the CPU oracle (diagnostic
 script; the asserting versions live in tests/).  Usage: python tools/gpu_stage_diff.py <scene> <iters>"""
 import sys, os, importlib, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 pkg = importlib.import_module("traj-opt-admm_amd")
 sc = pkg.scenes
