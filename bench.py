@@ -184,7 +184,7 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['cloud'].shape[0]} obstacle points, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}",
-                          "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else "1 GPU, whole iteration in one hipGraph (linear chain on one queue, union kernels)",
+                          "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else "1 GPU, whole iteration resident on the device: a linear chain of 10 kernels on one queue (union kernels), enqueued ahead, no host sync",
                           "iters_timed_from": "initial trajectory"}}
     if world == 1:
         # per-kernel device time with hipEvents on the solver's stream, same K iterations

@@ -11,6 +11,7 @@
 // fails with TJ_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,6 +35,7 @@ struct tj_ctx {
   std::vector<void*> allocs;
   std::string err;
   bool have_cloud = false, have_state = false;
+  bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
   bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
   // graph of one full iteration
   // hipGraphs: [0..2] the three phases of a sharded iteration, [3] one full iteration
@@ -204,6 +206,16 @@ int enqueue_body(tj_ctx* c, int which) {
 // Capture the body once into a hipGraph and replay it; fall back to eager launches if capture is
 // not possible on this stream.
 int launch_graph_or_eager(tj_ctx* c, int which) {
+  // Default: plain launches.  The iteration is a linear chain on one queue and the host enqueues far ahead of the device
+  // (10 launches ~ 35 us of host time per ~200 us iteration), so consecutive kernels already start back to back; a
+  // hipGraph replay of the same chain measured 4 us SLOWER per iteration (~8 us between consecutive graph launches),
+  // and ten iterations per graph 6 us slower still.  TJ_USE_GRAPH=1 selects the captured-graph replay.
+  if (!c->use_graph) {
+    int r = enqueue_body(c, which);
+    if (r == TJ_OK && which >= 3) c->maybe_deferred = true;
+    return r;
+  }
+
   if (!c->graph_ok[which] && !c->graph_failed[which]) {
     hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
@@ -308,6 +320,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   Dev& d = c->d;
   memset(&d, 0, sizeof(d));
   d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0;
+  c->use_graph = getenv("TJ_USE_GRAPH") != nullptr;
   d.fuse = (p->world == 1 && p->mode != TJ_MODE_MULTI_COUPLED) ? 1 : 0;
   d.u0 = (int)((long long)p->rank * d.U / p->world); d.u1 = (int)((long long)(p->rank + 1) * d.U / p->world);
   d.lambda = p->lambda; d.margin = p->margin; d.offset = p->offset; d.mu = p->mu; d.vel_limit = p->vel_limit; d.acc_limit = p->acc_limit;
