@@ -204,8 +204,9 @@ def main():
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": "tj::" + dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                           "traffic": pmc, "algorithmic_bytes_per_launch": bytes_it[dom], "avg_launch_ms": per_launch_ms[dom],
-                           "note": "latency-bound at this size: the 35 MB working set is Infinity-Cache resident (DESIGN.md 5)",
+                           "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None), "traffic_detail": pmc,
+                           "algorithmic_bytes_per_launch": bytes_it[dom], "avg_launch_ms": per_launch_ms[dom],
+                           "note": "latency-bound at this size: the ~60 MB working set is Infinity-Cache resident (DESIGN.md 5); traffic = rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch of the same kernel (profiles/pmc_latest.json)",
                            "whole_iteration": {"algorithmic_bytes": total_bytes, "achieved_GBps": total_bytes / (dt / K) / 1e9,
                                                "frac": total_bytes / (dt / K) / 1e9 / 8000.0},
                            "kernel_ms_per_launch": per_launch_ms}
