@@ -81,6 +81,10 @@ def main():
             print("   corr(total us, gjk iters) =", np.corrcoef(tot, gk)[0, 1], " corr(total us, newton) =", np.corrcoef(tot, np.maximum(nit, 0))[0, 1])
             o = np.argsort(-tot)[:8]
             print("   slowest:", [(round(float(tot[i]), 1), int(gk[i]), int(nit[i])) for i in o])
+        if name == "k_grad":
+            llt = (t[:, 7] - t[:, 4]) * 0.01; rest = (t[:, 5] - t[:, 7]) * 0.01
+            failed = rest > 2.0
+            print(f"   psd split: LLT check mean {llt.mean():.2f} max {llt.max():.2f} us; after the check: {failed.sum()} blocks repair, mean {rest[failed].mean() if failed.any() else 0:.2f} max {rest.max():.2f} us")
         worst = np.argsort(-tot)[:3]
         for w in worst:
             print(f"   slow block {np.flatnonzero(live)[w]:5d}: " + " ".join(f"{x:12.2f}" for x in d[w]))

@@ -260,7 +260,9 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
     const int row = min(tid, 18);
 #pragma unroll
     for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
-    if (!chol_check_wave<19>(r)) {
+    const bool llt_ok = chol_check_wave<19>(r);
+    TJ_TIC(D, K_GRAD, 7);
+    if (!llt_ok) {
       if (tid == 0) atomicAdd(&D.ctl->llt_fail_piece, 1ull);
 #pragma unroll
       for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
