@@ -1,0 +1,23 @@
+import importlib, sys, time
+import numpy as np
+sys.path.insert(0, "/root/repo")
+pkg = importlib.import_module("traj-opt-admm_amd")
+sc = pkg.scenes
+t0 = time.time()
+s = pkg.Solver(sc.scn_c(), stop=0.0)
+g, it, conv = s.iterate(3000)
+st = s.stats(); fin = s.get_state()
+print("3000 iterations SCN-C: gnorm %.3e iters %d error_bits %d finite %s  %.2f s" % (g, it, st["error_bits"], bool(np.isfinite(fin["spline"]).all()), time.time() - t0))
+s.close()
+import ctypes as C
+hip = C.CDLL("libamdhip64.so")
+def free_mem():
+    f, t = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+    return f.value
+free0 = free_mem()
+for k in range(30):
+    x = pkg.Solver(sc.scn_b(), stop=0.0); x.iterate(3); x.close()
+    y = pkg.Solver(dict(sc.scn_b(), mode=2), stop=0.0); y.iterate(3); y.close()
+free1 = free_mem()
+print("create/destroy x60: free memory before %.1f MB after %.1f MB" % (free0 / 2**20, free1 / 2**20))
