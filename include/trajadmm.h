@@ -56,7 +56,7 @@ typedef struct tj_params {
   int device;          /* HIP device ordinal */
   int rank, world;     /* robot sharding: this context owns robots [rank*U/world, (rank+1)*U/world) */
   int cap_obs;         /* max obstacle planes per (robot, segment); 0 = default 256 */
-  int cap_self;        /* max inter-robot planes per (robot, segment); 0 = default uav_num */
+  int cap_self;        /* max inter-robot planes per (robot, segment); 0 = default min(uav_num - 1, 64) */
   int cap_pairs;       /* max inter-robot CCD candidate pairs per segment; 0 = default */
 } tj_params;
 

@@ -119,7 +119,37 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   const int n = min(*D.pair_work_n, D.cap_work), U = D.U;
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
-  for (int w = bid; w < n; w += nwaves) {
+  // Long work list (hundreds of robots): a wave per pair is the lowest LATENCY but occupies 64 lanes for one chain of
+  // dependent steps; with thousands of pairs THROUGHPUT decides, and one pair per LANE (per-lane GJK + Newton, the same
+  // arithmetic: plane_pair == plane_pair_wave bit for bit) is ~20x cheaper per pair.  The switch is wave-uniform.
+  if (n > 4 * nwaves) {
+    unsigned long long nit_sum = 0, solved = 0; bool any_capped = false;
+    for (int base = bid * 64; base < n; base += nwaves * 64) {
+      const int w = base + lane;
+      if (w < n) {
+        const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+        const double* Ag = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
+        const double* Bg = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
+        double e0, e1c, e2c, dpl; bool capped; int nit = 0;
+        if (plane_pair(Ag, Bg, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
+          nit_sum += (unsigned long long)nit; solved++; any_capped = any_capped || capped;
+          const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
+          double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
+          q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
+          q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
+          D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { nit_sum += __shfl_xor(nit_sum, o); solved += __shfl_xor(solved, o); }
+    if (lane == 0 && solved) { atomicAdd(&D.ctl->newton_iters, nit_sum); atomicAdd(&D.ctl->pair_solves, solved); }
+    if (any_capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+    return;
+  }
+  // The first `nwaves` items are taken statically (no atomic on the common path: SCN-C has fewer pairs than waves); a
+  // wave that finishes early then draws further items from a shared cursor, so a long list (hundreds of robots) is
+  // balanced dynamically instead of striding -- solve times vary 1 : 30.
+  for (int w = bid; w < n;) {
     if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
     const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
     __syncthreads();
@@ -143,6 +173,9 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
       }
     }
     if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
+    int nxt = 0;
+    if (lane == 0) nxt = nwaves + atomicAdd(D.pair_work_n + 1, 1);
+    w = __shfl(nxt, 0);
   }
 }
 __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {

@@ -326,7 +326,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.lambda = p->lambda; d.margin = p->margin; d.offset = p->offset; d.mu = p->mu; d.vel_limit = p->vel_limit; d.acc_limit = p->acc_limit;
   d.ks = p->ks; d.kt = p->kt; d.stop = p->stop;
   d.cap_obs = p->cap_obs > 0 ? p->cap_obs : 256;
-  d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, d.U - 1);
+  d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, std::min(d.U - 1, 64));  // neighbours within offset + 2 margin of ONE segment; k_grad's LDS grows with it
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
   d.cap_row = std::max(1, std::min(d.cap_pairs, d.U));  // partners per (segment, lower robot)
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
@@ -375,7 +375,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.pair_count, S * U)) || (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
-      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 1)) || (r = dalloc(c, &d.ctl, 1)) ||
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 2)) || (r = dalloc(c, &d.ctl, 1)) ||
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs))) return r;
