@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--coupled", action="store_true", help='time the coupled mode ("decouple":0, one shared piece_time) instead of the shipped decoupled mode; single GPU only')
     ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
+    ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: every rank uses device 0 and the all-gathers are staged through host memory over gloo "
+                                                            "(RCCL refuses two ranks on one device); exercises the multi-process schedule on a 1-GPU box")
+    ap.add_argument("--state-checksum", action="store_true", help="each rank also prints 'CHECK <rank> <sha256 of its owned robots\' final control points and piece times>'")
     args = ap.parse_args()
 
     pkg = importlib.import_module("traj-opt-admm_amd")
@@ -107,7 +110,7 @@ def main():
         scene = dict(scene); scene["mode"] = 2; scene["name"] += "-coupled"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -120,7 +123,10 @@ def main():
             os.environ["NCCL_DEBUG"] = "WARN"   # no version banner on stdout next to the JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.same_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     if scene["U"] % world != 0:
         raise SystemExit("robot count must divide evenly over the ranks")
@@ -146,7 +152,15 @@ def main():
                 slv.iterate_phase(k)
 
         def _gather(what):  # RCCL all-gather straight on the library's device buffers (in place)
-            dist.all_gather_into_tensor(views[what][0], views[what][1])
+            if args.same_gpu:  # test path: device slice -> host -> gloo all-gather -> device
+                tstream.synchronize()
+                mine = views[what][1].cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                views[what][0].copy_(torch.cat(parts).to(views[what][0].device))
+                tstream.synchronize()
+            else:
+                dist.all_gather_into_tensor(views[what][0], views[what][1])
 
         def run(n_it):
             sharding.run_sharded(_Eng, _gather, n_it)
@@ -177,6 +191,12 @@ def main():
     if st["error_bits"]:
         raise SystemExit(f"device error bits {st['error_bits']}")
 
+    if args.state_checksum:
+        import hashlib
+        stt = slv.get_state()
+        u0, u1 = rank * scene["U"] // world, (rank + 1) * scene["U"] // world
+        h = hashlib.sha256(np.ascontiguousarray(stt["spline"][u0:u1]).tobytes() + np.ascontiguousarray(stt["piece_time"][u0:u1]).tobytes()).hexdigest()
+        print(f"CHECK {rank} {h}", flush=True)
     out = None
     if rank == 0:
         out = {"metric": "ADMM iterations/sec", "value": K / dt, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
