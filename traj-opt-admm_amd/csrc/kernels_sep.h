@@ -32,7 +32,9 @@ __device__ __forceinline__ bool box_hit(const double* b, const QBox& q, double m
 
 // Wave-cooperative query.  `process(pt)` is called by all 64 lanes with a candidate point index
 // (or -1) and may use wave collectives.  Returns candidates found; adds visited boxes to *visits.
-template <class F>
+// BQ_UNROLL: chunks of 8 frontier nodes whose box loads are in flight together (4 in the plane query, whose kernel has
+// registers to spare; 1 in the CCD query, where the per-lane GJK already fills the register file)
+template <int BQ_UNROLL, class F>
 __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb, int* cand, unsigned long long* visits, F&& process) {
   const int lane = lane_id();
   if (D.N == 0) return 0;
@@ -50,51 +52,75 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
   }
   __syncthreads();
   int* cur = fa; int* nxt = fb;
+  // Each step of the walk is a dependent global load (~0.7 us).  BQ_UNROLL chunks of 8 frontier nodes are therefore
+  // fetched together: all box loads of the group are issued first (branch-free, clamped addresses), then the chunks are
+  // tested and compacted one by one in frontier order (the order of the survivors, and with it of the candidate list,
+  // is unchanged).
   for (int lv = top - 1; lv >= 0; lv--) {
     int ncount = 0;
     const int nl = D.lvl_n[lv];
-    for (int base = 0; base < count; base += 8) {
-      const int slot = base + (lane >> 3);
-      bool hit = false; int child = -1;
-      if (slot < count) {
-        child = cur[slot] * 8 + (lane & 7);
-        if (child < nl) hit = box_hit(D.boxes + (size_t)(D.lvl_off[lv] + child) * 6, q, m);
+    const double* lvl = D.boxes + (size_t)D.lvl_off[lv] * 6;
+    bool overflow = false;
+    for (int base = 0; base < count && !overflow; base += 8 * BQ_UNROLL) {
+      int child[BQ_UNROLL]; bool live[BQ_UNROLL]; double bx[BQ_UNROLL][6];
+#pragma unroll
+      for (int c = 0; c < BQ_UNROLL; c++) {
+        const int slot = base + 8 * c + (lane >> 3);
+        const int node = cur[min(slot, count - 1)];
+        child[c] = node * 8 + (lane & 7);
+        live[c] = slot < count && child[c] < nl;
+        const double* b = lvl + (size_t)min(child[c], nl - 1) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) bx[c][k] = b[k];
       }
-      const unsigned long long mask = ballot(hit);
-      const int tot = __popcll(mask);
-      if (ncount + tot > FRONT_CAP) { if (lane == 0) atomicOr(&D.ctl->error, ERR_FRONT_OVERFLOW); break; }
-      if (hit) nxt[ncount + prefix_count(mask)] = child;
-      ncount += tot;
-      nv += 8 * min(8, count - base);
+#pragma unroll
+      for (int c = 0; c < BQ_UNROLL; c++) {
+        if (base + 8 * c >= count) break;
+        bool hit = live[c];
+#pragma unroll
+        for (int k = 0; k < 3; k++) hit = hit & !((bx[c][3 + k] + m < q.lo[k]) | (bx[c][k] > q.hi[k] + m));
+        const unsigned long long mask = ballot(hit);
+        const int tot = __popcll(mask);
+        if (ncount + tot > FRONT_CAP) { if (lane == 0) atomicOr(&D.ctl->error, ERR_FRONT_OVERFLOW); overflow = true; break; }
+        if (hit) nxt[ncount + prefix_count(mask)] = child[c];
+        ncount += tot;
+        nv += 8 * min(8, count - (base + 8 * c));
+      }
     }
     __syncthreads();
     int* t = cur; cur = nxt; nxt = t;
     count = ncount;
   }
   int nc = 0, found = 0;
-  for (int base = 0; base < count; base += 8) {
-    const int slot = base + (lane >> 3);
-    bool hit = false; int pt = -1;
-    if (slot < count) {
-      pt = cur[slot] * 8 + (lane & 7);
-      if (pt < D.N) {
-        const double x = D.px[pt], y = D.py[pt], z = D.pz[pt];
-        hit = !(x + m < q.lo[0] || x > q.hi[0] + m) && !(y + m < q.lo[1] || y > q.hi[1] + m) && !(z + m < q.lo[2] || z > q.hi[2] + m);
-      }
+  for (int base = 0; base < count; base += 8 * BQ_UNROLL) {
+    int pts[BQ_UNROLL]; bool live[BQ_UNROLL]; double px[BQ_UNROLL], py[BQ_UNROLL], pz[BQ_UNROLL];
+#pragma unroll
+    for (int c = 0; c < BQ_UNROLL; c++) {  // leaf boxes -> points: again all loads of the group first
+      const int slot = base + 8 * c + (lane >> 3);
+      const int pt = cur[min(slot, count - 1)] * 8 + (lane & 7);
+      pts[c] = pt; live[c] = slot < count && pt < D.N;
+      const int pc = min(pt, D.N - 1);
+      px[c] = D.px[pc]; py[c] = D.py[pc]; pz[c] = D.pz[pc];
     }
-    const unsigned long long mask = ballot(hit);
-    if (hit) cand[nc + prefix_count(mask)] = pt;
-    nc += __popcll(mask);
-    found += __popcll(mask);
-    __syncthreads();
-    if (nc >= 64) {
-      process(cand[lane]);
-      const int left = nc - 64;
-      const int keep = lane < left ? cand[64 + lane] : 0;
+#pragma unroll
+    for (int c = 0; c < BQ_UNROLL; c++) {
+      if (base + 8 * c >= count) break;
+      const double x = px[c], y = py[c], z = pz[c];
+      const bool hit = live[c] & !((x + m < q.lo[0]) | (x > q.hi[0] + m)) & !((y + m < q.lo[1]) | (y > q.hi[1] + m)) & !((z + m < q.lo[2]) | (z > q.hi[2] + m));
+      const unsigned long long mask = ballot(hit);
+      if (hit) cand[nc + prefix_count(mask)] = pts[c];
+      nc += __popcll(mask);
+      found += __popcll(mask);
       __syncthreads();
-      if (lane < left) cand[lane] = keep;
-      nc = left;
-      __syncthreads();
+      if (nc >= 64) {
+        process(cand[lane]);
+        const int left = nc - 64;
+        const int keep = lane < left ? cand[64 + lane] : 0;
+        __syncthreads();
+        if (lane < left) cand[lane] = keep;
+        nc = left;
+        __syncthreads();
+      }
     }
   }
   if (nc > 0) process(lane < nc ? cand[lane] : -1);
@@ -280,7 +306,7 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   int* list = D.ocand + seg * D.cap_obs;
   int base = 0;
   unsigned long long visits = 0;
-  const int found = bvh_query(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
+  const int found = bvh_query<4>(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
     bool ok = false;
     if (pt >= 0) ok = kdop_point_pass(D, klo, khi, V3{D.px[pt], D.py[pt], D.pz[pt]}, dist);
     const unsigned long long mask = ballot(ok);

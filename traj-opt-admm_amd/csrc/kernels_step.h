@@ -85,7 +85,7 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
   const double off = D.offset;
   unsigned long long visits = 0;
   int kmax = 0;
-  const int found = bvh_query(D, q, off, fa, fb, cand, &visits, [&](int pt) {
+  const int found = bvh_query<1>(D, q, off, fa, fb, cand, &visits, [&](int pt) {
     if (pt >= 0) {
       const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
       if (kdop_point_pass(D, info + 48, info + 97, qp, off)) {
