@@ -69,9 +69,12 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid) {
     bool hit = false;
     if (p1 < U && (own0 || (p1 >= D.u0 && p1 < D.u1))) {  // at least one robot of the pair belongs to this rank
       const double* b = D.hbox + (size_t)tr * 6 * U + p1;   // component k of partner p1: b[k * U], coalesced over lanes
+      double bv[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) bv[k] = b[k * U];   // six independent loads, no branch between them
       hit = true;
 #pragma unroll
-      for (int k = 0; k < 3; k++) hit = hit && !(b[(3 + k) * U] + dist < A[18 + k] || b[k * U] > A[21 + k] + dist);
+      for (int k = 0; k < 3; k++) hit = hit & !((bv[3 + k] + dist < A[18 + k]) | (bv[k] > A[21 + k] + dist));
     }
     unsigned long long box = ballot(hit);
     // 2. per box survivor, wave-cooperative 49-axis interval test: lanes over AXES, two coalesced

@@ -126,8 +126,12 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
     if (p1 < U) {
       const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
       const double* bb = D.cbox + (size_t)tr * 6 * U + p1;   // swept pair box of partner p1, coalesced over lanes
+      double bv[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) bv[k] = bb[k * U];   // six independent loads, no branch between them
       bool hit = true;
-      for (int k = 0; k < 3; k++) hit = hit && !(a[45 + k] + off < bb[k * U] || a[42 + k] > bb[(3 + k) * U] + off);
+#pragma unroll
+      for (int k = 0; k < 3; k++) hit = hit & !((a[45 + k] + off < bv[k]) | (a[42 + k] > bv[3 + k] + off));
       if (hit) {
         bool pass = true;
         for (int k = 0; k < 49 && pass; k++) if (b[97 + k] < a[48 + k] - off || a[97 + k] < b[48 + k] - off) pass = false;
