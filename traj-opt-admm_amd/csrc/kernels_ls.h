@@ -184,10 +184,18 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
   for (int i = tid; i < 18 * P; i += nth) { sm[L.slack + i] = D.p_slack[(size_t)u * 3 * P6 + i]; sm[L.lambda + i] = D.p_lambda[(size_t)u * 3 * P6 + i]; }
   for (int i = tid; i < P; i += nth) { sm[L.tsl + i] = D.t_slack[u * P + i]; sm[L.tla + i] = D.t_lambda[u * P + i]; }
   for (int i = tid; i < 3 * T; i += nth) { net[i] = gspline[i]; dir[i] = D.dirp(u)[i]; }
-  if (tid == 0) {
-    int acc = 0;
-    for (int tr = 0; tr < S; tr++) { pref[tr] = acc; acc += D.ocount[u * S + tr] + (D.multi() ? D.scount[u * S + tr] : 0); }
-    pref[S] = acc;
+  if (tid < 64) {  // plane-count prefix over the segments: lanes load, wave scan (a one-thread loop was 2S dependent loads, ~4 us)
+    int run = 0;
+    for (int base = 0; base < S; base += 64) {
+      const int tr = base + tid;
+      const int c = tr < S ? D.ocount[u * S + tr] + (D.multi() ? D.scount[u * S + tr] : 0) : 0;
+      int x = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (tid >= off) x += y; }
+      if (tr < S) pref[tr] = run + x - c;
+      run += __shfl(x, 63);
+    }
+    if (tid == 0) pref[S] = run;
   }
   __syncthreads();
   TJ_TIC(D, K_LINESEARCH, 1);

@@ -429,11 +429,14 @@ __global__ void k_begin(Dev D) {
   // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
   __shared__ int done;
   if (threadIdx.x == 0) {
-    if (D.ctl->pending) { D.ctl->iter++; D.ctl->pending = 0; }  // count the previous iteration (saves a launch)
-    D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0;
-    if (!D.ctl->done && D.stop > 0 && D.ctl->iter > 1 && D.ctl->gnorm < D.stop) D.ctl->done = 1;
-    done = D.ctl->done;
-    if (!done) { D.ctl->pending = 1; D.ctl->epoch++; D.ctl->slack_next = 1; }
+    Ctl h = *D.ctl;  // ONE wide read of the control block instead of a chain of dependent field loads
+    if (h.pending) { h.iter++; h.pending = 0; }  // count the previous iteration (saves a launch)
+    h.slack_now = h.slack_next; h.slack_next = 0;
+    if (!h.done && D.stop > 0 && h.iter > 1 && h.gnorm < D.stop) h.done = 1;
+    done = h.done;
+    if (!done) { h.pending = 1; h.epoch++; h.slack_next = 1; }
+    D.ctl->iter = h.iter; D.ctl->pending = h.pending; D.ctl->slack_now = h.slack_now; D.ctl->slack_next = h.slack_next;
+    D.ctl->done = h.done; D.ctl->epoch = h.epoch;   // error bits and counters are only ever touched by atomics elsewhere
   }
   __syncthreads();
   if (done) return;
