@@ -31,6 +31,8 @@ struct Ctl {
   int epoch;           // bumped by every k_begin: stamp that marks this iteration's pair-plane slots as valid
   int slack_now;       // the slack/dual update of the PREVIOUS iteration is due (deferred so it overlaps the next planes)
   int slack_next;      // the iteration that k_begin just started still owes its slack/dual update
+  int any_pair;        // some robot pair is within `offset` at full step this iteration: the sequential CCD replay has work
+  int pad0;
 
   double gnorm;        // reference global `gnorm`
   // statistics for the algorithmic-byte model; accumulated over iterations

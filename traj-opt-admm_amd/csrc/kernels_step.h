@@ -153,7 +153,10 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
     }
     base += __popcll(mask);
   }
-  if (lane == 0) D.pair_count[tr * U + p0] = min(base, D.cap_row);
+  if (lane == 0) {
+    D.pair_count[tr * U + p0] = min(base, D.cap_row);
+    if (base > 0) atomicOr(&D.ctl->any_pair, 1);
+  }
 }
 
 __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
@@ -170,12 +173,12 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   int* cnt = seen + D.U;  // [S*U] survivor counts, staged once so the segment loop never waits on HBM
   TJ_TIC(D, K_CCD_SELF_SEQ, 0);
   for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
-  int mine = 0;
-  if (D.multi()) for (int i = lane; i < D.S * D.U; i += 64) { const int v = D.pair_count[i]; cnt[i] = v; mine |= v; }
-  const bool any_pair = ballot(mine != 0) != 0ull;  // usually no pair is within `offset` at full step: skip the segment walk
+  // usually no pair is within `offset` at full step (the selection kernel raises a flag otherwise): skip staging and walk
+  const bool any_pair = D.multi() && D.ctl->any_pair != 0;
+  if (any_pair) for (int i = lane; i < D.S * D.U; i += 64) cnt[i] = D.pair_count[i];
   __syncthreads();
   TJ_TIC(D, K_CCD_SELF_SEQ, 1);
-  if (D.multi() && any_pair) {
+  if (any_pair) {
     const bool shared = D.coupled();  // Step::couple_self_step (Step.h:112-182): one step for all robots, held in ks[0]
     const double off2 = D.offset * D.offset;
     int ambiguous = 0;
@@ -436,7 +439,7 @@ __global__ void k_begin(Dev D) {
     done = h.done;
     if (!done) { h.pending = 1; h.epoch++; h.slack_next = 1; }
     D.ctl->iter = h.iter; D.ctl->pending = h.pending; D.ctl->slack_now = h.slack_now; D.ctl->slack_next = h.slack_next;
-    D.ctl->done = h.done; D.ctl->epoch = h.epoch;   // error bits and counters are only ever touched by atomics elsewhere
+    D.ctl->done = h.done; D.ctl->epoch = h.epoch; D.ctl->any_pair = 0;   // error bits and counters are only ever touched by atomics elsewhere
   }
   __syncthreads();
   if (done) return;
