@@ -149,6 +149,38 @@ class Engine:
         g = self._f("stage_update_spline", C.c_double)(C.byref(w))
         return g, w.value
 
+    # ---- "optimal_plane":1 -----------------------------------------------------------
+    def set_optimal_plane(self, on=True):
+        """switch the persistent-plane branch on (empties the caches); call right after construction"""
+        self._f("set_optimal_plane")(C.c_int(int(on)))
+
+    def get_obs_cache(self, cap=4096):
+        """single-UAV path: per segment (ids ascending, planes (c, d))"""
+        out = []
+        f = self._f("get_obs_cache", C.c_int)
+        for tr in range(self.S):
+            ids = np.zeros(cap, dtype=np.int32); cd = np.zeros((cap, 4))
+            n = f(C.c_int(tr), C.c_int(cap), _i(ids), _d(cd))
+            assert n <= cap
+            out.append((ids[:n].copy(), cd[:n].copy()))
+        return out
+
+    def set_obs_cache(self, cache):
+        f = self._f("set_obs_cache")
+        for tr, (ids, cd) in enumerate(cache):
+            ids = np.ascontiguousarray(ids, dtype=np.int32); cd = np.ascontiguousarray(cd, dtype=np.float64)
+            f(C.c_int(tr), C.c_int(len(ids)), _i(ids), _d(cd))
+
+    def get_pair_cache(self):
+        """multi-UAV paths: flags [S][U][U] (p0 < p1), planes [S][U][U][4] = (c, d) before the offset/2 split"""
+        fl = np.zeros((self.S, self.U, self.U), dtype=np.int32); cd = np.zeros((self.S, self.U, self.U, 4))
+        self._f("get_pair_cache")(_i(fl), _d(cd))
+        return fl, cd
+
+    def set_pair_cache(self, flags, cd):
+        fl = np.ascontiguousarray(flags, dtype=np.int32); cd = np.ascontiguousarray(cd, dtype=np.float64)
+        self._f("set_pair_cache")(_i(fl), _d(cd))
+
     def spline_energy(self, u):
         return self._f("spline_energy", C.c_double)(C.c_int(u))
 
@@ -190,6 +222,23 @@ class Prims:
         cd = np.zeros(4)
         ok = self._f("plane_self")(_d(self._cm(P)), _d(self._cm(Q)), C.c_double(dist), C.c_int(int(refine)), _d(cd))
         return bool(ok), cd
+
+    def min_eig_small(self, H):
+        """eigenvalues()(0) of Eigen::SelfAdjointEigenSolver on a fixed-size 2x2 / 3x3 matrix"""
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        return self._f("kat_min_eig_small", C.c_double)(C.c_int(H.shape[0]), _d(H))
+
+    def optimal_cd(self, P, q, cd):
+        """Optimal_plane::optimal_cd on one (hull, obstacle point) plane -> refined (c, d)"""
+        out = np.ascontiguousarray(cd, dtype=np.float64).copy(); q = np.ascontiguousarray(q, dtype=np.float64)
+        self._f("kat_optimal_cd", None)(_d(self._cm(P)), _d(q), _d(out))
+        return out
+
+    def self_optimal_cd(self, P, Q, cd):
+        """Optimal_plane::self_optimal_cd on one (hull, hull) plane -> refined (c, d)"""
+        out = np.ascontiguousarray(cd, dtype=np.float64).copy()
+        self._f("kat_self_optimal_cd", None)(_d(self._cm(P)), _d(self._cm(Q)), _d(out))
+        return out
 
     def kdop_dcd(self, P, q, d):
         q = np.ascontiguousarray(q, dtype=np.float64)

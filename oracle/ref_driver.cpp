@@ -187,6 +187,43 @@ void ref_set_optimal_plane(int on) {
   }
 }
 
+// the persistent caches, in the same exchange format as the oracle's orc_{get,set}_{obs,pair}_cache
+int ref_get_obs_cache(int tr, int cap, int* ids, double* cd) {
+  int n = 0;
+  for (size_t ob = 0; ob < is_seperate[tr].size(); ob++)
+    if (is_seperate[tr][ob]) {
+      if (n < cap) { ids[n] = (int)ob; for (int a = 0; a < 3; a++) cd[4 * n + a] = seperate_c[tr][ob](a); cd[4 * n + 3] = seperate_d[tr][ob]; }
+      n++;
+    }
+  return n;
+}
+void ref_set_obs_cache(int tr, int n, const int* ids, const double* cd) {
+  is_seperate[tr].assign(is_seperate[tr].size(), false);
+  for (int i = 0; i < n; i++) {
+    is_seperate[tr][ids[i]] = true;
+    seperate_c[tr][ids[i]] = Eigen::Vector3d(cd[4 * i], cd[4 * i + 1], cd[4 * i + 2]);
+    seperate_d[tr][ids[i]] = cd[4 * i + 3];
+  }
+}
+void ref_get_pair_cache(int* flags, double* cd) {
+  const int S = piece_num * res, U = uav_num;
+  for (int tr = 0; tr < S; tr++) for (int a = 0; a < U; a++) for (int b = 0; b < U; b++) {
+    const size_t i = ((size_t)tr * U + a) * U + b;
+    flags[i] = is_self_seperate[tr][a][b] ? 1 : 0;
+    for (int k = 0; k < 3; k++) cd[4 * i + k] = flags[i] ? self_seperate_c[tr][a][b](k) : 0.0;
+    cd[4 * i + 3] = flags[i] ? self_seperate_d[tr][a][b] : 0.0;
+  }
+}
+void ref_set_pair_cache(const int* flags, const double* cd) {
+  const int S = piece_num * res, U = uav_num;
+  for (int tr = 0; tr < S; tr++) for (int a = 0; a < U; a++) for (int b = 0; b < U; b++) {
+    const size_t i = ((size_t)tr * U + a) * U + b;
+    is_self_seperate[tr][a][b] = flags[i] != 0;
+    self_seperate_c[tr][a][b] = Eigen::Vector3d(cd[4 * i], cd[4 * i + 1], cd[4 * i + 2]);
+    self_seperate_d[tr][a][b] = cd[4 * i + 3];
+  }
+}
+
 int ref_T() { return trajectory_num; }
 
 void ref_get_state(int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time) {
@@ -384,6 +421,23 @@ int ref_plane_self(const double* P6x3, const double* Q6x3, double dist, int refi
   bool ok = Separate::selfgjk(P, Q, dist, c, d);
   if (ok && refine) Optimal_plane::optimal_d(P, Q, c, d);
   cd[0] = c(0); cd[1] = c(1); cd[2] = c(2); cd[3] = d; return ok;
+}
+double ref_kat_min_eig_small(int n, const double* a) {
+  if (n == 2) { Eigen::Matrix2d m; m << a[0], a[1], a[2], a[3]; Eigen::SelfAdjointEigenSolver<Eigen::Matrix2d> es(m); Eigen::MatrixXd ev = es.eigenvalues(); return ev(0); }
+  Eigen::Matrix3d m; m << a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8];
+  Eigen::SelfAdjointEigenSolver<Eigen::Matrix3d> es(m); Eigen::MatrixXd ev = es.eigenvalues(); return ev(0);
+}
+void ref_kat_optimal_cd(const double* P6x3, const double* q, double* cd) {
+  Data P = Eigen::Map<const Data>(P6x3, 6, 3); Eigen::RowVector3d Q(q[0], q[1], q[2]);
+  Eigen::Vector3d c(cd[0], cd[1], cd[2]); double d = cd[3];
+  Optimal_plane::optimal_cd(P, Q, c, d);
+  cd[0] = c(0); cd[1] = c(1); cd[2] = c(2); cd[3] = d;
+}
+void ref_kat_self_optimal_cd(const double* P6x3, const double* Q6x3, double* cd) {
+  Data P = Eigen::Map<const Data>(P6x3, 6, 3); Data Q = Eigen::Map<const Data>(Q6x3, 6, 3);
+  Eigen::Vector3d c(cd[0], cd[1], cd[2]); double d = cd[3];
+  Optimal_plane::self_optimal_cd(P, Q, c, d);
+  cd[0] = c(0); cd[1] = c(1); cd[2] = c(2); cd[3] = d;
 }
 int ref_kdop_dcd(const double* P6x3, const double* q, double d) {
   Data P = Eigen::Map<const Data>(P6x3, 6, 3); Data Q(1, 3); Q << q[0], q[1], q[2];
