@@ -57,6 +57,9 @@ def kernel_bytes(st, slv, iters):
         "k_linesearch": U * (S * 36 * 8 + 2 * 3 * T * 8 + P * (36 + 2 * 18 + 2) * 8) + planes * 32 + U * 3 * T * 8,
         "k_slack": U * P * ((18 + 36) * 8 + 2 * 18 * 8 * 2 + 4 * 8),
     }
+    # "optimal_plane":1 -- stored planes refined in place: single UAV id + point + plane r/w + list entry and the hull once per
+    # segment; multi UAV two hulls + plane r/w + the two published half-offset planes + stamps + list entry per stored pair
+    b["k_keep"] = (per["planes_obs"] * (4 + 24 + 3 * 32) + U * S * 144 + per["cand_dcd"] * 8) if slv.mode == 0 else (per["planes_self"] / 2) * (2 * 144 + 2 * 32 + 64 + 8 + 4)
     # union kernels of the single-GPU graph: sums of their constituents
     b["k_front"] = b["k_obs_query"] + b["k_sep_self_rows"]
     b["k_mid"] = b["k_slack"] + b["k_sep_self_solve"] + b["k_obs_solve"]
@@ -72,13 +75,15 @@ def kernel_bytes(st, slv, iters):
     return b
 
 
-def cpu_baseline(scene, steps):
+def cpu_baseline(scene, steps, optimal_plane=False):
     """Reference CPU path on this box's host cores: the unmodified reference (oracle/_ref/libref.so,
     prebuilt in the dev container) if present, else this repo's CPU restatement.  Single thread --
     the reference has no threading (no `#pragma omp` anywhere in its first-party code)."""
     from oracle import pyoracle
     kind = "reference" if pyoracle.available("ref") else "port"
     eng = pyoracle.Engine("ref" if kind == "reference" else "port", scene)
+    if optimal_plane:
+        eng.set_optimal_plane(True)
     n = min(steps, 20)
     t0 = time.perf_counter()
     for _ in range(n):
@@ -96,6 +101,7 @@ def main():
     ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "E", "H8"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--coupled", action="store_true", help='time the coupled mode ("decouple":0, one shared piece_time) instead of the shipped decoupled mode; single GPU only')
+    ap.add_argument("--optimal-plane", action="store_true", help='time the "optimal_plane":1 variant (persistent planes refined every iteration); not the headline')
     ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
     ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: every rank uses device 0 and the all-gathers are staged through host memory over gloo "
                                                             "(RCCL refuses two ranks on one device); exercises the multi-process schedule on a 1-GPU box")
@@ -130,7 +136,7 @@ def main():
 
     if scene["U"] % world != 0:
         raise SystemExit("robot count must divide evenly over the ranks")
-    slv = pkg.Solver(scene, device=local, rank=rank, world=world, stop=0.0)  # stop test off: time exactly K iterations
+    slv = pkg.Solver(scene, device=local, rank=rank, world=world, stop=0.0, optimal_plane=int(args.optimal_plane))  # stop test off: time exactly K iterations
     K, W = args.steps, args.warmup
 
     if sharded:
@@ -203,7 +209,7 @@ def main():
                "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['cloud'].shape[0]} obstacle points, "
-                                      f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}",
+                                      f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
                           "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else "1 GPU, whole iteration resident on the device: a linear chain of 10 kernels on one queue (union kernels), enqueued ahead, no host sync",
                           "iters_timed_from": "initial trajectory"}}
     if world == 1:
@@ -232,7 +238,7 @@ def main():
                            "kernel_ms_per_launch": per_launch_ms}
         out["stats_per_iter"] = {k: (v / K if k not in ("error_bits", "order_ambiguous", "iters") else v) for k, v in st2.items()}
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(scene, K)
+            out["cpu_baseline"] = cpu_baseline(scene, K, args.optimal_plane)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

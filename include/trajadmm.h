@@ -58,6 +58,10 @@ typedef struct tj_params {
   int cap_obs;         /* max obstacle planes per (robot, segment); 0 = default 256 */
   int cap_self;        /* max inter-robot planes per (robot, segment); 0 = default min(uav_num - 1, 64) */
   int cap_pairs;       /* max inter-robot CCD candidate pairs per segment; 0 = default */
+  int optimal_plane;   /* "optimal_plane" (global is_optimal_plane): 1 = separating planes persist across iterations and are refined
+                          by Optimal_plane::optimal_cd (single UAV, obstacle planes: Optimization3D_admm.h:120-192) /
+                          self_optimal_cd (multi UAV, robot-pair planes: Optimization3D_multi.h:276-338) instead of being
+                          rebuilt by GJK every iteration */
 } tj_params;
 
 /* Fills *p with the shipped 3D.json values ("Config File/3D.json") and the mode's ks/kt. */
@@ -123,6 +127,17 @@ int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, d
 int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361);
 int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_armijo);
 
+/* ---- "optimal_plane":1 : the persistent plane tables (the reference globals is_seperate / seperate_c / seperate_d and
+ * is_self_seperate / self_seperate_c / self_seperate_d, CCDUtils.cpp:30-36), for teacher-forced tests and checkpoints ---- */
+/* single UAV: stored obstacle planes of (robot u, segment seg): ids = indices into the cloud given to tj_set_cloud,
+ * cd[.][4] = (c, d); returns the number stored (may exceed cap; only min(n, cap) are written) */
+int tj_get_obs_cache(tj_ctx* c, int u, int seg, int cap, int* ids, double* cd);
+int tj_set_obs_cache(tj_ctx* c, int u, int seg, int n, const int* ids, const double* cd);
+/* multi UAV: flags[S][U][U] (only p0 < p1 is used) and cd[S][U][U][4] = (c, d) of the plane between robots p0 and p1
+ * before it is split into (c, d - offset/2) and (-c, -d - offset/2) */
+int tj_get_pair_cache(tj_ctx* c, int* flags, double* cd);
+int tj_set_pair_cache(tj_ctx* c, const int* flags, const double* cd);
+
 /* counters since tj_init_state, for the algorithmic-byte model */
 typedef struct tj_stats {
   unsigned long long iters, nodes_dcd, nodes_ccd, cand_dcd, cand_ccd, planes_obs, planes_self, energy_evals, pair_tests;
@@ -142,7 +157,9 @@ int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const dou
 /* what: 0 Separate::opengjk (Separate.h:18) P[n][6][3], Q = points [n][3] -> out[n][5] = ok,cx,cy,cz,d
  *       1 Separate::selfgjk + Optimal_plane::optimal_d (Separate.h:165, Optimal_plane.h:13), Q[n][6][3] -> ok,c,d
  *       2 CCD::KDOPDCD (CCD.h:354), 3 CCD::SelfKDOPDCD (CCD.h:535) -> out[n][5], out[.][0] = pass
- *       4 = 1 computed by one wavefront per pair (plane_pair_wave, the form k_sep_self_solve uses) */
+ *       4 = 1 computed by one wavefront per pair (plane_pair_wave, the form k_sep_self_solve uses)
+ *       5 Optimal_plane::optimal_cd (Optimal_plane.h:160), Q = points; 6 Optimal_plane::self_optimal_cd (:620), Q = hulls:
+ *         out[n][5] is IN/OUT, out[.][1..4] = the plane (c, d) to refine, out[.][0] = finished within the iteration caps */
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out);
 /* CCD::GJKCCD / SelfGJKCCD (CCD.h:116,227) on swept hulls, tu[n][2] = (tMax, _tMax): out[n][2] booleans */
 int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double* Q, const double* E, const double* q, const double* tu, double d, double* out);

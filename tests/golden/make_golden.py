@@ -192,10 +192,94 @@ def make_e2e(name, scene, max_iter=200, stop=1e-2):
                         cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), **{"final_" + k: v for k, v in st.items()})
 
 
+def _flat_obs_cache(cache):
+    n = np.array([len(ids) for ids, _ in cache], dtype=np.int32)
+    ids = np.concatenate([ids for ids, _ in cache]) if n.sum() else np.zeros(0, dtype=np.int32)
+    cd = np.concatenate([cd for _, cd in cache], axis=0) if n.sum() else np.zeros((0, 4))
+    return n, ids.astype(np.int32), cd
+
+
+def make_optplane():
+    """`optimal_plane:1`: known answers of Optimal_plane::optimal_cd / self_optimal_cd, the persistent tables and the
+    plane lists of the reference's plane stage at kept iterations (teacher-forcing data), and converged runs."""
+    pr = Prims("ref")
+    rng = np.random.default_rng(20261003)
+    off, mar = pkg_scenes.DEFAULT_PARAMS["offset"], pkg_scenes.DEFAULT_PARAMS["margin"]
+    P_o, q_o, in_o, out_o, P_s, Q_s, in_s, out_s = [], [], [], [], [], [], [], []
+    while len(P_o) < 400:
+        ctr = rng.normal(size=3); P = ctr + 0.3 * rng.normal(size=(6, 3))
+        dirn = rng.normal(size=3); dirn /= np.linalg.norm(dirn)
+        q = ctr + dirn * (0.9 + rng.random() * 0.3)
+        ok, cd = pr.plane_obs(P, q, off + mar + 5.0)
+        out = pr.optimal_cd(P, q, cd) if ok else None
+        if ok and np.isfinite(out).all():   # hulls that reach within `offset` of the point make the reference's barrier NaN
+            P_o.append(P); q_o.append(q); in_o.append(cd); out_o.append(out)
+    while len(P_s) < 400:
+        ctr = rng.normal(size=3); P = ctr + 0.3 * rng.normal(size=(6, 3))
+        dirn = rng.normal(size=3); dirn /= np.linalg.norm(dirn)
+        Q = ctr + dirn * (1.2 + rng.random() * 0.3) + 0.3 * rng.normal(size=(6, 3))
+        ok, cd = pr.plane_self(P, Q, off + 2 * mar + 5.0, refine=False)
+        out = pr.self_optimal_cd(P, Q, cd) if ok else None
+        if ok and np.isfinite(out).all():
+            P_s.append(P); Q_s.append(Q); in_s.append(cd); out_s.append(out)
+    mats2 = [rng.normal(size=(2, 2)) * 10 ** rng.uniform(-3, 3) for _ in range(300)]
+    mats3 = [rng.normal(size=(3, 3)) * 10 ** rng.uniform(-3, 3) for _ in range(300)]
+    for i, m in enumerate(mats3):
+        if i % 3 == 1: m[1, 1] = 0; m[1, 2] = m[2, 1] = 0      # the structure self_barrier_grad produces
+        if i % 3 == 2: m[2, 0] = m[0, 2] = 0
+    mats2 = [m + m.T for m in mats2]; mats3 = [m + m.T for m in mats3]
+    np.savez_compressed(os.path.join(HERE, "optplane_kat.npz"), P_obs=np.array(P_o), q_obs=np.array(q_o), in_obs=np.array(in_o), out_obs=np.array(out_o),
+                        P_self=np.array(P_s), Q_self=np.array(Q_s), in_self=np.array(in_s), out_self=np.array(out_s),
+                        mats2=np.array(mats2), eig2=np.array([pr.min_eig_small(m) for m in mats2]),
+                        mats3=np.array(mats3), eig3=np.array([pr.min_eig_small(m) for m in mats3]))
+
+    for name, scene, iters, keep in (("tiny_single", pkg_scenes.tiny(0, n_points=3000), 12, {0, 1, 4, 8, 11}), ("tiny_multi", pkg_scenes.tiny(1), 10, {0, 1, 3, 6, 9}),
+                                     ("tiny_multi_coupled", coupled(pkg_scenes.tiny(1)), 8, {0, 1, 4, 7})):
+        e = Engine("ref", scene); e.set_optimal_plane(True)
+        rec = {"cloud_sum": np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()])}
+        for it in range(iters):
+            pre = e.get_state()
+            pre_cache = e.get_obs_cache() if scene["mode"] == 0 else e.get_pair_cache()
+            counts, planes = e.stage_planes()
+            post_cache = e.get_obs_cache() if scene["mode"] == 0 else e.get_pair_cache()
+            if scene["mode"] == 2:
+                e.stage_update_spline()
+            else:
+                e.stage_direction(); e.stage_steps(); e.stage_linesearch()
+            e.stage_slack()
+            e.iters += 1
+            if it in keep:
+                k = f"it{it}_"
+                for n_, v in pre.items(): rec[k + "pre_" + n_] = v
+                rec[k + "counts"] = counts; rec[k + "planes"] = canon(counts, planes)
+                for tag, cache in (("pre", pre_cache), ("post", post_cache)):
+                    if scene["mode"] == 0:
+                        n, ids, cd = _flat_obs_cache(cache)
+                        rec[k + tag + "_cache_n"] = n; rec[k + tag + "_cache_ids"] = ids; rec[k + tag + "_cache_cd"] = cd
+                    else:
+                        rec[k + tag + "_cache_on"] = cache[0]; rec[k + tag + "_cache_cd"] = cache[1]
+        rec["kept"] = np.array(sorted(keep))
+        np.savez_compressed(os.path.join(HERE, f"optplane_stages_{name}.npz"), **rec)
+
+    for name, scene in (("tiny_single", pkg_scenes.tiny(0, n_points=3000)), ("tiny_multi", pkg_scenes.tiny(1))):
+        e = Engine("ref", scene); e.set_optimal_plane(True)
+        gn = []
+        for it in range(200):
+            g = e.iterate(); gn.append(g)
+            if it > 1 and g < 1e-2:
+                break
+        st = e.get_state()
+        np.savez_compressed(os.path.join(HERE, f"optplane_e2e_{name}.npz"), gnorm_hist=np.array(gn), iters=np.array(len(gn)),
+                            cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), **{"final_" + k: v for k, v in st.items()})
+
+
 if __name__ == "__main__":
     if "--coupled-only" in sys.argv:
         make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
         make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
+        sys.exit(0)
+    if "--optplane-only" in sys.argv:
+        make_optplane()
         sys.exit(0)
     make_tables()
     make_prims()
@@ -206,4 +290,5 @@ if __name__ == "__main__":
     make_e2e("scn_b", pkg_scenes.scn_b())
     make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
     make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
+    make_optplane()
     print("golden vectors written to", HERE)

@@ -1,0 +1,169 @@
+"""GPU (-m gpu): `optimal_plane:1` on the HIP path (k_keep + dev_optplane.h) through the C ABI, against golden vectors
+of the unmodified reference and against the CPU oracle live.
+
+Tolerances.  The reference's refinement is a Newton iteration whose Hessian is repaired to a smallest eigenvalue of
+1e-8, with unbounded zig-zagging on some inputs: it amplifies the 1-ulp differences between glibc's and the device's
+log / sin / cos.  Known answers therefore agree to 1e-9 on the bulk of the cases and a small fraction may drift; the
+per-iteration (teacher-forced) plane lists agree to 1e-7; converged runs are compared at the sensitivity the reference
+shows against itself.  The eigenvalue kernel itself is bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import canon, check_scene_matches_fixture, gold, maxdiff, rel
+
+pytestmark = pytest.mark.gpu
+STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
+
+
+def _scene(scenes, name):
+    if name == "tiny_single":
+        return scenes.tiny(0, n_points=3000)
+    sc = dict(scenes.tiny(1))
+    if name.endswith("coupled"):
+        sc["mode"] = 2
+    return sc
+
+
+def _unflat(n, ids, cd):
+    out, w = [], 0
+    for k in n:
+        out.append((ids[w:w + k], cd[w:w + k])); w += k
+    return out
+
+
+@pytest.fixture(scope="module")
+def katsolver(pkg, scenes):
+    s = pkg.Solver(scenes.tiny(1), stop=0.0)
+    yield s
+    s.close()
+
+
+def test_device_plane_refinement_known_answers(katsolver):
+    g = gold("optplane_kat.npz")
+    fin, out = katsolver.kat_refine_planes(5, g["P_obs"], g["q_obs"], g["in_obs"])
+    err = np.max(np.abs(out - g["out_obs"]), axis=1)
+    assert fin.all()
+    assert np.mean(err <= 1e-9) >= 0.97 and np.median(err) <= 1e-13, (np.mean(err <= 1e-9), np.median(err), err.max())
+    fin, out = katsolver.kat_refine_planes(6, g["P_self"], g["Q_self"], g["in_self"])
+    err = np.max(np.abs(out - g["out_self"]), axis=1)
+    assert fin.all()
+    assert np.mean(err <= 1e-9) >= 0.93 and np.median(err) <= 1e-13, (np.mean(err <= 1e-9), np.median(err), err.max())
+    # whatever path a case took, the result is a stationary point of the same barrier energy: unit normal
+    assert np.max(np.abs(np.linalg.norm(out[:, :3], axis=1) - 1.0)) <= 1e-9
+
+
+@pytest.mark.parametrize("name", ["tiny_single", "tiny_multi", "tiny_multi_coupled"])
+def test_persistent_plane_stage_teacher_forced_vs_reference(pkg, scenes, name):
+    g = gold(f"optplane_stages_{name}.npz"); scene = _scene(scenes, name)
+    check_scene_matches_fixture(scene, g)
+    s = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    for it in g["kept"]:
+        k = f"it{it}_"
+        s.set_state({n: g[k + "pre_" + n] for n in STATE})
+        if scene["mode"] == 0:
+            s.set_obs_cache(_unflat(g[k + "pre_cache_n"], g[k + "pre_cache_ids"], g[k + "pre_cache_cd"]))
+        else:
+            s.set_pair_cache(g[k + "pre_cache_on"], g[k + "pre_cache_cd"])
+        counts, planes = s.stage_planes()
+        assert np.array_equal(counts, g[k + "counts"]), f"it{it}: plane counts differ"
+        assert maxdiff(canon(counts, planes), g[k + "planes"]) <= 1e-7, it
+        if scene["mode"] == 0:   # the same SET of remembered obstacles, the same planes
+            for (ids, cd), k_n in zip(s.get_obs_cache(), g[k + "post_cache_n"]):
+                assert len(ids) == k_n
+            got = {(tr, int(i)): c for tr, (ids, cd) in enumerate(s.get_obs_cache()) for i, c in zip(ids, cd)}
+            want = {(tr, int(i)): c for tr, (ids, cd) in enumerate(_unflat(g[k + "post_cache_n"], g[k + "post_cache_ids"], g[k + "post_cache_cd"])) for i, c in zip(ids, cd)}
+            assert got.keys() == want.keys()
+            assert max((np.max(np.abs(got[key] - want[key])) for key in got), default=0.0) <= 1e-7
+        else:
+            on, cd = s.get_pair_cache()
+            assert np.array_equal(on, g[k + "post_cache_on"])
+            assert maxdiff(cd, g[k + "post_cache_cd"]) <= 1e-7
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_single", "tiny_multi", "scn_b"])
+def test_persistent_planes_every_iteration_vs_oracle_live(pkg, scenes, name):
+    """whole iterations through tj_iterate, each started from the oracle's state and tables"""
+    from oracle.pyoracle import Engine
+    scene = scenes.scn_b() if name == "scn_b" else _scene(scenes, name)
+    o = Engine("port", scene); o.set_optimal_plane(True)
+    s = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    worst = 0.0
+    for it in range(10):
+        s.set_state(o.get_state())
+        if scene["mode"] == 0:
+            s.set_obs_cache(o.get_obs_cache())
+        else:
+            s.set_pair_cache(*o.get_pair_cache())
+        o.iterate(); s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        worst = max(worst, max(rel(a[n], b[n]) for n in STATE))
+    assert worst <= 1e-6, worst
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+@pytest.mark.parametrize("name,tol", [("tiny_single", 2e-5), ("tiny_multi", 1e-6)])
+def test_converged_run_with_persistent_planes_vs_reference(pkg, scenes, name, tol):
+    g = gold(f"optplane_e2e_{name}.npz"); scene = _scene(scenes, name)
+    check_scene_matches_fixture(scene, g)
+    s = pkg.Solver(scene, optimal_plane=1)
+    gn, it, conv = s.iterate(300)
+    assert conv and abs(it - int(g["iters"])) <= 1
+    assert rel(s.get_state()["spline"], g["final_spline"]) <= tol
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+def test_persistent_tables_round_trip_and_reset(pkg, scenes):
+    scene = scenes.tiny(1)
+    s = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    s.iterate(3)
+    on, cd = s.get_pair_cache()
+    assert on.sum() > 0 and not np.triu(on.transpose(0, 2, 1), 1).any()   # only p0 < p1 slots are ever switched on
+    st = s.get_state()
+    s.iterate(2); ref = s.get_state()
+    s.set_state(st); s.set_pair_cache(on, cd); s.iterate(2); again = s.get_state()
+    for n in STATE:
+        assert np.array_equal(ref[n], again[n]), n       # a restored checkpoint replays bit for bit
+    s.reset()
+    assert s.get_pair_cache()[0].sum() == 0
+    with pytest.raises(pkg.TrajAdmmError):
+        s.get_obs_cache()
+    s.close()
+
+
+def test_sharded_persistent_pair_planes_equal_unsharded(pkg, scenes):
+    """two contexts (ranks 0/2, 1/2) with the exchanges done by plain copies: each rank tracks the pairs that touch
+    its robots and must reproduce the single-context run bit for bit"""
+    import ctypes as C
+    scene = scenes.scn_b()
+    ref = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    r0 = pkg.Solver(scene, stop=0.0, rank=0, world=2, optimal_plane=1)
+    r1 = pkg.Solver(scene, stop=0.0, rank=1, world=2, optimal_plane=1)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def exchange(what):
+        p0, per, f0, n0 = r0.exchange_buffer(what)
+        p1, _, f1, n1 = r1.exchange_buffer(what)
+        r0.sync(); r1.sync()
+        assert hip.hipMemcpy(p0 + f1 * per * 8, p1 + f1 * per * 8, n1 * per * 8, 3) == 0
+        assert hip.hipMemcpy(p1 + f0 * per * 8, p0 + f0 * per * 8, n0 * per * 8, 3) == 0
+
+    for it in range(6):
+        ref.iterate(1)
+        for ph in (0, 1, 2):
+            r0.iterate_phase(ph); r1.iterate_phase(ph)
+            if ph < 2:
+                exchange(ph)
+        r0.sync(); r1.sync()
+    a = ref.get_state(); b0 = r0.get_state(); b1 = r1.get_state()
+    h = scene["U"] // 2
+    assert np.isfinite(a["spline"]).all() and ref.get_pair_cache()[0].sum() > 0
+    for n in STATE:
+        assert np.array_equal(a[n][:h], b0[n][:h]), n
+        assert np.array_equal(a[n][h:], b1[n][h:]), n
+    for x in (ref, r0, r1):
+        x.close()

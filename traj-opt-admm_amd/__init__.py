@@ -26,6 +26,7 @@ EXPORTS = [
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
     "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
     "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
+    "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache",
 ]
 
 STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
@@ -36,7 +37,7 @@ class TjParams(C.Structure):
                 ("lambda_", C.c_double), ("margin", C.c_double), ("offset", C.c_double), ("mu", C.c_double),
                 ("vel_limit", C.c_double), ("acc_limit", C.c_double), ("ks", C.c_double), ("kt", C.c_double),
                 ("stop", C.c_double), ("device", C.c_int), ("rank", C.c_int), ("world", C.c_int),
-                ("cap_obs", C.c_int), ("cap_self", C.c_int), ("cap_pairs", C.c_int)]
+                ("cap_obs", C.c_int), ("cap_self", C.c_int), ("cap_pairs", C.c_int), ("optimal_plane", C.c_int)]
 
 
 class TjStats(C.Structure):
@@ -276,6 +277,41 @@ class Solver:
         n = P.shape[0]; out = np.zeros((n, 5))
         self._check(self.lib.tj_kat_planes(self._ctx, C.c_int(what), C.c_int(n), _d(P), _d(Q), C.c_double(dist), _d(out)))
         return out
+
+    def kat_refine_planes(self, what, P, Q, cd):
+        """what 5: Optimal_plane::optimal_cd (Q = points), 6: self_optimal_cd (Q = hulls); cd[n][4] = planes to refine.
+        Returns (finished[n], refined cd[n][4])."""
+        P = np.ascontiguousarray(P, dtype=np.float64); Q = np.ascontiguousarray(Q, dtype=np.float64)
+        n = P.shape[0]; out = np.zeros((n, 5)); out[:, 1:] = cd
+        self._check(self.lib.tj_kat_planes(self._ctx, C.c_int(what), C.c_int(n), _d(P), _d(Q), C.c_double(0.0), _d(out)))
+        return out[:, 0] != 0, out[:, 1:].copy()
+
+    # ---- "optimal_plane":1 : the persistent plane tables ----
+    def get_obs_cache(self, u=0, cap=4096):
+        """single UAV: per segment (ids into the scene's cloud, planes (c, d)) in insertion order"""
+        out = []
+        for tr in range(self.S):
+            ids = np.zeros(cap, dtype=np.int32); cd = np.zeros((cap, 4))
+            n = self.lib.tj_get_obs_cache(self._ctx, C.c_int(u), C.c_int(tr), C.c_int(cap), _i(ids), _d(cd))
+            self._check(n)
+            assert n <= cap
+            out.append((ids[:n].copy(), cd[:n].copy()))
+        return out
+
+    def set_obs_cache(self, cache, u=0):
+        for tr, (ids, cd) in enumerate(cache):
+            ids = np.ascontiguousarray(ids, dtype=np.int32); cd = np.ascontiguousarray(cd, dtype=np.float64).reshape(-1, 4)
+            self._check(self.lib.tj_set_obs_cache(self._ctx, C.c_int(u), C.c_int(tr), C.c_int(len(ids)), _i(ids), _d(cd)))
+
+    def get_pair_cache(self):
+        """multi UAV: flags [S][U][U] (p0 < p1) and planes [S][U][U][4] = (c, d) before the offset/2 split"""
+        fl = np.zeros((self.S, self.U, self.U), dtype=np.int32); cd = np.zeros((self.S, self.U, self.U, 4))
+        self._check(self.lib.tj_get_pair_cache(self._ctx, _i(fl), _d(cd)))
+        return fl, cd
+
+    def set_pair_cache(self, flags, cd):
+        fl = np.ascontiguousarray(flags, dtype=np.int32); cd = np.ascontiguousarray(cd, dtype=np.float64)
+        self._check(self.lib.tj_set_pair_cache(self._ctx, _i(fl), _d(cd)))
 
     def kat_ccd(self, P, D, Q, E, q, tu, d):
         arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (P, D, Q, E, q, tu)]

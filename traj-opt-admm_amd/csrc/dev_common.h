@@ -44,7 +44,9 @@ struct Ctl {
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
 // Union kernels (K_FRONT, K_MID, K_CCD; kernels_step.h) replace their constituents in the single-GPU iteration graph.
-enum { K_BEGIN = 0, K_HULLINFO, K_FRONT, K_SEP_OBS /* k_obs_query */, K_SEP_SELF_ROWS, K_MID, K_OBS_SOLVE, K_SEP_SELF_SOLVE, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE,
+enum { K_BEGIN = 0, K_HULLINFO, K_FRONT, K_SEP_OBS /* k_obs_query */, K_SEP_SELF_ROWS, K_MID, K_OBS_SOLVE, K_SEP_SELF_SOLVE,
+       K_KEEP,                      // "optimal_plane":1 only: persistent planes, refined every iteration (kernels_keep.h)
+       K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE,
        K_XSOLVE_C2,                 // coupled mode only ("decouple":0)
        K_CCD_PREP, K_CCD, K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH,
        K_LS_COUPLED, K_LS_COMMIT,   // coupled mode only
@@ -69,6 +71,7 @@ struct Dev {
                // folding k_ccd_prep into k_xsolve the same way was measured slower: 10 dependent segments per wave)
   double lambda, margin, offset, mu, vel_limit, acc_limit, ks, kt, stop;
   int cap_obs, cap_self, cap_pairs;
+  int optimal_plane;  // "optimal_plane":1 (Optimization3D_admm.h:126-192 obstacle planes in mode 0, Optimization3D_multi.h:276-338 pair planes)
   // ---- tables (row-major 6x6) ----
   const double* basis;    // [S][36]
   const double* convert;  // [P][36]
@@ -102,6 +105,12 @@ struct Dev {
   double *hbox, *cbox;
   double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
+  // "optimal_plane":1 -- planes that persist across iterations (the reference's is_seperate / seperate_c / seperate_d and
+  // is_self_seperate / self_seperate_c / self_seperate_d tables, CCDUtils.cpp:30-36).  Obstacle planes (mode 0): a list per
+  // (robot, segment) in insertion order, keyed by the sorted point index.  Pair planes (modes 1, 2): dense [S][U][U] table,
+  // p0 < p1 only, plus the list of switched-on slots that k_keep strides over.
+  int *kobs_id, *kobs_n; double *kobs_cd;       // [U][S][cap_obs], [U][S], [U][S][cap_obs][4]
+  int *kpair_on, *kpair_list, *kpair_n; double *kpair_cd;  // [S][U][U], [S*U*U], [2] = {count, count at iteration start}, [S][U][U][4]
   double *lg, *lh;                // per-piece gradient [U][P][19] and Hessian [U][P][361] (after PSD repair)
   // search direction record per robot, robot-major so a rank's robots are one slice for the
   // all-gather: [U][xs], xs = 3T+4 : direction (T x 3 col-major), t_direction, wolfe, |g|, pad

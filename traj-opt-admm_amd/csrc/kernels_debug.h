@@ -7,6 +7,7 @@
 #include "dev_common.h"
 #include "dev_linalg.h"
 #include "kernels_sep.h"
+#include "dev_optplane.h"
 
 namespace tj {
 
@@ -70,8 +71,16 @@ __global__ __launch_bounds__(64) void k_dbg_planes(Dev D, int what, int n, const
       klo[k] = lo; khi[k] = up;
     }
     o[0] = kdop_point_pass(D, klo, khi, V3{Q[3 * i], Q[3 * i + 1], Q[3 * i + 2]}, dist);
-  } else {
+  } else if (what == 3) {
     o[0] = kdop_hulls_pass(D, p, Q + (size_t)i * 18, dist);
+  } else if (what == 5) {  // Optimal_plane::optimal_cd: o[1..4] = (c, d) in/out, o[0] = finished within the iteration caps
+    double cx = o[1], cy = o[2], cz = o[3], d = o[4];
+    o[0] = opt_plane_obstacle(p, Q[3 * i], Q[3 * i + 1], Q[3 * i + 2], D.margin, D.offset, cx, cy, cz, d);
+    o[1] = cx; o[2] = cy; o[3] = cz; o[4] = d;
+  } else {                 // Optimal_plane::self_optimal_cd
+    double cx = o[1], cy = o[2], cz = o[3], d = o[4];
+    o[0] = opt_plane_pair(p, Q + (size_t)i * 18, D.margin, D.offset, cx, cy, cz, d);
+    o[1] = cx; o[2] = cy; o[3] = cz; o[4] = d;
   }
 }
 

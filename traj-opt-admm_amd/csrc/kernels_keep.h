@@ -1,0 +1,111 @@
+// kernels_keep.h -- "optimal_plane":1 : the planes that persist across iterations.
+//
+// Reference: single UAV, separate_plane (Optimization3D_admm.h:120-192) -- the first plane Separate::opengjk finds for a
+// (segment, obstacle) is stored in is_seperate / seperate_c / seperate_d and from then on EVERY stored plane of the
+// segment is refined by Optimal_plane::optimal_cd each iteration and used, whether or not the obstacle is still a
+// candidate.  Multi UAV, separate_self (Optimization3D_multi.h:276-338) -- the same for (segment, robot pair) with
+// Separate::selfgjk and Optimal_plane::self_optimal_cd; the obstacle planes of the multi-UAV paths have no such branch.
+//
+//   mode 0     one wavefront per (robot, segment): stamped candidate slots of this iteration that are not yet in the
+//              segment's list are appended (slot order, deterministic), then one lane per stored plane refines it and
+//              writes the segment's plane list (the reference emits in ascending obstacle id; the order only matters
+//              at rounding level, like the candidate order of the non-persistent path).
+//   modes 1,2  lanes stride over the list of switched-on (segment, p0, p1) slots: refine, store, and publish the two
+//              half-offset planes in the dense partner table that k_sep_self_compact reads (ascending partner = the
+//              reference's p0 < p1 lexicographic emission order).
+// The dense S x N bool table of the reference becomes a per-segment list here (a few hundred entries at most).
+#pragma once
+#include "dev_common.h"
+#include "dev_optplane.h"
+#include "kernels_pairs.h"
+
+namespace tj {
+
+__global__ __launch_bounds__(64) void k_keep(Dev D) {
+  if (D.ctl->done) return;
+  const int lane = lane_id();
+  const int epoch = D.ctl->epoch;
+  if (!D.multi()) {
+    const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S;
+    const size_t seg = (size_t)u * D.S + tr, base = seg * D.cap_obs;
+    __shared__ double P[18];
+    if (lane < 18) P[lane] = D.ohull[seg * 18 + lane];
+    __syncthreads();
+    const int n = D.ocand_n[seg], nk0 = D.kobs_n[seg];
+    int nk = nk0;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+      const int sl = s0 + lane;
+      bool fresh = sl < n && D.ostamp[base + min(sl, n - 1)] == epoch;
+      const int pt = D.ocand[base + min(sl, n - 1)];
+      for (int i = 0; i < nk0; i++) fresh = fresh & (D.kobs_id[base + i] != pt);   // uniform (broadcast) loads
+      const unsigned long long mask = ballot(fresh);
+      const int idx = nk + prefix_count(mask);
+      if (fresh) {
+        if (idx < D.cap_obs) {
+          D.kobs_id[base + idx] = pt;
+          const double* p = D.oraw + (base + sl) * 4;
+          double* o = D.kobs_cd + (base + idx) * 4;
+          o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3];
+        } else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
+      }
+      nk += __popcll(mask);
+    }
+    nk = min(nk, D.cap_obs);
+    __syncthreads();   // entries appended by other lanes are read below
+    bool capped = false;
+    for (int i = lane; i < nk; i += 64) {
+      const int pt = D.kobs_id[base + i];
+      double* k = D.kobs_cd + (base + i) * 4;
+      double cx = k[0], cy = k[1], cz = k[2], d = k[3];
+      capped |= !opt_plane_obstacle(P, D.px[pt], D.py[pt], D.pz[pt], D.margin, D.offset, cx, cy, cz, d);
+      k[0] = cx; k[1] = cy; k[2] = cz; k[3] = d;
+      double* o = D.oplanes + (base + i) * 4;
+      o[0] = cx; o[1] = cy; o[2] = cz; o[3] = d;
+    }
+    if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+    if (lane == 0) { D.kobs_n[seg] = nk; D.ocount[seg] = nk; D.seg_stats[seg * 6 + 4] += (unsigned long long)nk; }
+    return;
+  }
+  // multi UAV.  kpair_n[0] = switched-on slots, kpair_n[1] = its value when this iteration began (k_begin): slots
+  // [0, kpair_n[1]) are refined by part 2; a slot switched on in part 1 is refined right there by the lane that found it.
+  const int U = D.U;
+  const double m = D.margin, off = D.offset, dist = D.offset + 2 * D.margin;
+  bool capped = false;
+  auto refine_publish = [&](size_t s0, int tr, int p0, int q, const double* A, const double* B, double cx, double cy, double cz, double d) {
+    capped |= !opt_plane_pair(A, B, m, off, cx, cy, cz, d);
+    double* k = D.kpair_cd + 4 * s0;
+    k[0] = cx; k[1] = cy; k[2] = cz; k[3] = d;
+    const size_t s1 = ((size_t)tr * U + q) * U + p0;
+    double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
+    q0[0] = cx; q0[1] = cy; q0[2] = cz; q0[3] = d - 0.5 * off;
+    q1[0] = -cx; q1[1] = -cy; q1[2] = -cz; q1[3] = -d - 0.5 * off;
+    D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+  };
+  // part 1 (Optimization3D_multi.h:276-290): pairs that passed box + k-DOP this iteration and have no plane yet
+  const int nwork = min(D.pair_work_n[0], D.cap_work);
+  for (int w = blockIdx.x * 64 + lane; w < nwork; w += gridDim.x * 64) {
+    const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+    const size_t s0 = ((size_t)tr * U + p0) * U + q;
+    if (D.kpair_on[s0]) continue;
+    const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
+    const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
+    double e0, e1c, e2c, dpl; bool cp;
+    if (!plane_pair(A, B, dist, m, off, false, e0, e1c, e2c, dpl, cp)) continue;
+    D.kpair_on[s0] = 1;
+    D.kpair_list[atomicAdd(D.kpair_n, 1)] = (int)s0;
+    refine_publish(s0, tr, p0, q, A, B, e0, e1c, e2c, dpl);
+  }
+  // part 2 (:310-338): every plane stored before this iteration
+  const int nold = D.kpair_n[1];
+  for (int w = blockIdx.x * 64 + lane; w < nold; w += gridDim.x * 64) {
+    const size_t s0 = (size_t)D.kpair_list[w];
+    const int tr = (int)(s0 / ((size_t)U * U)), p0 = (int)((s0 / U) % U), q = (int)(s0 % U);
+    const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
+    const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
+    const double* k = D.kpair_cd + 4 * s0;
+    refine_publish(s0, tr, p0, q, A, B, k[0], k[1], k[2], k[3]);
+  }
+  if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+}
+
+}  // namespace tj

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
   const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S, lane = lane_id();
   const int U = D.U, epoch = D.ctl->epoch;
   const size_t seg = (size_t)u * D.S + tr;
-  {
+  if (!(D.optimal_plane && !D.multi())) {  // single-UAV "optimal_plane":1 -- k_keep wrote the obstacle plane list itself
     const int n = D.ocand_n[seg];
     double* out = D.oplanes + seg * D.cap_obs * 4;
     int base = 0;

@@ -445,6 +445,7 @@ __global__ void k_begin(Dev D) {
   if (done) return;
   for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
   if (threadIdx.x == 0) { D.pair_work_n[0] = 0; D.pair_work_n[1] = 0; *D.obs_work_n = 0; }  // [1] = cursor of the pair-solve waves
+  if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
 }
 // only used by the stage API: commit the iteration counter explicitly
 // hand a still-owed slack/dual update to the next k_slack(deferred) launch without starting an iteration

@@ -20,6 +20,7 @@
 #include "host_tables.h"
 #include "kernels_sep.h"
 #include "kernels_pairs.h"
+#include "kernels_keep.h"
 #include "kernels_newton.h"
 #include "kernels_step.h"
 #include "kernels_debug.h"
@@ -47,6 +48,7 @@ struct tj_ctx {
   LsLayout lsl;
   // cloud-dependent allocations (rebuilt by tj_set_cloud)
   std::vector<void*> cloud_allocs;
+  std::vector<int> cloud_order;   // sorted position -> index in the caller's cloud (ids of tj_get/set_obs_cache)
 };
 
 namespace {
@@ -85,7 +87,7 @@ void drop_graph(tj_ctx* c) {
 }
 
 // ---- kernels of one iteration, in stream order (also the unit of tj_profile_kernels) ----
-const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "k_obs_query", "k_sep_self_rows", "k_mid", "k_obs_solve", "k_sep_self_solve", "k_sep_self_compact",
+const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "k_obs_query", "k_sep_self_rows", "k_mid", "k_obs_solve", "k_sep_self_solve", "k_keep", "k_sep_self_compact",
                                            "k_grad", "k_xsolve", "k_xsolve_c2", "k_ccd_prep", "k_ccd", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
                                            "k_linesearch", "k_ls_coupled", "k_ls_commit", "k_slack"};
 
@@ -100,7 +102,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   // Waves striding over the two device-built work lists.  k_mid holds ~1 wave per SIMD (VGPR bound), i.e. 1024 resident
   // waves: a larger grid adds no parallelism, only dispatch time for blocks that find no work (measured: with
   // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
-  const int n_solve = multi ? std::min(d.cap_work, 1024) : 0;
+  const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 512 : 0;
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
@@ -110,7 +112,10 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false; hipLaunchKernelGGL(k_obs_solve, dim3(n_obs_solve), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_ROWS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
     case K_MID: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); return true;
-    case K_SEP_SELF_SOLVE: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
+    case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
+    case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
+      if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
+      hipLaunchKernelGGL(k_keep, dim3(multi ? 256 : owned * d.S), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_COMPACT: hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
     case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
@@ -134,8 +139,8 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr, bool in_graph =
   if (!s) s = c->stream;
   switch (stage) {
     case TJ_STAGE_BEGIN: launch_kernel(c, K_BEGIN, s); break;
-    case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); launch_kernel(c, K_OBS_SOLVE, s); launch_kernel(c, K_SEP_SELF_COMPACT, s); break;
-    case TJ_STAGE_PLANES_SELF: launch_kernel(c, K_HULLINFO, s); launch_kernel(c, K_SEP_SELF_ROWS, s); launch_kernel(c, K_SEP_SELF_SOLVE, s); launch_kernel(c, K_SEP_SELF_COMPACT, s); break;
+    case TJ_STAGE_PLANES_OBS: launch_kernel(c, K_SEP_OBS, s); launch_kernel(c, K_OBS_SOLVE, s); if (c->d.mode == 0) launch_kernel(c, K_KEEP, s); launch_kernel(c, K_SEP_SELF_COMPACT, s); break;
+    case TJ_STAGE_PLANES_SELF: launch_kernel(c, K_HULLINFO, s); launch_kernel(c, K_SEP_SELF_ROWS, s); launch_kernel(c, K_SEP_SELF_SOLVE, s); launch_kernel(c, K_KEEP, s); launch_kernel(c, K_SEP_SELF_COMPACT, s); break;
     case TJ_STAGE_GRAD: launch_kernel(c, K_GRAD, s); break;
     case TJ_STAGE_XSOLVE: launch_kernel(c, K_XSOLVE, s); launch_kernel(c, K_XSOLVE_C2, s); break;
     case TJ_STAGE_CCD_PREP: launch_kernel(c, K_CCD_PREP, s); break;
@@ -193,10 +198,10 @@ int flush_deferred(tj_ctx* c) {
 int enqueue_body(tj_ctx* c, int which) {
   if (which == 3) return enqueue_iteration(c);
   hipStream_t m = c->stream;
-  static const int ph0[] = {K_BEGIN, K_SEP_OBS}, ph1[] = {K_HULLINFO, K_SEP_SELF_ROWS, K_MID, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_XSOLVE_C2},
+  static const int ph0[] = {K_BEGIN, K_SEP_OBS}, ph1[] = {K_HULLINFO, K_SEP_SELF_ROWS, K_MID, K_KEEP, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_XSOLVE_C2},
                    ph2[] = {K_CCD_PREP, K_CCD, K_CCD_SELF_SEQ, K_LINESEARCH, K_LS_COUPLED, K_LS_COMMIT};
   const int* list = which == 0 ? ph0 : (which == 1 ? ph1 : ph2);
-  const int n = which == 0 ? 2 : (which == 1 ? 7 : 6);
+  const int n = which == 0 ? 2 : (which == 1 ? 8 : 6);
   for (int i = 0; i < n; i++) launch_kernel(c, list[i], m, 0, false, true);
   HIPCHK(c, hipGetLastError());
   if (which == 2) c->maybe_deferred = true;  // this iteration's slack/dual update is owed to the next k_mid (or the flush)
@@ -328,6 +333,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_obs = p->cap_obs > 0 ? p->cap_obs : 256;
   d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, std::min(d.U - 1, 64));  // neighbours within offset + 2 margin of ONE segment; k_grad's LDS grows with it
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
+  d.optimal_plane = p->optimal_plane ? 1 : 0;
   d.cap_row = std::max(1, std::min(d.cap_pairs, d.U));  // partners per (segment, lower robot)
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
@@ -379,6 +385,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs))) return r;
+  if (d.optimal_plane) {
+    const bool m0 = d.mode == 0;
+    if ((r = dalloc(c, &d.kobs_id, m0 ? U * S * d.cap_obs : 1)) || (r = dalloc(c, &d.kobs_n, U * S)) || (r = dalloc(c, &d.kobs_cd, m0 ? U * S * d.cap_obs * 4 : 1)) ||
+        (r = dalloc(c, &d.kpair_on, m0 ? 1 : S * U * U)) || (r = dalloc(c, &d.kpair_list, m0 ? 1 : S * U * U)) || (r = dalloc(c, &d.kpair_n, 2)) ||
+        (r = dalloc(c, &d.kpair_cd, m0 ? 1 : S * U * U * 4))) return r;
+  }
   if (d.mode == TJ_MODE_MULTI_COUPLED &&
       ((r = dalloc(c, &d.xL, U * (size_t)n * n)) || (r = dalloc(c, &d.xy, U * (size_t)n)) || (r = dalloc(c, &d.xg, U * (size_t)n)) ||
        (r = dalloc(c, &d.xcorner, U * 4)) || (r = dalloc(c, &d.ls_e, (size_t)LSC_ROUNDS * U * LS_GROUPS)))) return r;
@@ -402,6 +414,7 @@ int tj_set_cloud(tj_ctx* c, const double* xyz, int n) {
   c->cloud_allocs.clear();
   Dev& d = c->d;
   d.N = n; d.nlevels = 0; d.px = d.py = d.pz = d.boxes = nullptr;
+  c->cloud_order.clear();
   if (n > 0) {
     HostBvh b;
     build_bvh(xyz, n, b);
@@ -414,6 +427,7 @@ int tj_set_cloud(tj_ctx* c, const double* xyz, int n) {
         (r = upload(c, boxes, b.boxes.data(), b.boxes.size() * 8))) return r;
     d.px = px; d.py = py; d.pz = pz; d.boxes = boxes;
     d.nlevels = (int)b.lvl_n.size();
+    c->cloud_order = b.order;
     for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = b.lvl_off[i]; d.lvl_n[i] = b.lvl_n[i]; }
   }
   c->have_cloud = true;
@@ -470,6 +484,11 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemset(d.ocount, 0, (size_t)U * d.S * 4));
   HIPCHK(c, hipMemset(d.scount, 0, (size_t)U * d.S * 4));
   HIPCHK(c, hipMemset(d.ocand_n, 0, (size_t)U * d.S * 4));
+  if (d.optimal_plane) {  // the mains start with empty persistent tables (Main/admmPathPlanning3D.cpp:343-351, Main/multiPathPlanning3D.cpp:450-464)
+    HIPCHK(c, hipMemset(d.kobs_n, 0, (size_t)U * d.S * 4));
+    HIPCHK(c, hipMemset(d.kpair_n, 0, 8));
+    if (d.mode != 0) HIPCHK(c, hipMemset(d.kpair_on, 0, (size_t)d.S * U * U * 4));
+  }
   HIPCHK(c, hipMemset(d.ostamp, 0, (size_t)U * d.S * d.cap_obs * 4));  // epochs restart at 1
   HIPCHK(c, hipMemset(d.seg_stats, 0, (size_t)U * d.S * 6 * 8));
   if (d.mode >= 1) HIPCHK(c, hipMemset(d.pairstamp, 0, (size_t)d.S * U * U * 4));  // epochs restart at 1
@@ -738,16 +757,82 @@ int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const dou
 }
 
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out) {
-  if (!c || n < 0 || what < 0 || what > 4 || !P || !Q || !out) return TJ_ERR_INVALID;
-  const size_t qbytes = (what == 0 || what == 2) ? (size_t)n * 24 : (size_t)n * 144;  // what 1, 3, 4: hull vs hull
+  if (!c || n < 0 || what < 0 || what > 6 || !P || !Q || !out) return TJ_ERR_INVALID;
+  const size_t qbytes = (what == 0 || what == 2 || what == 5) ? (size_t)n * 24 : (size_t)n * 144;  // what 1, 3, 4, 6: hull vs hull
   DevBuf dp, dq, dout; int r;
   if ((r = to_dev(c, dp, P, (size_t)n * 144)) || (r = to_dev(c, dq, Q, qbytes)) || (r = to_dev(c, dout, nullptr, (size_t)n * 40))) return r;
   HIPCHK(c, hipMemset(dout.p, 0, std::max<size_t>((size_t)n * 40, 8)));
+  if (what >= 5 && n > 0) HIPCHK(c, hipMemcpy(dout.p, out, (size_t)n * 40, hipMemcpyHostToDevice));  // in/out: the plane to refine
   if (what == 4) hipLaunchKernelGGL(k_dbg_pair_wave, dim3(std::max(n, 1)), dim3(64), 0, c->stream, c->d, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
   else hipLaunchKernelGGL(k_dbg_planes, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, what, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
   HIPCHK(c, hipGetLastError());
   QUIESCE(c);
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 40, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+// ---- "optimal_plane":1 : host access to the persistent plane tables (teacher-forced parity tests, checkpointing) ----
+int tj_get_obs_cache(tj_ctx* c, int u, int seg, int cap, int* ids, double* cd) {
+  if (!c || u < 0 || u >= c->d.U || seg < 0 || seg >= c->d.S || cap < 0) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  if (!d.optimal_plane || d.mode != 0) { c->err = "tj_get_obs_cache: needs optimal_plane and TJ_MODE_SINGLE"; return TJ_ERR_INVALID; }
+  QUIESCE(c);
+  const size_t s = (size_t)u * d.S + seg;
+  int n = 0;
+  HIPCHK(c, hipMemcpy(&n, d.kobs_n + s, 4, hipMemcpyDeviceToHost));
+  const int m = std::min(n, cap);
+  if (m > 0 && ids) {
+    std::vector<int> tmp(m);
+    HIPCHK(c, hipMemcpy(tmp.data(), d.kobs_id + s * d.cap_obs, (size_t)m * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; i++) ids[i] = c->cloud_order[tmp[i]];
+  }
+  if (m > 0 && cd) HIPCHK(c, hipMemcpy(cd, d.kobs_cd + s * d.cap_obs * 4, (size_t)m * 32, hipMemcpyDeviceToHost));
+  return n;
+}
+int tj_set_obs_cache(tj_ctx* c, int u, int seg, int n, const int* ids, const double* cd) {
+  if (!c || u < 0 || u >= c->d.U || seg < 0 || seg >= c->d.S || n < 0 || (n > 0 && (!ids || !cd))) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  if (!d.optimal_plane || d.mode != 0) { c->err = "tj_set_obs_cache: needs optimal_plane and TJ_MODE_SINGLE"; return TJ_ERR_INVALID; }
+  if (n > d.cap_obs) { c->err = "tj_set_obs_cache: more planes than cap_obs"; return TJ_ERR_CAPACITY; }
+  QUIESCE(c);
+  std::vector<int> inv(c->cloud_order.size());
+  for (size_t i = 0; i < inv.size(); i++) inv[c->cloud_order[i]] = (int)i;
+  std::vector<int> tmp(std::max(n, 1));
+  for (int i = 0; i < n; i++) {
+    if (ids[i] < 0 || ids[i] >= d.N) { c->err = "tj_set_obs_cache: obstacle id out of range"; return TJ_ERR_INVALID; }
+    tmp[i] = inv[ids[i]];
+  }
+  const size_t s = (size_t)u * d.S + seg;
+  int r;
+  if ((r = upload(c, d.kobs_id + s * d.cap_obs, tmp.data(), (size_t)n * 4)) || (r = upload(c, d.kobs_cd + s * d.cap_obs * 4, cd, (size_t)n * 32)) || (r = upload(c, d.kobs_n + s, &n, 4))) return r;
+  return TJ_OK;
+}
+int tj_get_pair_cache(tj_ctx* c, int* flags, double* cd) {
+  if (!c || !flags || !cd) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  if (!d.optimal_plane || d.mode == 0) { c->err = "tj_get_pair_cache: needs optimal_plane and a multi-UAV mode"; return TJ_ERR_INVALID; }
+  QUIESCE(c);
+  const size_t n = (size_t)d.S * d.U * d.U;
+  HIPCHK(c, hipMemcpy(flags, d.kpair_on, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(cd, d.kpair_cd, n * 32, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; i++) if (!flags[i]) cd[4 * i] = cd[4 * i + 1] = cd[4 * i + 2] = cd[4 * i + 3] = 0.0;
+  return TJ_OK;
+}
+int tj_set_pair_cache(tj_ctx* c, const int* flags, const double* cd) {
+  if (!c || !flags || !cd) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  if (!d.optimal_plane || d.mode == 0) { c->err = "tj_set_pair_cache: needs optimal_plane and a multi-UAV mode"; return TJ_ERR_INVALID; }
+  QUIESCE(c);
+  const size_t n = (size_t)d.S * d.U * d.U;
+  std::vector<int> on(n, 0), list;
+  for (int tr = 0; tr < d.S; tr++) for (int a = 0; a < d.U; a++) for (int b = a + 1; b < d.U; b++) {
+    const size_t i = ((size_t)tr * d.U + a) * d.U + b;
+    const bool mine = (a >= d.u0 && a < d.u1) || (b >= d.u0 && b < d.u1);   // a rank only tracks pairs that touch its robots
+    if (flags[i] && mine) { on[i] = 1; list.push_back((int)i); }
+  }
+  const int cnt = (int)list.size();
+  int r;
+  if ((r = upload(c, d.kpair_on, on.data(), n * 4)) || (r = upload(c, d.kpair_cd, cd, n * 32)) || (r = upload(c, d.kpair_list, list.data(), (size_t)cnt * 4)) || (r = upload(c, d.kpair_n, &cnt, 4))) return r;  // [1] is re-snapshot by the next k_begin
   return TJ_OK;
 }
 
