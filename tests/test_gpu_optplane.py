@@ -167,3 +167,24 @@ def test_sharded_persistent_pair_planes_equal_unsharded(pkg, scenes):
         assert np.array_equal(a[n][h:], b1[n][h:]), n
     for x in (ref, r0, r1):
         x.close()
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_cli_optimal_plane_1(pkg, scenes, tmp_path, multi):
+    """`"optimal_plane":1` in Config_File/3D.json selects the persistent-plane branch in both command-line tools"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scene = scenes.tiny(1) if multi else scenes.tiny(0, n_points=3000)
+    mesh = "x.obj"
+    scenes.write_reference_files(scene, str(tmp_path), mesh)
+    os.makedirs(tmp_path / "Config_File", exist_ok=True)
+    (tmp_path / "Config_File" / "3D.json").write_text(
+        '{"auto":0,"init":1,"gui":0,"optimal_plane":1,"decouple":1,"res":8,"vel_limit":2,"acc_limit":2,"lambda":1e1,'
+        '"epsilon":1e-1,"margin":1e-1,"offset":1e-1,"stop":1e-2,"exit":0,"init_ob":1,"mu":0.1}')
+    exe = os.path.join(root, "traj-opt-admm_amd", "multiPathPlanning3D" if multi else "admmPathPlanning3D")
+    r = subprocess.run([exe, mesh, "--max-iter", "300"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    iters = int(open(tmp_path / "result" / (mesh + ("_result_file_multi.txt" if multi else "_result_file_admm.txt"))).read().split()[1])
+    g = gold(f"optplane_e2e_{'tiny_multi' if multi else 'tiny_single'}.npz")
+    assert abs(iters - int(g["iters"])) <= 1      # the reference's own iteration count in this mode

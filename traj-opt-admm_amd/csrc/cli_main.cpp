@@ -3,8 +3,8 @@
 // (Main/admmPathPlanning3D.cpp:355-547, Main/multiPathPlanning3D.cpp:470-695) with the per-iteration
 // call replaced by the C ABI of libtrajadmm.so.  Same working-directory layout, same config keys,
 // same result file.  `decouple:0` selects the coupled multi-robot mode (one shared piece_time,
-// Main/multiPathPlanning3D.cpp:674-677).  GUI (`gui:1`), OMPL initialisation (`init:2`) and
-// `optimal_plane:1` are outside the accelerated path and are rejected with a message instead of
+// Main/multiPathPlanning3D.cpp:674-677), `optimal_plane:1` the persistent-plane branch.  GUI (`gui:1`) and OMPL
+// initialisation (`init:2`) are outside the accelerated path and are rejected with a message instead of
 // being silently ignored.  On convergence the trajectory duration and sampled arc length are printed
 // like the mains' log_data ("ccd time:", "ccd len:").
 //
@@ -45,7 +45,6 @@ int main(int argc, char** argv) {
     (void)if_exit;
     if (gui) throw std::runtime_error("gui:1 is not part of the accelerated path (use gui:0)");
     if (init != 1) throw std::runtime_error("only init:1 (init/<mesh>_init_file.txt) is supported; init:2 needs OMPL");
-    if (optimal_plane) throw std::runtime_error("optimal_plane:1 is not implemented on the device path yet");
 
     std::vector<double> V = tjcli::read_obj_vertices(std::string(kMulti ? "model/multiple/" : "model/single/") + mesh);
     int U = 1, P = 0; std::vector<double> wp;
@@ -60,6 +59,7 @@ int main(int argc, char** argv) {
 
     tj_params p;
     tj_default_params(&p, kMulti ? (decouple ? TJ_MODE_MULTI_DECOUPLE : TJ_MODE_MULTI_COUPLED) : TJ_MODE_SINGLE, U, P);
+    p.optimal_plane = optimal_plane ? 1 : 0;  // persistent planes refined by Optimal_plane::optimal_cd / self_optimal_cd
     p.res = res; p.lambda = lambda; p.margin = margin; p.offset = offset; p.mu = mu; p.vel_limit = vel; p.acc_limit = acc; p.stop = stop;
     auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + tj_last_error(ctx)); };
     chk(tj_create(&p, &ctx), "tj_create");
