@@ -188,3 +188,26 @@ def test_cli_optimal_plane_1(pkg, scenes, tmp_path, multi):
     iters = int(open(tmp_path / "result" / (mesh + ("_result_file_multi.txt" if multi else "_result_file_admm.txt"))).read().split()[1])
     g = gold(f"optplane_e2e_{'tiny_multi' if multi else 'tiny_single'}.npz")
     assert abs(iters - int(g["iters"])) <= 1      # the reference's own iteration count in this mode
+
+
+def test_full_size_scn_c_persistent_planes_vs_oracle(pkg, scenes):
+    """BASELINE config 4 size (64 UAVs, 100k points) with `optimal_plane:1`: whole iterations, each started from the
+    oracle's state and pair table; ~900 stored pair planes refined per iteration"""
+    from oracle.pyoracle import Engine
+    scene = scenes.scn_c()
+    o = Engine("port", scene); o.set_optimal_plane(True)
+    s = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    for _ in range(3):
+        o.iterate()
+    worst = 0.0
+    for it in range(4):
+        s.set_state(o.get_state()); s.set_pair_cache(*o.get_pair_cache())
+        o.iterate(); s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        worst = max(worst, max(rel(a[n], b[n]) for n in STATE))
+        on_d, cd_d = s.get_pair_cache(); on_o, cd_o = o.get_pair_cache()
+        assert np.array_equal(on_d, on_o), it          # the same pairs were switched on
+    assert on_o.sum() > 500
+    assert worst <= 1e-6, worst
+    assert s.stats()["error_bits"] == 0
+    s.close()
