@@ -166,6 +166,22 @@ int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double*
 /* dense LLT failure test + smallest eigenvalue (Eigen LLT / SelfAdjointEigenSolver as used at Gradient_admm.h:38-53): out[nmat][2] */
 int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out);
 
+/* ---- initial-trajectory planner (replaces ompl_init + simplify_path + edge_collision, Main/multiPathPlanning3D.cpp:123-340
+ * and HighOrderCCD/OMPL/OMPL.cpp; OMPL itself is not needed) -------------------------------------------------------------- */
+/* The reference's motion validator for a batch of straight edges (OMPL.cpp:36-98, multiPathPlanning3D.cpp:123-160):
+ * hit[i] = 1 if edge i = edges[i][2][3] comes within d of a cloud point (BVH::EdgeCollision + CCD::GJKDCD) or of one of
+ * the prior edges (GJKDCD edge-edge).  The mains use d = offset + margin/2. */
+int tj_edge_collision(tj_ctx* c, int n, const double* edges, int n_prior, const double* prior, double d, int* hit);
+/* Plans way points for n_robots one after the other (a later robot treats the earlier robots' paths as obstacles, like
+ * ompl_init): a deterministic roadmap -- start, goal and `nodes` Halton samples of bound_scale * bounding box of the cloud
+ * (0 = the mains' 1.2 single / 1.5 multi), all-pairs visibility evaluated on the device with tj_edge_collision, shortest
+ * path -- followed by the reference's simplify_path and its padding to a common way-point count (>= min_waypoints,
+ * 0 = 6).  The reference plans with OMPL's randomised RRTConnect, so paths are not comparable point by point; what is kept
+ * is the validity predicate, the post-processing and the output contract.  starts/goals are [n_robots][3]; waypoints is
+ * [n_robots][cap_waypoints][3], the first *n_waypoints rows of each robot are written.  Any context with the cloud set
+ * will do (tj_create with piece_num = 2 before the number of pieces is known). */
+int tj_plan_init(tj_ctx* c, int n_robots, const double* starts, const double* goals, double bound_scale, int nodes, int min_waypoints, int cap_waypoints, double* waypoints, int* n_waypoints);
+
 /* ---- robot sharding across GPUs (one context per rank) -------------------------------------- */
 /* Device pointers + element counts of the two buffers that must be all-gathered per iteration
  * (robot-major, so a rank's owned robots are one contiguous slice): what = 0 control points

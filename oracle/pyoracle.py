@@ -181,6 +181,15 @@ class Engine:
         fl = np.ascontiguousarray(flags, dtype=np.int32); cd = np.ascontiguousarray(cd, dtype=np.float64)
         self._f("set_pair_cache")(_i(fl), _d(cd))
 
+    def edge_collision(self, edges, prior=None, d=None):
+        """the planner's motion validator on a batch of straight edges [n][2][3] -> bool[n]"""
+        edges = np.ascontiguousarray(edges, dtype=np.float64).reshape(-1, 6)
+        prior = np.zeros((0, 6)) if prior is None else np.ascontiguousarray(prior, dtype=np.float64).reshape(-1, 6)
+        d = self.params["offset"] + 0.5 * self.params["margin"] if d is None else d
+        hit = np.zeros(len(edges), dtype=np.int32)
+        self._f("edge_collision")(C.c_int(len(edges)), _d(edges), C.c_int(len(prior)), _d(prior), C.c_double(d), _i(hit))
+        return hit.astype(bool)
+
     def spline_energy(self, u):
         return self._f("spline_energy", C.c_double)(C.c_int(u))
 

@@ -224,6 +224,28 @@ void ref_set_pair_cache(const int* flags, const double* cd) {
   }
 }
 
+// The motion validator of the reference's OMPL set-up (HighOrderCCD/OMPL/OMPL.cpp:36-98; the same test is edge_collision in
+// Main/multiPathPlanning3D.cpp:123-160, which cannot be linked here because that file includes the OMPL headers): the
+// reference's own BVH::EdgeCollision and CCD::GJKDCD in the same sequence.
+void ref_edge_collision(int n, const double* edges, int n_prior, const double* prior, double d, int* hit) {
+  for (int e = 0; e < n; e++) {
+    Eigen::MatrixXd edge(2, 3);
+    for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) edge(r, k) = edges[6 * (size_t)e + 3 * r + k];
+    bool h = false;
+    if (!g_vertex_list.empty()) {
+      std::vector<unsigned int> pairs;
+      g_bvh->EdgeCollision(edge, pairs, d);
+      for (unsigned int ob : pairs) { Eigen::RowVector3d p = g_vertex_list[ob]; if (CCD::GJKDCD(edge, p, d)) { h = true; break; } }
+    }
+    for (int j = 0; j < n_prior && !h; j++) {
+      Eigen::MatrixXd pe(2, 3);
+      for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) pe(r, k) = prior[6 * (size_t)j + 3 * r + k];
+      if (CCD::GJKDCD(edge, pe, d)) h = true;
+    }
+    hit[e] = h;
+  }
+}
+
 int ref_T() { return trajectory_num; }
 
 void ref_get_state(int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time) {

@@ -273,10 +273,29 @@ def make_optplane():
                             cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), **{"final_" + k: v for k, v in st.items()})
 
 
+def make_planner():
+    """The reference's motion validator (BVH::EdgeCollision + CCD::GJKDCD, the predicate OMPL calls) on seeded edges
+    against the SCN-B cloud and 20 prior edges: inputs + decisions."""
+    scene = pkg_scenes.scn_b()
+    e = Engine("ref", scene)
+    rng = np.random.default_rng(20261004)
+    n = 4000
+    a = rng.uniform(-12, 12, size=(n, 3)); a[:, 2] = rng.uniform(-1.5, 3.5, size=n)
+    b = a + rng.normal(size=(n, 3)) * rng.uniform(0.05, 4, size=(n, 1))
+    edges = np.concatenate([a, b], axis=1)
+    prior = np.concatenate([rng.uniform(-6, 6, size=(20, 3)), rng.uniform(-6, 6, size=(20, 3))], axis=1)
+    prior[:, 2] = prior[:, 5] = rng.uniform(0, 1.5, size=20)
+    np.savez_compressed(os.path.join(HERE, "planner_kat.npz"), cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]),
+                        edges=edges, prior=prior, hit_cloud=e.edge_collision(edges), hit_all=e.edge_collision(edges, prior))
+
+
 if __name__ == "__main__":
     if "--coupled-only" in sys.argv:
         make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
         make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
+        sys.exit(0)
+    if "--planner-only" in sys.argv:
+        make_planner()
         sys.exit(0)
     if "--optplane-only" in sys.argv:
         make_optplane()
@@ -291,4 +310,5 @@ if __name__ == "__main__":
     make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
     make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
     make_optplane()
+    make_planner()
     print("golden vectors written to", HERE)

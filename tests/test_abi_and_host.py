@@ -102,11 +102,11 @@ def test_cli_usage_and_config_errors(name, tmp_path):
     (tmp_path / "Config_File" / "3D.json").write_text('{"auto":0,"init":1,"gui":0}')
     r = subprocess.run([exe, "x.obj"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "missing key" in r.stderr             # all 16 keys are mandatory
-    shipped = '{"auto":0,"init":2,"gui":0,"optimal_plane":0,"decouple":1,"res":8,"vel_limit":2,"acc_limit":2,"lambda":1e1,' \
+    shipped = '{"auto":0,"init":1,"gui":1,"optimal_plane":0,"decouple":1,"res":8,"vel_limit":2,"acc_limit":2,"lambda":1e1,' \
               '"epsilon":1e-1,"margin":1e-1,"offset":1e-1,"stop":1e-2,"exit":0,"init_ob":1,"mu":0.1}'
     (tmp_path / "Config_File" / "3D.json").write_text(shipped)
     r = subprocess.run([exe, "x.obj"], cwd=tmp_path, capture_output=True, text=True)
-    assert r.returncode == 1 and "init:2" in r.stderr                  # unsupported branch (OMPL initialisation) is rejected, not ignored
+    assert r.returncode == 1 and "gui:1" in r.stderr                   # unsupported branch is rejected, not ignored
 
 
 @pytest.mark.parametrize("P", [2, 5])

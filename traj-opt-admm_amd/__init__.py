@@ -26,7 +26,7 @@ EXPORTS = [
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
     "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
     "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
-    "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache",
+    "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
 ]
 
 STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
@@ -312,6 +312,23 @@ class Solver:
     def set_pair_cache(self, flags, cd):
         fl = np.ascontiguousarray(flags, dtype=np.int32); cd = np.ascontiguousarray(cd, dtype=np.float64)
         self._check(self.lib.tj_set_pair_cache(self._ctx, _i(fl), _d(cd)))
+
+    # ---- initial-trajectory planner (replaces ompl_init / simplify_path / edge_collision) ----
+    def edge_collision(self, edges, prior=None, d=None):
+        """the reference's motion validator on a batch of straight edges [n][2][3] -> bool[n]"""
+        edges = np.ascontiguousarray(edges, dtype=np.float64).reshape(-1, 6)
+        prior = np.zeros((0, 6)) if prior is None else np.ascontiguousarray(prior, dtype=np.float64).reshape(-1, 6)
+        d = self.params["offset"] + 0.5 * self.params["margin"] if d is None else d
+        hit = np.zeros(max(len(edges), 1), dtype=np.int32)
+        self._check(self.lib.tj_edge_collision(self._ctx, C.c_int(len(edges)), _d(edges), C.c_int(len(prior)), _d(prior), C.c_double(d), _i(hit)))
+        return hit[:len(edges)].astype(bool)
+
+    def plan_init(self, starts, goals, nodes=0, min_waypoints=0, bound_scale=0.0, cap=256):
+        """way points [n_robots][n][3] from start/goal pairs (tj_plan_init); n is common to all robots"""
+        starts = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3); goals = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 3)
+        U = len(starts); wp = np.zeros((U, cap, 3)); n = C.c_int()
+        self._check(self.lib.tj_plan_init(self._ctx, C.c_int(U), _d(starts), _d(goals), C.c_double(bound_scale), C.c_int(nodes), C.c_int(min_waypoints), C.c_int(cap), _d(wp), C.byref(n)))
+        return wp[:, :n.value].copy()
 
     def kat_ccd(self, P, D, Q, E, q, tu, d):
         arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (P, D, Q, E, q, tu)]

@@ -90,6 +90,23 @@ inline void read_waypoints(const std::string& path, bool multi, int& U, int& P, 
   }
 }
 
+// "init":2 -- start/goal pairs of the planner.  The reference hard-codes them (single: Main/admmPathPlanning3D.cpp:222-228,
+// multi: four robots, Main/multiPathPlanning3D.cpp:251-267); init/<mesh>_start_goal.txt (ours: one "sx sy sz gx gy gz" line
+// per robot, solver units) overrides them.
+inline void read_start_goal(const std::string& path, bool multi, std::vector<double>& starts, std::vector<double>& goals) {
+  starts.clear(); goals.clear();
+  std::ifstream f(path);
+  if (f) {
+    double v[6];
+    while (f >> v[0] >> v[1] >> v[2] >> v[3] >> v[4] >> v[5]) { starts.insert(starts.end(), v, v + 3); goals.insert(goals.end(), v + 3, v + 6); if (!multi) break; }
+    if (starts.empty()) throw std::runtime_error(path + ": need six numbers per robot");
+    return;
+  }
+  if (!multi) { starts = {2.7, 0, 0}; goals = {-2.7, 0, 0}; return; }
+  starts = {2.5, 1.7, 0.5, 2.5, 1.7, -0.5, -2.5, 1.7, 0.5, -2.5, 1.7, -0.5};
+  goals = {-2.5, 1.7, 0.5, -2.5, 1.7, -0.5, 2.5, 1.7, -0.5, 2.5, 1.7, 0.5};
+}
+
 // log_data (Main/admmPathPlanning3D.cpp:33-77, Main/multiPathPlanning3D.cpp:33-77): duration of a trajectory and
 // the length of its polyline sampled every `dt` seconds of flight time (0.05 single, 0.1 multi), evaluated on the
 // per-piece Bezier control points C_i x_i exactly like getPosFromBezier (:17-31).  spline is T x 3 column-major,

@@ -2,10 +2,10 @@
 // (-DTJ_CLI_MULTI): the headless branches of the reference mains
 // (Main/admmPathPlanning3D.cpp:355-547, Main/multiPathPlanning3D.cpp:470-695) with the per-iteration
 // call replaced by the C ABI of libtrajadmm.so.  Same working-directory layout, same config keys,
-// same result file.  `decouple:0` selects the coupled multi-robot mode (one shared piece_time,
-// Main/multiPathPlanning3D.cpp:674-677), `optimal_plane:1` the persistent-plane branch.  GUI (`gui:1`) and OMPL
-// initialisation (`init:2`) are outside the accelerated path and are rejected with a message instead of
-// being silently ignored.  On convergence the trajectory duration and sampled arc length are printed
+// same result file.  `init:2` plans the way points with the library's device planner instead of OMPL,
+// `decouple:0` selects the coupled multi-robot mode (one shared piece_time, Main/multiPathPlanning3D.cpp:674-677),
+// `optimal_plane:1` the persistent-plane branch.  The GUI (`gui:1`) is outside the accelerated path and is rejected
+// with a message instead of being silently ignored.  On convergence the trajectory duration and sampled arc length are printed
 // like the mains' log_data ("ccd time:", "ccd len:").
 //
 // Extras (ours): --max-iter N, --dump-state FILE (control points; the reference never writes the
@@ -44,17 +44,39 @@ int main(int argc, char** argv) {
     const int decouple = (int)tjcli::need(j, "decouple");
     (void)if_exit;
     if (gui) throw std::runtime_error("gui:1 is not part of the accelerated path (use gui:0)");
-    if (init != 1) throw std::runtime_error("only init:1 (init/<mesh>_init_file.txt) is supported; init:2 needs OMPL");
+    if (init != 1 && init != 2) throw std::runtime_error("init must be 1 (init/<mesh>_init_file.txt) or 2 (plan way points from start/goal pairs)");
 
     std::vector<double> V = tjcli::read_obj_vertices(std::string(kMulti ? "model/multiple/" : "model/single/") + mesh);
     int U = 1, P = 0; std::vector<double> wp;
-    tjcli::read_waypoints("init/" + mesh + "_init_file.txt", kMulti, U, P, wp);
-    if (kMulti) {  // Main/multiPathPlanning3D.cpp:107,536
-      for (double& x : V) x *= 5;
-      for (double& x : wp) x *= 5;
-      std::cout << "uav_num: " << U << "\n";
-    }
+    if (kMulti) for (double& x : V) x *= 5;  // Main/multiPathPlanning3D.cpp:107
     const int N = init_ob ? (int)(V.size() / 3) : 0;
+    if (init == 1) {
+      tjcli::read_waypoints("init/" + mesh + "_init_file.txt", kMulti, U, P, wp);
+      if (kMulti) for (double& x : wp) x *= 5;  // :536
+    } else {
+      // "init":2 -- ompl_init (Main/multiPathPlanning3D.cpp:205-340, Main/admmPathPlanning3D.cpp:190-247) without OMPL: the
+      // device planner of the library, in solver units, writing init/<mesh>_init_file.txt like the reference does
+      std::vector<double> starts, goals;
+      tjcli::read_start_goal("init/" + mesh + "_start_goal.txt", kMulti, starts, goals);
+      U = (int)starts.size() / 3;
+      tj_params pp; tj_ctx* pc = nullptr;
+      tj_default_params(&pp, kMulti ? TJ_MODE_MULTI_DECOUPLE : TJ_MODE_SINGLE, U, 2);
+      pp.margin = margin; pp.offset = offset;
+      auto pchk = [&](int rc, const char* what) { if (rc < 0) { std::string m = std::string(what) + ": " + tj_last_error(pc); if (pc) tj_destroy(pc); throw std::runtime_error(m); } };
+      pchk(tj_create(&pp, &pc), "tj_create");
+      pchk(tj_set_cloud(pc, V.data(), N), "tj_set_cloud");
+      const int cap = 256; int nw = 0;
+      std::vector<double> buf((size_t)U * cap * 3);
+      pchk(tj_plan_init(pc, U, starts.data(), goals.data(), 0.0, 0, 0, cap, buf.data(), &nw), "tj_plan_init");
+      tj_destroy(pc);
+      P = nw - 1;
+      wp.assign((size_t)U * nw * 3, 0.0);
+      for (int u = 0; u < U; u++) for (int k = 0; k < nw * 3; k++) wp[(size_t)u * nw * 3 + k] = buf[(size_t)u * cap * 3 + k];
+      std::ofstream f("init/" + mesh + "_init_file.txt");   // one line per way point, all robots side by side (:324-333)
+      for (int k = 0; k < nw; k++) { for (int u = 0; u < U; u++) for (int a = 0; a < 3; a++) f << wp[((size_t)u * nw + k) * 3 + a] << " "; f << std::endl; }
+      std::cout << "ompl end\n";
+    }
+    if (kMulti) std::cout << "uav_num: " << U << "\n";
     std::cout << "time_obstacle build: " << N << " points" << std::endl;
 
     tj_params p;

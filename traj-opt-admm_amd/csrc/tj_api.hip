@@ -24,6 +24,7 @@
 #include "kernels_newton.h"
 #include "kernels_step.h"
 #include "kernels_debug.h"
+#include "kernels_plan.h"
 
 using namespace tj;
 
@@ -49,6 +50,7 @@ struct tj_ctx {
   // cloud-dependent allocations (rebuilt by tj_set_cloud)
   std::vector<void*> cloud_allocs;
   std::vector<int> cloud_order;   // sorted position -> index in the caller's cloud (ids of tj_get/set_obs_cache)
+  double cloud_lo[3] = {0, 0, 0}, cloud_hi[3] = {0, 0, 0};   // bounding box of the cloud (planner bounds, Main/multiPathPlanning3D.cpp:211-218)
 };
 
 namespace {
@@ -428,6 +430,8 @@ int tj_set_cloud(tj_ctx* c, const double* xyz, int n) {
     d.px = px; d.py = py; d.pz = pz; d.boxes = boxes;
     d.nlevels = (int)b.lvl_n.size();
     c->cloud_order = b.order;
+    for (int k = 0; k < 3; k++) { c->cloud_lo[k] = INFINITY; c->cloud_hi[k] = -INFINITY; }
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { c->cloud_lo[k] = std::min(c->cloud_lo[k], xyz[3 * i + k]); c->cloud_hi[k] = std::max(c->cloud_hi[k], xyz[3 * i + k]); }
     for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = b.lvl_off[i]; d.lvl_n[i] = b.lvl_n[i]; }
   }
   c->have_cloud = true;
@@ -833,6 +837,147 @@ int tj_set_pair_cache(tj_ctx* c, const int* flags, const double* cd) {
   const int cnt = (int)list.size();
   int r;
   if ((r = upload(c, d.kpair_on, on.data(), n * 4)) || (r = upload(c, d.kpair_cd, cd, n * 32)) || (r = upload(c, d.kpair_list, list.data(), (size_t)cnt * 4)) || (r = upload(c, d.kpair_n, &cnt, 4))) return r;  // [1] is re-snapshot by the next k_begin
+  return TJ_OK;
+}
+
+// ---- initial-trajectory planner --------------------------------------------------------------------------
+namespace {
+// edge_collision for a batch of edges: cut into pieces no longer than `piece_len`, one wavefront per piece
+int edges_hit(tj_ctx* c, int n, const double* edges, int n_prior, const double* prior, double d, double piece_len, std::vector<int>& hit) {
+  hit.assign(n, 0);
+  if (n == 0) return TJ_OK;
+  std::vector<double> pieces; std::vector<int> owner;
+  for (int e = 0; e < n; e++) {
+    const double* a = edges + 6 * (size_t)e; const double* b = a + 3;
+    const double len = std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+    const int k = piece_len > 0 ? std::max(1, (int)std::ceil(len / piece_len)) : 1;
+    for (int i = 0; i < k; i++) {
+      for (int t = 0; t < 2; t++) {
+        const double s = double(i + t) / k;
+        for (int x = 0; x < 3; x++) pieces.push_back(i + t == 0 ? a[x] : (i + t == k ? b[x] : a[x] + s * (b[x] - a[x])));
+      }
+      owner.push_back(e);
+    }
+  }
+  const int np = (int)owner.size();
+  DevBuf dp, dow, dpr, dh; int r;
+  if ((r = to_dev(c, dp, pieces.data(), pieces.size() * 8)) || (r = to_dev(c, dow, owner.data(), (size_t)np * 4)) || (r = to_dev(c, dpr, prior, (size_t)n_prior * 48)) ||
+      (r = to_dev(c, dh, hit.data(), (size_t)n * 4))) return r;
+  hipLaunchKernelGGL(k_edge_hit, dim3(np), dim3(64), 0, c->stream, c->d, np, (const double*)dp.p, (const int*)dow.p, n_prior, (const double*)dpr.p, d, (int*)dh.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(hit.data(), dh.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return check_device_errors(c);
+}
+double halton(unsigned i, unsigned base) { double f = 1, r = 0; while (i) { f /= base; r += f * (i % base); i /= base; } return r; }
+}  // namespace
+
+int tj_edge_collision(tj_ctx* c, int n, const double* edges, int n_prior, const double* prior, double d, int* hit) {
+  if (!c || n < 0 || n_prior < 0 || (n > 0 && (!edges || !hit)) || (n_prior > 0 && !prior)) return TJ_ERR_INVALID;
+  if (!c->have_cloud) { c->err = "tj_edge_collision: call tj_set_cloud first"; return TJ_ERR_INVALID; }
+  QUIESCE(c);
+  double ext = 0;
+  for (int k = 0; k < 3; k++) ext = std::max(ext, c->cloud_hi[k] - c->cloud_lo[k]);
+  std::vector<int> h;
+  int r = edges_hit(c, n, edges, n_prior, prior, d, c->d.N > 0 ? ext / 16 : 0.0, h);
+  if (r) return r;
+  for (int i = 0; i < n; i++) hit[i] = h[i];
+  return TJ_OK;
+}
+
+int tj_plan_init(tj_ctx* c, int n_robots, const double* starts, const double* goals, double bound_scale, int nodes, int min_waypoints, int cap_waypoints, double* waypoints, int* n_waypoints) {
+  if (!c || n_robots < 1 || !starts || !goals || !waypoints || !n_waypoints || cap_waypoints < 3) return TJ_ERR_INVALID;
+  if (!c->have_cloud) { c->err = "tj_plan_init: call tj_set_cloud first"; return TJ_ERR_INVALID; }
+  QUIESCE(c);
+  const double d = c->d.offset + 0.5 * c->d.margin;   // the planner's clearance (OMPL.cpp:74, multiPathPlanning3D.cpp:127)
+  if (bound_scale <= 0) bound_scale = c->d.mode == TJ_MODE_SINGLE ? 1.2 : 1.5;   // admmPathPlanning3D.cpp:203-204, multiPathPlanning3D.cpp:216-217
+  if (min_waypoints < 3) min_waypoints = 6;
+  int K0 = nodes > 0 ? nodes : 254;
+  double lo[3], hi[3], ext = 0;
+  for (int k = 0; k < 3; k++) {
+    lo[k] = bound_scale * c->cloud_lo[k]; hi[k] = bound_scale * c->cloud_hi[k];
+    if (c->d.N == 0) { lo[k] = -10; hi[k] = 10; }
+    for (int u = 0; u < n_robots; u++) { lo[k] = std::min(lo[k], std::min(starts[3 * u + k], goals[3 * u + k])); hi[k] = std::max(hi[k], std::max(starts[3 * u + k], goals[3 * u + k])); }
+    ext = std::max(ext, hi[k] - lo[k]);
+  }
+  const double piece_len = c->d.N > 0 ? ext / 16 : 0.0;
+  std::vector<double> prior;                 // edges of the robots planned so far [.][6]
+  std::vector<std::vector<double>> paths(n_robots);
+  std::vector<int> hit;
+  int r;
+  for (int u = 0; u < n_robots; u++) {
+    std::vector<double> path;
+    for (int K = K0;; K = 2 * K + 2) {
+      // roadmap nodes: start, goal, K Halton points of the bounds (deterministic; the reference samples with OMPL's RNG)
+      const int V = K + 2;
+      std::vector<double> P((size_t)V * 3);
+      for (int k = 0; k < 3; k++) { P[k] = starts[3 * u + k]; P[3 + k] = goals[3 * u + k]; }
+      for (int i = 0; i < K; i++) { const unsigned h = (unsigned)(i + 1 + 409 * u); P[3 * (i + 2)] = lo[0] + (hi[0] - lo[0]) * halton(h, 2); P[3 * (i + 2) + 1] = lo[1] + (hi[1] - lo[1]) * halton(h, 3); P[3 * (i + 2) + 2] = lo[2] + (hi[2] - lo[2]) * halton(h, 5); }
+      // all-pairs visibility with the reference's motion validator, one device batch
+      std::vector<double> E; std::vector<int> ea, eb;
+      E.reserve((size_t)V * (V - 1) * 3);
+      for (int a = 0; a < V; a++) for (int b = a + 1; b < V; b++) { for (int k = 0; k < 3; k++) E.push_back(P[3 * a + k]); for (int k = 0; k < 3; k++) E.push_back(P[3 * b + k]); ea.push_back(a); eb.push_back(b); }
+      if ((r = edges_hit(c, (int)ea.size(), E.data(), (int)(prior.size() / 6), prior.data(), d, piece_len, hit))) return r;
+      // Dijkstra by Euclidean length, node 0 -> node 1 (dense: V is a few hundred)
+      std::vector<double> W((size_t)V * V, INFINITY), dist(V, INFINITY);
+      for (size_t e = 0; e < ea.size(); e++) if (!hit[e]) {
+        const double* a = &P[3 * ea[e]]; const double* b = &P[3 * eb[e]];
+        const double w = std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+        W[(size_t)ea[e] * V + eb[e]] = W[(size_t)eb[e] * V + ea[e]] = w;
+      }
+      std::vector<int> prev(V, -1); std::vector<char> done(V, 0);
+      dist[0] = 0;
+      for (int it = 0; it < V; it++) {
+        int best = -1;
+        for (int v = 0; v < V; v++) if (!done[v] && dist[v] < INFINITY && (best < 0 || dist[v] < dist[best])) best = v;
+        if (best < 0 || best == 1) break;
+        done[best] = 1;
+        for (int v = 0; v < V; v++) if (!done[v] && dist[best] + W[(size_t)best * V + v] < dist[v]) { dist[v] = dist[best] + W[(size_t)best * V + v]; prev[v] = best; }
+      }
+      if (dist[1] < INFINITY) {
+        std::vector<int> idx;
+        for (int v = 1; v != -1; v = prev[v]) idx.push_back(v);
+        for (auto it = idx.rbegin(); it != idx.rend(); ++it) for (int k = 0; k < 3; k++) path.push_back(P[3 * *it + k]);
+        break;
+      }
+      if (K > 1100) { c->err = "tj_plan_init: no collision-free path for robot " + std::to_string(u) + " (start or goal inside the clearance of an obstacle?)"; return TJ_ERR_NO_PROGRESS; }
+    }
+    // simplify_path (Main/multiPathPlanning3D.cpp:162-203): greedy shortcutting with the same predicate, one edge at a time
+    {
+      const int n = (int)path.size() / 3;
+      std::vector<char> rm(n, 0);
+      int prev = 0, next = 2;
+      for (int i = 1; i < n - 1; i++) {
+        double e6[6];
+        for (int k = 0; k < 3; k++) { e6[k] = path[3 * prev + k]; e6[3 + k] = path[3 * next + k]; }
+        if ((r = edges_hit(c, 1, e6, (int)(prior.size() / 6), prior.data(), d, piece_len, hit))) return r;
+        if (hit[0]) { prev = i; next += 1; } else { next += 1; rm[i] = 1; }
+      }
+      std::vector<double> kept;
+      for (int i = 0; i < n; i++) if (!rm[i]) for (int k = 0; k < 3; k++) kept.push_back(path[3 * i + k]);
+      path.swap(kept);
+    }
+    for (size_t i = 0; i + 5 < path.size(); i += 3) for (int k = 0; k < 6; k++) prior.push_back(path[i + k]);   // this robot's edges are obstacles for the next
+    paths[u] = path;
+  }
+  // equal way-point counts (Main/multiPathPlanning3D.cpp:297-322): interpolated points inserted before the last way point
+  int max_size = min_waypoints;
+  for (auto& p : paths) max_size = std::max(max_size, (int)p.size() / 3);
+  if (max_size > cap_waypoints) { c->err = "tj_plan_init: path needs more way points than cap_waypoints"; return TJ_ERR_CAPACITY; }
+  for (int u = 0; u < n_robots; u++) {
+    std::vector<double>& p = paths[u];
+    const int size = (int)p.size() / 3, len = max_size - size;
+    if (len > 0) {
+      const double A[3] = {p[3 * (size - 2)], p[3 * (size - 2) + 1], p[3 * (size - 2) + 2]}, B[3] = {p[3 * (size - 1)], p[3 * (size - 1) + 1], p[3 * (size - 1) + 2]};
+      for (int j = 1; j <= len; j++) {
+        double pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = j / double(len + 1) * A[k] + (len + 1 - j) / double(len + 1) * B[k];
+        p.insert(p.begin() + 3 * (size - 1), pos, pos + 3);
+      }
+    }
+    for (int i = 0; i < max_size * 3; i++) waypoints[(size_t)u * cap_waypoints * 3 + i] = p[i];
+  }
+  *n_waypoints = max_size;
   return TJ_OK;
 }
 
