@@ -175,8 +175,9 @@ int tj_edge_collision(tj_ctx* c, int n, const double* edges, int n_prior, const 
 /* Plans way points for n_robots one after the other (a later robot treats the earlier robots' paths as obstacles, like
  * ompl_init): a deterministic roadmap -- start, goal and `nodes` Halton samples of bound_scale * bounding box of the cloud
  * (0 = the mains' 1.2 single / 1.5 multi), all-pairs visibility evaluated on the device with tj_edge_collision, shortest
- * path -- followed by the reference's simplify_path and its padding to a common way-point count (>= min_waypoints,
- * 0 = 6).  The reference plans with OMPL's randomised RRTConnect, so paths are not comparable point by point; what is kept
+ * path -- followed by the reference's simplify_path, a corner check (the hull of the solver's initial control net cuts every
+ * corner; a fan of chords across the cut is validated and the edges at a failing corner are halved) and padding to a common
+ * way-point count (>= min_waypoints, 0 = 6) by splitting the longest edges.  The reference plans with OMPL's randomised RRTConnect, so paths are not comparable point by point; what is kept
  * is the validity predicate, the post-processing and the output contract.  starts/goals are [n_robots][3]; waypoints is
  * [n_robots][cap_waypoints][3], the first *n_waypoints rows of each robot are written.  Any context with the cloud set
  * will do (tj_create with piece_num = 2 before the number of pieces is known). */

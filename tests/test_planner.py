@@ -68,8 +68,11 @@ def test_planner_output_contract_and_solver_converges(pkg, scenes):
         assert not o.edge_collision(edges, prior).any(), u
         prior = np.concatenate([prior, edges], axis=0)
     s.close()
-    # the planned way points are a usable initial trajectory: the solver converges from them
+    # the planned way points are a usable initial trajectory: feasible at the start (finite barrier energy) ...
     scene = dict(sc, U=U, P=wp.shape[1] - 1, waypoints=wp)
+    o = Engine("port", scene); o.stage_planes()
+    assert all(np.isfinite(o.spline_energy(u)) for u in range(U)), [o.spline_energy(u) for u in range(U)]
+    # ... and the solver converges from them
     slv = pkg.Solver(scene)
     gn, it, conv = slv.iterate(400)
     assert conv and np.isfinite(slv.get_state()["spline"]).all() and slv.stats()["error_bits"] == 0

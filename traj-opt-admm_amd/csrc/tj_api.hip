@@ -957,23 +957,60 @@ int tj_plan_init(tj_ctx* c, int n_robots, const double* starts, const double* go
       for (int i = 0; i < n; i++) if (!rm[i]) for (int k = 0; k < 3; k++) kept.push_back(path[3 * i + k]);
       path.swap(kept);
     }
+    // Corner rounding (ours).  The solver's initial control net puts control points at thirds of the polyline edges
+    // (init_variable, Main/multiPathPlanning3D.cpp:363-375), so the hull of a piece cuts each corner W by the triangle
+    // (W + (A-W)/3, W, W + (B-W)/3).  A fan of chords across that triangle is validated with the same predicate; where it
+    // fails the two edges at W are halved by collinear way points, which shrinks the triangle by 2 per round.
+    for (int round = 0; round < 6; round++) {
+      const int n = (int)path.size() / 3;
+      std::vector<double> fan; std::vector<int> corner;
+      for (int i = 1; i < n - 1; i++) {
+        const double* A = &path[3 * (i - 1)]; const double* W = &path[3 * i]; const double* B = &path[3 * (i + 1)];
+        double a[3], b[3], cr[3];
+        for (int k = 0; k < 3; k++) { a[k] = W[k] + (A[k] - W[k]) / 3; b[k] = W[k] + (B[k] - W[k]) / 3; }
+        cr[0] = (a[1] - W[1]) * (b[2] - W[2]) - (a[2] - W[2]) * (b[1] - W[1]); cr[1] = (a[2] - W[2]) * (b[0] - W[0]) - (a[0] - W[0]) * (b[2] - W[2]); cr[2] = (a[0] - W[0]) * (b[1] - W[1]) - (a[1] - W[1]) * (b[0] - W[0]);
+        if (cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2] < 1e-24) continue;   // straight through W: nothing is cut
+        for (int sdiv = 1; sdiv <= 4; sdiv++) {
+          for (int k = 0; k < 3; k++) fan.push_back(a[k]);
+          for (int k = 0; k < 3; k++) fan.push_back(W[k] + (b[k] - W[k]) * sdiv / 4.0);
+          corner.push_back(i);
+        }
+      }
+      if (corner.empty()) break;
+      if ((r = edges_hit(c, (int)corner.size(), fan.data(), (int)(prior.size() / 6), prior.data(), d, piece_len, hit))) return r;
+      std::vector<char> bad(n, 0);
+      bool any = false;
+      for (size_t e = 0; e < corner.size(); e++) if (hit[e]) { bad[corner[e]] = 1; any = true; }
+      if (!any) break;
+      std::vector<double> np_;
+      for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) np_.push_back(path[3 * i + k]);
+        if (i + 1 < n && (bad[i] || bad[i + 1])) for (int k = 0; k < 3; k++) np_.push_back(0.5 * (path[3 * i + k] + path[3 * (i + 1) + k]));
+      }
+      path.swap(np_);
+    }
     for (size_t i = 0; i + 5 < path.size(); i += 3) for (int k = 0; k < 6; k++) prior.push_back(path[i + k]);   // this robot's edges are obstacles for the next
     paths[u] = path;
   }
-  // equal way-point counts (Main/multiPathPlanning3D.cpp:297-322): interpolated points inserted before the last way point
+  // Equal way-point counts.  The reference pads a shorter path with interpolated points between its LAST two way points
+  // (Main/multiPathPlanning3D.cpp:297-322), which leaves a cluster of very short pieces that all get the same piece time;
+  // here the currently longest edge is split at its midpoint until the count is reached (collinear points: the polyline and
+  // its validity are unchanged, the pieces come out as even as the corners allow).
   int max_size = min_waypoints;
   for (auto& p : paths) max_size = std::max(max_size, (int)p.size() / 3);
   if (max_size > cap_waypoints) { c->err = "tj_plan_init: path needs more way points than cap_waypoints"; return TJ_ERR_CAPACITY; }
   for (int u = 0; u < n_robots; u++) {
     std::vector<double>& p = paths[u];
-    const int size = (int)p.size() / 3, len = max_size - size;
-    if (len > 0) {
-      const double A[3] = {p[3 * (size - 2)], p[3 * (size - 2) + 1], p[3 * (size - 2) + 2]}, B[3] = {p[3 * (size - 1)], p[3 * (size - 1) + 1], p[3 * (size - 1) + 2]};
-      for (int j = 1; j <= len; j++) {
-        double pos[3];
-        for (int k = 0; k < 3; k++) pos[k] = j / double(len + 1) * A[k] + (len + 1 - j) / double(len + 1) * B[k];
-        p.insert(p.begin() + 3 * (size - 1), pos, pos + 3);
+    while ((int)p.size() / 3 < max_size) {
+      const int n = (int)p.size() / 3;
+      int best = 0; double bl = -1;
+      for (int i = 0; i + 1 < n; i++) {
+        const double l = (p[3 * i] - p[3 * i + 3]) * (p[3 * i] - p[3 * i + 3]) + (p[3 * i + 1] - p[3 * i + 4]) * (p[3 * i + 1] - p[3 * i + 4]) + (p[3 * i + 2] - p[3 * i + 5]) * (p[3 * i + 2] - p[3 * i + 5]);
+        if (l > bl) { bl = l; best = i; }
       }
+      double mid[3];
+      for (int k = 0; k < 3; k++) mid[k] = 0.5 * (p[3 * best + k] + p[3 * best + 3 + k]);
+      p.insert(p.begin() + 3 * (best + 1), mid, mid + 3);
     }
     for (int i = 0; i < max_size * 3; i++) waypoints[(size_t)u * cap_waypoints * 3 + i] = p[i];
   }
