@@ -159,6 +159,7 @@ int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const dou
  *       2 CCD::KDOPDCD (CCD.h:354), 3 CCD::SelfKDOPDCD (CCD.h:535) -> out[n][5], out[.][0] = pass
  *       4 = 1 computed by one wavefront per pair (plane_pair_wave, the form k_sep_self_solve uses)
  *       5 Optimal_plane::optimal_cd (Optimal_plane.h:160), Q = points; 6 Optimal_plane::self_optimal_cd (:620), Q = hulls:
+ *         7 = 6 computed by one wavefront per plane (opt_plane_pair_wave, the form k_keep uses for short lists);
  *         out[n][5] is IN/OUT, out[.][1..4] = the plane (c, d) to refine, out[.][0] = finished within the iteration caps */
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out);
 /* CCD::GJKCCD / SelfGJKCCD (CCD.h:116,227) on swept hulls, tu[n][2] = (tMax, _tMax): out[n][2] booleans */

@@ -48,6 +48,9 @@ def test_device_plane_refinement_known_answers(katsolver):
     err = np.max(np.abs(out - g["out_self"]), axis=1)
     assert fin.all()
     assert np.mean(err <= 1e-9) >= 0.93 and np.median(err) <= 1e-13, (np.mean(err <= 1e-9), np.median(err), err.max())
+    # the wave-cooperative form k_keep uses for short lists: same bits as the per-lane form
+    fin_w, out_w = katsolver.kat_refine_planes(7, g["P_self"], g["Q_self"], g["in_self"])
+    assert np.array_equal(fin_w, fin) and np.array_equal(out_w, out)
     # whatever path a case took, the result is a stationary point of the same barrier energy: unit normal
     assert np.max(np.abs(np.linalg.norm(out[:, :3], axis=1) - 1.0)) <= 1e-9
 

@@ -186,88 +186,177 @@ __device__ inline bool opt_plane_obstacle(const double* P, double qx, double qy,
 }
 
 // ---- Optimal_plane::self_optimal_cd ---------------------------------------------------------------------------------
-// A: hull of the lower robot index, B: hull of the higher; (c, d) in/out (d before the -+offset/2 split).
+// Shared by the per-lane and the wave-cooperative form (identical arithmetic => identical results):
+// tangent frame of c (Optimal_plane.h:635-639)
+struct OpFrame { double c0x, c0y, c0z, c1x, c1y, c1z; };
+__device__ __forceinline__ OpFrame op_frame(double cx, double cy, double cz) {
+  OpFrame f;
+  f.c0x = cy; f.c0y = -cx; f.c0z = 0.0; op_normalize(f.c0x, f.c0y, f.c0z);
+  f.c1x = f.c0y * cz - f.c0z * cy; f.c1y = f.c0z * cx - f.c0x * cz; f.c1z = f.c0x * cy - f.c0y * cx; op_normalize(f.c1x, f.c1y, f.c1z);
+  return f;
+}
+// one barrier term of self_barrier_grad (:554-618) for point r of the first (second = false) or second body
+struct OpTerm { double g0, g2, h00, h10, h20, h22; };
+__device__ __forceinline__ OpTerm op_pair_term(const double* r, bool second, const OpFrame& f, double cx, double cy, double cz, double d, double m, double off) {
+  OpTerm t{0, 0, 0, 0, 0, 0};
+  const double sg = second ? -1.0 : 1.0;
+  const double dc = op_dot_row(r, cx, cy, cz);
+  const double dist = second ? -dc - d - 0.5 * off : dc + d - 0.5 * off;
+  if (dist < m) {
+    const double pc = sg * dc, pc0 = sg * op_dot_row(r, f.c0x, f.c0y, f.c0z), pc1 = sg * op_dot_row(r, f.c1x, f.c1y, f.c1z);
+    const double lg = log(dist / m);
+    const double e1 = -(2 * (dist - m) * lg + (dist - m) * (dist - m) / dist);
+    const double e2 = -(2 * lg + 4 * (dist - m) / dist - (dist - m) * (dist - m) / (dist * dist));
+    t.g0 = e1 * pc0; t.g2 = sg * e1;
+    t.h00 = e2 * pc0 * pc0 - e1 * pc; t.h10 = e1 * pc1; t.h20 = sg * e2 * pc0; t.h22 = e2;
+  }
+  return t;
+}
+// one term of self_barrier_energy (:518-552): returns false when the point is on the wrong side (energy = INFINITY)
+__device__ __forceinline__ bool op_pair_energy_term(const double* r, bool second, double tx, double ty, double tz, double td, double m, double off, double& e) {
+  const double dc = op_dot_row(r, tx, ty, tz);
+  const double dist = second ? -dc - td - 0.5 * off : dc + td - 0.5 * off;
+  e = 0;
+  if (dist <= 0) return false;
+  if (dist < m) e = -(dist - m) * (dist - m) * log(dist / m);
+  return true;
+}
+// LLT (always fails on this matrix: h11 == 0), eigenvalue repair, solve, clamp (:652-732): Newton direction and first step
+__device__ inline void op_pair_direction(double g0, double g1, double g2, double h00, double h10, double h20, double h11, double h21, double h22,
+                                         double& dir0, double& dir1, double& dir2, double& w, double& step) {
+  double l00 = h00, l10 = h10, l20 = h20, l11 = h11, l21 = h21, l22 = h22;
+  auto llt3 = [&]() {  // Eigen llt_inplace<Lower>::unblocked; on a pivot <= 0 the matrix stays as it is at that point
+    if (l00 <= 0) return false;
+    l00 = sqrt(l00); l10 /= l00; l20 /= l00;
+    double x = l11 - l10 * l10;
+    if (x <= 0) return false;
+    l11 = x = sqrt(x);
+    l21 -= l20 * l10; l21 /= x;
+    x = l22 - (l20 * l20 + l21 * l21);
+    if (x <= 0) return false;
+    l22 = sqrt(x);
+    return true;
+  };
+  if (!llt3()) {
+    const double ev = op_min_eig<3>(h00, h10, h11, h20, h21, h22);
+    if (ev < 0) {
+      h00 = h00 - ev * 1.0 + 1e-8 * 1.0; h11 = h11 - ev * 1.0 + 1e-8 * 1.0; h22 = h22 - ev * 1.0 + 1e-8 * 1.0;
+      h10 = h10 - ev * 0.0 + 1e-8 * 0.0; h20 = h20 - ev * 0.0 + 1e-8 * 0.0; h21 = h21 - ev * 0.0 + 1e-8 * 0.0;
+    }
+    l00 = h00; l10 = h10; l20 = h20; l11 = h11; l21 = h21; l22 = h22;
+    llt3();
+  }
+  double y0 = g0 / l00;
+  double y1 = (g1 - l10 * y0) / l11;
+  double y2 = (g2 - (l20 * y0 + l21 * y1)) / l22;
+  y2 = y2 / l22;
+  y1 = (y1 - l21 * y2) / l11;
+  y0 = (y0 - (l10 * y1 + l20 * y2)) / l00;
+  dir0 = -y0; dir1 = -y1; dir2 = -y2;
+  w = -op_sum3v(g0 * dir0, g1 * dir1, g2 * dir2);
+  step = 1.0;
+  if (fabs(dir0) > 0.5 * TJ_PI || fabs(dir1) > 0.5 * TJ_PI) { const double a = 0.5 * fabs(TJ_PI / dir0), b = 0.5 * fabs(TJ_PI / dir1); step = 0.95 * (b < a ? b : a); }
+}
+__device__ __forceinline__ void op_rotate(double ct, double st, double cp, double sp, double cx, double cy, double cz, const OpFrame& f, double& tx, double& ty, double& tz) {  // current_c (:74-80)
+  tx = ct * cx + st * (cp * f.c0x + sp * f.c1x); ty = ct * cy + st * (cp * f.c0y + sp * f.c1y); tz = ct * cz + st * (cp * f.c0z + sp * f.c1z);
+}
+
+// A: hull of the lower robot index, B: hull of the higher; (c, d) in/out (d before the -+offset/2 split).  One plane per lane.
 __device__ inline bool opt_plane_pair(const double* A, const double* B, double m, double off, double& cx, double& cy, double& cz, double& d, int* rounds = nullptr) {
   int guard = 0;
   bool ok = false;
   for (; guard < PLANE_NEWTON_CAP; guard++) {
-    double c0x = cy, c0y = -cx, c0z = 0.0; op_normalize(c0x, c0y, c0z);
-    double c1x = c0y * cz - c0z * cy, c1y = c0z * cx - c0x * cz, c1z = c0x * cy - c0y * cx; op_normalize(c1x, c1y, c1z);
+    const OpFrame f = op_frame(cx, cy, cz);
     double g0 = 0, g1 = 0, g2 = 0, h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0;
     for (int j = 0; j < 12; j++) {
       const bool second = j >= 6;
-      const double* r = second ? B + 3 * (j - 6) : A + 3 * j;
-      const double sg = second ? -1.0 : 1.0;
-      const double dc = op_dot_row(r, cx, cy, cz);
-      const double dist = second ? -dc - d - 0.5 * off : dc + d - 0.5 * off;
-      if (dist < m) {
-        const double pc = sg * dc, pc0 = sg * op_dot_row(r, c0x, c0y, c0z), pc1 = sg * op_dot_row(r, c1x, c1y, c1z);
-        const double lg = log(dist / m);
-        const double e1 = -(2 * (dist - m) * lg + (dist - m) * (dist - m) / dist);
-        const double e2 = -(2 * lg + 4 * (dist - m) / dist - (dist - m) * (dist - m) / (dist * dist));
-        g0 += e1 * pc0; g1 += 0; g2 += sg * e1;
-        h00 += e2 * pc0 * pc0 - e1 * pc; h10 += e1 * pc1; h20 += sg * e2 * pc0; h11 += 0; h21 += 0; h22 += e2;
-      }
+      const OpTerm t = op_pair_term(second ? B + 3 * (j - 6) : A + 3 * j, second, f, cx, cy, cz, d, m, off);
+      g0 += t.g0; g1 += 0; g2 += t.g2; h00 += t.h00; h10 += t.h10; h20 += t.h20; h11 += 0; h21 += 0; h22 += t.h22;
     }
     if (sqrt(op_sum3v(g0 * g0, g1 * g1, g2 * g2)) < 1e-2) { ok = true; break; }
-    double l00 = h00, l10 = h10, l20 = h20, l11 = h11, l21 = h21, l22 = h22;
-    auto llt3 = [&]() {  // Eigen llt_inplace<Lower>::unblocked; on a pivot <= 0 the matrix stays as it is at that point
-      if (l00 <= 0) return false;
-      l00 = sqrt(l00); l10 /= l00; l20 /= l00;
-      double x = l11 - l10 * l10;
-      if (x <= 0) return false;
-      l11 = x = sqrt(x);
-      l21 -= l20 * l10; l21 /= x;
-      x = l22 - (l20 * l20 + l21 * l21);
-      if (x <= 0) return false;
-      l22 = sqrt(x);
-      return true;
-    };
-    if (!llt3()) {
-      const double ev = op_min_eig<3>(h00, h10, h11, h20, h21, h22);
-      if (ev < 0) {
-        h00 = h00 - ev * 1.0 + 1e-8 * 1.0; h11 = h11 - ev * 1.0 + 1e-8 * 1.0; h22 = h22 - ev * 1.0 + 1e-8 * 1.0;
-        h10 = h10 - ev * 0.0 + 1e-8 * 0.0; h20 = h20 - ev * 0.0 + 1e-8 * 0.0; h21 = h21 - ev * 0.0 + 1e-8 * 0.0;
-      }
-      l00 = h00; l10 = h10; l20 = h20; l11 = h11; l21 = h21; l22 = h22;
-      llt3();
-    }
-    double y0 = g0 / l00;
-    double y1 = (g1 - l10 * y0) / l11;
-    double y2 = (g2 - (l20 * y0 + l21 * y1)) / l22;
-    y2 = y2 / l22;
-    y1 = (y1 - l21 * y2) / l11;
-    y0 = (y0 - (l10 * y1 + l20 * y2)) / l00;
-    const double dir0 = -y0, dir1 = -y1, dir2 = -y2;
-    const double w = -op_sum3v(g0 * dir0, g1 * dir1, g2 * dir2);
-    double step = 1.0;
-    if (fabs(dir0) > 0.5 * TJ_PI || fabs(dir1) > 0.5 * TJ_PI) { const double a = 0.5 * fabs(TJ_PI / dir0), b = 0.5 * fabs(TJ_PI / dir1); step = 0.95 * (b < a ? b : a); }
+    double dir0, dir1, dir2, w, step;
+    op_pair_direction(g0, g1, g2, h00, h10, h20, h11, h21, h22, dir0, dir1, dir2, w, step);
     double tx, ty, tz, td;
-    auto cur_c = [&](double th, double ph) {
-      const double ct = cos(th), st = sin(th), cp = cos(ph), sp = sin(ph);
-      tx = ct * cx + st * (cp * c0x + sp * c1x); ty = ct * cy + st * (cp * c0y + sp * c1y); tz = ct * cz + st * (cp * c0z + sp * c1z);
-    };
     auto energy = [&]() {
       double e = 0;
       for (int j = 0; j < 12; j++) {
         const bool second = j >= 6;
-        const double* r = second ? B + 3 * (j - 6) : A + 3 * j;
-        const double dc = op_dot_row(r, tx, ty, tz);
-        const double dist = second ? -dc - td - 0.5 * off : dc + td - 0.5 * off;
-        if (dist <= 0) return (double)INFINITY;
-        if (dist < m) e += -(dist - m) * (dist - m) * log(dist / m);
+        double t;
+        if (!op_pair_energy_term(second ? B + 3 * (j - 6) : A + 3 * j, second, tx, ty, tz, td, m, off, t)) return (double)INFINITY;
+        e += t;
       }
       return e;
     };
-    cur_c(0.0, 0.0); td = d;
+    op_rotate(cos(0.0), sin(0.0), cos(0.0), sin(0.0), cx, cy, cz, f, tx, ty, tz); td = d;
     const double e0 = energy();
-    cur_c(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
+    op_rotate(cos(0.0 + step * dir0), sin(0.0 + step * dir0), cos(0.0 + step * dir1), sin(0.0 + step * dir1), cx, cy, cz, f, tx, ty, tz); td = d + step * dir2;
     double e1v = energy();
     int bo = 0;
     bool stuck = false;
     while (e0 - 1e-4 * w * step < e1v) {
       if (++bo > LOOP_CAP) { stuck = true; break; }
-      step *= 0.8; cur_c(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2; e1v = energy();
+      step *= 0.8;
+      op_rotate(cos(0.0 + step * dir0), sin(0.0 + step * dir0), cos(0.0 + step * dir1), sin(0.0 + step * dir1), cx, cy, cz, f, tx, ty, tz); td = d + step * dir2;
+      e1v = energy();
+    }
+    if (stuck) break;
+    cx = tx; cy = ty; cz = tz; d = td;
+  }
+  if (rounds) *rounds = guard;
+  return ok;
+}
+
+// The same refinement computed by a whole wave for ONE plane (all 64 lanes call it with the same arguments): the 12 barrier
+// terms -- the logarithms and divisions, i.e. nearly all of the work -- sit on lanes 0..11 and are summed in the reference's
+// order (an inactive term adds +0.0, which is exact); the 3x3 algebra is uniform; sin and cos of the two angles are taken by
+// lanes 0 and 1 in one call each.  Same expressions as opt_plane_pair => identical results, ~1/4 of the dependent-instruction
+// chain per Newton round.
+__device__ inline bool opt_plane_pair_wave(const double* A, const double* B, double m, double off, int lane, double& cx, double& cy, double& cz, double& d, int* rounds = nullptr) {
+  const int j = lane < 12 ? lane : 0;
+  const bool second = j >= 6;
+  const double* rp = second ? B + 3 * (j - 6) : A + 3 * j;
+  const double r[3] = {rp[0], rp[1], rp[2]};
+  int guard = 0;
+  bool ok = false;
+  for (; guard < PLANE_NEWTON_CAP; guard++) {
+    const OpFrame f = op_frame(cx, cy, cz);
+    OpTerm t = op_pair_term(r, second, f, cx, cy, cz, d, m, off);
+    if (lane >= 12) t = OpTerm{0, 0, 0, 0, 0, 0};
+    double g0 = 0, g1 = 0, g2 = 0, h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0;
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+      g0 += gjk_rl(t.g0, q); g1 += 0; g2 += gjk_rl(t.g2, q); h00 += gjk_rl(t.h00, q); h10 += gjk_rl(t.h10, q); h20 += gjk_rl(t.h20, q); h11 += 0; h21 += 0; h22 += gjk_rl(t.h22, q);
+    }
+    if (sqrt(op_sum3v(g0 * g0, g1 * g1, g2 * g2)) < 1e-2) { ok = true; break; }
+    double dir0, dir1, dir2, w, step;
+    op_pair_direction(g0, g1, g2, h00, h10, h20, h11, h21, h22, dir0, dir1, dir2, w, step);
+    double tx, ty, tz, td;
+    auto rotate = [&](double th, double ph) {
+      const double x = lane == 1 ? ph : th;
+      const double cv = cos(x), sv = sin(x);
+      op_rotate(gjk_rl(cv, 0), gjk_rl(sv, 0), gjk_rl(cv, 1), gjk_rl(sv, 1), cx, cy, cz, f, tx, ty, tz);
+    };
+    auto energy = [&]() {
+      double te;
+      const bool fine = op_pair_energy_term(r, second, tx, ty, tz, td, m, off, te) || lane >= 12;
+      if (__ballot(!fine) != 0ull) return (double)INFINITY;
+      if (lane >= 12) te = 0;
+      double e = 0;
+#pragma unroll
+      for (int q = 0; q < 12; q++) e += gjk_rl(te, q);
+      return e;
+    };
+    rotate(0.0, 0.0); td = d;
+    const double e0 = energy();
+    rotate(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
+    double e1v = energy();
+    int bo = 0;
+    bool stuck = false;
+    while (e0 - 1e-4 * w * step < e1v) {
+      if (++bo > LOOP_CAP) { stuck = true; break; }
+      step *= 0.8;
+      rotate(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
+      e1v = energy();
     }
     if (stuck) break;
     cx = tx; cy = ty; cz = tz; d = td;

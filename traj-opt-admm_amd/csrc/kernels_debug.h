@@ -84,6 +84,16 @@ __global__ __launch_bounds__(64) void k_dbg_planes(Dev D, int what, int n, const
   }
 }
 
+// Optimal_plane::self_optimal_cd by one wavefront per plane (opt_plane_pair_wave, the form k_keep uses for short lists)
+__global__ __launch_bounds__(64) void k_dbg_optpair_wave(Dev D, int n, const double* P, const double* Q, double* out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  double* o = out + (size_t)i * 5;
+  double cx = o[1], cy = o[2], cz = o[3], d = o[4];
+  const bool ok = opt_plane_pair_wave(P + (size_t)i * 18, Q + (size_t)i * 18, D.margin, D.offset, lane_id(), cx, cy, cz, d);
+  if (lane_id() == 0) { o[0] = ok; o[1] = cx; o[2] = cy; o[3] = cz; o[4] = d; }
+}
+
 // swept-hull CCD predicates at steps (t1,u1): out[0] = GJKCCD(P,D,q), out[1] = SelfGJKCCD(P,D,Q,E)
 __global__ __launch_bounds__(64) void k_dbg_ccd(int n, const double* P, const double* Dd, const double* Q, const double* E, const double* q, const double* tu, double d, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

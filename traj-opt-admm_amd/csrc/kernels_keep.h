@@ -71,8 +71,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
   const int U = D.U;
   const double m = D.margin, off = D.offset, dist = D.offset + 2 * D.margin;
   bool capped = false;
-  auto refine_publish = [&](size_t s0, int tr, int p0, int q, const double* A, const double* B, double cx, double cy, double cz, double d) {
-    capped |= !opt_plane_pair(A, B, m, off, cx, cy, cz, d);
+  auto publish = [&](size_t s0, int tr, int p0, int q, double cx, double cy, double cz, double d) {
     double* k = D.kpair_cd + 4 * s0;
     k[0] = cx; k[1] = cy; k[2] = cz; k[3] = d;
     const size_t s1 = ((size_t)tr * U + q) * U + p0;
@@ -81,29 +80,60 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     q1[0] = -cx; q1[1] = -cy; q1[2] = -cz; q1[3] = -d - 0.5 * off;
     D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
   };
+  const int nwork = min(D.pair_work_n[0], D.cap_work), nold = D.kpair_n[1];
+  // Few planes (up to a handful per wave of the grid): one WAVE per plane -- the 12 barrier terms of a Newton round on 12
+  // lanes (opt_plane_pair_wave), a quarter of the dependent chain; the kernel is as long as its slowest plane.  Many planes
+  // (hundreds of robots): one plane per LANE, the same arithmetic bit for bit, for throughput.  The switch is grid-uniform.
+  if (nwork + nold <= 4 * (int)gridDim.x) {
+    for (int w = blockIdx.x; w < nwork; w += gridDim.x) {    // part 1 (Optimization3D_multi.h:276-290)
+      const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+      const size_t s0 = ((size_t)tr * U + p0) * U + q;
+      if (D.kpair_on[s0]) continue;
+      const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
+      const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
+      double cx, cy, cz, d; bool cp;
+      if (!plane_pair(A, B, dist, m, off, false, cx, cy, cz, d, cp)) continue;   // every lane, same arguments: uniform
+      if (lane == 0) { D.kpair_on[s0] = 1; D.kpair_list[atomicAdd(D.kpair_n, 1)] = (int)s0; }
+      capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d);
+      if (lane == 0) publish(s0, tr, p0, q, cx, cy, cz, d);
+    }
+    for (int w = blockIdx.x; w < nold; w += gridDim.x) {     // part 2 (:310-338)
+      const size_t s0 = (size_t)D.kpair_list[w];
+      const int tr = (int)(s0 / ((size_t)U * U)), p0 = (int)((s0 / U) % U), q = (int)(s0 % U);
+      const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
+      const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
+      const double* k = D.kpair_cd + 4 * s0;
+      double cx = k[0], cy = k[1], cz = k[2], d = k[3];
+      capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d);
+      if (lane == 0) publish(s0, tr, p0, q, cx, cy, cz, d);
+    }
+    if (capped && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+    return;
+  }
   // part 1 (Optimization3D_multi.h:276-290): pairs that passed box + k-DOP this iteration and have no plane yet
-  const int nwork = min(D.pair_work_n[0], D.cap_work);
   for (int w = blockIdx.x * 64 + lane; w < nwork; w += gridDim.x * 64) {
     const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
     const size_t s0 = ((size_t)tr * U + p0) * U + q;
     if (D.kpair_on[s0]) continue;
     const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
     const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
-    double e0, e1c, e2c, dpl; bool cp;
-    if (!plane_pair(A, B, dist, m, off, false, e0, e1c, e2c, dpl, cp)) continue;
+    double cx, cy, cz, d; bool cp;
+    if (!plane_pair(A, B, dist, m, off, false, cx, cy, cz, d, cp)) continue;
     D.kpair_on[s0] = 1;
     D.kpair_list[atomicAdd(D.kpair_n, 1)] = (int)s0;
-    refine_publish(s0, tr, p0, q, A, B, e0, e1c, e2c, dpl);
+    capped |= !opt_plane_pair(A, B, m, off, cx, cy, cz, d);
+    publish(s0, tr, p0, q, cx, cy, cz, d);
   }
   // part 2 (:310-338): every plane stored before this iteration
-  const int nold = D.kpair_n[1];
   for (int w = blockIdx.x * 64 + lane; w < nold; w += gridDim.x * 64) {
     const size_t s0 = (size_t)D.kpair_list[w];
     const int tr = (int)(s0 / ((size_t)U * U)), p0 = (int)((s0 / U) % U), q = (int)(s0 % U);
     const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
     const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
     const double* k = D.kpair_cd + 4 * s0;
-    refine_publish(s0, tr, p0, q, A, B, k[0], k[1], k[2], k[3]);
+    double cx = k[0], cy = k[1], cz = k[2], d = k[3];
+    capped |= !opt_plane_pair(A, B, m, off, cx, cy, cz, d);
+    publish(s0, tr, p0, q, cx, cy, cz, d);
   }
   if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
 }

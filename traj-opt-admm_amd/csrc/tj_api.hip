@@ -117,7 +117,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
-      hipLaunchKernelGGL(k_keep, dim3(multi ? 256 : owned * d.S), dim3(64), 0, s, d); return true;
+      hipLaunchKernelGGL(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_COMPACT: hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
     case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
@@ -761,13 +761,14 @@ int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const dou
 }
 
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out) {
-  if (!c || n < 0 || what < 0 || what > 6 || !P || !Q || !out) return TJ_ERR_INVALID;
+  if (!c || n < 0 || what < 0 || what > 7 || !P || !Q || !out) return TJ_ERR_INVALID;
   const size_t qbytes = (what == 0 || what == 2 || what == 5) ? (size_t)n * 24 : (size_t)n * 144;  // what 1, 3, 4, 6: hull vs hull
   DevBuf dp, dq, dout; int r;
   if ((r = to_dev(c, dp, P, (size_t)n * 144)) || (r = to_dev(c, dq, Q, qbytes)) || (r = to_dev(c, dout, nullptr, (size_t)n * 40))) return r;
   HIPCHK(c, hipMemset(dout.p, 0, std::max<size_t>((size_t)n * 40, 8)));
   if (what >= 5 && n > 0) HIPCHK(c, hipMemcpy(dout.p, out, (size_t)n * 40, hipMemcpyHostToDevice));  // in/out: the plane to refine
-  if (what == 4) hipLaunchKernelGGL(k_dbg_pair_wave, dim3(std::max(n, 1)), dim3(64), 0, c->stream, c->d, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
+  if (what == 7) hipLaunchKernelGGL(k_dbg_optpair_wave, dim3(std::max(n, 1)), dim3(64), 0, c->stream, c->d, n, (const double*)dp.p, (const double*)dq.p, (double*)dout.p);
+  else if (what == 4) hipLaunchKernelGGL(k_dbg_pair_wave, dim3(std::max(n, 1)), dim3(64), 0, c->stream, c->d, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
   else hipLaunchKernelGGL(k_dbg_planes, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, what, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
   HIPCHK(c, hipGetLastError());
   QUIESCE(c);
