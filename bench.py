@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--coupled", action="store_true", help='time the coupled mode ("decouple":0, one shared piece_time) instead of the shipped decoupled mode; single GPU only')
     ap.add_argument("--optimal-plane", action="store_true", help='time the "optimal_plane":1 variant (persistent planes refined every iteration); not the headline')
+    ap.add_argument("--overlap-gather", action="store_true", help="sharded schedule: start the control-point all-gather before phase 0 and join it after (async RCCL op); "
+                                                                  "off by default: with one rank it measured 13 us slower per iteration, its effect with real peers is unmeasured")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
     ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: every rank uses device 0 and the all-gathers are staged through host memory over gloo "
                                                             "(RCCL refuses two ranks on one device); exercises the multi-process schedule on a 1-GPU box")
@@ -126,7 +128,7 @@ def main():
     if sharded:
         import torch.distributed as dist
         if "TJ_KEEP_NCCL_DEBUG" not in os.environ:
-            os.environ["NCCL_DEBUG"] = "WARN"   # no version banner on stdout next to the JSON line
+            os.environ["NCCL_DEBUG"] = "NONE"   # RCCL prints its version banner and WARN lines on stdout, next to the JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if args.same_gpu:
@@ -168,8 +170,14 @@ def main():
             else:
                 dist.all_gather_into_tensor(views[what][0], views[what][1])
 
+        def _gather_begin(what):  # start the RCCL all-gather on torch's collective stream; the returned call joins it
+            if args.same_gpu or not args.overlap_gather:
+                return lambda: _gather(what)
+            work = dist.all_gather_into_tensor(views[what][0], views[what][1], async_op=True)
+            return work.wait
+
         def run(n_it):
-            sharding.run_sharded(_Eng, _gather, n_it)
+            sharding.run_sharded(_Eng, _gather, n_it, gather_begin=_gather_begin)
     else:
         def run(n_it):
             slv.iterate_async(n_it)

@@ -21,7 +21,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n_iters, out_dir):
+def _worker(rank, world, port, n_iters, out_dir, overlap):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -73,17 +73,33 @@ def _worker(rank, world, port, n_iters, out_dir):
             for u in range(U):
                 e.set_direction(u, packed[u, :3 * T].reshape(3, T), packed[u, 3 * T], packed[u, 3 * T + 1], packed[u, 3 * T + 2])
 
-    sharding.run_sharded(Eng, gather, n_iters)
+    def gather_begin(what):
+        """asynchronous variant: the control points are snapshotted and sent BEFORE phase 0 runs, joined after it"""
+        st = e.get_state()
+        t = torch.from_numpy(np.ascontiguousarray(st["spline"][u0:u1]))
+        parts = [torch.empty_like(t) for _ in range(world)]
+        work = dist.all_gather(parts, t, async_op=True)
+
+        def finish():
+            work.wait()
+            st2 = e.get_state()
+            st2["spline"] = np.concatenate([p.numpy() for p in parts], axis=0)
+            e.set_state(st2)
+        return finish
+
+    sharding.run_sharded(Eng, gather, n_iters, gather_begin=gather_begin if overlap else None)
     st = e.get_state()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u0=u0, u1=u1, **st)
     dist.destroy_process_group()
 
 
-def test_two_rank_schedule_matches_unsharded(scenes, tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_schedule_matches_unsharded(scenes, tmp_path, overlap):
+    """overlap = the control-point all-gather is started before phase 0 and joined after it (what bench.py does over RCCL)"""
     from oracle.pyoracle import Engine
     n_iters = 6
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_iters, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, n_iters, str(tmp_path), overlap), nprocs=2, join=True)
     ref = Engine("port", scenes.hard(4, 4000))
     for _ in range(n_iters):
         ref.iterate()
