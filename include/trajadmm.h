@@ -190,8 +190,8 @@ int tj_plan_init(tj_ctx* c, int n_robots, const double* starts, const double* go
  * (spline, 3T doubles per robot), what = 1 search directions (3T + 4 doubles per robot:
  * direction, t_direction, wolfe, |g|, pad). */
 int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_robot, int* first_owned, int* n_owned);
-/* Iteration split for external collectives: phase 0 = up to the point where all control points
- * are needed, 1 = ... see INTEGRATION.md. */
+/* Iteration split for external collectives: phase 0 = the stop test; all-gather control points; phase 1 = planes, gradient,
+ * Newton direction; all-gather directions; phase 2 = CCD clamps and line search. */
 int tj_iterate_phase(tj_ctx* c, int phase);
 
 #ifdef __cplusplus

@@ -109,10 +109,10 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
-    case K_FRONT: if (!in_graph) return false; hipLaunchKernelGGL(k_front, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
-    case K_SEP_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_obs_query, dim3(owned * d.S), dim3(64), 0, s, d); return true;  // stage API and sharded phase 0
+    case K_FRONT: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_front, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
+    case K_SEP_OBS: if (in_graph || in_phase) return false; hipLaunchKernelGGL(k_obs_query, dim3(owned * d.S), dim3(64), 0, s, d); return true;  // stage API and sharded phase 0
     case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false; hipLaunchKernelGGL(k_obs_solve, dim3(n_obs_solve), dim3(64), 0, s, d); return true;
-    case K_SEP_SELF_ROWS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
+    case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
     case K_MID: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); return true;
     case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
@@ -194,16 +194,16 @@ int flush_deferred(tj_ctx* c) {
 // Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two all-gathers), 3 = one full
 // iteration.  The phases are linear chains on the context's stream as well and reuse the union kernels where the
 // stages they join fall into the same phase (k_mid, k_ccd); the slack/dual update is the deferred one inside k_mid.
-//   phase 0: begin, obstacle candidate query (owned robots)                               -> all-gather control points
-//   phase 1: hull cache (ALL robots), pair rows, k_mid, compaction, gradient, Newton solve -> all-gather directions
+//   phase 0: begin (stop test)                                                            -> all-gather control points
+//   phase 1: hull cache (ALL robots), k_front {obstacle query | pair rows}, k_mid, compaction, gradient, Newton solve -> all-gather directions
 //   phase 2: swept-hull cache (ALL robots), k_ccd, sequential pair clamp + gnorm, line search
 int enqueue_body(tj_ctx* c, int which) {
   if (which == 3) return enqueue_iteration(c);
   hipStream_t m = c->stream;
-  static const int ph0[] = {K_BEGIN, K_SEP_OBS}, ph1[] = {K_HULLINFO, K_SEP_SELF_ROWS, K_MID, K_KEEP, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_XSOLVE_C2},
+  static const int ph0[] = {K_BEGIN}, ph1[] = {K_HULLINFO, K_FRONT, K_MID, K_KEEP, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_XSOLVE_C2},
                    ph2[] = {K_CCD_PREP, K_CCD, K_CCD_SELF_SEQ, K_LINESEARCH, K_LS_COUPLED, K_LS_COMMIT};
   const int* list = which == 0 ? ph0 : (which == 1 ? ph1 : ph2);
-  const int n = which == 0 ? 2 : (which == 1 ? 8 : 6);
+  const int n = which == 0 ? 1 : (which == 1 ? 8 : 6);
   for (int i = 0; i < n; i++) launch_kernel(c, list[i], m, 0, false, true);
   HIPCHK(c, hipGetLastError());
   if (which == 2) c->maybe_deferred = true;  // this iteration's slack/dual update is owed to the next k_mid (or the flush)

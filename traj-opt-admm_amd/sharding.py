@@ -6,9 +6,9 @@ The reference is single-process.  Cross-robot data dependencies of one decoupled
 line search uses the LAST robot's `wolfe` (Optimization3D_multi.h:730 vs :792) and `gnorm` is the mean
 of all |g| (:57,72).  Everything else is per robot.  Hence two all-gathers per iteration:
 
-    phase 0   stop test, obstacle planes of owned robots   } gather 0 may run concurrently with phase 0
+    phase 0   stop test                                    } gather 0 may run concurrently with phase 0
     gather 0  control points of all robots                 } (run_sharded's gather_begin)
-    phase 1   robot-pair planes, gradient/Hessian, Newton direction (owned robots)
+    phase 1   obstacle planes of owned robots, robot-pair planes, gradient/Hessian, Newton direction (owned robots)
     gather 1  direction records (direction, t_direction, wolfe, |g|) of all robots
     phase 2   CCD clamps (pair clamp replicated on every rank), line search, slack + dual (owned)
 
@@ -27,10 +27,9 @@ def run_sharded(engine, gather, n_iters, gather_begin=None):
     """engine.phase(k) runs phase k for the robots this rank owns; gather(what) all-gathers buffer
     `what` (0 = control points, 1 = direction records) in place.
 
-    gather_begin(what) (optional) STARTS that all-gather and returns a callable that completes it.  Phase 0 reads and
-    writes nothing but the rank's own robots (stop test, obstacle candidate query), and the control points are final
-    when the previous phase 2 ends, so gather 0 is started before phase 0 and completed after it: the collective's
-    latency hides behind the obstacle query instead of sitting on the critical path."""
+    gather_begin(what) (optional) STARTS that all-gather and returns a callable that completes it.  Phase 0 touches no
+    exchanged buffer and the control points are final when the previous phase 2 ends, so gather 0 may be started before
+    phase 0 and completed after it."""
     for _ in range(n_iters):
         finish = gather_begin(0) if gather_begin is not None else None
         engine.phase(0)
