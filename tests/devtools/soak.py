@@ -21,3 +21,18 @@ for k in range(30):
     y = pkg.Solver(dict(sc.scn_b(), mode=2), stop=0.0); y.iterate(3); y.close()
 free1 = free_mem()
 print("create/destroy x60: free memory before %.1f MB after %.1f MB" % (free0 / 2**20, free1 / 2**20))
+# "optimal_plane":1 -- long run (the persistent tables only ever grow) and create/destroy with the planner in the loop
+t0 = time.time()
+s = pkg.Solver(sc.scn_c(), stop=0.0, optimal_plane=1)
+g, it, conv = s.iterate(1500)
+st = s.stats(); fin = s.get_state(); on, _ = s.get_pair_cache()
+print("1500 iterations SCN-C optimal_plane: gnorm %.3e error_bits %d finite %s stored pair planes %d  %.2f s" % (g, st["error_bits"], bool(np.isfinite(fin["spline"]).all()), int(on.sum()), time.time() - t0))
+s.close()
+free0 = free_mem()
+for k in range(20):
+    x = pkg.Solver(sc.scn_b(), stop=0.0, optimal_plane=1); x.iterate(3)
+    wp = x.plan_init([[-9.0, -3.0, 0.5]], [[9.0, 3.0, 0.5]], nodes=62)
+    x.close()
+    y = pkg.Solver(sc.scn_a(), stop=0.0, optimal_plane=1); y.iterate(3); y.get_obs_cache(); y.close()
+free1 = free_mem()
+print("create/destroy x40 with optimal_plane + planner: free memory before %.1f MB after %.1f MB" % (free0 / 2**20, free1 / 2**20))
