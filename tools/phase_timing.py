@@ -21,9 +21,7 @@ PHASES = {
     "k_sep_obs": ["hull+kdop", "bvh+planes"],
     "k_ccd_self_seq": ["stage counts", "segment loop", "k_self + gn stage", "gnorm"],
 }
-NAMES = ["k_begin", "k_hullinfo", "k_front", "k_sep_obs", "k_sep_self_rows", "k_mid", "k_obs_solve", "k_sep_self_solve", "k_sep_self_compact", "k_grad", "k_xsolve", "k_xsolve_c2",
-         "k_ccd_prep", "k_ccd", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq", "k_linesearch", "k_ls_coupled", "k_ls_commit", "k_slack"]
-
+NAMES = []   # filled from tj_kernel_name() in main(): the library's own enumeration order
 
 def main():
     ap = argparse.ArgumentParser()
@@ -36,6 +34,8 @@ def main():
     s = pkg.Solver(scene, stop=0.0)
     s.iterate(a.iter)
     lib = C.CDLL(os.environ["TRAJADMM_LIB"])
+    lib.tj_kernel_name.restype = C.c_char_p
+    NAMES[:] = [lib.tj_kernel_name(i).decode() for i in range(lib.tj_kernel_count())]
     out = np.zeros((len(NAMES), 4096, 8), dtype=np.int64)
     lib.tj_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.tj_debug_phase_times(s._ctx, out.ctypes.data) == len(NAMES)
