@@ -112,3 +112,16 @@ def test_cli_init_2_plans_and_writes_the_init_file(pkg, scenes, tmp_path):
     first = np.array(rows[0], dtype=float).reshape(-1, 3); last = np.array(rows[-1], dtype=float).reshape(-1, 3)
     assert np.allclose(first, starts, rtol=1e-5) and np.allclose(last, goals, rtol=1e-5)
     assert open(tmp_path / "result" / (mesh + "_result_file_multi.txt")).read().startswith("iter: ")
+
+
+@pytest.mark.gpu
+def test_planner_at_scn_c_size_reproduces_the_straight_crossing(pkg, scenes):
+    """64 robots through the 100k-point cloud of SCN-C: every straight start-goal line is free (the robots fly at
+    different heights), so the planner must return exactly the evenly spaced straight way points of the scene --
+    and 63 robots' edges are prior obstacles for the last one"""
+    sc = scenes.scn_c()
+    s = pkg.Solver(sc, stop=0.0)
+    wp = s.plan_init(sc["waypoints"][:, 0], sc["waypoints"][:, -1])
+    s.close()
+    assert wp.shape == sc["waypoints"].shape
+    assert np.max(np.abs(wp - sc["waypoints"])) <= 1e-12

@@ -995,23 +995,29 @@ int tj_plan_init(tj_ctx* c, int n_robots, const double* starts, const double* go
   }
   // Equal way-point counts.  The reference pads a shorter path with interpolated points between its LAST two way points
   // (Main/multiPathPlanning3D.cpp:297-322), which leaves a cluster of very short pieces that all get the same piece time;
-  // here the currently longest edge is split at its midpoint until the count is reached (collinear points: the polyline and
-  // its validity are unchanged, the pieces come out as even as the corners allow).
+  // here the extra points go to the edges with the longest sub-segments and sit uniformly inside an edge (collinear points:
+  // the polyline and its validity are unchanged, the pieces come out as even as the corners allow).
   int max_size = min_waypoints;
   for (auto& p : paths) max_size = std::max(max_size, (int)p.size() / 3);
   if (max_size > cap_waypoints) { c->err = "tj_plan_init: path needs more way points than cap_waypoints"; return TJ_ERR_CAPACITY; }
   for (int u = 0; u < n_robots; u++) {
     std::vector<double>& p = paths[u];
-    while ((int)p.size() / 3 < max_size) {
-      const int n = (int)p.size() / 3;
-      int best = 0; double bl = -1;
-      for (int i = 0; i + 1 < n; i++) {
-        const double l = (p[3 * i] - p[3 * i + 3]) * (p[3 * i] - p[3 * i + 3]) + (p[3 * i + 1] - p[3 * i + 4]) * (p[3 * i + 1] - p[3 * i + 4]) + (p[3 * i + 2] - p[3 * i + 5]) * (p[3 * i + 2] - p[3 * i + 5]);
-        if (l > bl) { bl = l; best = i; }
+    const int n = (int)p.size() / 3, extra = max_size - n;
+    if (extra > 0) {
+      // give the extra points to the edges greedily by largest sub-segment length, then place them uniformly inside each edge
+      std::vector<double> len(n - 1); std::vector<int> parts(n - 1, 1);
+      for (int i = 0; i + 1 < n; i++) len[i] = std::sqrt((p[3 * i] - p[3 * i + 3]) * (p[3 * i] - p[3 * i + 3]) + (p[3 * i + 1] - p[3 * i + 4]) * (p[3 * i + 1] - p[3 * i + 4]) + (p[3 * i + 2] - p[3 * i + 5]) * (p[3 * i + 2] - p[3 * i + 5]));
+      for (int k = 0; k < extra; k++) {
+        int best = 0;
+        for (int i = 1; i + 1 < n; i++) if (len[i] / parts[i] > len[best] / parts[best]) best = i;
+        parts[best]++;
       }
-      double mid[3];
-      for (int k = 0; k < 3; k++) mid[k] = 0.5 * (p[3 * best + k] + p[3 * best + 3 + k]);
-      p.insert(p.begin() + 3 * (best + 1), mid, mid + 3);
+      std::vector<double> q;
+      for (int i = 0; i + 1 < n; i++)
+        for (int j = 0; j < parts[i]; j++)
+          for (int k = 0; k < 3; k++) q.push_back(j == 0 ? p[3 * i + k] : p[3 * i + k] + (p[3 * i + 3 + k] - p[3 * i + k]) * (double(j) / parts[i]));
+      for (int k = 0; k < 3; k++) q.push_back(p[3 * (n - 1) + k]);
+      p.swap(q);
     }
     for (int i = 0; i < max_size * 3; i++) waypoints[(size_t)u * cap_waypoints * 3 + i] = p[i];
   }
