@@ -153,17 +153,18 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   // wave that finishes early then draws further items from a shared cursor, so a long list (hundreds of robots) is
   // balanced dynamically instead of striding -- solve times vary 1 : 30.
   for (int w = bid; w < n;) {
-    if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
+    const bool first = w == bid;   // phase stamps (timing build only) describe a wave's first work item
+    if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
     const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
     __syncthreads();
     if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
     __syncthreads();
-    if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
+    if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
     {
       double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
       const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk);  // whole wave, uniform result
 #ifdef TJ_PHASE_TIMING
-      if (lane == 0 && w == blockIdx.x && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
+      if (lane == 0 && first && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
 #endif
       if (okp && lane == 0) {
         atomicAdd(&D.ctl->newton_iters, (unsigned long long)nit); atomicAdd(&D.ctl->pair_solves, 1ull);
@@ -175,7 +176,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
       }
     }
-    if (w == blockIdx.x) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
+    if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
     int nxt = 0;
     if (lane == 0) nxt = nwaves + atomicAdd(D.pair_work_n + 1, 1);
     w = __shfl(nxt, 0);
