@@ -188,6 +188,11 @@ def main():
         slv.sync()
         torch.cuda.synchronize()
 
+    # clock ramp: a freshly started process finds the GPU at its idle clock (543 MHz sclk on the bench box); ~60 ms of the same
+    # work, untimed and before the W warm-up steps, lets the power management settle so that K short steps are not timed on the ramp
+    run(300)
+    barrier()
+    slv.reset()
     # warmup (also instantiates the hipGraph), then restart from the initial trajectory
     run(max(W, 1))
     barrier()
