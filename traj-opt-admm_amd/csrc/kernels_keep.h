@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
       capped |= !opt_plane_obstacle(P, D.px[pt], D.py[pt], D.pz[pt], D.margin, D.offset, cx, cy, cz, d);
       k[0] = cx; k[1] = cy; k[2] = cz; k[3] = d;
       double* o = D.oplanes + (base + i) * 4;
-      o[0] = cx; o[1] = cy; o[2] = cz; o[3] = d;
+      if (!(isfinite(cx) && isfinite(cy) && isfinite(cz) && isfinite(d))) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 1e300; }   // inert, see the pair planes below
+      else { o[0] = cx; o[1] = cy; o[2] = cz; o[3] = d; }
     }
     if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
     if (lane == 0) { D.kobs_n[seg] = nk; D.ocount[seg] = nk; D.seg_stats[seg * 6 + 4] += (unsigned long long)nk; }
@@ -76,8 +77,17 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     k[0] = cx; k[1] = cy; k[2] = cz; k[3] = d;
     const size_t s1 = ((size_t)tr * U + q) * U + p0;
     double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
+    if (!(isfinite(cx) && isfinite(cy) && isfinite(cz) && isfinite(d))) {
+      // The reference's refinement can return NaN (its gradient takes log(dist/m) of a point on the wrong side).  Every consumer
+      // of the reference tests `dist < margin` / `dist <= 0` first, which a NaN fails: such a plane is inert but stays in the
+      // lists.  The kernels here multiply inactive terms by an exact 0 instead of branching, so the plane is published in an
+      // inert finite form (c = 0, d = huge); the table keeps the NaN, from which the next refinement returns at once.
+      q0[0] = 0; q0[1] = 0; q0[2] = 0; q0[3] = 1e300;
+      q1[0] = 0; q1[1] = 0; q1[2] = 0; q1[3] = 1e300;
+    } else {
     q0[0] = cx; q0[1] = cy; q0[2] = cz; q0[3] = d - 0.5 * off;
     q1[0] = -cx; q1[1] = -cy; q1[2] = -cz; q1[3] = -d - 0.5 * off;
+    }
     D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
   };
   const int nwork = min(D.pair_work_n[0], D.cap_work), nold = D.kpair_n[1];
