@@ -144,7 +144,9 @@ typedef struct tj_stats {
   unsigned long long llt_fail_piece, llt_fail_robot; /* PSD repairs taken: per-piece 19x19 blocks, per-robot reduced systems */
   unsigned long long newton_iters, pair_solves;      /* Optimal_plane::optimal_d iterations, robot pairs solved */
   int order_ambiguous; /* segments whose inter-robot clamp could depend on pair order (diagnostic) */
-  int error_bits;
+  int error_bits;      /* 1 plane list overflow, 2 BVH frontier overflow, 4 a loop hit its cap (detail: 32 coupled Armijo range, 64 plane
+                          refinement, 128 CCD contact at every step = state in collision, 256 slack Armijo), 8 pair list overflow,
+                          16 coupled Newton system not SPD */
 } tj_stats;
 int tj_get_stats(tj_ctx* c, tj_stats* s);
 

@@ -20,6 +20,12 @@ enum : int {
   ERR_PAIR_OVERFLOW = 8,     // inter-robot CCD survivor list overflow
   ERR_NOT_SPD = 16,          // coupled mode: the arrowhead Newton system is not positive definite (the reference's
                              // SimplicialLLT has no fallback there either, Optimization3D_multi.h:553-557)
+  // detail bits, set together with ERR_LOOP_CAP
+  ERR_LS_RANGE = 32,         // coupled mode: no step among the 8 * LSC_ROUNDS evaluated Armijo candidates (0.8^0 .. 0.8^30) was accepted
+  ERR_CCD_STUCK = 128,       // a CCD clamp found a contact at every step down to 0.8^LOOP_CAP: the state itself is in collision (the
+                             // reference spins forever there, Step.h:83-97)
+  ERR_SLACK_ARMIJO = 256,    // the slack update's Armijo loop
+  ERR_PLANE_REFINE = 64,     // "optimal_plane":1 -- a plane's Newton refinement hit PLANE_NEWTON_CAP / PLANE_BACKOFF_CAP
 };
 
 struct Ctl {

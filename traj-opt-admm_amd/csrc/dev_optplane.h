@@ -14,13 +14,16 @@
 // eigenvalue by 1e-8 relative.  Summation orders follow Eigen: reductions over a row of a dynamic matrix are sequential,
 // fixed-size Vector3d reductions pair (e0 + e1) + e2, `c.dot(row)` pairs e0 + (e1 + e2).
 // The loops are unbounded in the reference (self_optimal_cd zig-zags for thousands of rounds on some pairs); here they
-// stop after PLANE_NEWTON_CAP rounds / LOOP_CAP back-offs and report it.
+// stop after PLANE_NEWTON_CAP rounds / PLANE_BACKOFF_CAP back-offs and report it.
 #pragma once
 #include "dev_common.h"
 
 namespace tj {
 
 constexpr int PLANE_NEWTON_CAP = 200000;
+// back-offs of one Newton round: the offset component of the step is not clamped, a direction of 1e8 (the repaired eigenvalue
+// is 1e-8) needs ~250 factors of 0.8 before the trial point equals the start in fp64 and the reference's loop ends
+constexpr int PLANE_BACKOFF_CAP = 2000;
 constexpr double TJ_PI = 3.14159265358979323846;
 
 __device__ __forceinline__ double op_dot_row(const double* r, double c0, double c1, double c2) { return (r[0] * c0 + r[1] * c1) + r[2] * c2; }
@@ -175,7 +178,7 @@ __device__ inline bool opt_plane_obstacle(const double* P, double qx, double qy,
     double e1v = energy();
     int bo = 0;
     while (e0 - 1e-4 * w * step < e1v) {
-      if (++bo > LOOP_CAP) return false;
+      if (++bo > PLANE_BACKOFF_CAP) return false;
       step *= 0.8; cur_c(0.0 + step * dir0, 0.0 + step * dir1); e1v = energy();
     }
     cx = tx; cy = ty; cz = tz;
@@ -294,7 +297,7 @@ __device__ inline bool opt_plane_pair(const double* A, const double* B, double m
     int bo = 0;
     bool stuck = false;
     while (e0 - 1e-4 * w * step < e1v) {
-      if (++bo > LOOP_CAP) { stuck = true; break; }
+      if (++bo > PLANE_BACKOFF_CAP) { stuck = true; break; }
       step *= 0.8;
       op_rotate(cos(0.0 + step * dir0), sin(0.0 + step * dir0), cos(0.0 + step * dir1), sin(0.0 + step * dir1), cx, cy, cz, f, tx, ty, tz); td = d + step * dir2;
       e1v = energy();
@@ -353,7 +356,7 @@ __device__ inline bool opt_plane_pair_wave(const double* A, const double* B, dou
     int bo = 0;
     bool stuck = false;
     while (e0 - 1e-4 * w * step < e1v) {
-      if (++bo > LOOP_CAP) { stuck = true; break; }
+      if (++bo > PLANE_BACKOFF_CAP) { stuck = true; break; }
       step *= 0.8;
       rotate(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
       e1v = energy();

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
       if (!(isfinite(cx) && isfinite(cy) && isfinite(cz) && isfinite(d))) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 1e300; }   // inert, see the pair planes below
       else { o[0] = cx; o[1] = cy; o[2] = cz; o[3] = d; }
     }
-    if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+    if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PLANE_REFINE);
     if (lane == 0) { D.kobs_n[seg] = nk; D.ocount[seg] = nk; D.seg_stats[seg * 6 + 4] += (unsigned long long)nk; }
     return;
   }
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
       capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d);
       if (lane == 0) publish(s0, tr, p0, q, cx, cy, cz, d);
     }
-    if (capped && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+    if (capped && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PLANE_REFINE);
     return;
   }
   // part 1 (Optimization3D_multi.h:276-290): pairs that passed box + k-DOP this iteration and have no plane yet
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     capped |= !opt_plane_pair(A, B, m, off, cx, cy, cz, d);
     publish(s0, tr, p0, q, cx, cy, cz, d);
   }
-  if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+  if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PLANE_REFINE);
 }
 
 }  // namespace tj

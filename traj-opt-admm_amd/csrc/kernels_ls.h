@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
   if (s_acc[0] < 0) {  // no acceptable step within the evaluated range: take the last candidate and report it
     step = step0;
     for (int i = 0; i < kacc; i++) step *= 0.8;
-    if (tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+    if (tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_LS_RANGE);
   }
   double* gspline = D.spline + (size_t)u * 3 * T;
   const double* dir = D.dirp(u);

@@ -95,7 +95,7 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
           if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off * off)) break;
           k++;
         }
-        if (k >= LOOP_CAP) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+        if (k >= LOOP_CAP) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
         if (k > kmax) { kmax = k; atomicMax(&D.k_obs[u], k); }
       }
     }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
           if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off2)) break;
           k0++; k1++; seg_hit = true;
         }
-        if (guard > LOOP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+        if (guard > LOOP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
         __syncthreads();
         if (lane == 0) { if (shared) ks[0] = k0; else { ks[p0] = k0; ks[p1] = k1; } }
         __syncthreads();
@@ -367,7 +367,7 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
       for (int i = 0; i < 18; i++) zt[i] = z[i] + step * dirz[i];
       const double en = z_energy(D, cx, pt, zt, tt, lam, tl);
       if (!(e - 1e-4 * wolfe * step < en)) break;
-      if (++guard >= LOOP_CAP) { atomicOr(&D.ctl->error, ERR_LOOP_CAP); break; }
+      if (++guard >= LOOP_CAP) { atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_SLACK_ARMIJO); break; }
       step *= 0.8;
       tt = t_init + step * t_dir;
     }

@@ -250,7 +250,14 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
     c->err = "device list overflow (error bits " + std::to_string(h.error) + "): raise cap_obs/cap_self/cap_pairs";
     return TJ_ERR_CAPACITY;
   }
-  if (h.error & ERR_LOOP_CAP) { c->err = "a device back-off/Newton/Armijo loop hit its cap (infeasible state)"; return TJ_ERR_NO_PROGRESS; }
+  if (h.error & ERR_LOOP_CAP) {
+    c->err = "a device back-off/Newton/Armijo loop hit its cap (infeasible state)";
+    if (h.error & ERR_LS_RANGE) c->err += ": coupled mode, no acceptable step among the 31 evaluated Armijo back-offs (step < 1.2e-3: no progress)";
+    if (h.error & ERR_CCD_STUCK) c->err += ": a CCD clamp found contact at every step (the state itself is in collision; the reference loops forever here)";
+    if (h.error & ERR_SLACK_ARMIJO) c->err += ": the slack update's Armijo search";
+    if (h.error & ERR_PLANE_REFINE) c->err += ": optimal_plane, a plane refinement did not terminate within its caps";
+    return TJ_ERR_NO_PROGRESS;
+  }
   if (h.error & ERR_NOT_SPD) { c->err = "coupled mode: the arrowhead Newton system is not positive definite (the reference has no fallback either)"; return TJ_ERR_NO_PROGRESS; }
   return TJ_OK;
 }
