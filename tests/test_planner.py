@@ -125,3 +125,21 @@ def test_planner_at_scn_c_size_reproduces_the_straight_crossing(pkg, scenes):
     s.close()
     assert wp.shape == sc["waypoints"].shape
     assert np.max(np.abs(wp - sc["waypoints"])) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_planner_without_cloud_and_second_robot_avoids_the_first(pkg, scenes):
+    """`init_ob:0` (no obstacle cloud): the first robot gets its straight line, evenly split; a second robot whose straight
+    line crosses it must leave the line (the first path is an obstacle with clearance offset + margin/2)"""
+    sc = dict(scenes.scn_b(), cloud=np.zeros((0, 3)))
+    s = pkg.Solver(sc, stop=0.0)
+    starts = np.array([[-5.0, 0.0, 0.0], [0.0, -5.0, 0.0]]); goals = np.array([[5.0, 0.0, 0.0], [0.0, 5.0, 0.0]])
+    wp = s.plan_init(starts, goals)
+    assert wp.shape[0] == 2 and wp.shape[1] >= 6
+    n = wp.shape[1]
+    assert np.allclose(wp[0], starts[0] + np.linspace(0, 1, n)[:, None] * (goals[0] - starts[0]), atol=1e-12)
+    d = s.params["offset"] + 0.5 * s.params["margin"]
+    e0 = np.concatenate([wp[0, :-1], wp[0, 1:]], axis=1); e1 = np.concatenate([wp[1, :-1], wp[1, 1:]], axis=1)
+    assert not s.edge_collision(e1, e0, d).any()                 # clear of the first robot's path
+    assert s.edge_collision(np.concatenate([starts[1], goals[1]])[None], e0, d).all()   # the straight line is not
+    s.close()
