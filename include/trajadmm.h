@@ -134,7 +134,8 @@ int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_ar
 int tj_get_obs_cache(tj_ctx* c, int u, int seg, int cap, int* ids, double* cd);
 int tj_set_obs_cache(tj_ctx* c, int u, int seg, int n, const int* ids, const double* cd);
 /* multi UAV: flags[S][U][U] (only p0 < p1 is used) and cd[S][U][U][4] = (c, d) of the plane between robots p0 and p1
- * before it is split into (c, d - offset/2) and (-c, -d - offset/2) */
+ * before it is split into (c, d - offset/2) and (-c, -d - offset/2).  A sharded context (world > 1) tracks, returns and
+ * accepts only the pairs that touch one of its own robots. */
 int tj_get_pair_cache(tj_ctx* c, int* flags, double* cd);
 int tj_set_pair_cache(tj_ctx* c, const int* flags, const double* cd);
 
