@@ -117,6 +117,7 @@ struct Dev {
   // p0 < p1 only, plus the list of switched-on slots that k_keep strides over.
   int *kobs_id, *kobs_n; double *kobs_cd;       // [U][S][cap_obs], [U][S], [U][S][cap_obs][4]
   int *kpair_on, *kpair_list, *kpair_n; double *kpair_cd;  // [S][U][U], [S*U*U], [2] = {count, count at iteration start}, [S][U][U][4]
+  int grad_npl; double* grad_scr;  // k_grad: planes its LDS buffer holds; per-block HBM staging [owned*P][16*(cap_obs+cap_self)] for larger segments
   double *lg, *lh;                // per-piece gradient [U][P][19] and Hessian [U][P][361] (after PSD repair)
   // search direction record per robot, robot-major so a rank's robots are one slice for the
   // all-gather: [U][xs], xs = 3T+4 : direction (T x 3 col-major), t_direction, wolfe, |g|, pad

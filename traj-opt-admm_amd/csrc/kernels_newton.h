@@ -30,10 +30,69 @@ __host__ __device__ inline size_t grad_lds_doubles(int npl, int res) {  // sized
   return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 23 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
 }
 
+// One batch of segments [sb, se) of a piece: planes -> staging buffer, barrier derivatives, accumulation into this
+// thread's Hessian / gradient entry.  The staging buffer is LDS (the common case) or the block's HBM scratch (a segment
+// with more planes than the LDS buffer holds); one instantiation per address space, same summation order.
+struct GradRole { int tid, hi, ai, qi, ak, qk, vr, av, qv; };
+__device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
+                                                 const double* Pall, const double* Ball, const int* segn, int* sego, const GradRole R, double Hacc, double gacc, double& Hacc_out, double& gacc_out) {   // running sums in, running sums out
+  const int tid = R.tid, hi_ = R.hi, ai = R.ai, qi = R.qi, ak = R.ak, qk = R.qk, vr = R.vr, av = R.av, qv = R.qv;
+    __syncthreads();
+    if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
+    __syncthreads();
+    // planes of the batch: obstacle list first, then inter-robot list, per segment
+    for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
+      const int w = it >> 2, c = it & 3;
+      int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
+      const int tr = sp * res + i, k = w - sego[i], no = D.ocount[u * D.S + tr];
+      pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
+                      : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
+    }
+    __syncthreads();
+    // barrier derivatives for every (plane, control point) of the batch, stored [segment][j][k]
+    for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
+      int i = sb; while (i + 1 < se && 6 * sego[i + 1] <= it) i++;
+      const int n = segn[i], loc = it - 6 * sego[i], j = loc / n, k = loc % n;
+      const double* P = Pall + i * 18; const double* pl = pcb + 4 * (sego[i] + k);
+      const double d = P[3 * j] * pl[0] + P[3 * j + 1] * pl[1] + P[3 * j + 2] * pl[2] + pl[3];
+      double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
+      if (d < m) barrier_d(seg_weight(D, sp * res + i), d, m, e1, e2);
+      E1b[it] = e1; E2b[it] = e2;
+    }
+    __syncthreads();
+    for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
+      const int n = segn[i];
+      if (n == 0) continue;
+      const double* Bs = Ball + i * 36; const double* pls = pcb + 4 * sego[i];
+      const double* e1s = E1b + 6 * sego[i]; const double* e2s = E2b + 6 * sego[i];
+      if (hi_ >= 0) {
+        double seg = 0;
+        for (int j = 0; j < 6; j++) {
+          const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
+#pragma unroll 4
+          for (int k = 0; k < n; k++) {
+            const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
+            seg += (e2s[j * n + k] * dxi) * dxk;
+          }
+        }
+        Hacc += seg;
+      } else if (vr >= 0) {
+        double seg = 0;
+        for (int j = 0; j < 6; j++) {
+          const double bv = Bs[j * 6 + av];
+#pragma unroll 4
+          for (int k = 0; k < n; k++) seg += e1s[j * n + k] * (bv * pls[4 * k + qv]);
+        }
+        gacc += seg;
+      }
+    }
+  Hacc_out = Hacc; gacc_out = gacc;
+}
+
 __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
   if (D.ctl->done) return;
   extern __shared__ double sm[];
-  const int npl = D.cap_obs + D.cap_self;
+  const int npl = D.grad_npl;
   double* Pall = sm;                          // [res][18] hulls of the piece's segments, row-major [6][3]
   double* Ball = Pall + D.res * 18;           // [res][36] their bases
   double* pc = Ball + D.res * 36;             // [npl][4] planes of the current batch of segments
@@ -71,59 +130,17 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
 
   TJ_TIC(D, K_GRAD, 1);
   // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
+  // The buffer holds `npl` planes (16 doubles each: plane, e1[6], e2[6]) -- sized for what segments really carry, not for the
+  // configured capacity, so that several blocks share a CU when there are hundreds of robots.  A segment with more planes
+  // than that (a robot inside a dense obstacle slab) is staged through a per-block HBM scratch buffer instead: same code,
+  // same summation order, instantiated once per address space.
+  const GradRole role{tid, hi_, ai, qi, ak, qk, vr, av, qv};
   for (int sb = 0; sb < res;) {
     int se = sb, tot = 0;
     while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
     if (tot > 0) {
-      __syncthreads();
-      if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
-      __syncthreads();
-      // planes of the batch: obstacle list first, then inter-robot list, per segment
-      for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
-        const int w = it >> 2, c = it & 3;
-        int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
-        const int tr = sp * res + i, k = w - sego[i], no = D.ocount[u * D.S + tr];
-        pc[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
-                        : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
-      }
-      __syncthreads();
-      // barrier derivatives for every (plane, control point) of the batch, stored [segment][j][k]
-      for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
-        int i = sb; while (i + 1 < se && 6 * sego[i + 1] <= it) i++;
-        const int n = segn[i], loc = it - 6 * sego[i], j = loc / n, k = loc % n;
-        const double* P = Pall + i * 18; const double* pl = pc + 4 * (sego[i] + k);
-        const double d = P[3 * j] * pl[0] + P[3 * j + 1] * pl[1] + P[3 * j + 2] * pl[2] + pl[3];
-        double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
-        if (d < m) barrier_d(seg_weight(D, sp * res + i), d, m, e1, e2);
-        E1[it] = e1; E2[it] = e2;
-      }
-      __syncthreads();
-      for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
-        const int n = segn[i];
-        if (n == 0) continue;
-        const double* Bs = Ball + i * 36; const double* pls = pc + 4 * sego[i];
-        const double* e1s = E1 + 6 * sego[i]; const double* e2s = E2 + 6 * sego[i];
-        if (hi_ >= 0) {
-          double seg = 0;
-          for (int j = 0; j < 6; j++) {
-            const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
-#pragma unroll 4
-            for (int k = 0; k < n; k++) {
-              const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
-              seg += (e2s[j * n + k] * dxi) * dxk;
-            }
-          }
-          Hacc += seg;
-        } else if (vr >= 0) {
-          double seg = 0;
-          for (int j = 0; j < 6; j++) {
-            const double bv = Bs[j * 6 + av];
-#pragma unroll 4
-            for (int k = 0; k < n; k++) seg += e1s[j * n + k] * (bv * pls[4 * k + qv]);
-          }
-          gacc += seg;
-        }
-      }
+      if (tot <= npl) grad_plane_batch(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, Hacc, gacc, Hacc, gacc);
+      else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, Hacc, gacc, Hacc, gacc); }
     }
     sb = se;
   }

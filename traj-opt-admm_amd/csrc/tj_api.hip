@@ -347,7 +347,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
-  c->lds_grad = grad_lds_doubles(d.cap_obs + d.cap_self, d.res) * sizeof(double);
+  d.grad_npl = std::min(d.cap_obs + d.cap_self, 96);   // what a batch of segments really carries (SCN-C: <= 40); more goes through grad_scr
+  c->lds_grad = grad_lds_doubles(d.grad_npl, d.res) * sizeof(double);
   c->lds_xs = xsolve_lds_doubles(n) * sizeof(double);
   c->lds_xs2 = ((size_t)n * n + 4 * (size_t)n) * sizeof(double);
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
@@ -360,7 +361,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   c->lds_seq = (2 * (size_t)d.U + (size_t)d.S * d.U) * sizeof(int);
   const size_t lds_max = 160 * 1024 - 1024;
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max) {
-    c->err = "problem does not fit the 160 KB LDS of one CU (piece_num <= 10 and cap_obs+cap_self <= ~1100 supported in this version)";
+    c->err = "problem does not fit the 160 KB LDS of one CU (piece_num <= 10 supported in this version)";
     return TJ_ERR_UNSUPPORTED;
   }
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
@@ -393,7 +394,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 2)) || (r = dalloc(c, &d.ctl, 1)) ||
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
-      (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs))) return r;
+      (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
+      (r = dalloc(c, &d.grad_scr, (size_t)(d.u1 - d.u0) * P * 16 * (size_t)(d.cap_obs + d.cap_self)))) return r;
   if (d.optimal_plane) {
     const bool m0 = d.mode == 0;
     if ((r = dalloc(c, &d.kobs_id, m0 ? U * S * d.cap_obs : 1)) || (r = dalloc(c, &d.kobs_n, U * S)) || (r = dalloc(c, &d.kobs_cd, m0 ? U * S * d.cap_obs * 4 : 1)) ||
