@@ -75,6 +75,61 @@ def kernel_bytes(st, slv, iters):
     return b
 
 
+def survey_bytes(st, slv, iters):
+    """SURVEY.md section 8(d)'s algorithmic bytes, w = 8 (fp64), attributed to the kernel that performs each term:
+      B_state  = 2 U (3T + 2*18P + 2P + 1) w      (state read + written once per iteration)
+      B_bvh    = (V_dcd + V_ccd) * box bytes       (boxes visited; this implementation's box is 24 B: outward-rounded fp32)
+      B_cand   = (C_dcd + C_ccd) * 3w              (candidate primitives fetched; 3 vertices each for triangle obstacles)
+      B_planes = N_pl * 4w * (1 + 1 + E)           (written once, read by the gradient, read by each of E energy evaluations)
+      B_hess   = U P (19^2 + 19) w * 2 + U (9P-2)^2 w * 2
+      B_pair   = 2 * S U 18 w                      (all hulls read once per pair pass: DCD, CCD)
+    The hull / swept-hull caches this implementation keeps in HBM between kernels are NOT counted (implementation traffic).
+    Returns ({kernel: bytes per launch}, whole-iteration bytes)."""
+    U, S, P, T, w = slv.U, slv.S, slv.P, slv.T, 8
+    it = max(1, iters)
+    per = {k: st[k] / it for k in ("nodes_dcd", "cand_dcd", "nodes_ccd", "cand_ccd", "planes_obs", "planes_self", "energy_evals")}
+    npl = per["planes_obs"] + per["planes_self"]
+    E = per["energy_evals"] / U
+    box, prim = slv.box_bytes, 3 * w * slv.prim_vertices
+    x_state = U * (3 * T + 1) * w                    # control net + piece_time
+    z_state = U * (2 * 18 * P + 2 * P) * w           # slack + dual blocks
+    n = 9 * P - 2
+    multi = slv.mode >= 1
+    b = {
+        "k_begin": 0,
+        "k_front": per["nodes_dcd"] * box + per["cand_dcd"] * prim + x_state + (S * U * 18 * w if multi else 0),
+        "k_mid": npl * 4 * w + 2 * z_state + x_state,                   # planes written; slack/dual read + written
+        "k_sep_self_compact": 0,
+        "k_keep": npl * 4 * w * 2,
+        "k_grad": npl * 4 * w + U * P * (361 + 19) * w + x_state + z_state,
+        "k_xsolve": U * P * (361 + 19) * w + 2 * U * n * n * w + U * 3 * T * w,
+        "k_xsolve_c2": 2 * U * n * n * w,
+        "k_ccd_prep": 0,
+        "k_ccd": per["nodes_ccd"] * box + per["cand_ccd"] * prim + 2 * x_state + (S * U * 18 * w if multi else 0),
+        "k_ccd_self_seq": 0,
+        "k_linesearch": npl * 4 * w * E + 2 * x_state + z_state,
+        "k_ls_coupled": npl * 4 * w * E / 4 + x_state + z_state,
+        "k_ls_commit": 2 * x_state,
+        "k_hullinfo": 0, "k_slack": 2 * z_state + x_state,
+    }
+    b["k_obs_query"] = b["k_front"]; b["k_sep_self_rows"] = 0; b["k_obs_solve"] = per["planes_obs"] * 4 * w; b["k_sep_self_solve"] = per["planes_self"] * 4 * w
+    b["k_ccd_obs"] = b["k_ccd"]; b["k_ccd_self_pairs"] = 0
+    total = (2 * (x_state + z_state) + (per["nodes_dcd"] + per["nodes_ccd"]) * box + (per["cand_dcd"] + per["cand_ccd"]) * prim + npl * 4 * w * (2 + E)
+             + 2 * U * P * (361 + 19) * w + 2 * U * n * n * w + (2 * S * U * 18 * w if multi else 0))
+    return b, total
+
+
+def source_id():
+    """sha256 over the product sources: keys profile files to the build they were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "traj-opt-admm_amd", "csrc")
+    for f in sorted(os.listdir(src)) + ["../../include/trajadmm.h"]:
+        if f.endswith((".h", ".hip", ".cpp", "Makefile")):
+            h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(scene, steps, optimal_plane=False):
     """Reference CPU path on this box's host cores: the unmodified reference (oracle/_ref/libref.so,
     prebuilt in the dev container) if present, else this repo's CPU restatement.  Single thread --
@@ -209,6 +264,8 @@ def main():
     st = slv.stats()
     if st["error_bits"]:
         raise SystemExit(f"device error bits {st['error_bits']}")
+    if st["order_unresolved"]:
+        raise SystemExit(f"inter-robot CCD clamp: {st['order_unresolved']} segments whose pair order could not be replayed in the reference's tree order")
 
     if args.state_checksum:
         import hashlib
@@ -230,25 +287,36 @@ def main():
         slv.reset()
         prof = slv.profile_kernels(K)
         st2 = slv.stats()
-        bytes_it = kernel_bytes(st2, slv, K)
+        impl_bytes = kernel_bytes(st2, slv, K)           # this implementation's record sizes, caches included
+        alg_bytes, alg_total = survey_bytes(st2, slv, K)   # the figure `achieved` is priced on
         per_launch_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
         dom = max(per_launch_ms, key=per_launch_ms.get)
-        ach = bytes_it[dom] / (per_launch_ms[dom] * 1e-3) / 1e9
-        total_bytes = sum(bytes_it[k] for k, v in prof.items() if v[1])
-        pmc = None
-        try:  # PMC traffic of the same command, measured with rocprofv3 --pmc in separate passes (profiles/)
+        ach = alg_bytes[dom] / (per_launch_ms[dom] * 1e-3) / 1e9
+        impl_total = sum(impl_bytes[k] for k, v in prof.items() if v[1])
+        # PMC traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_round.sh) is only quoted when the
+        # profile was taken on THIS build (same source id) and scene; otherwise null
+        pmc, pmc_note = None, "no PMC profile for this build: run tools/profile_round.sh on the GPU box"
+        try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pj.get("scene") == scene["name"]:
+            if pj.get("scene") != scene["name"] or args.coupled or args.optimal_plane:
+                pmc_note = f"profiles/pmc_latest.json is for {pj.get('scene')}, default mode"
+            elif pj.get("source_id") != source_id():
+                pmc_note = f"profiles/pmc_latest.json was measured on build {pj.get('source_id')}, this is {source_id()}: stale, not quoted"
+            else:
                 pmc = pj["kernels"].get(dom)
+                pmc_note = (f"rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) per launch of the same kernel on build {source_id()}; FETCH_SIZE raw -- "
+                            "the accesses here are 8-byte scattered reads, which the guide lists as uncalibrated (x2 figure in traffic_detail)")
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": "tj::" + dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                           "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None), "traffic_detail": pmc,
-                           "algorithmic_bytes_per_launch": bytes_it[dom], "avg_launch_ms": per_launch_ms[dom],
-                           "note": "latency-bound at this size: the ~60 MB working set is Infinity-Cache resident (DESIGN.md 5); traffic = rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch of the same kernel (profiles/pmc_latest.json)",
-                           "whole_iteration": {"algorithmic_bytes": total_bytes, "achieved_GBps": total_bytes / (dt / K) / 1e9,
-                                               "frac": total_bytes / (dt / K) / 1e9 / 8000.0},
-                           "kernel_ms_per_launch": per_launch_ms}
+                           "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None), "traffic_detail": pmc, "traffic_note": pmc_note,
+                           "algorithmic_bytes_per_launch": alg_bytes[dom], "implementation_bytes_per_launch": impl_bytes[dom], "avg_launch_ms": per_launch_ms[dom],
+                           "note": "latency-bound at this size: the working set is Infinity-Cache resident (DESIGN.md 5).  achieved = SURVEY 8(d) algorithmic bytes of the dominant kernel / its hipEvent time; "
+                                   "implementation_bytes adds the hull / swept-hull caches this implementation moves through HBM",
+                           "whole_iteration": {"algorithmic_bytes": alg_total, "achieved_GBps": alg_total / (dt / K) / 1e9, "frac": alg_total / (dt / K) / 1e9 / 8000.0,
+                                               "implementation_bytes": impl_total, "implementation_frac": impl_total / (dt / K) / 1e9 / 8000.0},
+                           "kernel_ms_per_launch": per_launch_ms, "source_id": source_id()}
+        out["timed_window_ms"] = 1e3 * dt
         out["stats_per_iter"] = {k: (v / K if k not in ("error_bits", "order_ambiguous", "iters") else v) for k, v in st2.items()}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(scene, K, args.optimal_plane)

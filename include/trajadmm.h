@@ -126,6 +126,8 @@ int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes);
 int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, double* wolfe, double* gn);
 int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361);
 int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_armijo);
+/* teacher forcing of the CCD / line-search stages: overwrite robot u's search direction record (direction T x 3 column-major) */
+int tj_set_direction(tj_ctx* c, int u, const double* direction, double t_direction, double wolfe, double gn);
 
 /* ---- "optimal_plane":1 : the persistent plane tables (the reference globals is_seperate / seperate_c / seperate_d and
  * is_self_seperate / self_seperate_c / self_seperate_d, CCDUtils.cpp:30-36), for teacher-forced tests and checkpoints ---- */
@@ -144,10 +146,13 @@ typedef struct tj_stats {
   unsigned long long iters, nodes_dcd, nodes_ccd, cand_dcd, cand_ccd, planes_obs, planes_self, energy_evals, pair_tests;
   unsigned long long llt_fail_piece, llt_fail_robot; /* PSD repairs taken: per-piece 19x19 blocks, per-robot reduced systems */
   unsigned long long newton_iters, pair_solves;      /* Optimal_plane::optimal_d iterations, robot pairs solved */
-  int order_ambiguous; /* segments whose inter-robot clamp could depend on pair order (diagnostic) */
+  int order_ambiguous; /* segments whose inter-robot clamp depended on pair order (two acting pairs sharing a robot): replayed in the
+                          order of the reference's per-segment dynamic AABB tree (Step.h:213-251, AABB.cc:669-734) */
   int error_bits;      /* 1 plane list overflow, 2 BVH frontier overflow, 4 a loop hit its cap (detail: 32 coupled Armijo range, 64 plane
                           refinement, 128 CCD contact at every step = state in collision, 256 slack Armijo), 8 pair list overflow,
                           16 coupled Newton system not SPD */
+  int order_unresolved; /* such segments for which the tree order could NOT be established (result may differ from the reference's;
+                           tj_iterate returns TJ_ERR_UNSUPPORTED) -- 0 unless uav_num is in the thousands */
 } tj_stats;
 int tj_get_stats(tj_ctx* c, tj_stats* s);
 

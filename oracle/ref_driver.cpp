@@ -353,6 +353,13 @@ void ref_get_direction(int u, double* direction /*T*3*/, double* t_direction, do
   memcpy(direction, g_direction[u].data(), sizeof(double) * trajectory_num * 3);
   *t_direction = g_t_direction[u]; *wolfe_u = g_wolfe_each[u]; *gn_u = g_gn_each[u];
 }
+// teacher forcing of the CCD / line-search stages: overwrite robot u's search direction record
+void ref_set_direction(int u, const double* direction, double t_direction, double wolfe_u, double gn_u) {
+  int U = uav_num;
+  if ((int)g_direction.size() != U) { g_direction.assign(U, Data::Zero(trajectory_num, 3)); g_t_direction.assign(U, 0); g_wolfe_each.assign(U, 0); g_gn_each.assign(U, 0); }
+  g_direction[u] = Eigen::Map<const Data>(direction, trajectory_num, 3);
+  g_t_direction[u] = t_direction; g_wolfe_each[u] = wolfe_u; g_gn_each[u] = gn_u;
+}
 // per-piece local gradient/Hessian before the PSD shift (Gradient_admm.h:67-164)
 void ref_local_grad(int u, int sp_id, double* g19, double* h361) {
   Eigen::VectorXd g; Eigen::MatrixXd h;

@@ -76,3 +76,19 @@ def check_scene_matches_fixture(scene, g):
     """the fixtures were generated for seeded scenes; make sure numpy still generates the same cloud"""
     cs = np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()])
     assert np.allclose(cs, g["cloud_sum"], rtol=1e-13), "seeded scene differs from the one the golden file was made for"
+
+
+def ccd_order_case(seed, U=7):
+    """same construction as tests/golden/make_golden.py:ccd_order_case (robots of the `hard` family all heading for one
+    point: many colliding robot pairs per segment that share robots)"""
+    scenes = importlib.import_module("traj-opt-admm_amd").scenes
+    from oracle.pyoracle import Engine
+    scene = scenes.hard(U=U, n_points=500, seed=seed, dz=0.13)
+    sp = Engine("port", scene).get_state()["spline"]
+    rng = np.random.default_rng(seed)
+    tgt = rng.normal(0, 0.3, 3)
+    dirs = np.zeros_like(sp)
+    for u in range(U):
+        dirs[u] = 0.9 * (tgt[:, None] - sp[u]) + rng.normal(0, 0.05, (3, sp.shape[2]))
+        dirs[u][:, :2] = 0; dirs[u][:, -2:] = 0
+    return scene, dirs

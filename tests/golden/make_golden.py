@@ -122,9 +122,10 @@ def make_prims():
     np.savez_compressed(os.path.join(HERE, "prims_kat.npz"), **d)
 
 
-def make_stages(name, scene, iters, keep):
+def make_stages(name, scene, iters, keep, with_canon=True):
     """Per-iteration intermediates of the reference's own stage sequence, starting each kept
-    iteration from the reference's state (so consumers can teacher-force)."""
+    iteration from the reference's state (so consumers can teacher-force).  with_canon=False leaves out the
+    order-free copy of the plane lists (large scenes: consumers sort `planes_raw` themselves)."""
     e = Engine("ref", scene)
     rec = {"cloud_sum": np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), "waypoints": scene["waypoints"]}
     for it in range(iters):
@@ -140,7 +141,8 @@ def make_stages(name, scene, iters, keep):
         if it in keep:
             k = f"it{it}_"
             for n_, v in pre.items(): rec[k + "pre_" + n_] = v
-            rec[k + "counts"] = counts; rec[k + "planes_raw"] = planes; rec[k + "planes"] = canon(counts, planes)
+            rec[k + "counts"] = counts; rec[k + "planes_raw"] = planes
+            if with_canon: rec[k + "planes"] = canon(counts, planes)
             rec[k + "direction"] = d["direction"]; rec[k + "t_direction"] = d["t_direction"]; rec[k + "wolfe"] = d["wolfe"]; rec[k + "gn"] = d["gn"]
             rec[k + "gnorm"] = np.array(d["gnorm"])
             rec[k + "step_self"] = s_self; rec[k + "step_pos"] = s_pos; rec[k + "step_armijo"] = arm
@@ -190,6 +192,70 @@ def make_e2e(name, scene, max_iter=200, stop=1e-2):
     st = e.get_state()
     np.savez_compressed(os.path.join(HERE, f"e2e_{name}.npz"), gnorm_hist=np.array(gn), iters=np.array(len(gn)),
                         cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), **{"final_" + k: v for k, v in st.items()})
+
+
+def make_envelope(name, scene, snap=(0, 2, 4, 6, 8), max_iter=200, stop=1e-2):
+    """The headline scene's end-to-end pin.  The unmodified reference is run twice to the mains' stop test: on the scene
+    and on the scene with its way points multiplied by (1 + 2.3e-16) -- a ONE-ULP input change.  Recorded: both
+    iteration counts, the relative distance of the two runs' control points after every iteration (`div_hist`: how
+    fast the reference leaves ITSELF), control-point snapshots of the unperturbed run at a few early iterations, and
+    both final control nets.  Consumers check that an implementation tracks the snapshots while the reference still
+    reproduces itself, and ends inside the reference's own 1-ulp envelope."""
+    def run(pert):
+        sc = dict(scene); sc["waypoints"] = scene["waypoints"] * (1.0 + pert)
+        e = Engine("ref", sc)
+        gn, hist = [], []
+        for it in range(max_iter):
+            gn.append(e.iterate()); hist.append(e.get_state())
+            if it > 1 and gn[-1] < stop:
+                break
+        return gn, hist
+    ga, ha = run(0.0)
+    gb, hb = run(2.3e-16)
+    n = min(len(ha), len(hb))
+    div = np.array([np.max(np.abs(ha[i]["spline"] - hb[i]["spline"])) / np.max(np.abs(ha[i]["spline"])) for i in range(n)])
+    rec = dict(cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), iters=np.array(len(ga)), iters_pert=np.array(len(gb)),
+               gnorm_hist=np.array(ga), div_hist=div, snap=np.array(snap),
+               final_spline=ha[-1]["spline"], final_piece_time=ha[-1]["piece_time"], final_spline_pert=hb[-1]["spline"], final_piece_time_pert=hb[-1]["piece_time"])
+    for i in snap:
+        rec[f"it{i}_spline"] = ha[i]["spline"]; rec[f"it{i}_piece_time"] = ha[i]["piece_time"]
+    np.savez_compressed(os.path.join(HERE, f"envelope_{name}.npz"), **rec)
+
+
+def ccd_order_case(seed, U=7):
+    """robots of the `hard` family all heading for one point: many robot pairs collide in the same segment and share
+    robots, so Step::self_step's result depends on the pair ORDER of the reference's per-segment dynamic tree"""
+    scene = pkg_scenes.hard(U=U, n_points=500, seed=seed, dz=0.13)
+    sp = Engine("port", scene).get_state()["spline"]
+    rng = np.random.default_rng(seed)
+    tgt = rng.normal(0, 0.3, 3)
+    dirs = np.zeros_like(sp)
+    for u in range(U):
+        dirs[u] = 0.9 * (tgt[:, None] - sp[u]) + rng.normal(0, 0.05, (3, sp.shape[2]))
+        dirs[u][:, :2] = 0; dirs[u][:, -2:] = 0
+    return scene, dirs
+
+
+def make_ccd_order():
+    import ctypes as C
+    rec = {}
+    for seed in range(6):
+        scene, dirs = ccd_order_case(seed)
+        e = Engine("ref", scene)
+        e.stage_planes(); e.stage_direction()
+        for u in range(scene["U"]):
+            e.set_direction(u, dirs[u], 0.0, 1.0, 1.0)
+        s_self, s_pos = e.stage_steps()
+        rec[f"s{seed}_dirs"] = dirs; rec[f"s{seed}_step_self"] = s_self; rec[f"s{seed}_step_pos"] = s_pos
+        rec[f"s{seed}_cloud_sum"] = np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()])
+    rec["seeds"] = np.arange(6)
+    np.savez_compressed(os.path.join(HERE, "ccd_order_kat.npz"), **rec)
+
+
+def make_scn_c():
+    """BASELINE config 4 (the headline bench scene): per-iteration teacher-forcing data and the end-to-end envelope"""
+    make_stages("scn_c", pkg_scenes.scn_c(), 14, {0, 1, 3, 6, 9, 13}, with_canon=False)
+    make_envelope("scn_c", pkg_scenes.scn_c())
 
 
 def _flat_obs_cache(cache):
@@ -294,6 +360,12 @@ if __name__ == "__main__":
         make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
         make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
         sys.exit(0)
+    if "--ccd-order-only" in sys.argv:
+        make_ccd_order()
+        sys.exit(0)
+    if "--scn-c-only" in sys.argv:
+        make_scn_c()
+        sys.exit(0)
     if "--planner-only" in sys.argv:
         make_planner()
         sys.exit(0)
@@ -311,4 +383,6 @@ if __name__ == "__main__":
     make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
     make_optplane()
     make_planner()
+    make_scn_c()
+    make_ccd_order()
     print("golden vectors written to", HERE)

@@ -4,6 +4,8 @@
 Tolerances: bit-exact for GJK witness vectors / planes / CCD exponents / candidate counts;
 1e-12-class absolute for per-stage floating point (SURVEY 8c: teacher-forced 1e-12);
 1e-8 relative end-to-end on the control points (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -22,9 +24,15 @@ def katsolver(pkg, scenes):
 
 def test_native_library_is_loaded(pkg, katsolver):
     """the parity tests below must exercise the in-tree HIP library, never a fallback"""
-    maps = open("/proc/self/maps").read()
-    assert "libtrajadmm.so" in maps
-    assert "liboracle" not in [m for m in maps.split() if "traj-opt-admm_amd" in m]
+    paths = {ln.split()[-1] for ln in open("/proc/self/maps") if "/" in ln}
+    mine = [p for p in paths if p.endswith("libtrajadmm.so")]
+    assert len(mine) == 1 and os.path.samefile(mine[0], pkg.LIB_PATH), mine      # the in-tree build, exactly once
+    assert os.path.dirname(os.path.realpath(mine[0])) == os.path.dirname(os.path.realpath(pkg.__file__))
+    # nothing of the CPU checker lives inside the product package, and the product library does not link it
+    assert not [p for p in paths if "oracle" in os.path.basename(p) and os.path.dirname(os.path.realpath(p)) == os.path.dirname(os.path.realpath(pkg.__file__))]
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liboracle" not in needed and "libref" not in needed
 
 
 @pytest.mark.parametrize("shape", ["6v1", "6v6", "12v1", "12v12"])
@@ -92,7 +100,8 @@ def _teacher_forced(pkg, scene, g, tol_dir=1e-9):
         assert np.array_equal(counts, g[k + "counts"]), f"it{it}: plane counts differ"
         # list ORDER is implementation defined (static BVH vs the reference's dynamic tree); the
         # planes themselves are bit-exact for obstacles, 1e-13 for pair offsets (device log)
-        assert maxdiff(canon(counts, planes), g[k + "planes"]) <= 1e-13
+        want = g[k + "planes"] if k + "planes" in g else canon(g[k + "counts"], g[k + "planes_raw"])
+        assert maxdiff(canon(counts, planes), want) <= 1e-13
         s.set_planes(g[k + "counts"], g[k + "planes_raw"])       # then continue from the reference's exact lists
         d = s.stage_direction()
         assert maxdiff(d["gn"], g[k + "gn"]) <= 1e-11 * max(1.0, np.abs(g[k + "gn"]).max())
@@ -116,7 +125,7 @@ def _teacher_forced(pkg, scene, g, tol_dir=1e-9):
     s.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_multi", "tiny_single", "hard"])
+@pytest.mark.parametrize("name", ["tiny_multi", "tiny_single", "hard", "scn_c"])
 def test_stages_teacher_forced_vs_reference(pkg, scenes, name):
     g = gold(f"stages_{name}.npz")
     scene = scene_by_name(scenes, name)
@@ -167,6 +176,63 @@ def test_end_to_end_vs_reference(pkg, scenes, name):
     assert rel(st["piece_time"], g["final_piece_time"]) <= 1e-8
     assert abs(gnorm - g["gnorm_hist"][-1]) <= 1e-3 * g["gnorm_hist"][-1]
     assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+def test_inter_robot_clamp_replays_the_references_tree_order(pkg, monkeypatch):
+    """Step::self_step is order dependent when two acting pairs of a segment share a robot (Step.h:213-251).  Robots all
+    heading for one point: the device rebuilds the reference's per-segment dynamic tree for such segments and must give the
+    unmodified reference's steps bit for bit; with the tree switched off the library must REFUSE (never silently differ)."""
+    from conftest import ccd_order_case
+    g = gold("ccd_order_kat.npz")
+    hit = 0
+    for seed in g["seeds"]:
+        scene, dirs = ccd_order_case(int(seed))
+        assert np.array_equal(dirs, g[f"s{seed}_dirs"])
+        s = pkg.Solver(scene, stop=0.0)
+        s.run_stage("begin")
+        for u in range(scene["U"]):
+            s.set_direction(u, dirs[u], 0.0, 1.0, 1.0)
+        s_self, s_pos = s.stage_steps()
+        st = s.stats()
+        assert np.array_equal(s_self, g[f"s{seed}_step_self"]), (int(seed), s_self, g[f"s{seed}_step_self"])
+        assert np.array_equal(s_pos, g[f"s{seed}_step_pos"])
+        assert st["order_unresolved"] == 0 and st["error_bits"] == 0
+        hit += st["order_ambiguous"]
+        s.close()
+    assert hit > 0, "fixture no longer exercises the order-dependent case"
+    monkeypatch.setenv("TJ_NO_SEQ_TREE", "1")
+    scene, dirs = ccd_order_case(0)
+    s = pkg.Solver(scene, stop=0.0)
+    s.run_stage("begin")
+    for u in range(scene["U"]):
+        s.set_direction(u, dirs[u], 0.0, 1.0, 1.0)
+    with pytest.raises(pkg.TrajAdmmError, match="pair order"):
+        s.stage_steps()
+    s.close()
+
+
+def test_headline_scene_free_running_within_reference_envelope(pkg, scenes):
+    """SCN-C (BASELINE config 4, the bench scene), free-running through the production path against the UNMODIFIED
+    reference: early iterations track the reference as closely as the reference tracks itself under a 1-ulp input change,
+    same iteration count +-1, final control points inside 3x the reference's own 1-ulp envelope (which is ~1e-2: the
+    fixture shows that north_star's 1e-8 cannot be met on this scene by anything short of bit-identity)."""
+    from test_oracle_golden import envelope_check
+    g = gold("envelope_scn_c.npz")
+    scene = scene_by_name(scenes, "scn_c")
+    check_scene_matches_fixture(scene, g)
+    s = pkg.Solver(scene)
+    snaps, iters, conv = {}, 0, False
+    for it in range(200):
+        _, iters, conv = s.iterate(1)
+        if it in g["snap"]:
+            snaps[it] = s.get_state()["spline"]
+        if conv:
+            break
+    assert conv
+    st = s.stats()
+    assert st["error_bits"] == 0 and st["order_ambiguous"] == 0
+    envelope_check(g, snaps, s.get_state()["spline"], iters)
     s.close()
 
 

@@ -75,7 +75,7 @@ def test_llt_and_min_eigenvalue():
         assert abs(pr.min_eig(m) - ev) <= 1e-12 * max(1.0, np.abs(m).max())
 
 
-@pytest.mark.parametrize("name", ["tiny_multi", "tiny_single", "hard"])
+@pytest.mark.parametrize("name", ["tiny_multi", "tiny_single", "hard", "scn_c"])
 def test_stages_teacher_forced(scenes, name):
     """every stage of one ADMM iteration, started from the reference's own state (tol 1e-12 abs per
     SURVEY 8c; planes / gnorm / CCD steps are bit-exact)"""
@@ -126,6 +126,56 @@ def test_end_to_end_vs_reference(scenes, name):
     assert rel(st["piece_time"], g["final_piece_time"]) <= 1e-8
     # the residual gradient norm is a difference of nearly cancelling terms: compare loosely
     assert abs(gn[-1] - g["gnorm_hist"][-1]) <= 1e-3 * g["gnorm_hist"][-1]
+
+
+def test_inter_robot_clamp_in_the_references_tree_order():
+    """Step::self_step where many colliding pairs of one segment share robots (order dependent, Step.h:213-251)"""
+    from conftest import ccd_order_case
+    g = gold("ccd_order_kat.npz")
+    for seed in g["seeds"]:
+        scene, dirs = ccd_order_case(int(seed))
+        assert np.allclose([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()], g[f"s{seed}_cloud_sum"], rtol=1e-13)
+        assert np.array_equal(dirs, g[f"s{seed}_dirs"])
+        e = Engine("port", scene)
+        e.stage_planes()
+        for u in range(scene["U"]):
+            e.set_direction(u, dirs[u], 0.0, 1.0, 1.0)
+        s_self, s_pos = e.stage_steps()
+        assert np.array_equal(s_self, g[f"s{seed}_step_self"]) and np.array_equal(s_pos, g[f"s{seed}_step_pos"])
+
+
+def envelope_check(g, snapshots, final, iters):
+    """Shared by the CPU (oracle) and GPU (HIP) tests of the headline scene.  `g` = tests/golden/envelope_scn_c.npz, made
+    from two runs of the unmodified reference whose inputs differ by ONE ULP.  An implementation must (1) track the
+    reference's control points at the early snapshot iterations as closely as the reference tracks itself (floor 1e-10: a
+    different libm / summation order is a perturbation of the same kind as the 1-ulp input change), (2) converge in the
+    reference's iteration count +-1, (3) end no farther from the reference than 3x the reference's own 1-ulp envelope.
+    The fixture also records that this envelope is ~1e-2 >> 1e-8: BASELINE's end-to-end 1e-8 is not attainable on this
+    scene by anything that is not bit-identical to the reference in every operation, the reference under a 1-ulp input
+    change included."""
+    div = g["div_hist"]
+    assert div[int(g["iters"]) - 1] > 1e-4, "fixture: the reference no longer leaves itself on this scene -- tighten this test to 1e-8"
+    for it in g["snap"]:
+        tol = max(1e-10, 30 * float(div[it]))
+        assert rel(snapshots[int(it)], g[f"it{it}_spline"]) <= tol, (int(it), rel(snapshots[int(it)], g[f"it{it}_spline"]), tol)
+    assert abs(iters - int(g["iters"])) <= 1
+    env = rel(g["final_spline_pert"], g["final_spline"])
+    assert rel(final, g["final_spline"]) <= 3 * env, (rel(final, g["final_spline"]), env)
+
+
+def test_headline_scene_free_running_within_reference_envelope(scenes):
+    g = gold("envelope_scn_c.npz")
+    scene = scene_by_name(scenes, "scn_c")
+    check_scene_matches_fixture(scene, g)
+    e = Engine("port", scene)
+    gn, snaps = [], {}
+    for it in range(200):
+        gn.append(e.iterate())
+        if it in g["snap"]:
+            snaps[it] = e.get_state()["spline"]
+        if it > 1 and gn[-1] < 1e-2:
+            break
+    envelope_check(g, snaps, e.get_state()["spline"], len(gn))
 
 
 # ---- coupled mode ("decouple":0): Optimization3D_multi::optimization, one shared piece_time ----------------

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): profiles the default bench.py command of the CURRENT build and leaves the summaries
+# under gpurun_out/<tag>/ -- copy them into profiles/ afterwards.
+#   tools/profile_round.sh <tag> [bench args...]        e.g.  tools/profile_round.sh round2_v1 --scene C
+# 1. rocprofv3 --kernel-trace --stats : per-kernel durations (rocpd database -> CSV + one iteration's timeline)
+# 2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots")
+# The PMC json carries the source id of the build it was measured on; bench.py only quotes it for that build.
+set -u
+TAG=${1:-round}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+ARGS="--steps 20 --warmup 3 --no-cpu $*"
+python3 $REPO/bench.py --steps 20 --warmup 3 $* > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python3 $REPO/bench.py $ARGS > $OUT/kt.log 2>&1
+DB=$(find $OUT/kt -name '*_results.db' | head -1)
+python3 $REPO/tools/rocpd_timeline.py "$DB" --csv $OUT/kernel_stats.csv > $OUT/timeline.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o x -- python3 $REPO/bench.py $ARGS > $OUT/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o x -- python3 $REPO/bench.py $ARGS > $OUT/pw.log 2>&1
+F=$(find $OUT/pf -name '*_results.db' | head -1); W=$(find $OUT/pw -name '*_results.db' | head -1)
+SCENE=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['workload'].split(':')[0])")
+python3 $REPO/tools/pmc_traffic.py "$F" "$W" --scene "$SCENE" --command "python3 bench.py $ARGS" --out $OUT/pmc.json > $OUT/pmc.txt 2>&1
+rm -rf $OUT/kt $OUT/pf $OUT/pw      # the databases are large; the summaries are what is kept
+tail -n 3 $OUT/bench.json | cut -c1-600
+head -20 $OUT/timeline.txt

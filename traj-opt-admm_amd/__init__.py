@@ -24,7 +24,7 @@ _ip = C.POINTER(C.c_int)
 EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
-    "tj_set_planes", "tj_get_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
+    "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
     "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
 ]
@@ -43,7 +43,7 @@ class TjParams(C.Structure):
 class TjStats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in ("iters", "nodes_dcd", "nodes_ccd", "cand_dcd", "cand_ccd", "planes_obs",
                                              "planes_self", "energy_evals", "pair_tests", "llt_fail_piece", "llt_fail_robot", "newton_iters", "pair_solves")] + \
-               [("order_ambiguous", C.c_int), ("error_bits", C.c_int)]
+               [("order_ambiguous", C.c_int), ("error_bits", C.c_int), ("order_unresolved", C.c_int)]
 
 
 class TrajAdmmError(RuntimeError):
@@ -226,6 +226,10 @@ class Solver:
             out["t_direction"][u], out["wolfe"][u], out["gn"][u] = a.value, b.value, c.value
         out["gnorm"] = float(np.sum(out["gn"]) / self.U) if self.mode == 1 else float(out["gn"][0])
         return out
+
+    def set_direction(self, u, direction, t_direction, wolfe, gn):
+        d = np.ascontiguousarray(direction, dtype=np.float64)
+        self._check(self.lib.tj_set_direction(self._ctx, C.c_int(u), _d(d), C.c_double(t_direction), C.c_double(wolfe), C.c_double(gn)))
 
     def local_grad(self, u, sp):
         g = np.zeros(19); h = np.zeros((19, 19))

@@ -32,13 +32,13 @@ struct Ctl {
   int iter;            // completed iterations (reference global `iter`)
   int done;            // stop test fired: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
   int error;           // ERR_* bits
-  int order_ambiguous; // segments whose inter-robot CCD result depended on pair order (see k_ccd_self_seq)
+  int order_ambiguous; // segments whose inter-robot CCD result depended on pair order and were replayed in the reference's tree order (k_ccd_self_seq)
   int pending;         // an iteration was started by k_begin and is not yet counted in `iter`
   int epoch;           // bumped by every k_begin: stamp that marks this iteration's pair-plane slots as valid
   int slack_now;       // the slack/dual update of the PREVIOUS iteration is due (deferred so it overlaps the next planes)
   int slack_next;      // the iteration that k_begin just started still owes its slack/dual update
   int any_pair;        // some robot pair is within `offset` at full step this iteration: the sequential CCD replay has work
-  int pad0;
+  int order_unresolved; // segments whose pair order mattered but could not be replayed in the reference's tree order
 
   double gnorm;        // reference global `gnorm`
   // statistics for the algorithmic-byte model; accumulated over iterations
@@ -72,6 +72,7 @@ struct Dev {
   // ---- parameters (3D.json + hard-coded constants of the mains) ----
   int mode, U, P, res, S, T, N;
   int u0, u1;  // robots owned by this rank: [u0,u1)
+  int seq_tree; // k_ccd_self_seq has LDS for the reference's per-segment dynamic tree (dev_dyntree.h)
   int fuse;    // single-GPU iteration graph: k_linesearch leaves the next iteration's hull cache, so k_hullinfo is not
                // launched (the sharded schedule needs the cache for ALL robots after its all-gather and keeps the kernel;
                // folding k_ccd_prep into k_xsolve the same way was measured slower: 10 dependent segments per wave)

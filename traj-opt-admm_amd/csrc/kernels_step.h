@@ -23,6 +23,7 @@
 #include "dev_linalg.h"
 #include "kernels_sep.h"
 #include "kernels_ls.h"
+#include "dev_dyntree.h"
 
 namespace tj {
 
@@ -165,12 +166,31 @@ __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
 }
 
 // Phase B + gnorm.  One workgroup of one wave; control flow is wave uniform.
+// Per segment the acting pairs (phase A's survivors) are gathered in lexicographic order.  Pairs that share no robot
+// commute; if two of them DO share a robot the result depends on the order in which the reference meets them, which is
+// the emission order of its per-segment dynamic AABB tree: that tree is then rebuilt here (dev_dyntree.h, lane 0, LDS)
+// and the segment's pairs are replayed in its order.  Ctl::order_ambiguous counts such segments; Ctl::order_unresolved
+// those for which the order could not be established (tree does not fit LDS / more than SEQ_ACT_CAP acting pairs in one
+// segment) -- tj_iterate reports that as TJ_ERR_UNSUPPORTED instead of silently continuing.
+constexpr int SEQ_ACT_CAP = 256;   // acting pairs of ONE segment
+constexpr int SEQ_STK_CAP = 1024;  // node-pair stack of the tree's self query
+__host__ __device__ inline size_t seq_lds_bytes(int U, int S, bool with_tree) {
+  size_t b = (with_tree ? dyntree_lds_bytes(U) + 6 * (size_t)U * sizeof(double) : 0);
+  b += (2 * (size_t)U + (size_t)S * U + 3 * SEQ_ACT_CAP + (with_tree ? 2 * SEQ_STK_CAP : 0)) * sizeof(int);
+  return b;
+}
 __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   if (D.ctl->done) return;
   const int lane = lane_id();
-  extern __shared__ int ks[];  // [U] exponents, [U] last segment in which the robot appeared
-  int* seen = ks + D.U;
-  int* cnt = seen + D.U;  // [S*U] survivor counts, staged once so the segment loop never waits on HBM
+  extern __shared__ double seq_sm[];
+  // doubles first (alignment): tree nodes + the segment's swept boxes, then the int arrays
+  double* tbox = seq_sm; double* tarea = tbox + (D.seq_tree ? 12 * (size_t)D.U : 0); double* bx = tarea + (D.seq_tree ? 2 * (size_t)D.U : 0);
+  int* ti = (int*)(bx + (D.seq_tree ? 6 * (size_t)D.U : 0));   // [5][2U] parent, left, right, height, particle
+  int* ks = ti + (D.seq_tree ? 10 * (size_t)D.U : 0);           // [U] exponents
+  int* seen = ks + D.U;                                          // [U] last segment in which the robot appeared
+  int* cnt = seen + D.U;                                         // [S*U] survivor counts, staged once so the segment loop never waits on HBM
+  int* act0 = cnt + (size_t)D.S * D.U; int* act1 = act0 + SEQ_ACT_CAP; int* ord = act1 + SEQ_ACT_CAP;
+  int* stk = ord + SEQ_ACT_CAP;
   TJ_TIC(D, K_CCD_SELF_SEQ, 0);
   for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
   // usually no pair is within `offset` at full step (the selection kernel raises a flag otherwise): skip staging and walk
@@ -181,39 +201,65 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   if (any_pair) {
     const bool shared = D.coupled();  // Step::couple_self_step (Step.h:112-182): one step for all robots, held in ks[0]
     const double off2 = D.offset * D.offset;
-    int ambiguous = 0;
+    int ambiguous = 0, unresolved = 0;
     for (int tr = 0; tr < D.S; tr++) {
-      bool seg_hit = false, seg_share = false;
+      // 1. this segment's acting pairs, lexicographic (p0, p1); does any robot appear twice?
+      int m = 0; bool share = false;
       for (int r0 = 0; r0 < D.U; r0 += 64) {  // rows with survivors, found 64 at a time
-      unsigned long long rows = ballot(r0 + lane < D.U && cnt[tr * D.U + min(r0 + lane, D.U - 1)] > 0);
-      while (rows) {
-      const int p0 = r0 + __ffsll((long long)rows) - 1;
-      rows &= rows - 1;
-      const int n = cnt[tr * D.U + p0];
-      for (int i = 0; i < n; i++) {
-        const int p1 = D.pair_list[((size_t)tr * D.U + p0) * D.cap_row + i];
+        unsigned long long rows = ballot(r0 + lane < D.U && cnt[tr * D.U + min(r0 + lane, D.U - 1)] > 0);
+        while (rows) {
+          const int p0 = r0 + __ffsll((long long)rows) - 1;
+          rows &= rows - 1;
+          const int n = cnt[tr * D.U + p0];
+          for (int i = 0; i < n; i++) {
+            const int p1 = D.pair_list[((size_t)tr * D.U + p0) * D.cap_row + i];
+            if (seen[p0] == tr || seen[p1] == tr) share = true;
+            blk_sync<true>();
+            if (lane == 0) { seen[p0] = tr; seen[p1] = tr; if (m < SEQ_ACT_CAP) { act0[m] = p0; act1[m] = p1; } }
+            blk_sync<true>();
+            m++;
+          }
+        }
+      }
+      if (m == 0) continue;
+      if (m > SEQ_ACT_CAP) { if (lane == 0) atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW); m = SEQ_ACT_CAP; unresolved += share && !shared; share = false; }
+      // 2. order: lexicographic unless two acting pairs share a robot, then the reference's tree order
+      bool tree_order = false;
+      if (share && !shared && m >= 2) {
+        if (D.seq_tree) {
+          for (int i = lane; i < 6 * D.U; i += 64) { const int k = i / D.U, u = i % D.U; bx[6 * u + k] = D.cbox[((size_t)tr * 6 + k) * D.U + u]; }  // swept boxes of ALL robots (BVH.cpp:301-325)
+          blk_sync<true>();
+          if (lane == 0) {
+            DynTree t{tbox, tarea, ti, ti + 2 * D.U, ti + 4 * D.U, ti + 6 * D.U, ti + 8 * D.U, DT_NIL, 0};
+            for (int u = 0; u < D.U; u++) dt_insert(t, u, bx + 6 * u);
+            stk[2 * SEQ_STK_CAP - 1] = dt_pair_order(t, D.offset, act0, act1, m, ord, stk, SEQ_STK_CAP - 1);
+          }
+          blk_sync<true>();
+          tree_order = stk[2 * SEQ_STK_CAP - 1] == m;
+        }
+        if (tree_order) ambiguous++; else unresolved++;
+      }
+      // 3. the joint back-off, pair after pair (Step.h:213-251)
+      for (int j = 0; j < m; j++) {
+        const int i = tree_order ? ord[j] : j;
+        const int p0 = act0[i], p1 = act1[i];
         const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
         const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
         int k0 = ks[shared ? 0 : p0], k1 = ks[shared ? 0 : p1];
-        if (!shared && (seen[p0] == tr || seen[p1] == tr)) seg_share = true;
-        __syncthreads();
-        if (lane == 0) { seen[p0] = tr; seen[p1] = tr; }
         int guard = 0;
         while (guard++ < LOOP_CAP) {
           const V3 v = gjk_wave(BodySwept{a, a + 18, D.pow08[min(k0, LOOP_CAP)]}, BodySwept{b, b + 18, D.pow08[min(k1, LOOP_CAP)]}, lane);  // the wave is uniform here: solve the pair cooperatively
           if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off2)) break;
-          k0++; k1++; seg_hit = true;
+          k0++; k1++;
         }
         if (guard > LOOP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
-        __syncthreads();
+        blk_sync<true>();
         if (lane == 0) { if (shared) ks[0] = k0; else { ks[p0] = k0; ks[p1] = k1; } }
-        __syncthreads();
+        blk_sync<true>();
       }
-      }
-      }
-      if (seg_hit && seg_share) ambiguous++;
     }
     if (lane == 0 && ambiguous) atomicAdd(&D.ctl->order_ambiguous, ambiguous);
+    if (lane == 0 && unresolved) atomicAdd(&D.ctl->order_unresolved, unresolved);
   }
   __syncthreads();
   TJ_TIC(D, K_CCD_SELF_SEQ, 2);

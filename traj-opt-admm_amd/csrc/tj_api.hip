@@ -68,7 +68,7 @@ template <class T>
 int dalloc(tj_ctx* c, T** p, size_t n, std::vector<void*>* list = nullptr) {
   void* q = nullptr;
   HIPCHK(c, hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
-  HIPCHK(c, hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  HIPCHK(c, hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), c->stream));  // ordered on the solver's stream like every kernel and copy that follows
   (list ? *list : c->allocs).push_back(q);
   *p = (T*)q;
   return TJ_OK;
@@ -76,7 +76,10 @@ int dalloc(tj_ctx* c, T** p, size_t n, std::vector<void*>* list = nullptr) {
 
 int upload(tj_ctx* c, const void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return TJ_OK;
-  HIPCHK(c, hipMemcpy((void*)dst, src, bytes, hipMemcpyHostToDevice));
+  // on the solver's stream (a non-blocking stream has no implicit ordering against the null stream), then waited for:
+  // the host buffer may be reused as soon as this returns
+  HIPCHK(c, hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return TJ_OK;
 }
 
@@ -258,6 +261,7 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
     if (h.error & ERR_PLANE_REFINE) c->err += ": optimal_plane, a plane refinement did not terminate within its caps";
     return TJ_ERR_NO_PROGRESS;
   }
+  if (h.order_unresolved) { c->err = "inter-robot CCD clamp: two acting pairs of a segment share a robot and the reference's pair order could not be replayed (fleet too large for the LDS-resident tree)"; return TJ_ERR_UNSUPPORTED; }
   if (h.error & ERR_NOT_SPD) { c->err = "coupled mode: the arrowhead Newton system is not positive definite (the reference has no fallback either)"; return TJ_ERR_NO_PROGRESS; }
   return TJ_OK;
 }
@@ -358,8 +362,10 @@ int tj_create(const tj_params* p, tj_ctx** out) {
 #endif
   if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
   if (d.res > GRAD_MAXRES) { c->err = "res > 16 segments per piece is not supported by the gradient kernel"; return TJ_ERR_UNSUPPORTED; }
-  c->lds_seq = (2 * (size_t)d.U + (size_t)d.S * d.U) * sizeof(int);
   const size_t lds_max = 160 * 1024 - 1024;
+  d.seq_tree = (d.mode == TJ_MODE_MULTI_DECOUPLE && seq_lds_bytes(d.U, d.S, true) <= lds_max) ? 1 : 0;
+  if (getenv("TJ_NO_SEQ_TREE")) d.seq_tree = 0;  // test hook: behave like a fleet too large for the LDS-resident tree
+  c->lds_seq = seq_lds_bytes(d.U, d.S, d.seq_tree != 0);
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (piece_num <= 10 supported in this version)";
     return TJ_ERR_UNSUPPORTED;
@@ -493,18 +499,18 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   h.gnorm = 1.0;  // Main/multiPathPlanning3D.cpp:594
   if ((r = upload(c, d.ctl, &h, sizeof(h)))) return r;
   c->hull_valid = false;
-  HIPCHK(c, hipMemset(d.xdir, 0, (size_t)U * d.xs * 8));
-  HIPCHK(c, hipMemset(d.ocount, 0, (size_t)U * d.S * 4));
-  HIPCHK(c, hipMemset(d.scount, 0, (size_t)U * d.S * 4));
-  HIPCHK(c, hipMemset(d.ocand_n, 0, (size_t)U * d.S * 4));
+  HIPCHK(c, hipMemsetAsync(d.xdir, 0, (size_t)U * d.xs * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(d.ocount, 0, (size_t)U * d.S * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(d.scount, 0, (size_t)U * d.S * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(d.ocand_n, 0, (size_t)U * d.S * 4, c->stream));
   if (d.optimal_plane) {  // the mains start with empty persistent tables (Main/admmPathPlanning3D.cpp:343-351, Main/multiPathPlanning3D.cpp:450-464)
-    HIPCHK(c, hipMemset(d.kobs_n, 0, (size_t)U * d.S * 4));
-    HIPCHK(c, hipMemset(d.kpair_n, 0, 8));
-    if (d.mode != 0) HIPCHK(c, hipMemset(d.kpair_on, 0, (size_t)d.S * U * U * 4));
+    HIPCHK(c, hipMemsetAsync(d.kobs_n, 0, (size_t)U * d.S * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(d.kpair_n, 0, 8, c->stream));
+    if (d.mode != 0) HIPCHK(c, hipMemsetAsync(d.kpair_on, 0, (size_t)d.S * U * U * 4, c->stream));
   }
-  HIPCHK(c, hipMemset(d.ostamp, 0, (size_t)U * d.S * d.cap_obs * 4));  // epochs restart at 1
-  HIPCHK(c, hipMemset(d.seg_stats, 0, (size_t)U * d.S * 6 * 8));
-  if (d.mode >= 1) HIPCHK(c, hipMemset(d.pairstamp, 0, (size_t)d.S * U * U * 4));  // epochs restart at 1
+  HIPCHK(c, hipMemsetAsync(d.ostamp, 0, (size_t)U * d.S * d.cap_obs * 4, c->stream));  // epochs restart at 1
+  HIPCHK(c, hipMemsetAsync(d.seg_stats, 0, (size_t)U * d.S * 6 * 8, c->stream));
+  if (d.mode >= 1) HIPCHK(c, hipMemsetAsync(d.pairstamp, 0, (size_t)d.S * U * U * 4, c->stream));  // epochs restart at 1
   c->have_state = true;
   return TJ_OK;
 }
@@ -673,11 +679,10 @@ int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes) {
   std::vector<int> zero(d.S, 0);
   for (int tr = 0; tr < d.S; tr++) {
     if (counts[tr] > d.cap_obs) { c->err = "tj_set_planes: more planes than cap_obs"; return TJ_ERR_CAPACITY; }
-    if (counts[tr]) HIPCHK(c, hipMemcpy(d.oplanes + ((size_t)u * d.S + tr) * d.cap_obs * 4, planes + 4 * w, (size_t)counts[tr] * 32, hipMemcpyHostToDevice));
+    if (counts[tr]) { int ur = upload(c, d.oplanes + ((size_t)u * d.S + tr) * d.cap_obs * 4, planes + 4 * w, (size_t)counts[tr] * 32); if (ur) return ur; }
     w += counts[tr];
   }
-  HIPCHK(c, hipMemcpy(d.ocount + (size_t)u * d.S, counts, d.S * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(d.scount + (size_t)u * d.S, zero.data(), d.S * 4, hipMemcpyHostToDevice));
+  { int ur; if ((ur = upload(c, d.ocount + (size_t)u * d.S, counts, d.S * 4)) || (ur = upload(c, d.scount + (size_t)u * d.S, zero.data(), d.S * 4))) return ur; }
   return TJ_OK;
 }
 
@@ -698,6 +703,16 @@ int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, d
     if (gn) *gn = h.gnorm;
   }
   return TJ_OK;
+}
+
+int tj_set_direction(tj_ctx* c, int u, const double* direction, double t_direction, double wolfe, double gn) {
+  if (!c || u < 0 || u >= c->d.U || !direction) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  QUIESCE(c);
+  std::vector<double> rec(d.xs, 0.0);
+  memcpy(rec.data(), direction, 3 * d.T * 8);
+  rec[3 * d.T] = t_direction; rec[3 * d.T + 1] = wolfe; rec[3 * d.T + 2] = gn;
+  return upload(c, d.xdir + (size_t)u * d.xs, rec.data(), d.xs * 8);
 }
 
 int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361) {
@@ -730,7 +745,7 @@ struct DevBuf {
 };
 int to_dev(tj_ctx* c, DevBuf& b, const void* src, size_t bytes) {
   HIPCHK(c, hipMalloc(&b.p, std::max<size_t>(bytes, 8)));
-  if (src && bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  if (src && bytes) return upload(c, b.p, src, bytes);
   return TJ_OK;
 }
 }  // namespace
@@ -774,8 +789,8 @@ int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, 
   const size_t qbytes = (what == 0 || what == 2 || what == 5) ? (size_t)n * 24 : (size_t)n * 144;  // what 1, 3, 4, 6: hull vs hull
   DevBuf dp, dq, dout; int r;
   if ((r = to_dev(c, dp, P, (size_t)n * 144)) || (r = to_dev(c, dq, Q, qbytes)) || (r = to_dev(c, dout, nullptr, (size_t)n * 40))) return r;
-  HIPCHK(c, hipMemset(dout.p, 0, std::max<size_t>((size_t)n * 40, 8)));
-  if (what >= 5 && n > 0) HIPCHK(c, hipMemcpy(dout.p, out, (size_t)n * 40, hipMemcpyHostToDevice));  // in/out: the plane to refine
+  HIPCHK(c, hipMemsetAsync(dout.p, 0, std::max<size_t>((size_t)n * 40, 8), c->stream));
+  if (what >= 5 && n > 0) { int ur = upload(c, dout.p, out, (size_t)n * 40); if (ur) return ur; }  // in/out: the plane to refine
   if (what == 7) hipLaunchKernelGGL(k_dbg_optpair_wave, dim3(std::max(n, 1)), dim3(64), 0, c->stream, c->d, n, (const double*)dp.p, (const double*)dq.p, (double*)dout.p);
   else if (what == 4) hipLaunchKernelGGL(k_dbg_pair_wave, dim3(std::max(n, 1)), dim3(64), 0, c->stream, c->d, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
   else hipLaunchKernelGGL(k_dbg_planes, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, what, n, (const double*)dp.p, (const double*)dq.p, dist, (double*)dout.p);
@@ -1075,7 +1090,7 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   s->nodes_dcd = tot[0]; s->cand_dcd = tot[1]; s->nodes_ccd = tot[2]; s->cand_ccd = tot[3]; s->planes_obs = tot[4]; s->planes_self = tot[5];
   s->energy_evals = h.energy_evals; s->llt_fail_piece = h.llt_fail_piece; s->llt_fail_robot = h.llt_fail_robot; s->newton_iters = h.newton_iters; s->pair_solves = h.pair_solves;
   s->pair_tests = d.mode >= 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
-  s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error;
+  s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error; s->order_unresolved = h.order_unresolved;
   return TJ_OK;
 }
 
