@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "E", "H8"])
+    ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "Dtri", "E", "H8"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--coupled", action="store_true", help='time the coupled mode ("decouple":0, one shared piece_time) instead of the shipped decoupled mode; single GPU only')
     ap.add_argument("--optimal-plane", action="store_true", help='time the "optimal_plane":1 variant (persistent planes refined every iteration); not the headline')
@@ -167,7 +167,7 @@ def main():
 
     pkg = importlib.import_module("traj-opt-admm_amd")
     sc = pkg.scenes
-    scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d, "E": sc.scn_e, "H8": lambda: sc.hard(8, 20000)}[args.scene]()
+    scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d, "Dtri": sc.scn_d_tri, "E": sc.scn_e, "H8": lambda: sc.hard(8, 20000)}[args.scene]()
 
     if args.coupled:
         scene = dict(scene); scene["mode"] = 2; scene["name"] += "-coupled"
@@ -278,7 +278,7 @@ def main():
         out = {"metric": "ADMM iterations/sec", "value": K / dt, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['cloud'].shape[0]} obstacle points, "
+               "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['tris'].shape[0] if scene.get('tris') is not None else scene['cloud'].shape[0]} obstacle {'triangles (fp64 narrow phase, fp32 outward-rounded BVH boxes)' if scene.get('tris') is not None else 'points'}, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
                           "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else "1 GPU, whole iteration resident on the device: a linear chain of 10 kernels on one queue (union kernels), enqueued ahead, no host sync",
                           "iters_timed_from": "initial trajectory"}}

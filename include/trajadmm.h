@@ -81,6 +81,16 @@ const char* tj_last_error(const tj_ctx* c);
  * obstacle cloud (row-major n x 3) and builds the static device BVH.  n may be 0 ("init_ob":0). */
 int tj_set_cloud(tj_ctx* c, const double* xyz, int n);
 
+/* Obstacles as a TRIANGLE mesh instead of a point cloud (BASELINE config 5).  Replaces BVH::InitObstacle(V, F)
+ * (HighOrderCCD/BVH/BVH.cpp:15-51) -- a path the reference ships but never calls: its OBJ reader keeps `v` lines only
+ * (CCDUtils.h:320-390) and its live narrow phase hard-wires one-vertex obstacle bodies.  Semantics here = that path with
+ * the body-2 loops the reference left commented out enabled (Separate.h:123-131: d0 = min over the triangle's vertices;
+ * CCD.h:448-458: k-DOP interval over its vertices; GJK / GJKDCD / KDOPDCD already take the body size from their arguments):
+ * broad phase on the triangle's box (BVH.cpp:26-46), then k-DOP, then GJK hull-vs-triangle, CCD clamp like Step::mix_step
+ * (Step.h:380-404).  A triangle with three equal vertices behaves bit for bit like the cloud point.
+ * vertices is row-major n_vertices x 3, faces row-major n_faces x 3 (0-based).  Replaces any cloud set before. */
+int tj_set_mesh(tj_ctx* c, const double* vertices, int n_vertices, const int* faces, int n_faces);
+
 /* Replaces init_variable (Main/admmPathPlanning3D.cpp:249-353 single,
  * Main/multiPathPlanning3D.cpp:342-467 multi): waypoints is [uav_num][piece_num+1][3], already
  * in solver units; builds spline, p_slack = C x, zero duals, t_slack = piece_time = piece_time0,
@@ -121,6 +131,11 @@ int tj_run_stage(tj_ctx* c, int stage);
 /* planes of robot u: counts[S] (obstacle planes first, then inter-robot), planes[total][4] = (cx,cy,cz,d);
  * returns total (>=0) or an error; planes may be NULL to query the size. */
 int tj_get_planes(tj_ctx* c, int u, int* counts_obs, int* counts_self, double* planes, int cap);
+/* broad phase of the last plane stage for (robot u, segment seg): ids[<= cap] = obstacle primitives (indices into the cloud /
+ * face list given to tj_set_cloud / tj_set_mesh, BVH traversal order) that passed BVH::DCDCollision (BVH.cpp:149-193) AND the
+ * k-DOP cull (CCD::KDOPDCD); *n_broad = how many the box query alone returned for this segment SINCE tj_init_state
+ * (a running total: read it after exactly one plane stage).  Returns the number of ids. */
+int tj_get_candidates(tj_ctx* c, int u, int seg, int cap, int* ids, int* n_broad);
 /* teacher forcing: overwrite robot u's plane lists (obstacle list only is used; self list emptied) */
 int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes);
 int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, double* wolfe, double* gn);
@@ -158,7 +173,8 @@ int tj_get_stats(tj_ctx* c, tj_stats* s);
 
 /* ---- known-answer hooks: the device primitives of the hot path on caller-supplied batches -------
  * (host pointers; one case per GPU lane; used by the parity tests against tests/golden/) */
-/* GJK witness vector (replaces gjk(), lib/opengjk/src/openGJK.c:754): n1,n2 in {1,6,12}; a[n][n1][3], b[n][n2][3], v[n][3] */
+/* GJK witness vector (replaces gjk(), lib/opengjk/src/openGJK.c:754): n1 in {6,12}, n2 in {1,3,6,12} (3 = obstacle triangle);
+ * a[n][n1][3], b[n][n2][3], v[n][3] */
 int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
 /* the same query solved cooperatively by a whole wavefront (the form the inter-robot kernels use): must give the same bits */
 int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
@@ -172,6 +188,13 @@ int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const dou
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out);
 /* CCD::GJKCCD / SelfGJKCCD (CCD.h:116,227) on swept hulls, tu[n][2] = (tMax, _tMax): out[n][2] booleans */
 int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double* Q, const double* E, const double* q, const double* tu, double d, double* out);
+/* broad phase alone (replaces aabb::Tree::query(AABB, margin), AABB.cc:829-839 / :608-667, on the tree of BVH::InitPointcloud or
+ * BVH::InitObstacle): boxes[nq][6] = lo.xyz, hi.xyz; counts[nq]; ids[nq][cap] = indices into the caller's cloud / face list */
+int tj_kat_query(tj_ctx* c, int nq, const double* boxes, double margin, int cap, int* counts, int* ids);
+/* triangle obstacle bodies (tj_set_mesh): P, D [n][6][3] hull and direction hull, tri[n][3][3], t[n] step; out[n][8] =
+ * plane ok, cx, cy, cz, d of Separate::opengjk with a 3-vertex body at distance dist | CCD::KDOPDCD(P, tri, dist) |
+ * CCD::KDOPDCD({P, P + t D}, tri, off) | CCD::GJKDCD({P, P + t D}, tri, off)  -- the predicates Step::mix_step uses (Step.h:390-404) */
+int tj_kat_tri(tj_ctx* c, int n, const double* P, const double* D, const double* tri, const double* t, double dist, double off, double* out);
 /* dense LLT failure test + smallest eigenvalue (Eigen LLT / SelfAdjointEigenSolver as used at Gradient_admm.h:38-53): out[nmat][2] */
 int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out);
 

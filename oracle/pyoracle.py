@@ -48,10 +48,19 @@ class Engine:
         self.res = p["res"]
         self.S = self.P * self.res
         self.T = 3 * self.P + 3
-        cloud = np.ascontiguousarray(scene["cloud"], dtype=np.float64)
-        self.N = cloud.shape[0]
         pr = np.array([p["lam"], p["margin"], p["offset"], p["mu"], p["vel_limit"], p["acc_limit"], scene["ks"], p["kt"]], dtype=np.float64)
-        self._f("setup", C.c_int)(C.c_int(self.mode), C.c_int(self.U), C.c_int(self.P), C.c_int(self.res), _d(pr), _d(cloud), C.c_int(self.N))
+        if scene.get("tris") is not None:
+            # obstacle TRIANGLES [N][3][3] (an extension: the reference's live path reads point clouds only);
+            # only the port implements it
+            if kind != "port":
+                raise ValueError("triangle obstacles exist in the port only: the reference's triangle path is dead code")
+            tris = np.ascontiguousarray(scene["tris"], dtype=np.float64).reshape(-1, 9)
+            self.N = tris.shape[0]
+            self._f("setup_prim", C.c_int)(C.c_int(self.mode), C.c_int(self.U), C.c_int(self.P), C.c_int(self.res), _d(pr), _d(tris), C.c_int(self.N), C.c_int(3))
+        else:
+            cloud = np.ascontiguousarray(scene["cloud"], dtype=np.float64)
+            self.N = cloud.shape[0]
+            self._f("setup", C.c_int)(C.c_int(self.mode), C.c_int(self.U), C.c_int(self.P), C.c_int(self.res), _d(pr), _d(cloud), C.c_int(self.N))
         wp = np.ascontiguousarray(scene["waypoints"], dtype=np.float64)
         self._f("init_state", C.c_int)(_d(wp), C.c_double(p["piece_time0"]))
         self.iters = 0
@@ -230,6 +239,39 @@ class Prims:
     def plane_self(self, P, Q, dist, refine=True):
         cd = np.zeros(4)
         ok = self._f("plane_self")(_d(self._cm(P)), _d(self._cm(Q)), C.c_double(dist), C.c_int(int(refine)), _d(cd))
+        return bool(ok), cd
+
+    def query_kat(self, verts, boxes, d):
+        """ref only: raw broad-phase candidate sets of query boxes [nq][6] on the reference's own tree over points
+        (verts [n][3], BVH::InitPointcloud) or triangles (verts [n][3][3], BVH::InitObstacle): list of sorted id arrays"""
+        verts = np.ascontiguousarray(verts, dtype=np.float64)
+        prim = 1 if verts.ndim == 2 else 3
+        n = verts.shape[0]
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        nq = boxes.shape[0]; counts = np.zeros(nq, dtype=np.int32)
+        cap = 1 << 22
+        ids = np.zeros(cap, dtype=np.int32)
+        tot = self._f("query_kat")(C.c_int(prim), _d(verts), C.c_int(n), C.c_int(nq), _d(boxes), C.c_double(d), _i(counts), _i(ids), C.c_int(cap))
+        assert tot <= cap
+        out, w = [], 0
+        for q in range(nq):
+            out.append(np.sort(ids[w:w + counts[q]])); w += counts[q]
+        return out
+
+    def kdop_general(self, A, B, d):
+        """CCD::KDOPDCD on row-major point sets of any size (6 or 12 rows vs 1 or 3 rows)"""
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64).reshape(-1, 3)
+        return bool(self._f("kdop_general")(C.c_int(A.shape[0]), _d(A), C.c_int(B.shape[0]), _d(B), C.c_double(d)))
+
+    def gjk_dcd_general(self, A, B, d):
+        """CCD::GJKDCD on row-major point sets of any size"""
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64).reshape(-1, 3)
+        return bool(self._f("gjk_dcd_general")(C.c_int(A.shape[0]), _d(A), C.c_int(B.shape[0]), _d(B), C.c_double(d)))
+
+    def plane_tri(self, P, tri, dist):
+        """port only: Separate::opengjk with a 3-vertex obstacle body (d0 = min over the vertices)"""
+        cd = np.zeros(4); tri = np.ascontiguousarray(tri, dtype=np.float64).reshape(9)
+        ok = self._f("plane_tri")(_d(self._cm(P)), _d(tri), C.c_double(dist), _d(cd))
         return bool(ok), cd
 
     def min_eig_small(self, H):

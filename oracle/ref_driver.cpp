@@ -492,6 +492,48 @@ int ref_self_gjk_ccd(const double* P, const double* D, const double* Q, const do
   Data Pm = Eigen::Map<const Data>(P, 6, 3), Dm = Eigen::Map<const Data>(D, 6, 3), Qm = Eigen::Map<const Data>(Q, 6, 3), Em = Eigen::Map<const Data>(E, 6, 3);
   return CCD::SelfGJKCCD(Pm, Dm, Qm, Em, d, 0, t1, 0, u1);
 }
+// The same two predicates with body sizes taken from the arguments (CCD::KDOPDCD and CCD::GJKDCD loop over position.rows() /
+// _position.rows(), CCD.h:17-114, :354-413): known answers for 3-vertex obstacle bodies (triangles) and 12-row swept hulls.
+// A, B row-major n x 3.
+int ref_kdop_general(int n1, const double* A, int n2, const double* B, double d) {
+  Data Am(n1, 3), Bm(n2, 3);
+  for (int i = 0; i < n1; i++) for (int k = 0; k < 3; k++) Am(i, k) = A[3 * i + k];
+  for (int i = 0; i < n2; i++) for (int k = 0; k < 3; k++) Bm(i, k) = B[3 * i + k];
+  return CCD::KDOPDCD(Am, Bm, d);
+}
+int ref_gjk_dcd_general(int n1, const double* A, int n2, const double* B, double d) {
+  Data Am(n1, 3), Bm(n2, 3);
+  for (int i = 0; i < n1; i++) for (int k = 0; k < 3; k++) Am(i, k) = A[3 * i + k];
+  for (int i = 0; i < n2; i++) for (int k = 0; k < 3; k++) Bm(i, k) = B[3 * i + k];
+  return CCD::GJKDCD(Am, Bm, d);
+}
+// Broad phase known answers on the reference's own trees: prim = 1 BVH::InitPointcloud(V) + pc_tree.query, prim = 3
+// BVH::InitObstacle(V, F) + ob_tree.query (the dormant triangle path, BVH.cpp:15-51).  verts row-major [n][prim][3];
+// boxes [nq][6] = lo, hi.  ids are appended query after query; returns the total (may exceed cap: then call again).
+int ref_query_kat(int prim, const double* verts, int n, int nq, const double* boxes, double d, int* counts, int* ids, int cap) {
+  BVH bvh;
+  NullBuf nb; std::streambuf* old = std::cout.rdbuf(&nb);
+  if (prim == 1) {
+    Eigen::MatrixXd V(n, 3);
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) V(i, k) = verts[3 * (size_t)i + k];
+    bvh.InitPointcloud(V);
+  } else {
+    Eigen::MatrixXd V(3 * n, 3); Eigen::MatrixXi F(n, 3);
+    for (int i = 0; i < 3 * n; i++) for (int k = 0; k < 3; k++) V(i, k) = verts[3 * (size_t)i + k];
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) F(i, j) = 3 * i + j;
+    bvh.InitObstacle(V, F);
+  }
+  std::cout.rdbuf(old);
+  int w = 0;
+  for (int q = 0; q < nq; q++) {
+    std::vector<double> lo(boxes + 6 * (size_t)q, boxes + 6 * (size_t)q + 3), hi(boxes + 6 * (size_t)q + 3, boxes + 6 * (size_t)q + 6);
+    aabb::AABB box(lo, hi);
+    std::vector<unsigned int> r = prim == 1 ? bvh.pc_tree.query(box, d) : bvh.ob_tree.query(box, d);
+    counts[q] = (int)r.size();
+    for (unsigned int id : r) { if (w < cap) ids[w] = (int)id; w++; }
+  }
+  return w;
+}
 // Broad phase: candidates of every segment of robot u (BVH::DCDCollision / CCDCollision).
 // use_dir=0: DCD with margin d; use_dir=1: CCD using the stage-2 direction.
 int ref_candidates(int u, int use_dir, double d, int* counts /*S*/, int* ids, int cap) {

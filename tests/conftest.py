@@ -68,6 +68,8 @@ def scene_by_name(scenes, name):
         sc = dict(scene_by_name(scenes, name[:-len("_coupled")]))
         sc["mode"] = 2
         return sc
+    if name == "hard_single":   # one UAV (admmPathPlanning3D mode, ks = 1e-8) through a cloud 0.13 from its path: obstacle planes active from iteration 0
+        return dict(scenes.hard(U=1, n_points=2500, seed=12), mode=0, ks=1e-8, name="hard-single")
     return {"tiny_multi": lambda: scenes.tiny(1), "tiny_single": lambda: scenes.tiny(0, n_points=3000), "hard": scenes.hard,
             "scn_a": scenes.scn_a, "scn_b": scenes.scn_b, "scn_c": scenes.scn_c}[name]()
 
@@ -92,3 +94,16 @@ def ccd_order_case(seed, U=7):
         dirs[u] = 0.9 * (tgt[:, None] - sp[u]) + rng.normal(0, 0.05, (3, sp.shape[2]))
         dirs[u][:, :2] = 0; dirs[u][:, -2:] = 0
     return scene, dirs
+
+
+def bvh_kat_case(prim):
+    """same construction as tests/golden/make_golden.py:bvh_kat_case"""
+    rng = np.random.default_rng(4242 + prim)
+    n = 20000
+    pts = rng.uniform(-3, 3, (n, 3))
+    pts[: n // 4] = np.round(pts[: n // 4] * 8) / 8
+    verts = pts if prim == 1 else pts[:, None, :] + rng.normal(0, 0.05, (n, 3, 3))
+    lo = rng.uniform(-3, 3, (400, 3)); ext = rng.uniform(0.0, 1.0, (400, 3)) * rng.choice([0.05, 0.3, 1.5], (400, 1))
+    lo[:100] = np.round(lo[:100] * 8) / 8; ext[:100] = np.round(ext[:100] * 8) / 8
+    boxes = np.concatenate([lo, lo + ext], axis=1)
+    return np.ascontiguousarray(verts), boxes

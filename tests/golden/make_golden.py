@@ -222,6 +222,96 @@ def make_envelope(name, scene, snap=(0, 2, 4, 6, 8), max_iter=200, stop=1e-2):
     np.savez_compressed(os.path.join(HERE, f"envelope_{name}.npz"), **rec)
 
 
+def plane_from_witness(v, tri, dist, offset):
+    """The plane Separate::opengjk builds from the GJK witness vector (Separate.h:107-151) with the body-2 loop the
+    reference keeps commented out (:123-131) enabled: d0 = min_i(-c . B_i).  Plain float64 arithmetic in the reference's
+    association order, so this IS the expected bit pattern given the reference's witness vector."""
+    cn = np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    if cn > dist:
+        return np.zeros(5)
+    c = v / cn
+    d0 = np.inf
+    for b in np.asarray(tri).reshape(-1, 3):
+        d_ = -c[0] * b[0] - c[1] * b[1] - c[2] * b[2]
+        if d0 > d_:
+            d0 = d_
+    return np.array([1.0, c[0], c[1], c[2], d0 - offset])
+
+
+def make_tri_prims():
+    """Known answers for 3-vertex obstacle bodies (BASELINE config 5's "obstacle triangles"; the reference's triangle path
+    BVH::InitObstacle / Step::mix_step is dormant, but gjk(), CCD::KDOPDCD and CCD::GJKDCD take the body sizes from their
+    arguments): witness vectors 6v3 / 12v3, k-DOP truth tables 6v3 / 12v3, the CCD boolean 12v3, and the planes that
+    follow from the witness vectors."""
+    rng = np.random.default_rng(2025)
+    pr = Prims("ref")
+    off, mar = pkg_scenes.DEFAULT_PARAMS["offset"], pkg_scenes.DEFAULT_PARAMS["margin"]
+    d = {}
+    for name, n1 in (("6v3", 6), ("12v3", 12)):
+        A, B, V = [], [], []
+        for i in range(480):
+            kind = i % 8
+            a = rng.uniform(-1, 1, 3) + rng.normal(0, 0.4, (n1, 3))
+            b = rng.uniform(-1, 1, 3) + rng.normal(0, 0.4, (3, 3))
+            if kind == 1:    # overlapping
+                b = b - b.mean(0) + a.mean(0)
+            elif kind == 2:  # collinear body 1
+                t = np.linspace(0, 1, n1)[:, None]; a = a[0] + t * (a[1] - a[0])
+            elif kind == 3:  # degenerate triangle: three equal vertices (must behave like the point body)
+                b[1] = b[0]; b[2] = b[0]
+            elif kind == 4:  # needle triangle: collinear vertices
+                b[2] = b[0] + 0.3 * (b[1] - b[0])
+            elif kind == 5:  # far apart
+                b = b + 50.0
+            elif kind == 6:  # just outside the plane distance
+                b = b - b.mean(0) + a.mean(0) + np.array([1.1, 0, 0])
+            A.append(a); B.append(b); V.append(pr.gjk(a, b))
+        d[f"gjk_{name}_a"] = np.array(A); d[f"gjk_{name}_b"] = np.array(B); d[f"gjk_{name}_v"] = np.array(V)
+    # hull / swept hull vs triangle at realistic distances: planes, k-DOP, CCD
+    P, Dd, T, tu, pl, k6, k12, g12 = [], [], [], [], [], [], [], []
+    for i in range(600):
+        a = rand_hull(rng); da = rng.normal(0, 0.4, (6, 3))
+        gap = rng.uniform(0.02, 0.5)
+        dirn = rng.normal(0, 1, 3); dirn /= np.linalg.norm(dirn)
+        far = a[np.argmax(a @ dirn)]
+        tri = far + dirn * gap + rng.normal(0, 0.25, (3, 3)) * (0.0 if i % 7 == 0 else 1.0)   # every 7th: degenerate (a point)
+        t1 = 0.8 ** rng.integers(0, 6)
+        sw = np.concatenate([a, a + t1 * da], axis=0)
+        P.append(a); Dd.append(da); T.append(tri); tu.append(t1)
+        pl.append(plane_from_witness(pr.gjk(a, tri), tri, off + mar, off))
+        k6.append(pr.kdop_general(a, tri, off + mar)); k12.append(pr.kdop_general(sw, tri, off)); g12.append(pr.gjk_dcd_general(sw, tri, off))
+    d.update(P=np.array(P), D=np.array(Dd), tri=np.array(T), t=np.array(tu), plane_tri=np.array(pl), kdop_dcd_tri=np.array(k6), kdop_ccd_tri=np.array(k12), gjk_ccd_tri=np.array(g12))
+    np.savez_compressed(os.path.join(HERE, "tri_kat.npz"), **d)
+
+
+def bvh_kat_case(prim):
+    """seeded obstacles + query boxes for the broad-phase known answers (shared with the tests)"""
+    rng = np.random.default_rng(4242 + prim)
+    n = 20000
+    pts = rng.uniform(-3, 3, (n, 3))
+    pts[: n // 4] = np.round(pts[: n // 4] * 8) / 8          # a quarter on a lattice: coordinates that touch query faces exactly
+    verts = pts if prim == 1 else pts[:, None, :] + rng.normal(0, 0.05, (n, 3, 3))
+    lo = rng.uniform(-3, 3, (400, 3)); ext = rng.uniform(0.0, 1.0, (400, 3)) * rng.choice([0.05, 0.3, 1.5], (400, 1))
+    lo[:100] = np.round(lo[:100] * 8) / 8; ext[:100] = np.round(ext[:100] * 8) / 8          # lattice-aligned boxes: d = 0.125 makes faces touch lattice points
+    boxes = np.concatenate([lo, lo + ext], axis=1)
+    return np.ascontiguousarray(verts), boxes
+
+
+def make_bvh_kat():
+    """candidate SETS (SURVEY 8c golden item 4) of aabb::Tree::query on the reference's own trees: point cloud
+    (BVH::InitPointcloud) and triangles (BVH::InitObstacle), margins 0.125 (touching cases on the lattice), 0.2, 0.1"""
+    pr = Prims("ref")
+    rec = {}
+    for prim in (1, 3):
+        verts, boxes = bvh_kat_case(prim)
+        for d in (0.125, 0.2, 0.1):
+            sets = pr.query_kat(verts, boxes, d)
+            rec[f"p{prim}_d{d}_n"] = np.array([len(x) for x in sets], dtype=np.int32)
+            rec[f"p{prim}_d{d}_ids"] = np.concatenate(sets).astype(np.int32)
+        rec[f"p{prim}_sum"] = np.array([verts.sum(), np.abs(verts).sum(), boxes.sum()])
+    np.savez_compressed(os.path.join(HERE, "bvh_kat.npz"), **rec)
+
+
 def ccd_order_case(seed, U=7):
     """robots of the `hard` family all heading for one point: many robot pairs collide in the same segment and share
     robots, so Step::self_step's result depends on the pair ORDER of the reference's per-segment dynamic tree"""
@@ -360,6 +450,12 @@ if __name__ == "__main__":
         make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
         make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
         sys.exit(0)
+    if "--bvh-only" in sys.argv:
+        make_bvh_kat()
+        sys.exit(0)
+    if "--tri-only" in sys.argv:
+        make_tri_prims()
+        sys.exit(0)
     if "--ccd-order-only" in sys.argv:
         make_ccd_order()
         sys.exit(0)
@@ -385,4 +481,6 @@ if __name__ == "__main__":
     make_planner()
     make_scn_c()
     make_ccd_order()
+    make_tri_prims()
+    make_bvh_kat()
     print("golden vectors written to", HERE)

@@ -1,0 +1,185 @@
+"""GPU (-m gpu): BASELINE config 5's geometry -- obstacle TRIANGLES (tj_set_mesh) -- and the fp32 outward-rounded BVH boxes.
+
+The reference ships a triangle path it never calls (BVH::InitObstacle BVH.cpp:15-51, Step::mix_step Step.h:313-411) and its
+live narrow phase hard-wires one-vertex bodies, so there is no end-to-end reference run with triangles.  The pin is:
+ (1) known answers from the unmodified reference for everything that IS callable with a 3-vertex body: gjk() 6v3 / 12v3,
+     CCD::KDOPDCD, CCD::GJKDCD, and aabb::Tree::query on the tree BVH::InitObstacle builds (candidate SETS);
+ (2) the size-independent property that a triangle with three equal vertices is the cloud point: such a scene must give
+     the point-cloud results (which ARE reference-pinned) bit for bit;
+ (3) the CPU oracle (pinned by the same vectors) on whole iterations, incl. the 256-UAV / 1M-triangle scene."""
+import numpy as np
+import pytest
+
+from conftest import canon, gold, maxdiff
+
+pytestmark = pytest.mark.gpu
+STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
+
+
+@pytest.fixture(scope="module")
+def katsolver(pkg, scenes):
+    s = pkg.Solver(scenes.tiny(1), stop=0.0)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("shape", ["6v3", "12v3"])
+def test_device_gjk_triangle_body_bit_exact_vs_reference(katsolver, shape):
+    g = gold("tri_kat.npz")
+    want = g[f"gjk_{shape}_v"]
+    for v in (katsolver.kat_gjk(g[f"gjk_{shape}_a"], g[f"gjk_{shape}_b"]), katsolver.kat_gjk_wave(g[f"gjk_{shape}_a"], g[f"gjk_{shape}_b"])):
+        same = (v == want) | (np.isnan(v) & np.isnan(want))
+        assert same.all(), f"{(~same).any(axis=1).sum()} of {len(v)} witness vectors differ"
+
+
+def test_device_triangle_planes_kdop_ccd_vs_reference(katsolver):
+    g = gold("tri_kat.npz")
+    out = katsolver.kat_tri(g["P"], g["D"], g["tri"], g["t"], 0.2, 0.1)
+    assert np.array_equal(out[:, 0], g["plane_tri"][:, 0])
+    ok = out[:, 0] == 1
+    assert np.array_equal(out[ok, 1:5], g["plane_tri"][ok, 1:])            # planes from the reference's witness vectors: bit-exact
+    assert np.array_equal(out[:, 5], g["kdop_dcd_tri"].astype(float))       # CCD::KDOPDCD(hull, triangle)
+    assert np.array_equal(out[:, 6], g["kdop_ccd_tri"].astype(float))       # CCD::KDOPDCD(swept hull, triangle)
+    assert np.array_equal(out[:, 7], g["gjk_ccd_tri"].astype(float))        # CCD::GJKDCD(swept hull, triangle)
+
+
+@pytest.mark.parametrize("prim", [1, 3])
+def test_broad_phase_candidate_sets_vs_reference_trees(pkg, scenes, prim):
+    """aabb::Tree::query on the reference's own trees (InitPointcloud / InitObstacle) vs the static fp32-box BVH: identical
+    candidate SETS for 400 query boxes x 3 margins, incl. lattice cases where a face touches a point exactly"""
+    from conftest import bvh_kat_case
+    g = gold("bvh_kat.npz")
+    verts, boxes = bvh_kat_case(prim)
+    assert np.allclose([verts.sum(), np.abs(verts).sum(), boxes.sum()], g[f"p{prim}_sum"], rtol=1e-13)
+    sc = dict(scenes.tiny(1))
+    if prim == 1:
+        sc["cloud"] = verts
+    else:
+        sc["tris"] = verts
+    s = pkg.Solver(sc, stop=0.0)
+    for d in (0.125, 0.2, 0.1):
+        got = s.kat_query(boxes, d)
+        n = g[f"p{prim}_d{d}_n"]; ids = g[f"p{prim}_d{d}_ids"]
+        assert np.array_equal(np.array([len(x) for x in got]), n)
+        assert np.array_equal(np.concatenate(got), ids)
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["hard", "scn_b", "tiny_single", "hard_single"])
+def test_degenerate_triangles_reproduce_the_point_cloud_bitwise(pkg, scenes, name):
+    """three equal vertices = the cloud point: every stage (BVH over triangle boxes, k-DOP, GJK hull-vs-triangle, CCD) must
+    give the point-cloud path's bits, which are pinned to the reference"""
+    from conftest import scene_by_name
+    sc = scene_by_name(scenes, name)
+    a = pkg.Solver(sc, stop=0.0)
+    b = pkg.Solver(scenes.triangulate(sc, degenerate=True), stop=0.0)
+    for it in range(10):
+        a.iterate(1); b.iterate(1)
+        sa, sb = a.get_state(), b.get_state()
+        for n in STATE:
+            assert np.array_equal(sa[n], sb[n]), (it, n)
+    ca, pa = a.get_planes(); cb, pb = b.get_planes()
+    assert np.array_equal(ca, cb) and np.array_equal(pa, pb)
+    assert a.stats()["error_bits"] == 0 and b.stats()["error_bits"] == 0
+    assert a.stats()["cand_dcd"] == b.stats()["cand_dcd"] and a.stats()["cand_ccd"] == b.stats()["cand_ccd"]
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", ["hard", "scn_b", "hard_single"])
+def test_triangle_scene_stages_vs_oracle(pkg, scenes, name):
+    """real triangles (vertices within 0.025 of the cloud point, so the initial trajectory stays feasible: the `hard` cloud is
+    0.13 from the paths and offset is 0.1): every stage teacher-forced from the CPU oracle's state"""
+    from conftest import scene_by_name
+    from oracle.pyoracle import Engine
+    sc = scenes.triangulate(scene_by_name(scenes, name), size=0.025)
+    o = Engine("port", sc)
+    s = pkg.Solver(sc, stop=0.0)
+    seen_planes = 0
+    for it in range(10):
+        s.set_state(o.get_state())
+        co, po = o.stage_planes(); cg, pg = s.stage_planes()
+        assert np.array_equal(co, cg)
+        assert maxdiff(canon(co, po), canon(cg, pg)) <= 1e-13
+        seen_planes += int(co.sum())
+        s.set_planes(co, po)
+        do = o.stage_direction(); dg = s.stage_direction()
+        assert np.isfinite(do["direction"]).all()
+        assert maxdiff(do["direction"], dg["direction"]) <= 1e-9
+        so = o.stage_steps(); sg = s.stage_steps()
+        assert np.array_equal(so[0], sg[0]) and np.array_equal(so[1], sg[1])
+        lo = o.stage_linesearch(); lg = s.stage_linesearch()
+        if sc["mode"] == 1:
+            assert maxdiff(lo, lg) <= 1e-12
+        s.set_state(o.get_state())
+        o.stage_slack(); s.stage_slack()
+        a, b = s.get_state(), o.get_state()
+        for n in STATE:
+            assert maxdiff(a[n], b[n]) <= 1e-12 * max(1.0, np.abs(b[n]).max())
+    assert seen_planes > 0 and s.stats()["error_bits"] == 0
+    s.close()
+
+
+def test_config5_256_uavs_1m_triangles(pkg, scenes):
+    """BASELINE config 5 as stated (256 UAVs, 1M obstacle triangles): two whole iterations against the CPU oracle, then
+    size-independent properties: bitwise determinism, no device error, fixed end control points, convergence"""
+    from oracle.pyoracle import Engine
+    sc = scenes.scn_d_tri()
+    o = Engine("port", sc)
+    s = pkg.Solver(sc, stop=0.0)
+    for it in range(2):
+        s.set_state(o.get_state())
+        go = o.iterate()
+        gg, _, _ = s.iterate(1)
+        a, b = s.get_state(), o.get_state()
+        assert abs(gg - go) <= 1e-10 * max(1.0, go), (it, gg, go)
+        for n in STATE:
+            assert maxdiff(a[n], b[n]) <= 1e-9 * max(1.0, np.abs(b[n]).max()), (it, n, maxdiff(a[n], b[n]))
+    assert s.stats()["cand_dcd"] > 0
+    s.close()
+    r1 = pkg.Solver(sc); r2 = pkg.Solver(sc)
+    init = r1.get_state()
+    r1.iterate(6); r2.iterate(6)
+    a, b = r1.get_state(), r2.get_state()
+    for n in STATE:
+        assert np.array_equal(a[n], b[n]), f"{n} is not bitwise reproducible"
+    gnorm, iters, conv = r1.iterate(80)
+    assert conv
+    fin = r1.get_state()
+    assert r1.stats()["error_bits"] == 0
+    assert np.isfinite(fin["spline"]).all() and (fin["piece_time"] > 0).all()
+    assert np.array_equal(fin["spline"][:, :, :2], init["spline"][:, :, :2]) and np.array_equal(fin["spline"][:, :, -2:], init["spline"][:, :, -2:])
+    r1.close(); r2.close()
+
+
+def test_cli_triangle_front_end(pkg, scenes, tmp_path):
+    """multiPathPlanning3D --triangles: OBJ `f` lines -> tj_set_mesh (the reference's reader drops faces, CCDUtils.h:320-390);
+    same working-directory layout, result file and state dump as the point-cloud CLI"""
+    import os, subprocess
+    from conftest import ROOT, rel
+    scene = scenes.triangulate(scenes.scn_b(), size=0.04)
+    mesh = "t.obj"
+    scenes.write_reference_files(scene, str(tmp_path), mesh)
+    os.makedirs(tmp_path / "Config_File", exist_ok=True)
+    (tmp_path / "Config_File" / "3D.json").write_text(
+        '{"auto":0,"init":1,"gui":0,"optimal_plane":0,"decouple":1,"res":8,"vel_limit":2,"acc_limit":2,"lambda":1e1,'
+        '"epsilon":1e-1,"margin":1e-1,"offset":1e-1,"stop":1e-2,"exit":0,"init_ob":1,"mu":0.1}')
+    exe = os.path.join(ROOT, "traj-opt-admm_amd", "multiPathPlanning3D")
+    r = subprocess.run([exe, mesh, "--triangles", "--dump-state", "state.txt", "--max-iter", "300"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f"time_obstacle build: {scene['tris'].shape[0]} triangles" in r.stdout
+    iters = int(open(tmp_path / "result" / (mesh + "_result_file_multi.txt")).read().split("\n")[0].split()[1])
+    s = pkg.Solver(scene)
+    g, it, conv = s.iterate(300)
+    assert conv and abs(it - iters) <= 1
+    lines = open(tmp_path / "state.txt").read().strip().split("\n")
+    T = 3 * scene["P"] + 3
+    cli_spline = np.array([[float(x) for x in l.split()] for l in lines if len(l.split()) == 3 and l[0] not in "u"]).reshape(scene["U"], T, 3)
+    assert rel(cli_spline, s.get_state()["spline"].transpose(0, 2, 1)) <= 1e-6       # x0.2 / x5 file round trip is not bit exact
+    s.close()
+
+
+def test_unsupported_combination_is_refused(pkg, scenes):
+    """Optimal_plane::optimal_cd is defined for obstacle POINTS only: single-UAV optimal_plane:1 + triangles must fail loudly"""
+    sc = scenes.triangulate(scenes.tiny(0, n_points=500))
+    with pytest.raises(pkg.TrajAdmmError, match="triangle"):
+        pkg.Solver(sc, optimal_plane=1)

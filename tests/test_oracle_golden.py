@@ -128,6 +128,41 @@ def test_end_to_end_vs_reference(scenes, name):
     assert abs(gn[-1] - g["gnorm_hist"][-1]) <= 1e-3 * g["gnorm_hist"][-1]
 
 
+def test_triangle_body_primitives_vs_reference():
+    """3-vertex obstacle bodies (BASELINE config 5): gjk 6v3 / 12v3 witness vectors, CCD::KDOPDCD and CCD::GJKDCD booleans from
+    the unmodified reference; planes derived from its witness vectors (tests/golden/make_golden.py:plane_from_witness)"""
+    g = gold("tri_kat.npz")
+    pr = Prims("port")
+    for nm in ("6v3", "12v3"):
+        for a, b, v in zip(g[f"gjk_{nm}_a"], g[f"gjk_{nm}_b"], g[f"gjk_{nm}_v"]):
+            got = pr.gjk(a, b)
+            assert np.array_equal(got, v) or (np.isnan(got).all() and np.isnan(v).all())
+    for i in range(len(g["P"])):
+        ok, cd = pr.plane_tri(g["P"][i], g["tri"][i], 0.2)
+        w = g["plane_tri"][i]
+        assert ok == bool(w[0]) and (not ok or np.array_equal(cd, w[1:]))
+        sw = np.concatenate([g["P"][i], g["P"][i] + g["t"][i] * g["D"][i]])
+        assert pr.kdop_general(g["P"][i], g["tri"][i], 0.2) == bool(g["kdop_dcd_tri"][i])
+        assert pr.kdop_general(sw, g["tri"][i], 0.1) == bool(g["kdop_ccd_tri"][i])
+        assert pr.gjk_dcd_general(sw, g["tri"][i], 0.1) == bool(g["gjk_ccd_tri"][i])
+
+
+@pytest.mark.parametrize("name", ["hard", "tiny_single"])
+def test_degenerate_triangles_are_the_point_cloud_in_the_oracle(scenes, name):
+    """a triangle with three equal vertices must be the cloud point, bit for bit, through whole iterations"""
+    sc = scene_by_name(scenes, name)
+    a = Engine("port", sc)
+    st = []
+    for it in range(6):
+        a.iterate(); st.append(a.get_state())
+    b = Engine("port", scenes.triangulate(sc, degenerate=True))
+    for it in range(6):
+        b.iterate()
+        sb = b.get_state()
+        for n in sb:
+            assert np.array_equal(st[it][n], sb[n]), (it, n)
+
+
 def test_inter_robot_clamp_in_the_references_tree_order():
     """Step::self_step where many colliding pairs of one segment share robots (order dependent, Step.h:213-251)"""
     from conftest import ccd_order_case

@@ -22,10 +22,10 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
 EXPORTS = [
-    "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_init_state", "tj_get_state",
-    "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes",
+    "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_set_mesh", "tj_init_state", "tj_get_state",
+    "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes", "tj_get_candidates",
     "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_linalg",
+    "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
 ]
 
@@ -97,6 +97,7 @@ class Solver:
         self.mode, self.U, self.P = scene["mode"], scene["U"], scene["P"]
         self.res = p["res"]
         self.S, self.T = self.P * self.res, 3 * self.P + 3
+        self.box_bytes, self.prim_vertices = 24, 1   # BVH box record; vertices per obstacle primitive (bench.py's byte model)
         tp = TjParams()
         self.lib.tj_default_params(C.byref(tp), self.mode, self.U, self.P)
         tp.res = self.res
@@ -109,9 +110,16 @@ class Solver:
         self._ctx = C.c_void_p()
         rc = self.lib.tj_create(C.byref(tp), C.byref(self._ctx))
         self._check(rc)
-        cloud = np.ascontiguousarray(scene["cloud"], dtype=np.float64).reshape(-1, 3)
-        self.N = cloud.shape[0]
-        self._check(self.lib.tj_set_cloud(self._ctx, _d(cloud), C.c_int(self.N)))
+        if scene.get("tris") is not None:   # obstacle triangles [N][3][3] (BASELINE config 5): tj_set_mesh with an unshared vertex list
+            verts = np.ascontiguousarray(scene["tris"], dtype=np.float64).reshape(-1, 3)
+            self.N = verts.shape[0] // 3
+            faces = np.arange(3 * self.N, dtype=np.int32).reshape(-1, 3)
+            self._check(self.lib.tj_set_mesh(self._ctx, _d(verts), C.c_int(3 * self.N), _i(faces), C.c_int(self.N)))
+            self.prim_vertices = 3
+        else:
+            cloud = np.ascontiguousarray(scene["cloud"], dtype=np.float64).reshape(-1, 3)
+            self.N = cloud.shape[0]
+            self._check(self.lib.tj_set_cloud(self._ctx, _d(cloud), C.c_int(self.N)))
         self._wp = np.ascontiguousarray(scene["waypoints"], dtype=np.float64)
         self._pt0 = float(p["piece_time0"])
         self.reset()
@@ -205,6 +213,15 @@ class Solver:
             counts[u] = co + cs
             chunks.append(buf[:n])
         return counts, np.concatenate(chunks, axis=0)
+
+    def get_candidates(self, u, cap=4096):
+        """per segment: (obstacle ids that passed box query + k-DOP cull, number the box query alone returned since reset)"""
+        out = []
+        for tr in range(self.S):
+            ids = np.zeros(cap, dtype=np.int32); nb = C.c_int()
+            n = self._check(self.lib.tj_get_candidates(self._ctx, C.c_int(u), C.c_int(tr), C.c_int(cap), _i(ids), C.byref(nb)))
+            out.append((ids[:n].copy(), nb.value))
+        return out
 
     def set_planes(self, counts, planes):
         counts = np.ascontiguousarray(counts, dtype=np.int32).reshape(self.U, self.S)
@@ -338,6 +355,19 @@ class Solver:
         arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (P, D, Q, E, q, tu)]
         n = arrs[0].shape[0]; out = np.zeros((n, 2))
         self._check(self.lib.tj_kat_ccd(self._ctx, C.c_int(n), *[_d(x) for x in arrs], C.c_double(d), _d(out)))
+        return out
+
+    def kat_query(self, boxes, margin, cap=2048):
+        """raw broad-phase candidate SETS of caller-supplied query boxes [nq][6] (lo, hi): list of sorted id arrays"""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        nq = boxes.shape[0]; counts = np.zeros(nq, dtype=np.int32); ids = np.zeros((nq, cap), dtype=np.int32)
+        self._check(self.lib.tj_kat_query(self._ctx, C.c_int(nq), _d(boxes), C.c_double(margin), C.c_int(cap), _i(counts), _i(ids)))
+        return [np.sort(ids[q, :counts[q]]) for q in range(nq)]
+
+    def kat_tri(self, P, D, tri, t, dist, off):
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (P, D, tri, t)]
+        n = arrs[0].shape[0]; out = np.zeros((n, 8))
+        self._check(self.lib.tj_kat_tri(self._ctx, C.c_int(n), *[_d(x) for x in arrs], C.c_double(dist), C.c_double(off), _d(out)))
         return out
 
     def kat_linalg(self, mats):

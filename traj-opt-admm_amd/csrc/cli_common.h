@@ -67,6 +67,37 @@ inline std::vector<double> read_obj_vertices(const std::string& path) {
   return v;
 }
 
+// Triangle-mesh front end (ours: `--triangles` / "triangles":1 in 3D.json; BASELINE config 5).  The reference's reader drops
+// the faces (above) although the library it links has a triangle broad phase (BVH::InitObstacle, BVH.cpp:15-51).  Reads the
+// WHOLE file: every `v x y z` and every `f` line (1-based or negative indices, `i`, `i/t`, `i//n`, `i/t/n` tokens; polygons
+// are fan-triangulated).  F holds 0-based vertex indices, 3 per triangle.
+inline void read_obj_mesh(const std::string& path, std::vector<double>& V, std::vector<int>& F) {
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  V.clear(); F.clear();
+  std::string line;
+  while (std::getline(f, line)) {
+    std::istringstream ls(line);
+    std::string type;
+    if (!(ls >> type)) continue;
+    if (type == "v") {
+      double x, y, z;
+      if (ls >> x >> y >> z) { V.push_back(x); V.push_back(y); V.push_back(z); }
+    } else if (type == "f") {
+      std::vector<int> idx; std::string tok;
+      const int nv = (int)(V.size() / 3);
+      while (ls >> tok) {
+        const long i = strtol(tok.c_str(), nullptr, 10);   // stops at the first '/'
+        if (i == 0) throw std::runtime_error(path + ": bad face token '" + tok + "'");
+        const long v = i > 0 ? i - 1 : nv + i;
+        if (v < 0 || v >= nv) throw std::runtime_error(path + ": face refers to vertex " + std::to_string(i) + " of " + std::to_string(nv));
+        idx.push_back((int)v);
+      }
+      for (size_t k = 1; k + 1 < idx.size(); k++) { F.push_back(idx[0]); F.push_back(idx[k]); F.push_back(idx[k + 1]); }
+    }
+  }
+}
+
 // single: one "x y z" per line.  multi: 3*U numbers per line, U from the first line.
 inline void read_waypoints(const std::string& path, bool multi, int& U, int& P, std::vector<double>& wp /*[U][P+1][3]*/) {
   std::ifstream f(path);

@@ -10,7 +10,9 @@
 //
 // Extras (ours): --max-iter N, --dump-state FILE (control points; the reference never writes the
 // trajectory), --sample-traj FILE (positions sampled like log_data, one "uav t x y z" per line),
-// --batch N iterations per device batch (the stop test runs on the device before every iteration).
+// --batch N iterations per device batch (the stop test runs on the device before every iteration),
+// --triangles (or the optional key "triangles":1 in 3D.json): obstacles are the TRIANGLES of the OBJ (`f` lines, tj_set_mesh)
+// instead of its vertices as a point cloud.
 #include <chrono>
 #include "../../include/trajadmm.h"
 #include "cli_common.h"
@@ -22,15 +24,16 @@ static const bool kMulti = false;
 #endif
 
 int main(int argc, char** argv) {
-  if (argc < 2) { std::cerr << "Syntax: " << argv[0] << " <mesh file> [--max-iter N] [--batch N] [--dump-state FILE] [--sample-traj FILE]" << std::endl; return -1; }
+  if (argc < 2) { std::cerr << "Syntax: " << argv[0] << " <mesh file> [--max-iter N] [--batch N] [--dump-state FILE] [--sample-traj FILE] [--triangles]" << std::endl; return -1; }
   const std::string mesh = argv[1];
-  long max_iter = 1000000; int batch = 8; std::string dump, sample_file;
+  long max_iter = 1000000; int batch = 8; std::string dump, sample_file; bool triangles = false;
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--max-iter" && i + 1 < argc) max_iter = atol(argv[++i]);
     else if (a == "--batch" && i + 1 < argc) batch = atoi(argv[++i]);
     else if (a == "--dump-state" && i + 1 < argc) dump = argv[++i];
     else if (a == "--sample-traj" && i + 1 < argc) sample_file = argv[++i];
+    else if (a == "--triangles") triangles = true;
     else { std::cerr << "unknown argument " << a << std::endl; return -1; }
   }
   tj_ctx* ctx = nullptr;
@@ -46,10 +49,14 @@ int main(int argc, char** argv) {
     if (gui) throw std::runtime_error("gui:1 is not part of the accelerated path (use gui:0)");
     if (init != 1 && init != 2) throw std::runtime_error("init must be 1 (init/<mesh>_init_file.txt) or 2 (plan way points from start/goal pairs)");
 
-    std::vector<double> V = tjcli::read_obj_vertices(std::string(kMulti ? "model/multiple/" : "model/single/") + mesh);
+    if (j.count("triangles") && j["triangles"] != 0) triangles = true;   // optional key (ours); the 16 reference keys stay mandatory
+    const std::string model = std::string(kMulti ? "model/multiple/" : "model/single/") + mesh;
+    std::vector<double> V; std::vector<int> F;
+    if (triangles) tjcli::read_obj_mesh(model, V, F); else V = tjcli::read_obj_vertices(model);
     int U = 1, P = 0; std::vector<double> wp;
     if (kMulti) for (double& x : V) x *= 5;  // Main/multiPathPlanning3D.cpp:107
-    const int N = init_ob ? (int)(V.size() / 3) : 0;
+    const int N = init_ob ? (int)(triangles ? F.size() / 3 : V.size() / 3) : 0;
+    auto set_obstacles = [&](tj_ctx* c) { return triangles ? tj_set_mesh(c, V.data(), (int)(V.size() / 3), F.data(), N) : tj_set_cloud(c, V.data(), N); };
     if (init == 1) {
       tjcli::read_waypoints("init/" + mesh + "_init_file.txt", kMulti, U, P, wp);
       if (kMulti) for (double& x : wp) x *= 5;  // :536
@@ -64,7 +71,7 @@ int main(int argc, char** argv) {
       pp.margin = margin; pp.offset = offset;
       auto pchk = [&](int rc, const char* what) { if (rc < 0) { std::string m = std::string(what) + ": " + tj_last_error(pc); if (pc) tj_destroy(pc); throw std::runtime_error(m); } };
       pchk(tj_create(&pp, &pc), "tj_create");
-      pchk(tj_set_cloud(pc, V.data(), N), "tj_set_cloud");
+      pchk(set_obstacles(pc), "tj_set_cloud / tj_set_mesh");
       const int cap = 256; int nw = 0;
       std::vector<double> buf((size_t)U * cap * 3);
       pchk(tj_plan_init(pc, U, starts.data(), goals.data(), 0.0, 0, 0, cap, buf.data(), &nw), "tj_plan_init");
@@ -77,7 +84,7 @@ int main(int argc, char** argv) {
       std::cout << "ompl end\n";
     }
     if (kMulti) std::cout << "uav_num: " << U << "\n";
-    std::cout << "time_obstacle build: " << N << " points" << std::endl;
+    std::cout << "time_obstacle build: " << N << (triangles ? " triangles" : " points") << std::endl;
 
     tj_params p;
     tj_default_params(&p, kMulti ? (decouple ? TJ_MODE_MULTI_DECOUPLE : TJ_MODE_MULTI_COUPLED) : TJ_MODE_SINGLE, U, P);
@@ -85,7 +92,7 @@ int main(int argc, char** argv) {
     p.res = res; p.lambda = lambda; p.margin = margin; p.offset = offset; p.mu = mu; p.vel_limit = vel; p.acc_limit = acc; p.stop = stop;
     auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + tj_last_error(ctx)); };
     chk(tj_create(&p, &ctx), "tj_create");
-    chk(tj_set_cloud(ctx, V.data(), N), "tj_set_cloud");
+    chk(set_obstacles(ctx), "tj_set_cloud / tj_set_mesh");
     chk(tj_init_state(ctx, wp.data(), 20.0), "tj_init_state");  // piece_time = 20 (admmPathPlanning3D.cpp:482)
 
     std::ofstream result("result/" + mesh + (kMulti ? "_result_file_multi.txt" : "_result_file_admm.txt"));

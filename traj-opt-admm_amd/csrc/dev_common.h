@@ -85,11 +85,19 @@ struct Dev {
   const double* mdyn;     // [36]
   const double* kdop;     // [49][3]
   const double* pow08;    // [LOOP_CAP+1]  0.8^k by repeated multiplication
-  // ---- obstacle cloud: Morton-sorted points + implicit 8-ary box hierarchy ----
-  const double *px, *py, *pz;   // [Npad] sorted, padded with +inf
-  int nlevels;                  // level 0 = boxes over 8 consecutive points; top level has <= 64 boxes
+  // ---- obstacles: Morton-sorted primitives + implicit 8-ary box hierarchy ----
+  // prim = 1: a point cloud (the reference's live path, BVH::InitPointcloud BVH.cpp:53-93); prim = 3: triangles (the
+  // reference's dormant BVH::InitObstacle / Step::mix_step path, BVH.cpp:15-51, Step.h:313-411: BASELINE config 5)
+  int prim;
+  const double *px, *py, *pz;   // [N] sorted points (prim == 1)
+  const double* tri;            // [N][9] sorted triangles, three vertices row-major (prim == 3)
+  const float* leafbox;         // [N][6] outward-rounded fp32 box of each triangle: pre-filter before the exact fp64 test (prim == 3)
+  int nlevels;                  // level 0 = boxes over 8 consecutive primitives; top level has <= 64 boxes
   int lvl_off[MAX_LEVELS], lvl_n[MAX_LEVELS];
-  const double* boxes;          // [total][6] lo.xyz hi.xyz, padded slots are empty (lo=+inf, hi=-inf)
+  // Inner boxes are fp32, rounded OUTWARD (lo down, hi up): 24 B instead of 48 B per box visited.  A conservative box can
+  // only add visits, never lose a primitive, and the leaf predicate is evaluated in fp64 on the primitive itself
+  // (AABB.cc:131-148, touching counts) -- so the candidate SET and its order are exactly those of fp64 boxes.
+  const float* boxes;           // [total][6] lo.xyz hi.xyz, padded slots are empty (lo=+inf, hi=-inf)
   // ---- ADMM state, column-major per robot like the reference's Eigen matrices ----
   double *spline;      // [U][3][T]
   double *p_slack;     // [U][3][6P]

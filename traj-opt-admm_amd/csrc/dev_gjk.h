@@ -31,6 +31,11 @@ struct BodyPoint {  // one obstacle point held in registers
   static constexpr int N = 1;
   __device__ __forceinline__ V3 get(int) const { return q; }
 };
+struct BodyTri {  // one obstacle triangle held in registers (body 2 of the reference's dormant triangle path, Step.h:390-404)
+  V3 a, b, c;
+  static constexpr int N = 3;
+  __device__ __forceinline__ V3 get(int i) const { return i == 0 ? a : (i == 1 ? b : c); }
+};
 struct BodyHull {  // 6 control points of one Bezier segment, row-major [6][3] (LDS or global)
   const double* p;
   static constexpr int N = 6;

@@ -119,10 +119,15 @@ inline void build_tables(int P, int res, int loop_cap, HostTables& t) {
 }
 
 // ---- static BVH ----------------------------------------------------------------------------
+// Obstacle primitives (prim = 1: points, prim = 3: triangles given as 3 vertices each) sorted along a 63-bit Morton curve
+// of their centroids, under an implicit 8-ary pyramid of boxes.  Boxes are stored in fp32 rounded OUTWARD.
 struct HostBvh {
-  std::vector<double> px, py, pz;   // Morton order
+  int prim = 1;
+  std::vector<double> px, py, pz;   // Morton order (prim == 1)
+  std::vector<double> tri;          // [n][9] Morton order (prim == 3)
+  std::vector<float> leafbox;       // [n][6] outward-rounded box of each triangle (prim == 3)
   std::vector<int> order;           // sorted position -> original index
-  std::vector<double> boxes;        // all levels, [node][6]
+  std::vector<float> boxes;         // all levels, [node][6]
   std::vector<int> lvl_off, lvl_n;
 };
 
@@ -135,50 +140,73 @@ inline uint64_t spread21(uint64_t v) {
   v = (v | v << 2) & 0x1249249249249249ULL;
   return v;
 }
+// largest float <= x / smallest float >= x
+inline float f32_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
+inline float f32_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
 
-inline void build_bvh(const double* xyz, int n, HostBvh& b) {
+// 63-bit Morton key of a centroid inside [lo, hi]  (shared with the device build, kernels_bvh.h: same expression, same bits)
+inline uint64_t morton_key(const double* c, const double* lo, const double* hi) {
+  uint64_t code = 0;
+  for (int k = 0; k < 3; k++) {
+    const double ext = hi[k] - lo[k];
+    const double f = ext > 0 ? (c[k] - lo[k]) / ext : 0.0;
+    const uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, f * 2097152.0));
+    code |= spread21(q) << k;
+  }
+  return code;
+}
+inline void prim_centroid(const double* v, int prim, double* c) {
+  for (int k = 0; k < 3; k++) c[k] = prim == 1 ? v[k] : (v[k] + v[3 + k] + v[6 + k]) / 3.0;
+}
+
+// verts: [n][prim][3]
+inline void build_bvh(const double* verts, int n, int prim, HostBvh& b) {
   b = HostBvh();
+  b.prim = prim;
   if (n <= 0) return;
+  const size_t st = 3 * (size_t)prim;
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], xyz[3 * i + k]); hi[k] = std::max(hi[k], xyz[3 * i + k]); }
-  std::vector<std::pair<uint64_t, int>> key(n);
+  std::vector<double> cen((size_t)n * 3);
   for (int i = 0; i < n; i++) {
-    uint64_t code = 0;
+    prim_centroid(verts + st * i, prim, &cen[3 * (size_t)i]);
+    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], cen[3 * (size_t)i + k]); hi[k] = std::max(hi[k], cen[3 * (size_t)i + k]); }
+  }
+  std::vector<std::pair<uint64_t, int>> key(n);
+  for (int i = 0; i < n; i++) key[i] = {morton_key(&cen[3 * (size_t)i], lo, hi), i};
+  std::sort(key.begin(), key.end());   // ties broken by the original index: the order is a function of the input alone
+  b.order.resize(n);
+  if (prim == 1) { b.px.resize(n); b.py.resize(n); b.pz.resize(n); } else { b.tri.resize((size_t)n * 9); b.leafbox.resize((size_t)n * 6); }
+  std::vector<double> plo((size_t)n * 3), phi((size_t)n * 3);   // exact fp64 box of every primitive, sorted order
+  for (int i = 0; i < n; i++) {
+    const int o = key[i].second; b.order[i] = o;
+    const double* v = verts + st * o;
     for (int k = 0; k < 3; k++) {
-      const double ext = hi[k] - lo[k];
-      double f = ext > 0 ? (xyz[3 * i + k] - lo[k]) / ext : 0.0;
-      uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, f * 2097152.0));
-      code |= spread21(q) << k;
+      double l = INFINITY, h = -INFINITY;
+      for (int j = 0; j < prim; j++) { l = std::min(l, v[3 * j + k]); h = std::max(h, v[3 * j + k]); }
+      plo[3 * (size_t)i + k] = l; phi[3 * (size_t)i + k] = h;
     }
-    key[i] = {code, i};
+    if (prim == 1) { b.px[i] = v[0]; b.py[i] = v[1]; b.pz[i] = v[2]; }
+    else {
+      for (int k = 0; k < 9; k++) b.tri[(size_t)i * 9 + k] = v[k];
+      for (int k = 0; k < 3; k++) { b.leafbox[(size_t)i * 6 + k] = f32_down(plo[3 * (size_t)i + k]); b.leafbox[(size_t)i * 6 + 3 + k] = f32_up(phi[3 * (size_t)i + k]); }
+    }
   }
-  std::sort(key.begin(), key.end());
-  b.px.resize(n); b.py.resize(n); b.pz.resize(n); b.order.resize(n);
-  for (int i = 0; i < n; i++) { const int o = key[i].second; b.order[i] = o; b.px[i] = xyz[3 * o]; b.py[i] = xyz[3 * o + 1]; b.pz[i] = xyz[3 * o + 2]; }
-  // level 0: boxes over 8 consecutive points; higher levels: boxes over 8 consecutive boxes
+  // level 0: boxes over 8 consecutive primitives; higher levels: boxes over 8 consecutive boxes.  Unions are taken in fp64
+  // and rounded outward once per box.
+  std::vector<double> cl, ch;   // current level, fp64
   int cnt = (n + 7) / 8;
-  b.lvl_off.push_back(0); b.lvl_n.push_back(cnt);
-  b.boxes.assign((size_t)cnt * 6, 0.0);
-  for (int g = 0; g < cnt; g++) {
-    double l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = 8 * g; i < std::min(n, 8 * g + 8); i++) {
-      const double p[3] = {b.px[i], b.py[i], b.pz[i]};
-      for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], p[k]); h[k] = std::max(h[k], p[k]); }
-    }
-    for (int k = 0; k < 3; k++) { b.boxes[(size_t)g * 6 + k] = l[k]; b.boxes[(size_t)g * 6 + 3 + k] = h[k]; }
-  }
-  while (cnt > 64) {
-    const int prev_off = b.lvl_off.back(), prev_n = cnt;
-    cnt = (cnt + 7) / 8;
+  cl.assign((size_t)cnt * 3, INFINITY); ch.assign((size_t)cnt * 3, -INFINITY);
+  for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { cl[3 * (size_t)(i / 8) + k] = std::min(cl[3 * (size_t)(i / 8) + k], plo[3 * (size_t)i + k]); ch[3 * (size_t)(i / 8) + k] = std::max(ch[3 * (size_t)(i / 8) + k], phi[3 * (size_t)i + k]); }
+  for (;;) {
     const int off = (int)(b.boxes.size() / 6);
     b.lvl_off.push_back(off); b.lvl_n.push_back(cnt);
     b.boxes.resize((size_t)(off + cnt) * 6);
-    for (int g = 0; g < cnt; g++) {
-      double l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
-      for (int i = 8 * g; i < std::min(prev_n, 8 * g + 8); i++)
-        for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], b.boxes[(size_t)(prev_off + i) * 6 + k]); h[k] = std::max(h[k], b.boxes[(size_t)(prev_off + i) * 6 + 3 + k]); }
-      for (int k = 0; k < 3; k++) { b.boxes[(size_t)(off + g) * 6 + k] = l[k]; b.boxes[(size_t)(off + g) * 6 + 3 + k] = h[k]; }
-    }
+    for (int g = 0; g < cnt; g++) for (int k = 0; k < 3; k++) { b.boxes[(size_t)(off + g) * 6 + k] = f32_down(cl[3 * (size_t)g + k]); b.boxes[(size_t)(off + g) * 6 + 3 + k] = f32_up(ch[3 * (size_t)g + k]); }
+    if (cnt <= 64) break;
+    const int nn = (cnt + 7) / 8;
+    std::vector<double> nl((size_t)nn * 3, INFINITY), nh((size_t)nn * 3, -INFINITY);
+    for (int i = 0; i < cnt; i++) for (int k = 0; k < 3; k++) { nl[3 * (size_t)(i / 8) + k] = std::min(nl[3 * (size_t)(i / 8) + k], cl[3 * (size_t)i + k]); nh[3 * (size_t)(i / 8) + k] = std::max(nh[3 * (size_t)(i / 8) + k], ch[3 * (size_t)i + k]); }
+    cl.swap(nl); ch.swap(nh); cnt = nn;
   }
 }
 

@@ -105,6 +105,56 @@ __global__ __launch_bounds__(64) void k_dbg_ccd(int n, const double* P, const do
   out[2 * i + 1] = (w.x * w.x + w.y * w.y + w.z * w.z <= d * d);
 }
 
+// triangle obstacle bodies (BASELINE config 5), one case per lane: out[i][8] = plane ok, c, d (hull P vs triangle, distance
+// dist) | k-DOP pass hull/triangle at dist | k-DOP pass swept hull {P, P + t D}/triangle at off | GJK CCD hit at off
+__global__ __launch_bounds__(64) void k_dbg_tri(Dev D, int n, const double* P, const double* Dd, const double* tri, const double* t, double dist, double off, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* p = P + (size_t)i * 18; const double* dd = Dd + (size_t)i * 18; const double* q = tri + (size_t)i * 9;
+  const BodyTri tb{V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]}};
+  double* o = out + (size_t)i * 8;
+  double c0 = 0, c1 = 0, c2 = 0, pd = 0;
+  const bool ok = plane_from_witness_body(gjk(BodyHull{p}, tb), tb, dist, D.offset, c0, c1, c2, pd);
+  o[0] = ok; o[1] = c0; o[2] = c1; o[3] = c2; o[4] = pd;
+  double klo[49], khi[49];
+  for (int pass = 0; pass < 2; pass++) {
+    for (int k = 0; k < 49; k++) {
+      const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+      double up = -INFINITY, lo = INFINITY;
+      for (int j = 0; j < 6; j++) { const double lv = x * p[3 * j] + y * p[3 * j + 1] + z * p[3 * j + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+      if (pass) for (int j = 0; j < 6; j++) {
+        const double lv = x * (p[3 * j] + t[i] * dd[3 * j]) + y * (p[3 * j + 1] + t[i] * dd[3 * j + 1]) + z * (p[3 * j + 2] + t[i] * dd[3 * j + 2]);
+        if (lv < lo) lo = lv; if (lv > up) up = lv;
+      }
+      klo[k] = lo; khi[k] = up;
+    }
+    o[5 + pass] = kdop_body_pass(D, klo, khi, tb, pass ? off : dist);
+  }
+  const V3 v = gjk(BodySwept{p, dd, t[i]}, tb);
+  o[7] = (v.x * v.x + v.y * v.y + v.z * v.z <= off * off);
+}
+
+// broad-phase known answers: one wavefront per caller-supplied query box, raw candidate list (sorted primitive indices,
+// traversal order) of aabb::Tree::query(box, margin) (AABB.cc:608-667) on the static BVH
+template <int PRIM>
+__global__ __launch_bounds__(64) void k_dbg_query(Dev D, int nq, const double* boxes, double m, int cap, int* out_ids, int* out_n) {
+  const int b = blockIdx.x;
+  if (b >= nq) return;
+  __shared__ int fa[FRONT_CAP], fb[FRONT_CAP], cand[128];
+  QBox q;
+  for (int k = 0; k < 3; k++) { q.lo[k] = boxes[6 * (size_t)b + k]; q.hi[k] = boxes[6 * (size_t)b + 3 + k]; }
+  int base = 0;
+  unsigned long long visits = 0;
+  bvh_query<4, PRIM>(D, q, m, fa, fb, cand, &visits, [&](int pt) {
+    const bool ok = pt >= 0;
+    const unsigned long long mask = ballot(ok);
+    const int idx = base + prefix_count(mask);
+    if (ok && idx < cap) out_ids[(size_t)b * cap + idx] = pt;
+    base += __popcll(mask);
+  });
+  if (lane_id() == 0) out_n[b] = base;
+}
+
 // one workgroup per matrix: out[2*i] = LLT fails, out[2*i+1] = smallest eigenvalue
 __global__ __launch_bounds__(64) void k_dbg_linalg(int nmat, int n, const double* mats, double* out) {
   extern __shared__ double sm[];

@@ -22,7 +22,10 @@ struct BodyEdge {  // a straight edge: 2 vertices held in registers
   __device__ __forceinline__ V3 get(int i) const { return i == 0 ? a : b; }
 };
 
-// pieces[n][6] = (a, b); owner[n] = edge the piece belongs to; hit[edge] is OR-ed (must be zeroed by the caller)
+// pieces[n][6] = (a, b); owner[n] = edge the piece belongs to; hit[edge] is OR-ed (must be zeroed by the caller).
+// PRIM = 3: triangle obstacles -- GJKDCD takes the body sizes from its arguments (CCD.h:31-35), so an edge against a
+// triangle is the same call with a 3-row _position.
+template <int PRIM>
 __global__ __launch_bounds__(64) void k_edge_hit(Dev D, int n, const double* pieces, const int* owner, int n_prior, const double* prior, double d, int* hit) {
   const int e = blockIdx.x, lane = lane_id();
   if (e >= n) return;
@@ -39,9 +42,9 @@ __global__ __launch_bounds__(64) void k_edge_hit(Dev D, int n, const double* pie
 #pragma unroll
   for (int k = 0; k < 3; k++) { q.lo[k] = fmin(E[k], E[3 + k]); q.hi[k] = fmax(E[k], E[3 + k]); }
   unsigned long long visits = 0;
-  bvh_query<1>(D, q, d, fa, fb, cand, &visits, [&](int pt) {
+  bvh_query<1, PRIM>(D, q, d, fa, fb, cand, &visits, [&](int pt) {
     if (pt >= 0) {
-      const V3 v = gjk(eb, BodyPoint{V3{D.px[pt], D.py[pt], D.pz[pt]}});
+      const V3 v = gjk(eb, PrimOf<PRIM>::load(D, pt));
       h |= (v.x * v.x + v.y * v.y + v.z * v.z <= d * d);
     }
   });

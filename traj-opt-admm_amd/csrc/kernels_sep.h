@@ -10,11 +10,11 @@
 //   plane_pair  device function for one robot pair (hull-hull GJK + 1-D Newton on the offset),
 //               used by kernels_pairs.h which replaces separate_self (Optimization3D_multi.h:237-342).
 //
-// The BVH is an implicit 8-ary box hierarchy over Morton-sorted points.  A wave walks it level
-// by level: 64 lanes test 8 frontier nodes x 8 children per step (coalesced 48-B boxes, 384 B per
-// parent), survivors are compacted into the next frontier with ballot + popcount.  The tree
-// shape is free: the candidate SET is defined by the reference's leaf predicate
-// (AABB.cc:141, touching counts) which is evaluated here on the points themselves in fp64.
+// The BVH is an implicit 8-ary box hierarchy over Morton-sorted primitives (points, or triangles for BASELINE config 5).
+// A wave walks it level by level: 64 lanes test 8 frontier nodes x 8 children per step (coalesced 24-B fp32 boxes,
+// rounded outward; 192 B per parent), survivors are compacted into the next frontier with ballot + popcount.  The tree
+// shape is free: the candidate SET is defined by the reference's leaf predicate (AABB.cc:141, touching counts), which
+// is evaluated here in fp64 on the primitives themselves (a point, or the exact box of a triangle's three vertices).
 #pragma once
 #include "dev_common.h"
 
@@ -22,19 +22,33 @@ namespace tj {
 
 struct QBox { double lo[3], hi[3]; };
 
-__device__ __forceinline__ bool box_hit(const double* b, const QBox& q, double m) {
+__device__ __forceinline__ bool box_hit(const float* b, const QBox& q, double m) {
   // query.overlaps(node): reject if node.hi + m < q.lo or node.lo > q.hi + m on any axis
   bool hit = true;
 #pragma unroll
-  for (int k = 0; k < 3; k++) hit = hit && !(b[3 + k] + m < q.lo[k] || b[k] > q.hi[k] + m);
+  for (int k = 0; k < 3; k++) hit = hit && !((double)b[3 + k] + m < q.lo[k] || (double)b[k] > q.hi[k] + m);
   return hit;
 }
+
+// ---- obstacle primitives as GJK bodies ----
+template <int PRIM> struct PrimOf;
+template <> struct PrimOf<1> {
+  using Body = BodyPoint;
+  static __device__ __forceinline__ Body load(const Dev& D, int i) { return BodyPoint{V3{D.px[i], D.py[i], D.pz[i]}}; }
+};
+template <> struct PrimOf<3> {
+  using Body = BodyTri;
+  static __device__ __forceinline__ Body load(const Dev& D, int i) {
+    const double* t = D.tri + (size_t)i * 9;
+    return BodyTri{V3{t[0], t[1], t[2]}, V3{t[3], t[4], t[5]}, V3{t[6], t[7], t[8]}};
+  }
+};
 
 // Wave-cooperative query.  `process(pt)` is called by all 64 lanes with a candidate point index
 // (or -1) and may use wave collectives.  Returns candidates found; adds visited boxes to *visits.
 // BQ_UNROLL: chunks of 8 frontier nodes whose box loads are in flight together (4 in the plane query, whose kernel has
 // registers to spare; 1 in the CCD query, where the per-lane GJK already fills the register file)
-template <int BQ_UNROLL, class F>
+template <int BQ_UNROLL, int PRIM, class F>
 __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb, int* cand, unsigned long long* visits, F&& process) {
   const int lane = lane_id();
   if (D.N == 0) return 0;
@@ -59,17 +73,17 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
   for (int lv = top - 1; lv >= 0; lv--) {
     int ncount = 0;
     const int nl = D.lvl_n[lv];
-    const double* lvl = D.boxes + (size_t)D.lvl_off[lv] * 6;
+    const float* lvl = D.boxes + (size_t)D.lvl_off[lv] * 6;
     bool overflow = false;
     for (int base = 0; base < count && !overflow; base += 8 * BQ_UNROLL) {
-      int child[BQ_UNROLL]; bool live[BQ_UNROLL]; double bx[BQ_UNROLL][6];
+      int child[BQ_UNROLL]; bool live[BQ_UNROLL]; float bx[BQ_UNROLL][6];
 #pragma unroll
       for (int c = 0; c < BQ_UNROLL; c++) {
         const int slot = base + 8 * c + (lane >> 3);
         const int node = cur[min(slot, count - 1)];
         child[c] = node * 8 + (lane & 7);
         live[c] = slot < count && child[c] < nl;
-        const double* b = lvl + (size_t)min(child[c], nl - 1) * 6;
+        const float* b = lvl + (size_t)min(child[c], nl - 1) * 6;
 #pragma unroll
         for (int k = 0; k < 6; k++) bx[c][k] = b[k];
       }
@@ -78,7 +92,7 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
         if (base + 8 * c >= count) break;
         bool hit = live[c];
 #pragma unroll
-        for (int k = 0; k < 3; k++) hit = hit & !((bx[c][3 + k] + m < q.lo[k]) | (bx[c][k] > q.hi[k] + m));
+        for (int k = 0; k < 3; k++) hit = hit & !(((double)bx[c][3 + k] + m < q.lo[k]) | ((double)bx[c][k] > q.hi[k] + m));
         const unsigned long long mask = ballot(hit);
         const int tot = __popcll(mask);
         if (ncount + tot > FRONT_CAP) { if (lane == 0) atomicOr(&D.ctl->error, ERR_FRONT_OVERFLOW); overflow = true; break; }
@@ -93,20 +107,44 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
   }
   int nc = 0, found = 0;
   for (int base = 0; base < count; base += 8 * BQ_UNROLL) {
-    int pts[BQ_UNROLL]; bool live[BQ_UNROLL]; double px[BQ_UNROLL], py[BQ_UNROLL], pz[BQ_UNROLL];
+    int pts[BQ_UNROLL]; bool live[BQ_UNROLL]; double px[BQ_UNROLL], py[BQ_UNROLL], pz[BQ_UNROLL]; float lb[BQ_UNROLL][6];
 #pragma unroll
-    for (int c = 0; c < BQ_UNROLL; c++) {  // leaf boxes -> points: again all loads of the group first
+    for (int c = 0; c < BQ_UNROLL; c++) {  // leaf boxes -> primitives: again all loads of the group first
       const int slot = base + 8 * c + (lane >> 3);
       const int pt = cur[min(slot, count - 1)] * 8 + (lane & 7);
       pts[c] = pt; live[c] = slot < count && pt < D.N;
       const int pc = min(pt, D.N - 1);
-      px[c] = D.px[pc]; py[c] = D.py[pc]; pz[c] = D.pz[pc];
+      if constexpr (PRIM == 1) { px[c] = D.px[pc]; py[c] = D.py[pc]; pz[c] = D.pz[pc]; }
+      else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) lb[c][k] = D.leafbox[(size_t)pc * 6 + k];
+      }
     }
 #pragma unroll
     for (int c = 0; c < BQ_UNROLL; c++) {
       if (base + 8 * c >= count) break;
-      const double x = px[c], y = py[c], z = pz[c];
-      const bool hit = live[c] & !((x + m < q.lo[0]) | (x > q.hi[0] + m)) & !((y + m < q.lo[1]) | (y > q.hi[1] + m)) & !((z + m < q.lo[2]) | (z > q.hi[2] + m));
+      bool hit;
+      if constexpr (PRIM == 1) {
+        const double x = px[c], y = py[c], z = pz[c];
+        hit = live[c] & !((x + m < q.lo[0]) | (x > q.hi[0] + m)) & !((y + m < q.lo[1]) | (y > q.hi[1] + m)) & !((z + m < q.lo[2]) | (z > q.hi[2] + m));
+      } else {
+        // fp32 pre-filter (conservative), then the exact box of the three vertices in fp64 (BVH::InitObstacle, BVH.cpp:26-46)
+        bool pre = live[c];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pre = pre & !(((double)lb[c][3 + k] + m < q.lo[k]) | ((double)lb[c][k] > q.hi[k] + m));
+        hit = false;
+        if (pre) {
+          const double* t = D.tri + (size_t)pts[c] * 9;
+          hit = true;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            double lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { const double lv = t[3 * j + k]; if (lv < lo) lo = lv; if (lv > hi) hi = lv; }
+            hit = hit & !((hi + m < q.lo[k]) | (lo > q.hi[k] + m));
+          }
+        }
+      }
       const unsigned long long mask = ballot(hit);
       if (hit) cand[nc + prefix_count(mask)] = pts[c];
       nc += __popcll(mask);
@@ -151,6 +189,25 @@ __device__ __forceinline__ bool kdop_point_pass(const Dev& D, const double* klo,
   return true;
 }
 
+// obstacle primitive (1 or 3 vertices) vs cached hull intervals: CCD::KDOPDCD / KDOPCCD with the body-2 loop over
+// _position.rows() (CCD.h:391-400; for one vertex it is kdop_point_pass)
+template <class B>
+__device__ __forceinline__ bool kdop_body_pass(const Dev& D, const double* klo, const double* khi, const B& body, double d) {
+  for (int k = 0; k < 49; k++) {
+    const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+    double up = -INFINITY, lo = INFINITY;
+#pragma unroll
+    for (int i = 0; i < B::N; i++) {
+      const V3 p = body.get(i);
+      const double lv = x * p.x + y * p.y + z * p.z;
+      if (lv < lo) lo = lv;
+      if (lv > up) up = lv;
+    }
+    if (up < klo[k] - d || khi[k] < lo - d) return false;
+  }
+  return true;
+}
+
 // Separate::opengjk (Separate.h:18-163): plane (c,d) between a 6-point hull and one cloud point
 // plane (c,d) from the GJK witness vector v of hull - point (Separate.h:107-151): rejected if |v| > dist
 __device__ __forceinline__ bool plane_from_witness(const V3& v, const V3& qp, double dist, double offset, double& c0, double& c1, double& c2, double& dd) {
@@ -158,6 +215,19 @@ __device__ __forceinline__ bool plane_from_witness(const V3& v, const V3& qp, do
   if (cn > dist) return false;
   c0 = v.x / cn; c1 = v.y / cn; c2 = v.z / cn;
   const double d0 = -c0 * qp.x - c1 * qp.y - c2 * qp.z;
+  dd = d0 - offset;
+  return true;
+}
+// the same for a body of B::N vertices: d0 = min_i(-c . B_i), the loop the reference keeps commented out at Separate.h:123-131
+template <class B>
+__device__ __forceinline__ bool plane_from_witness_body(const V3& v, const B& body, double dist, double offset, double& c0, double& c1, double& c2, double& dd) {
+  const double cn = norm3(v.x, v.y, v.z);
+  if (cn > dist) return false;
+  c0 = v.x / cn; c1 = v.y / cn; c2 = v.z / cn;
+  const V3 q0 = body.get(0);
+  double d0 = -c0 * q0.x - c1 * q0.y - c2 * q0.z;
+#pragma unroll
+  for (int i = 1; i < B::N; i++) { const V3 q = body.get(i); const double d_ = -c0 * q.x - c1 * q.y - c2 * q.z; if (d0 > d_) d0 = d_; }
   dd = d0 - offset;
   return true;
 }
@@ -281,6 +351,7 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
 // per round) they made a 45 us tail on a 5 us kernel.  One wave per candidate runs them all at once.
 // Plane order = candidate order = what the fused version produced, so downstream sums see the same sequence.
 constexpr int OBS_SINGLE_MAX = 16;  // candidates of a segment that still get a wave each
+template <int PRIM>
 __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
@@ -306,9 +377,9 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   int* list = D.ocand + seg * D.cap_obs;
   int base = 0;
   unsigned long long visits = 0;
-  const int found = bvh_query<4>(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
+  const int found = bvh_query<4, PRIM>(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
     bool ok = false;
-    if (pt >= 0) ok = kdop_point_pass(D, klo, khi, V3{D.px[pt], D.py[pt], D.pz[pt]}, dist);
+    if (pt >= 0) ok = kdop_body_pass(D, klo, khi, PrimOf<PRIM>::load(D, pt), dist);
     const unsigned long long mask = ballot(ok);
     const int idx = base + prefix_count(mask);
     if (ok) {
@@ -337,6 +408,7 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
 }
 
 // Separate::opengjk (Separate.h:18-163) for one candidate, by one wave
+template <int PRIM>
 __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves) {
   const int lane = lane_id();
   __shared__ double P[18];
@@ -353,12 +425,12 @@ __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves
     const int mine = batch ? first + lane : first;                     // candidate of this lane
     const bool live = !batch || mine < D.ocand_n[seg];
     const int pt = D.ocand[(size_t)seg * D.cap_obs + (live ? mine : first)];
-    const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
+    const typename PrimOf<PRIM>::Body qb = PrimOf<PRIM>::load(D, pt);
     V3 v;
-    if (batch) v = gjk(BodyHull{P}, BodyPoint{qp});                    // one candidate per lane
-    else v = gjk_wave(BodyHull{P}, BodyPoint{qp}, lane);               // one candidate for the whole wave
+    if (batch) v = gjk(BodyHull{P}, qb);                               // one candidate per lane
+    else v = gjk_wave(BodyHull{P}, qb, lane);                          // one candidate for the whole wave
     double c0, c1, c2, dd;
-    if (plane_from_witness(v, qp, dist, D.offset, c0, c1, c2, dd) && live && (batch || lane == 0)) {
+    if (plane_from_witness_body(v, qb, dist, D.offset, c0, c1, c2, dd) && live && (batch || lane == 0)) {
       double* o = D.oraw + ((size_t)seg * D.cap_obs + mine) * 4;
       o[0] = c0; o[1] = c1; o[2] = c2; o[3] = dd;
       D.ostamp[(size_t)seg * D.cap_obs + mine] = epoch;
@@ -366,13 +438,15 @@ __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves
   }
 }
 
+template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_query(Dev D) {
   if (D.ctl->done) return;
-  obs_query_body(D, blockIdx.x);
+  obs_query_body<PRIM>(D, blockIdx.x);
 }
+template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_solve(Dev D) {
   if (D.ctl->done) return;
-  obs_solve_body(D, blockIdx.x, gridDim.x);
+  obs_solve_body<PRIM>(D, blockIdx.x, gridDim.x);
 }
 
 }  // namespace tj

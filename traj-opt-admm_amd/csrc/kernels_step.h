@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
   ccd_prep_segment(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane_id(), sh);
 }
 
+template <int PRIM>
 __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
@@ -86,13 +87,13 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
   const double off = D.offset;
   unsigned long long visits = 0;
   int kmax = 0;
-  const int found = bvh_query<1>(D, q, off, fa, fb, cand, &visits, [&](int pt) {
+  const int found = bvh_query<1, PRIM>(D, q, off, fa, fb, cand, &visits, [&](int pt) {
     if (pt >= 0) {
-      const V3 qp{D.px[pt], D.py[pt], D.pz[pt]};
-      if (kdop_point_pass(D, info + 48, info + 97, qp, off)) {
+      const typename PrimOf<PRIM>::Body qb = PrimOf<PRIM>::load(D, pt);
+      if (kdop_body_pass(D, info + 48, info + 97, qb, off)) {
         int k = max(kmax, atomicAdd(&D.k_obs[u], 0));  // any earlier value is a valid lower bound
         while (k < LOOP_CAP) {
-          const V3 v = gjk(BodySwept{info, info + 18, D.pow08[k]}, BodyPoint{qp});
+          const V3 v = gjk(BodySwept{info, info + 18, D.pow08[k]}, qb);
           if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off * off)) break;
           k++;
         }
@@ -107,9 +108,10 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
   }
 }
 
+template <int PRIM>
 __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
   if (D.ctl->done) return;
-  ccd_obs_body(D, blockIdx.x);
+  ccd_obs_body<PRIM>(D, blockIdx.x);
 }
 
 // Phase A: one wave per (segment, lower robot p0); lanes over the partners p1 > p0.  Survivors are
@@ -446,16 +448,18 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
 //   k_front  obstacle candidate query (owned * S)  |  robot-pair rows (S * U)
 //   k_mid    slack + dual update the previous iteration still owes (owned * P)  |  robot-pair solves  |  obstacle-candidate solves
 //   k_ccd    obstacle CCD clamp (owned * S)  |  robot-pair CCD selection (S * U)
+template <int PRIM>
 __global__ __launch_bounds__(64) void k_front(Dev D) {
   if (D.ctl->done) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
-  if ((int)blockIdx.x < n_obs) obs_query_body(D, blockIdx.x);
+  if ((int)blockIdx.x < n_obs) obs_query_body<PRIM>(D, blockIdx.x);
   else sep_self_rows_body(D, blockIdx.x - n_obs);
   TJ_TIC(D, K_FRONT, 1);
 }
 // two waves per SIMD (<= 256 VGPRs): all 320 + 1024 + 512 blocks of SCN-C are resident at once; at the natural 340 VGPRs a
 // third of them started only when an earlier block had finished, 18-33 us into the kernel
+template <int PRIM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
   const int n_slack = (D.u1 - D.u0) * D.P;
   const int b = blockIdx.x;
@@ -463,13 +467,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
   else if (D.ctl->done) return;
   else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves);
-  else obs_solve_body(D, b - n_slack - n_pair_waves, n_obs_waves);
+  else obs_solve_body<PRIM>(D, b - n_slack - n_pair_waves, n_obs_waves);
   TJ_TIC(D, K_MID, 1);
 }
+template <int PRIM>
 __global__ __launch_bounds__(64) void k_ccd(Dev D) {
   if (D.ctl->done) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
-  if ((int)blockIdx.x < n_obs) ccd_obs_body(D, blockIdx.x);
+  if ((int)blockIdx.x < n_obs) ccd_obs_body<PRIM>(D, blockIdx.x);
   else ccd_self_pairs_body(D, blockIdx.x - n_obs);
 }
 

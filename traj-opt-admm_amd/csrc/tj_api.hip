@@ -103,7 +103,7 @@ const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "
 bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false, bool in_phase = false) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
-  const bool multi = d.mode >= 1, coupled = d.mode == 2;
+  const bool multi = d.mode >= 1, coupled = d.mode == 2, tri = d.prim == 3;
   // Waves striding over the two device-built work lists.  k_mid holds ~1 wave per SIMD (VGPR bound), i.e. 1024 resident
   // waves: a larger grid adds no parallelism, only dispatch time for blocks that find no work (measured: with
   // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
@@ -112,11 +112,19 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   switch (kid) {
     case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
-    case K_FRONT: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_front, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
-    case K_SEP_OBS: if (in_graph || in_phase) return false; hipLaunchKernelGGL(k_obs_query, dim3(owned * d.S), dim3(64), 0, s, d); return true;  // stage API and sharded phase 0
-    case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false; hipLaunchKernelGGL(k_obs_solve, dim3(n_obs_solve), dim3(64), 0, s, d); return true;
+    case K_FRONT: if (!in_graph && !in_phase) return false;
+      if (tri) hipLaunchKernelGGL((k_front<3>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_front<1>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d);
+      return true;
+    case K_SEP_OBS: if (in_graph || in_phase) return false;  // stage API and sharded phase 0
+      if (tri) hipLaunchKernelGGL((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d);
+      return true;
+    case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false;
+      if (tri) hipLaunchKernelGGL((k_obs_solve<3>), dim3(n_obs_solve), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_solve<1>), dim3(n_obs_solve), dim3(64), 0, s, d);
+      return true;
     case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
-    case K_MID: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_mid, dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); return true;
+    case K_MID: if (!in_graph && !in_phase) return false;
+      if (tri) hipLaunchKernelGGL((k_mid<3>), dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else hipLaunchKernelGGL((k_mid<1>), dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
+      return true;
     case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
@@ -126,8 +134,12 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
     case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
     case K_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
-    case K_CCD: if (!in_graph && !in_phase) return false; hipLaunchKernelGGL(k_ccd, dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); return true;
-    case K_CCD_OBS: if (in_graph) return false; hipLaunchKernelGGL(k_ccd_obs, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_CCD: if (!in_graph && !in_phase) return false;
+      if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d);
+      return true;
+    case K_CCD_OBS: if (in_graph) return false;
+      if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d);
+      return true;
     case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
     case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); return !coupled;
@@ -337,7 +349,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   Dev& d = c->d;
   memset(&d, 0, sizeof(d));
-  d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0;
+  d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0; d.prim = 1;
   c->use_graph = getenv("TJ_USE_GRAPH") != nullptr;
   d.fuse = (p->world == 1 && p->mode != TJ_MODE_MULTI_COUPLED) ? 1 : 0;
   d.u0 = (int)((long long)p->rank * d.U / p->world); d.u1 = (int)((long long)(p->rank + 1) * d.U / p->world);
@@ -423,34 +435,64 @@ void tj_destroy(tj_ctx* c) {
   delete c;
 }
 
-int tj_set_cloud(tj_ctx* c, const double* xyz, int n) {
-  if (!c || n < 0 || (n > 0 && !xyz)) return TJ_ERR_INVALID;
+namespace {
+// verts: [n][prim][3] in the caller's order
+int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
   QUIESCE(c);
   drop_graph(c);
   for (void* p : c->cloud_allocs) hipFree(p);
   c->cloud_allocs.clear();
   Dev& d = c->d;
-  d.N = n; d.nlevels = 0; d.px = d.py = d.pz = d.boxes = nullptr;
+  d.N = n; d.nlevels = 0; d.prim = prim; d.px = d.py = d.pz = d.tri = nullptr; d.boxes = d.leafbox = nullptr;
   c->cloud_order.clear();
+  if (prim == 3 && d.optimal_plane && d.mode == TJ_MODE_SINGLE) {
+    c->err = "triangle obstacles with optimal_plane:1 in single-UAV mode are not supported (Optimal_plane::optimal_cd is defined for obstacle points only, Optimal_plane.h:160)";
+    return TJ_ERR_UNSUPPORTED;
+  }
   if (n > 0) {
     HostBvh b;
-    build_bvh(xyz, n, b);
-    if ((int)b.lvl_n.size() > MAX_LEVELS) { c->err = "cloud too large for MAX_LEVELS"; return TJ_ERR_UNSUPPORTED; }
-    double *px, *py, *pz, *boxes;
-    int r;
-    if ((r = dalloc(c, &px, n, &c->cloud_allocs)) || (r = dalloc(c, &py, n, &c->cloud_allocs)) || (r = dalloc(c, &pz, n, &c->cloud_allocs)) ||
-        (r = dalloc(c, &boxes, b.boxes.size(), &c->cloud_allocs))) return r;
-    if ((r = upload(c, px, b.px.data(), (size_t)n * 8)) || (r = upload(c, py, b.py.data(), (size_t)n * 8)) || (r = upload(c, pz, b.pz.data(), (size_t)n * 8)) ||
-        (r = upload(c, boxes, b.boxes.data(), b.boxes.size() * 8))) return r;
-    d.px = px; d.py = py; d.pz = pz; d.boxes = boxes;
+    build_bvh(verts, n, prim, b);
+    if ((int)b.lvl_n.size() > MAX_LEVELS) { c->err = "too many obstacle primitives for MAX_LEVELS"; return TJ_ERR_UNSUPPORTED; }
+    float* boxes; int r;
+    if ((r = dalloc(c, &boxes, b.boxes.size(), &c->cloud_allocs)) || (r = upload(c, boxes, b.boxes.data(), b.boxes.size() * 4))) return r;
+    d.boxes = boxes;
+    if (prim == 1) {
+      double *px, *py, *pz;
+      if ((r = dalloc(c, &px, n, &c->cloud_allocs)) || (r = dalloc(c, &py, n, &c->cloud_allocs)) || (r = dalloc(c, &pz, n, &c->cloud_allocs)) ||
+          (r = upload(c, px, b.px.data(), (size_t)n * 8)) || (r = upload(c, py, b.py.data(), (size_t)n * 8)) || (r = upload(c, pz, b.pz.data(), (size_t)n * 8))) return r;
+      d.px = px; d.py = py; d.pz = pz;
+    } else {
+      double* tri; float* lb;
+      if ((r = dalloc(c, &tri, (size_t)n * 9, &c->cloud_allocs)) || (r = dalloc(c, &lb, (size_t)n * 6, &c->cloud_allocs)) ||
+          (r = upload(c, tri, b.tri.data(), (size_t)n * 72)) || (r = upload(c, lb, b.leafbox.data(), (size_t)n * 24))) return r;
+      d.tri = tri; d.leafbox = lb;
+    }
     d.nlevels = (int)b.lvl_n.size();
     c->cloud_order = b.order;
     for (int k = 0; k < 3; k++) { c->cloud_lo[k] = INFINITY; c->cloud_hi[k] = -INFINITY; }
-    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { c->cloud_lo[k] = std::min(c->cloud_lo[k], xyz[3 * i + k]); c->cloud_hi[k] = std::max(c->cloud_hi[k], xyz[3 * i + k]); }
+    for (size_t i = 0; i < (size_t)n * prim; i++) for (int k = 0; k < 3; k++) { c->cloud_lo[k] = std::min(c->cloud_lo[k], verts[3 * i + k]); c->cloud_hi[k] = std::max(c->cloud_hi[k], verts[3 * i + k]); }
     for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = b.lvl_off[i]; d.lvl_n[i] = b.lvl_n[i]; }
   }
   c->have_cloud = true;
   return TJ_OK;
+}
+}  // namespace
+
+int tj_set_cloud(tj_ctx* c, const double* xyz, int n) {
+  if (!c || n < 0 || (n > 0 && !xyz)) return TJ_ERR_INVALID;
+  return set_obstacles(c, xyz, n, 1);
+}
+
+int tj_set_mesh(tj_ctx* c, const double* vertices, int n_vertices, const int* faces, int n_faces) {
+  if (!c || n_vertices < 0 || n_faces < 0 || (n_faces > 0 && (!vertices || !faces))) return TJ_ERR_INVALID;
+  std::vector<double> tri((size_t)n_faces * 9);
+  for (int f = 0; f < n_faces; f++)
+    for (int j = 0; j < 3; j++) {
+      const int v = faces[3 * (size_t)f + j];
+      if (v < 0 || v >= n_vertices) { c->err = "tj_set_mesh: face " + std::to_string(f) + " refers to vertex " + std::to_string(v); return TJ_ERR_INVALID; }
+      for (int k = 0; k < 3; k++) tri[(size_t)f * 9 + 3 * j + k] = vertices[3 * (size_t)v + k];
+    }
+  return set_obstacles(c, tri.data(), n_faces, 3);
 }
 
 int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
@@ -671,6 +713,27 @@ int tj_get_planes(tj_ctx* c, int u, int* counts_obs, int* counts_self, double* p
   return total;
 }
 
+int tj_get_candidates(tj_ctx* c, int u, int seg, int cap, int* ids, int* n_broad) {
+  if (!c || u < 0 || u >= c->d.U || seg < 0 || seg >= c->d.S || cap < 0) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  QUIESCE(c);
+  const size_t s = (size_t)u * d.S + seg;
+  int n = 0;
+  HIPCHK(c, hipMemcpy(&n, d.ocand_n + s, 4, hipMemcpyDeviceToHost));
+  const int m = std::min(n, cap);
+  if (m > 0 && ids) {
+    std::vector<int> tmp(m);
+    HIPCHK(c, hipMemcpy(tmp.data(), d.ocand + s * d.cap_obs, (size_t)m * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; i++) ids[i] = c->cloud_order[tmp[i]];
+  }
+  if (n_broad) {
+    unsigned long long st[6];
+    HIPCHK(c, hipMemcpy(st, d.seg_stats + s * 6, sizeof(st), hipMemcpyDeviceToHost));
+    *n_broad = (int)st[1];
+  }
+  return n;
+}
+
 int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes) {
   if (!c || u < 0 || u >= c->d.U || !counts) return TJ_ERR_INVALID;
   const Dev& d = c->d;
@@ -760,7 +823,9 @@ int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* 
   else if (n1 == 6 && n2 == 6) hipLaunchKernelGGL((k_dbg_gjk<6, 6>), g, t, 0, c->stream, n, A, B, V);
   else if (n1 == 12 && n2 == 1) hipLaunchKernelGGL((k_dbg_gjk<12, 1>), g, t, 0, c->stream, n, A, B, V);
   else if (n1 == 12 && n2 == 12) hipLaunchKernelGGL((k_dbg_gjk<12, 12>), g, t, 0, c->stream, n, A, B, V);
-  else { c->err = "tj_kat_gjk: body sizes must be 6v1, 6v6, 12v1 or 12v12"; return TJ_ERR_INVALID; }
+  else if (n1 == 6 && n2 == 3) hipLaunchKernelGGL((k_dbg_gjk<6, 3>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 12 && n2 == 3) hipLaunchKernelGGL((k_dbg_gjk<12, 3>), g, t, 0, c->stream, n, A, B, V);
+  else { c->err = "tj_kat_gjk: body sizes must be 6v1, 6v3, 6v6, 12v1, 12v3 or 12v12"; return TJ_ERR_INVALID; }
   HIPCHK(c, hipGetLastError());
   QUIESCE(c);
   HIPCHK(c, hipMemcpy(v, dv.p, (size_t)n * 24, hipMemcpyDeviceToHost));
@@ -777,7 +842,9 @@ int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const dou
   else if (n1 == 12 && n2 == 12) hipLaunchKernelGGL((k_dbg_gjk_wave<12, 12>), g, t, 0, c->stream, n, A, B, V);
   else if (n1 == 6 && n2 == 1) hipLaunchKernelGGL((k_dbg_gjk_wave<6, 1>), g, t, 0, c->stream, n, A, B, V);
   else if (n1 == 12 && n2 == 1) hipLaunchKernelGGL((k_dbg_gjk_wave<12, 1>), g, t, 0, c->stream, n, A, B, V);
-  else { c->err = "tj_kat_gjk_wave: body sizes must be 6v1, 6v6, 12v1 or 12v12"; return TJ_ERR_INVALID; }
+  else if (n1 == 6 && n2 == 3) hipLaunchKernelGGL((k_dbg_gjk_wave<6, 3>), g, t, 0, c->stream, n, A, B, V);
+  else if (n1 == 12 && n2 == 3) hipLaunchKernelGGL((k_dbg_gjk_wave<12, 3>), g, t, 0, c->stream, n, A, B, V);
+  else { c->err = "tj_kat_gjk_wave: body sizes must be 6v1, 6v3, 6v6, 12v1, 12v3 or 12v12"; return TJ_ERR_INVALID; }
   HIPCHK(c, hipGetLastError());
   QUIESCE(c);
   HIPCHK(c, hipMemcpy(v, dv.p, (size_t)n * 24, hipMemcpyDeviceToHost));
@@ -888,7 +955,8 @@ int edges_hit(tj_ctx* c, int n, const double* edges, int n_prior, const double* 
   DevBuf dp, dow, dpr, dh; int r;
   if ((r = to_dev(c, dp, pieces.data(), pieces.size() * 8)) || (r = to_dev(c, dow, owner.data(), (size_t)np * 4)) || (r = to_dev(c, dpr, prior, (size_t)n_prior * 48)) ||
       (r = to_dev(c, dh, hit.data(), (size_t)n * 4))) return r;
-  hipLaunchKernelGGL(k_edge_hit, dim3(np), dim3(64), 0, c->stream, c->d, np, (const double*)dp.p, (const int*)dow.p, n_prior, (const double*)dpr.p, d, (int*)dh.p);
+  if (c->d.prim == 3) hipLaunchKernelGGL((k_edge_hit<3>), dim3(np), dim3(64), 0, c->stream, c->d, np, (const double*)dp.p, (const int*)dow.p, n_prior, (const double*)dpr.p, d, (int*)dh.p);
+  else hipLaunchKernelGGL((k_edge_hit<1>), dim3(np), dim3(64), 0, c->stream, c->d, np, (const double*)dp.p, (const int*)dow.p, n_prior, (const double*)dpr.p, d, (int*)dh.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(hit.data(), dh.p, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -1061,6 +1129,39 @@ int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double*
   HIPCHK(c, hipGetLastError());
   QUIESCE(c);
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_kat_query(tj_ctx* c, int nq, const double* boxes, double margin, int cap, int* counts, int* ids) {
+  if (!c || nq < 0 || cap < 1 || !boxes || !counts || !ids) return TJ_ERR_INVALID;
+  if (!c->have_cloud) { c->err = "tj_kat_query: set the obstacles first"; return TJ_ERR_INVALID; }
+  DevBuf db, di, dn; int r;
+  if ((r = to_dev(c, db, boxes, (size_t)nq * 48)) || (r = to_dev(c, di, nullptr, (size_t)nq * cap * 4)) || (r = to_dev(c, dn, nullptr, (size_t)nq * 4))) return r;
+  if (c->d.prim == 3) hipLaunchKernelGGL((k_dbg_query<3>), dim3(std::max(nq, 1)), dim3(64), 0, c->stream, c->d, nq, (const double*)db.p, margin, cap, (int*)di.p, (int*)dn.p);
+  else hipLaunchKernelGGL((k_dbg_query<1>), dim3(std::max(nq, 1)), dim3(64), 0, c->stream, c->d, nq, (const double*)db.p, margin, cap, (int*)di.p, (int*)dn.p);
+  HIPCHK(c, hipGetLastError());
+  QUIESCE(c);
+  if (nq == 0) return TJ_OK;
+  HIPCHK(c, hipMemcpy(counts, dn.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(ids, di.p, (size_t)nq * cap * 4, hipMemcpyDeviceToHost));
+  for (int q = 0; q < nq; q++) {
+    if (counts[q] > cap) { c->err = "tj_kat_query: a query returned more candidates than cap"; return TJ_ERR_CAPACITY; }
+    for (int i = 0; i < counts[q]; i++) ids[(size_t)q * cap + i] = c->cloud_order[ids[(size_t)q * cap + i]];
+  }
+  return check_device_errors(c);
+}
+
+int tj_kat_tri(tj_ctx* c, int n, const double* P, const double* D, const double* tri, const double* t, double dist, double off, double* out) {
+  if (!c || n < 0 || !P || !D || !tri || !t || !out) return TJ_ERR_INVALID;
+  DevBuf b[4], dout; int r;
+  const void* src[4] = {P, D, tri, t};
+  const size_t sz[4] = {(size_t)n * 144, (size_t)n * 144, (size_t)n * 72, (size_t)n * 8};
+  for (int i = 0; i < 4; i++) if ((r = to_dev(c, b[i], src[i], sz[i]))) return r;
+  if ((r = to_dev(c, dout, nullptr, (size_t)n * 64))) return r;
+  hipLaunchKernelGGL(k_dbg_tri, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d, n, (const double*)b[0].p, (const double*)b[1].p, (const double*)b[2].p, (const double*)b[3].p, dist, off, (double*)dout.p);
+  HIPCHK(c, hipGetLastError());
+  QUIESCE(c);
+  HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 64, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
 

@@ -69,6 +69,33 @@ def scn_e():
     return s
 
 
+def triangulate(scene, size=0.06, seed=11, degenerate=False):
+    """The same scene with TRIANGLE obstacles (BASELINE config 5's geometry type; Solver -> tj_set_mesh): every cloud point
+    becomes a small randomly oriented triangle that contains it (vertices within `size` of the point), tris [N][3][3].
+    degenerate=True: three EQUAL vertices -- such a scene must reproduce the point-cloud results bit for bit."""
+    pts = scene["cloud"]
+    n = pts.shape[0]
+    if degenerate:
+        tris = np.repeat(pts[:, None, :], 3, axis=1)
+    else:
+        rng = np.random.default_rng(seed)
+        off = rng.normal(0.0, 1.0, size=(n, 3, 3))
+        off -= off.mean(axis=1, keepdims=True)                       # centroid stays at the cloud point
+        off *= size / np.maximum(1e-12, np.linalg.norm(off, axis=2).max(axis=1))[:, None, None]
+        tris = pts[:, None, :] + off
+    out = dict(scene)
+    out["tris"] = np.ascontiguousarray(tris)
+    out["name"] = scene["name"] + ("-tri0" if degenerate else "-tri")
+    return out
+
+
+def scn_d_tri():
+    """BASELINE config 5 as stated: 256 UAVs, 1M obstacle TRIANGLES"""
+    s = triangulate(scn_d(), size=0.05)
+    s["name"] = "SCN-D-tri"
+    return s
+
+
 def tiny(mode=1, U=3, n_points=600, seed=5):
     """Small scene for fast oracle-vs-HIP unit tests."""
     if mode == 0:
@@ -96,8 +123,14 @@ def write_reference_files(scene, root, mesh_name):
     os.makedirs(os.path.join(root, "result"), exist_ok=True)
     scale = 0.2 if multi else 1.0
     with open(os.path.join(root, "model", sub, mesh_name), "w") as f:
-        for p in scene["cloud"] * scale:
-            f.write("v %.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
+        if scene.get("tris") is not None:   # triangle obstacles: unshared vertices + `f` lines (the CLIs' --triangles front end)
+            for p in scene["tris"].reshape(-1, 3) * scale:
+                f.write("v %.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
+            for i in range(scene["tris"].shape[0]):
+                f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+        else:
+            for p in scene["cloud"] * scale:
+                f.write("v %.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
     with open(os.path.join(root, "init", mesh_name + "_init_file.txt"), "w") as f:
         wp = scene["waypoints"] * scale
         for k in range(wp.shape[1]):
