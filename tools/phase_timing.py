@@ -15,7 +15,7 @@ os.environ["TRAJADMM_LIB"] = os.path.join(ROOT, "traj-opt-admm_amd", "libtrajadm
 PHASES = {
     "k_begin": ["hull", "planes", "velacc", "reduce", "consensus"],
     "k_grad": ["stage", "planes", "vel/acc", "consensus", "psd", "store"],
-    "k_xsolve": ["load", "assemble", "chol+fwd", "backsolve"],
+    "k_xsolve": ["load", "assemble", "chol+fwd", "backsolve", "finish", "swept-hull tail"],
     "k_linesearch": ["stage", "planes->lds", "setup", "E round0", "later rounds"],
     "k_sep_self_solve": ["load", "gjk+newton+store"],
     "k_sep_obs": ["hull+kdop", "bvh+planes"],

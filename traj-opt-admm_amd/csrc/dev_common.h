@@ -39,6 +39,8 @@ struct Ctl {
   int slack_next;      // the iteration that k_begin just started still owes its slack/dual update
   int any_pair;        // some robot pair is within `offset` at full step this iteration: the sequential CCD replay has work
   int order_unresolved; // segments whose pair order mattered but could not be replayed in the reference's tree order
+  int ticket;          // k_linesearch blocks that have finished (the last one does the next iteration's k_begin work)
+  int pad1;
 
   double gnorm;        // reference global `gnorm`
   // statistics for the algorithmic-byte model; accumulated over iterations

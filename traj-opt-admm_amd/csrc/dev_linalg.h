@@ -208,7 +208,8 @@ __device__ __forceinline__ double sturm_div(double a, double& q) {
   r = fma(r, fma(-q, r, 1.0), r);
   return a * r;
 }
-constexpr int STURM_ROUNDS = 10;  // 64-way multisection: 65^10 > 2^60 subdivisions of the Gershgorin interval
+constexpr int STURM_ROUNDS = 9;   // 64-way multisection: 65^9 > 2^54 subdivisions of the Gershgorin interval (its width is a few times the
+                                  // matrix norm, so the result is good to ~1e-16 of the norm; the parity bar is 1e-12 of it)
 
 // Smallest eigenvalue of the symmetric row-major n x n matrix A (lower triangle authoritative;
 // A is destroyed).  d,e,v,p are LDS scratch of length n.  Called by the whole block.
@@ -301,11 +302,13 @@ __device__ inline double min_eig_lds(double* A, int n, double* d, double* e, dou
 // min_eig_lds for an N x N block held one FULL row per lane in the registers of one wave (both
 // triangles).  Identical arithmetic, in the same order (sequential sums via v_readlane), so the
 // two agree bit for bit; no LDS round trips, no barriers, nothing serialised on one thread.
+// stop (optional, LDS): the caller no longer needs the result once *stop == 1 (checked between Householder steps; uniform)
 template <int N>
-__device__ __forceinline__ double min_eig_wave(double (&r)[N], int lane) {
+__device__ __forceinline__ double min_eig_wave(double (&r)[N], int lane, const volatile int* stop = nullptr) {
   double d[N], e[N];  // wave-uniform
 #pragma unroll
   for (int k = 0; k + 2 < N; k++) {
+    if (stop && *stop == 1) return 0.0;
     double sig = 0;
 #pragma unroll
     for (int i = k + 2; i < N; i++) { const double a = readlane_f64(r[k], i); sig += a * a; }

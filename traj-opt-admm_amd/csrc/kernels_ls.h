@@ -244,8 +244,36 @@ __device__ __forceinline__ void ls_publish_hullinfo(const Dev& D, int u, const d
   }
 }
 
-__global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
-  if (D.ctl->done) return;
+// The work of k_begin, callable by any workgroup: the standalone kernel runs it before the first iteration of a batch, the
+// last k_linesearch block to finish runs it for the NEXT iteration of the same batch (one kernel boundary less per iteration).
+__device__ __forceinline__ void begin_body(const Dev& D) {
+  // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
+  __shared__ int done;
+  if (threadIdx.x == 0) {
+    Ctl h = *D.ctl;  // ONE wide read of the control block instead of a chain of dependent field loads
+    if (h.pending) { h.iter++; h.pending = 0; }  // count the previous iteration (saves a launch)
+    h.slack_now = h.slack_next; h.slack_next = 0;
+    if (!h.done && D.stop > 0 && h.iter > 1 && h.gnorm < D.stop) h.done = 1;
+    done = h.done;
+    if (!done) { h.pending = 1; h.epoch++; h.slack_next = 1; }
+    D.ctl->iter = h.iter; D.ctl->pending = h.pending; D.ctl->slack_now = h.slack_now; D.ctl->slack_next = h.slack_next;
+    D.ctl->done = h.done; D.ctl->epoch = h.epoch; D.ctl->any_pair = 0;   // error bits and counters are only ever touched by atomics elsewhere
+  }
+  __syncthreads();
+  if (done) return;
+  for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
+  if (threadIdx.x == 0) { D.pair_work_n[0] = 0; D.pair_work_n[1] = 0; *D.obs_work_n = 0; }  // [1] = cursor of the pair-solve waves
+  if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
+}
+
+// begin_next = 1: the last block to finish also starts the NEXT iteration (begin_body): the stop test and the counter resets
+// need every block of this kernel to be done, which the ticket establishes; the host then omits the k_begin launch.
+__global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, int begin_next) {
+  if (D.ctl->done) {
+    // converged: the only begin work left for the next iteration is to retire the slack/dual update that k_mid has just paid
+    if (begin_next && blockIdx.x == 0 && threadIdx.x == 0) { D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0; }
+    return;
+  }
   extern __shared__ double sm[];
   __shared__ int pref[512];   // plane prefix per segment (S <= 511 checked on the host)
   __shared__ int s_accept;
@@ -314,6 +342,20 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L) {
   if (D.fuse && D.multi()) ls_publish_hullinfo(D, u, sm + L.ghull + (size_t)wg * S * 18, tid, LS_THREADS);
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
+  if (begin_next) {
+    // No fence: nothing another block of THIS kernel writes is read here (gnorm and the counters come from earlier kernels;
+    // what begin_body resets was consumed by every block before its ticket), and what is written here is read by later
+    // kernels only.  The agent-scope atomic alone orders the tickets.  (An agent-scope release here would write back the
+    // XCD's L2 -- ~40 KB of hull cache per block -- from every block: measured +14 us.)
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&D.ctl->ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (s_last) {
+      if (tid == 0) D.ctl->ticket = 0;
+      begin_body(D);
+    }
+  }
 }
 
 // ---- coupled mode ("decouple":0): Armijo search on the SUM of all robots' energies ---------------

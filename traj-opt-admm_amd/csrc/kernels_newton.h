@@ -19,10 +19,12 @@
 #pragma once
 #include "dev_common.h"
 #include "dev_linalg.h"
+#include "kernels_pairs.h"
 
 namespace tj {
 
 constexpr int GRAD_THREADS = 192;
+constexpr int GRAD_FOLD_THREADS = 512;   // FOLD: 8 waves compact the piece's segments (one each) before 3 of them go on
 
 // dynamic LDS layout of k_grad, in doubles; npl = cap_obs + cap_self (capacity of one plane batch)
 constexpr int GRAD_MAXRES = 16;  // segments per piece staged at once ("res" of 3D.json, shipped value 8)
@@ -89,8 +91,18 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
   Hacc_out = Hacc; gacc_out = gacc;
 }
 
-__global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
+// FOLD: the block first turns the stamped candidate / partner slots of ITS OWN segments into plane lists (the work of
+// k_sep_self_compact, one wave per segment), so that kernel -- and its boundary -- drops out of the single-GPU chain.
+template <bool FOLD>
+__global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
   if (D.ctl->done) return;
+  if constexpr (FOLD) {
+    const int u_ = D.u0 + blockIdx.x / D.P, sp_ = blockIdx.x % D.P;
+    for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64) compact_segment(D, u_, sp_ * D.res + i, threadIdx.x & 63);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x >= GRAD_THREADS) return;   // the remaining barriers count surviving waves only
+  }
   extern __shared__ double sm[];
   const int npl = D.grad_npl;
   double* Pall = sm;                          // [res][18] hulls of the piece's segments, row-major [6][3]
@@ -272,20 +284,32 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
 
   TJ_TIC(D, K_GRAD, 4);
   // ---- PSD repair: only if LLT fails and lambda_min < 0 (Gradient_admm.h:38-53) ----
-  if (tid < 64) {  // wave 0 works on the block in registers, one row per lane; the other waves wait
+  // Wave 0 runs the LLT check (~4 us) while wave 1 already works on the smallest eigenvalue (~15 us) of the same block, both in
+  // registers, one row per lane.  A successful check stops the eigenvalue wave at its next Householder step; a failed one
+  // finds the eigenvalue 4 us further along than if it had been started afterwards -- and it is the repaired blocks
+  // (a third of them in the early iterations) that set the kernel's duration.
+  __shared__ int s_llt;      // -1 unknown, 0 failed, 1 passed
+  __shared__ double s_ev;
+  if (tid == 0) s_llt = -1;
+  __syncthreads();
+  if (tid < 128) {
     double r[19];
-    const int row = min(tid, 18);
+    const int row = min(tid & 63, 18);
 #pragma unroll
     for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
-    const bool llt_ok = chol_check_wave<19>(r);
-    TJ_TIC(D, K_GRAD, 7);
-    if (!llt_ok) {
-      if (tid == 0) atomicAdd(&D.ctl->llt_fail_piece, 1ull);
-#pragma unroll
-      for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
-      const double ev = min_eig_wave<19>(r, tid);
-      if (ev < 0 && tid < 19) H[tid * 19 + tid] = H[tid * 19 + tid] - ev * 1.0 + 0.01 * 1.0;
+    if (tid < 64) {
+      const bool llt_ok = chol_check_wave<19>(r);
+      if (tid == 0) { s_llt = llt_ok ? 1 : 0; if (!llt_ok) atomicAdd(&D.ctl->llt_fail_piece, 1ull); }
+      TJ_TIC(D, K_GRAD, 7);
+    } else {
+      const double ev = min_eig_wave<19>(r, tid & 63, &s_llt);
+      if (tid == 64) s_ev = ev;
     }
+  }
+  __syncthreads();
+  if (s_llt == 0) {
+    const double ev = s_ev;
+    if (ev < 0 && tid < 19) H[tid * 19 + tid] = H[tid * 19 + tid] - ev * 1.0 + 0.01 * 1.0;
   }
   __syncthreads();
   TJ_TIC(D, K_GRAD, 5);
@@ -298,9 +322,16 @@ __global__ __launch_bounds__(GRAD_THREADS) void k_grad(Dev D) {
 
 // ---- per-robot reduced Newton solve -------------------------------------------------------------
 constexpr int XS_THREADS = 64;   // the factorisation runs in one wave per robot: its sync points are wave-local
-constexpr int XS_LOAD_THREADS = 256;  // the whole block streams the piece blocks in and assembles; waves 1..3 then retire
+constexpr int XS_LOAD_THREADS = 512;  // the whole block streams the piece blocks in and assembles; waves 1..7 then retire, or (Dev::fuse) wait for the solve and share the swept-hull tail
 constexpr int XS_BAND = 17;      // pieces couple reduced coordinates at most 17 apart
-__host__ __device__ inline size_t xsolve_lds_doubles(int n) { return 2 * (size_t)n * n + 8 * (size_t)n + 16 + ((size_t)(n + 2) / 9) * 380; }
+// n = 9P-2.  Layout: H[n*n] L[n*n] g0[n] x0[n] scr[6n] lhu[P*361] lgu[P*19] | tail: net[3T] dir[3T].  The swept-hull tail
+// (Dev::fuse) reuses the front of the buffer for its S x 54 hull values, so the front part is at least that large.
+__host__ __device__ inline size_t xsolve_front_doubles(int n) {
+  const size_t P = ((size_t)n + 2) / 9, base = 2 * (size_t)n * n + 8 * (size_t)n + 16 + P * 380;
+  const size_t hulls = 8 * P * 54 * 2;   // res <= 16 segments per piece
+  return base > hulls ? base : hulls;
+}
+__host__ __device__ inline size_t xsolve_lds_doubles(int n) { return xsolve_front_doubles(n) + 6 * (((size_t)n + 2) / 3 + 4) + 8; }
 
 // Factor the reduced system held in LDS (L, row-major n x n) with the register-resident wave kernel when
 // n = 9P-2 fits one row per lane (P <= 7); the factor's band + arrow row and the forward-substituted
@@ -333,12 +364,93 @@ __device__ __forceinline__ bool xs_factor_regs(double* L, double* x0, int n, int
   handled = false;
   return false;
 }
+// x = L^-T y for the arrowhead-band factor in LDS (row-major n x n), by ONE wave with y in registers (lane i = y_i, n <= 64).
+// Same operations as chol_arrow_backsolve_lds (x_j = y_j / l_jj, then y_i -= x_j * l_ji), but the row of L needed by the next
+// step is fetched while the current division runs, x_j travels by v_readlane, and there is no LDS round trip or barrier on
+// the dependent chain: ~0.1 us per unknown instead of ~0.19.
+__device__ __forceinline__ double backsolve_wave(const double* L, int n, int bw, double y, int lane) {
+  const int last = n - 1;
+  {  // the arrow row is dense
+    const double lrow = L[last * n + min(lane, last)];
+    const double xl = readlane_f64(y, last) / readlane_f64(lrow, last);
+    y = lane == last ? xl : (lane < last ? y - xl * lrow : y);
+  }
+  double lrow = L[max(last - 1, 0) * n + min(lane, last)];
+#pragma unroll 1
+  for (int j = last - 1; j >= 0; j--) {
+    const double nxt = L[max(j - 1, 0) * n + min(lane, last)];   // next step's row: independent of the chain
+    const double xj = readlane_f64(y, j) / readlane_f64(lrow, j);
+    y = lane == j ? xj : ((lane < j && lane + bw >= j) ? y - xj * lrow : y);
+    lrow = nxt;
+  }
+  return y;
+}
+
 // one factorisation attempt: registers when the size allows, LDS otherwise
 __device__ __forceinline__ bool xs_factor(double* L, double* x0, int n, int tid, int npiv) {
   bool handled;
   const bool ok = xs_factor_regs(L, x0, n, tid, npiv, handled);
   if (handled) return ok;
   return chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0, npiv);
+}
+
+// wave 0 of k_xsolve: factor, solve, direction record (all sync points are wave-local)
+__device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, int m, double* H, double* L, double* g0, double* x0, double* scr) {
+  const int T = D.T;
+  TJ_TIC(D, K_XSOLVE, 2);
+  if (D.coupled()) {
+    // Optimization3D_multi::update_spline (Optimization3D_multi.h:519-557): this robot's block of the
+    // arrowhead system.  Eliminate the m control-point unknowns; what is left of the last row is the
+    // robot's contribution to the shared-time corner (Schur complement) -- k_xsolve_c2 completes it.
+    if (!xs_factor(L, x0, n, tid, n - 1)) {
+      if (tid == 0) { atomicAdd(&D.ctl->llt_fail_robot, 1ull); atomicOr(&D.ctl->error, ERR_NOT_SPD); }
+    }
+    blk_sync<true>();
+    double* oL = D.xL + (size_t)u * n * n; double* oy = D.xy + (size_t)u * n; double* og = D.xg + (size_t)u * n;
+    for (int idx = tid; idx < n * n; idx += XS_THREADS) oL[idx] = L[idx];
+    for (int i = tid; i < n; i += XS_THREADS) { oy[i] = x0[i]; og[i] = g0[i]; }
+    if (tid == 0) { double* oc = D.xcorner + (size_t)u * 4; oc[0] = L[m * n + m]; oc[1] = x0[m]; oc[2] = g0[m]; oc[3] = 0; }
+    return;
+  }
+  if (!xs_factor(L, x0, n, tid, n)) {  // forward substitution fused: x0 <- L^-1 g0
+    if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
+    blk_sync<true>();
+    if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
+      for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
+      blk_sync<true>();
+      const double ev = min_eig_lds(L, n, scr, scr + n, scr + 2 * n, scr + 3 * n, tid, XS_THREADS);
+      if (ev < 0) for (int i = tid; i < n; i += XS_THREADS) H[i * n + i] = H[i * n + i] - ev * 1.0 + 0.01 * 1.0;
+      blk_sync<true>();
+    }
+    for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
+    for (int i = tid; i < n; i += XS_THREADS) x0[i] = g0[i];
+    blk_sync<true>();
+    xs_factor(L, x0, n, tid, n);  // like the reference, the second factorisation is not re-checked
+    blk_sync<true>();
+  }
+  TJ_TIC(D, K_XSOLVE, 3);
+  if (n <= 64) {
+    double yv = x0[min(tid, n - 1)];
+    yv = backsolve_wave(L, n, XS_BAND, yv, tid);
+    blk_sync<true>();
+    if (tid < n) x0[tid] = yv;
+    blk_sync<true>();
+  } else chol_arrow_backsolve_lds<true>(L, n, XS_BAND, x0, tid, XS_THREADS);
+  TJ_TIC(D, K_XSOLVE, 4);
+  for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
+  blk_sync<true>();
+  for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
+  blk_sync<true>();
+  double* dir = D.dirp(u);
+  for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
+    const int row = idx % T, a = idx / T;
+    dir[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0;
+  }
+  if (tid == 0) {
+    D.wolfe(u) = -esum(scr, n);
+    D.gn(u) = sqrt(esum(scr + n, n));
+    D.tdir(u) = x0[m];
+  }
 }
 
 __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
@@ -399,55 +511,69 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     g0[ra] = acc; x0[ra] = acc;
   }
   __syncthreads();
-  if (tid >= XS_THREADS) return;  // from here on the block IS wave 0 (s_barrier counts surviving waves only)
-  TJ_TIC(D, K_XSOLVE, 2);
-  if (D.coupled()) {
-    // Optimization3D_multi::update_spline (Optimization3D_multi.h:519-557): this robot's block of the
-    // arrowhead system.  Eliminate the m control-point unknowns; what is left of the last row is the
-    // robot's contribution to the shared-time corner (Schur complement) -- k_xsolve_c2 completes it.
-    if (!xs_factor(L, x0, n, tid, n - 1)) {
-      if (tid == 0) { atomicAdd(&D.ctl->llt_fail_robot, 1ull); atomicOr(&D.ctl->error, ERR_NOT_SPD); }
+  // From here on wave 0 works alone (its sync points are wave-local: blk_sync<true>).  Without the swept-hull tail the other
+  // waves retire (s_barrier counts surviving waves only); with it (Dev::fuse) they wait at the barrier below.
+  const bool tail = D.fuse != 0;
+  if (tid >= XS_THREADS && !tail) return;
+  if (tid < XS_THREADS) xs_wave0(D, u, tid, n, m, H, L, g0, x0, scr);
+  if (!tail) return;
+  __syncthreads();
+  TJ_TIC(D, K_XSOLVE, 5);
+  // ---- swept-hull cache of this robot for the two CCD stages (what k_ccd_prep computes; same expressions, same bits) ----
+  // BVH::CCDCollision box (BVH.cpp:195-250), SelfCCDCollision box (:289-330), k-DOP intervals of {P, P + D} (CCD.h:416-533).
+  // Flat over the whole block: 54 hull values per segment into LDS (the front of the buffer is free now), then boxes and the
+  // 49 x S interval pairs.  Folding this into the solve kernel removes one kernel boundary from the chain.
+  {
+    const int S = D.S;
+    double* netl = sm + xsolve_front_doubles(n);   // [3T] control net, [3T] direction (rows 0,1,T-2,T-1 are zero)
+    double* dl = netl + 3 * T;
+    const double* gnet = D.spline + (size_t)u * 3 * T;
+    for (int idx = tid; idx < 3 * T; idx += XS_LOAD_THREADS) {
+      const int row = idx % T, a = idx / T;
+      netl[idx] = gnet[idx];
+      dl[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0;
     }
-    blk_sync<true>();
-    double* oL = D.xL + (size_t)u * n * n; double* oy = D.xy + (size_t)u * n; double* og = D.xg + (size_t)u * n;
-    for (int idx = tid; idx < n * n; idx += XS_THREADS) oL[idx] = L[idx];
-    for (int i = tid; i < n; i += XS_THREADS) { oy[i] = x0[i]; og[i] = g0[i]; }
-    if (tid == 0) { double* oc = D.xcorner + (size_t)u * 4; oc[0] = L[m * n + m]; oc[1] = x0[m]; oc[2] = g0[m]; oc[3] = 0; }
-    return;
-  }
-  if (!xs_factor(L, x0, n, tid, n)) {  // forward substitution fused: x0 <- L^-1 g0
-    if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
-    blk_sync<true>();
-    if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
-      for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
-      blk_sync<true>();
-      const double ev = min_eig_lds(L, n, scr, scr + n, scr + 2 * n, scr + 3 * n, tid, XS_THREADS);
-      if (ev < 0) for (int i = tid; i < n; i += XS_THREADS) H[i * n + i] = H[i * n + i] - ev * 1.0 + 0.01 * 1.0;
-      blk_sync<true>();
+    __syncthreads();
+    double* Ph = sm;   // [S][54]: P[18], Dh[18], PD[18]; PS = P + Dh is formed on the fly
+    for (int idx = tid; idx < S * 18; idx += XS_LOAD_THREADS) {
+      const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
+      const double* B = D.basis + (size_t)tr * 36 + j * 6;
+      const int r0 = (tr / D.res) * 3 + T * a;
+      double p = 0, dh = 0, pd = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { p += B[k] * netl[r0 + k]; dh += B[k] * dl[r0 + k]; pd += B[k] * (netl[r0 + k] + dl[r0 + k]); }
+      Ph[tr * 54 + e] = p; Ph[tr * 54 + 18 + e] = dh; Ph[tr * 54 + 36 + e] = pd;
     }
-    for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
-    for (int i = tid; i < n; i += XS_THREADS) x0[i] = g0[i];
-    blk_sync<true>();
-    xs_factor(L, x0, n, tid, n);  // like the reference, the second factorisation is not re-checked
-    blk_sync<true>();
+    __syncthreads();
+    for (int idx = tid; idx < S * 36; idx += XS_LOAD_THREADS) {   // P, Dh
+      const int tr = idx / 36, e = idx % 36;
+      D.ccdinfo[((size_t)u * S + tr) * CCD_STRIDE + e] = Ph[tr * 54 + e];
+    }
+    for (int idx = tid; idx < S * 3; idx += XS_LOAD_THREADS) {    // obstacle box over {P, PD}, pair box over {P, P + Dh}
+      const int tr = idx / 3, a = idx % 3;
+      const double* q = Ph + tr * 54;
+      double lo = INFINITY, hi = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
+      for (int j = 0; j < 6; j++) {
+        double v = q[3 * j + a]; if (v < lo) lo = v; if (v > hi) hi = v; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
+        v = q[36 + 3 * j + a]; if (v < lo) lo = v; if (v > hi) hi = v;
+        v = q[3 * j + a] + q[18 + 3 * j + a]; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
+      }
+      double* o = D.ccdinfo + ((size_t)u * S + tr) * CCD_STRIDE;
+      o[36 + a] = lo; o[39 + a] = hi; o[42 + a] = lo2; o[45 + a] = hi2;
+      D.cbox[((size_t)tr * 6 + a) * D.U + u] = lo2; D.cbox[((size_t)tr * 6 + 3 + a) * D.U + u] = hi2;
+    }
+    for (int idx = tid; idx < S * 49; idx += XS_LOAD_THREADS) {   // 49-axis intervals of the swept hull at step 1
+      const int tr = idx / 49, k = idx % 49;
+      const double* q = Ph + tr * 54;
+      const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+      double up = -INFINITY, lo = INFINITY;
+      for (int i = 0; i < 6; i++) { const double lv = x * q[3 * i] + y * q[3 * i + 1] + z * q[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+      for (int i = 0; i < 6; i++) { const double lv = x * (q[3 * i] + q[18 + 3 * i]) + y * (q[3 * i + 1] + q[18 + 3 * i + 1]) + z * (q[3 * i + 2] + q[18 + 3 * i + 2]); if (lv < lo) lo = lv; if (lv > up) up = lv; }
+      double* o = D.ccdinfo + ((size_t)u * S + tr) * CCD_STRIDE;
+      o[48 + k] = lo; o[97 + k] = up;
+    }
   }
-  TJ_TIC(D, K_XSOLVE, 3);
-  chol_arrow_backsolve_lds<true>(L, n, XS_BAND, x0, tid, XS_THREADS);
-  TJ_TIC(D, K_XSOLVE, 4);
-  for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
-  blk_sync<true>();
-  for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
-  blk_sync<true>();
-  double* dir = D.dirp(u);
-  for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
-    const int row = idx % T, a = idx / T;
-    dir[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0;
-  }
-  if (tid == 0) {
-    D.wolfe(u) = -esum(scr, n);
-    D.gn(u) = sqrt(esum(scr + n, n));
-    D.tdir(u) = x0[m];
-  }
+  TJ_TIC(D, K_XSOLVE, 6);
 }
 
 // Coupled mode, second half of the arrowhead solve: one wave per robot.  The Schur corner

@@ -189,9 +189,7 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
 
 // per (owned robot, segment): obstacle planes from the stamped candidate slots (slot order), then -- multi-robot modes --
 // the robot-pair planes from the stamped partner slots (ascending partner): deterministic lists, no atomics
-__global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
-  if (D.ctl->done) return;
-  const int u = D.u0 + blockIdx.x / D.S, tr = blockIdx.x % D.S, lane = lane_id();
+__device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int lane) {   // one wave
   const int U = D.U, epoch = D.ctl->epoch;
   const size_t seg = (size_t)u * D.S + tr;
   if (!(D.optimal_plane && !D.multi())) {  // single-UAV "optimal_plane":1 -- k_keep wrote the obstacle plane list itself
@@ -227,6 +225,10 @@ __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
     D.scount[seg] = min(base, D.cap_self);
     D.seg_stats[seg * 6 + 5] += (unsigned long long)base;
   }
+}
+__global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
+  if (D.ctl->done) return;
+  compact_segment(D, D.u0 + blockIdx.x / D.S, blockIdx.x % D.S, lane_id());
 }
 
 }  // namespace tj

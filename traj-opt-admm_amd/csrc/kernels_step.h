@@ -479,25 +479,7 @@ __global__ __launch_bounds__(64) void k_ccd(Dev D) {
 }
 
 // ---- iteration bookkeeping ---------------------------------------------------------------------
-__global__ void k_begin(Dev D) {
-  // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
-  __shared__ int done;
-  if (threadIdx.x == 0) {
-    Ctl h = *D.ctl;  // ONE wide read of the control block instead of a chain of dependent field loads
-    if (h.pending) { h.iter++; h.pending = 0; }  // count the previous iteration (saves a launch)
-    h.slack_now = h.slack_next; h.slack_next = 0;
-    if (!h.done && D.stop > 0 && h.iter > 1 && h.gnorm < D.stop) h.done = 1;
-    done = h.done;
-    if (!done) { h.pending = 1; h.epoch++; h.slack_next = 1; }
-    D.ctl->iter = h.iter; D.ctl->pending = h.pending; D.ctl->slack_now = h.slack_now; D.ctl->slack_next = h.slack_next;
-    D.ctl->done = h.done; D.ctl->epoch = h.epoch; D.ctl->any_pair = 0;   // error bits and counters are only ever touched by atomics elsewhere
-  }
-  __syncthreads();
-  if (done) return;
-  for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
-  if (threadIdx.x == 0) { D.pair_work_n[0] = 0; D.pair_work_n[1] = 0; *D.obs_work_n = 0; }  // [1] = cursor of the pair-solve waves
-  if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
-}
+__global__ void k_begin(Dev D) { begin_body(D); }
 // only used by the stage API: commit the iteration counter explicitly
 // hand a still-owed slack/dual update to the next k_slack(deferred) launch without starting an iteration
 __global__ void k_flush(Dev D) {

@@ -100,7 +100,10 @@ const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "
 // in_graph: the launch belongs to the single-GPU iteration graph, a linear chain on one queue in which independent
 // stages share a launch (union kernels k_front / k_mid / k_ccd instead of their constituents), the slack/dual update
 // is the deferred one inside k_mid, and -- except in coupled mode -- the hull cache comes from k_linesearch (Dev::fuse).
-bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false, bool in_phase = false) {
+// chain_pos (single-GPU chain only): 0 = an iteration on its own (k_begin launched, k_linesearch plain); bit 1 = this iteration's
+// begin work was done by the previous iteration's k_linesearch (no k_begin launch); bit 2 = this iteration's k_linesearch also
+// does the next iteration's begin work.
+bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false, bool in_phase = false, int chain_pos = 0) {
   const Dev& d = c->d;
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2, tri = d.prim == 3;
@@ -110,7 +113,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 512 : 0;
   switch (kid) {
-    case K_BEGIN: hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
+    case K_BEGIN: if (chain_pos & 1) return false; hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
     case K_FRONT: if (!in_graph && !in_phase) return false;
       if (tri) hipLaunchKernelGGL((k_front<3>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_front<1>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d);
@@ -129,11 +132,16 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
       hipLaunchKernelGGL(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
-    case K_SEP_SELF_COMPACT: hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
-    case K_GRAD: hipLaunchKernelGGL(k_grad, dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d); return true;
+    case K_SEP_SELF_COMPACT: if (in_graph) return false;   // single-GPU chain: folded into k_grad
+      hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+    case K_GRAD:
+      if (in_graph) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad, s, d);
+      else hipLaunchKernelGGL((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
+      return true;
     case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
     case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
-    case K_CCD_PREP: hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
+    case K_CCD_PREP: if (in_graph && d.fuse) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
+      hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
     case K_CCD: if (!in_graph && !in_phase) return false;
       if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d);
       return true;
@@ -142,7 +150,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       return true;
     case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
-    case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl); return !coupled;
+    case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED: if (coupled) for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r); return coupled;
     case K_LS_COMMIT: if (coupled) hipLaunchKernelGGL(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;
@@ -180,8 +188,8 @@ int enqueue_stage(tj_ctx* c, int stage, hipStream_t s = nullptr, bool in_graph =
 // search already committed, so that iteration's slack/dual update (touches z, Lambda, t_z, tau only) is deferred into
 // k_mid; flush_deferred() pays the last one before anything on the host looks at the state.  The iteration counter is
 // committed by the next k_begin.
-int enqueue_iteration(tj_ctx* c) {
-  for (int k = 0; k < K_COUNT; k++) launch_kernel(c, k, c->stream, 0, true);
+int enqueue_iteration(tj_ctx* c, int chain_pos = 0) {
+  for (int k = 0; k < K_COUNT; k++) launch_kernel(c, k, c->stream, 0, true, false, chain_pos);
   HIPCHK(c, hipGetLastError());
   c->maybe_deferred = true;
   return TJ_OK;
@@ -212,8 +220,8 @@ int flush_deferred(tj_ctx* c) {
 //   phase 0: begin (stop test)                                                            -> all-gather control points
 //   phase 1: hull cache (ALL robots), k_front {obstacle query | pair rows}, k_mid, compaction, gradient, Newton solve -> all-gather directions
 //   phase 2: swept-hull cache (ALL robots), k_ccd, sequential pair clamp + gnorm, line search
-int enqueue_body(tj_ctx* c, int which) {
-  if (which == 3) return enqueue_iteration(c);
+int enqueue_body(tj_ctx* c, int which, int chain_pos = 0) {
+  if (which == 3) return enqueue_iteration(c, chain_pos);
   hipStream_t m = c->stream;
   static const int ph0[] = {K_BEGIN}, ph1[] = {K_HULLINFO, K_FRONT, K_MID, K_KEEP, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_XSOLVE_C2},
                    ph2[] = {K_CCD_PREP, K_CCD, K_CCD_SELF_SEQ, K_LINESEARCH, K_LS_COUPLED, K_LS_COMMIT};
@@ -227,13 +235,13 @@ int enqueue_body(tj_ctx* c, int which) {
 
 // Capture the body once into a hipGraph and replay it; fall back to eager launches if capture is
 // not possible on this stream.
-int launch_graph_or_eager(tj_ctx* c, int which) {
+int launch_graph_or_eager(tj_ctx* c, int which, int chain_pos = 0) {
   // Default: plain launches.  The iteration is a linear chain on one queue and the host enqueues far ahead of the device
   // (10 launches ~ 35 us of host time per ~200 us iteration), so consecutive kernels already start back to back; a
   // hipGraph replay of the same chain measured 4 us SLOWER per iteration (~8 us between consecutive graph launches),
   // and ten iterations per graph 6 us slower still.  TJ_USE_GRAPH=1 selects the captured-graph replay.
   if (!c->use_graph) {
-    int r = enqueue_body(c, which);
+    int r = enqueue_body(c, which, chain_pos);
     if (r == TJ_OK && which >= 3) c->maybe_deferred = true;
     return r;
   }
@@ -382,7 +390,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     c->err = "problem does not fit the 160 KB LDS of one CU (piece_num <= 10 supported in this version)";
     return TJ_ERR_UNSUPPORTED;
   }
-  HIPCHK(c, hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_linesearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ls_coupled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
@@ -590,7 +599,13 @@ int tj_iterate_async(tj_ctx* c, int n_iters) {
   if (!c || n_iters < 0) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
   if (n_iters > 0) { int r = ensure_hull_cache(c); if (r) return r; }
-  for (int i = 0; i < n_iters; i++) { int r = launch_graph_or_eager(c, 3); if (r) return r; }
+  // inside a batch the begin work of iteration i+1 rides on iteration i's k_linesearch (not in coupled mode, whose line search
+  // is several kernels, and not in the captured-graph replay, which is one fixed iteration)
+  const bool chain = !c->use_graph && c->d.mode != TJ_MODE_MULTI_COUPLED;
+  for (int i = 0; i < n_iters; i++) {
+    const int pos = chain ? ((i > 0 ? 1 : 0) | (i + 1 < n_iters ? 2 : 0)) : 0;
+    int r = launch_graph_or_eager(c, 3, pos); if (r) return r;
+  }
   return TJ_OK;
 }
 
@@ -624,8 +639,9 @@ int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
   for (int it = 0; it < n_iters; it++) {
     hipEvent_t* e = &ev[(size_t)it * (K_COUNT + 1)];
     HIPCHK(c, hipEventRecord(e[0], c->stream));
+    const int pos = (c->d.mode != TJ_MODE_MULTI_COUPLED) ? ((it > 0 ? 1 : 0) | (it + 1 < n_iters ? 2 : 0)) : 0;
     for (int k = 0; k < K_COUNT; k++) {
-      if (launch_kernel(c, k, c->stream, 0, true)) ran[k]++;
+      if (launch_kernel(c, k, c->stream, 0, true, false, pos)) ran[k]++;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipEventRecord(e[k + 1], c->stream));
     }
