@@ -32,6 +32,10 @@ class DynTree {
   bool leaf(uint32_t n) const { return nodes_[n].left == NIL; }
 };
 
+// ---- Eigen's SimplicialLLT with AMD ordering on the sparse view of a dense symmetric matrix (orc_amd.cpp) ----
+void amd_order(int n, const std::vector<int>& colptr, const std::vector<int>& rowidx, std::vector<int>& order);
+bool sparse_llt_solve(int n, const double* H, const double* b, double* x, int* order_out = nullptr);
+
 // ---- tables (orc_tables.cpp; reference HighOrderCCD/Utils/CCDUtils.h:110-315) ----
 // All 6x6 matrices are row-major m[row*6+col] in the oracle.
 struct Tables {

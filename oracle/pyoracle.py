@@ -258,6 +258,14 @@ class Prims:
             out.append(np.sort(ids[w:w + counts[q]])); w += counts[q]
         return out
 
+    def sparse_llt_solve(self, H, b):
+        """Eigen::SimplicialLLT (AMD ordering) on H.sparseView(), as the single-UAV Newton solve uses it
+        (Optimization3D_admm.h:470-475) -> (ok, x, permutationPinv indices)"""
+        H = np.asfortranarray(H, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        n = H.shape[0]; x = np.zeros(n); order = np.zeros(n, dtype=np.int32)
+        ok = self._f("sparse_llt_solve")(C.c_int(n), _d(H), _d(b), _d(x), _i(order))
+        return bool(ok), x, order
+
     def kdop_general(self, A, B, d):
         """CCD::KDOPDCD on row-major point sets of any size (6 or 12 rows vs 1 or 3 rows)"""
         A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64).reshape(-1, 3)

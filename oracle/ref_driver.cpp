@@ -366,6 +366,13 @@ void ref_local_grad(int u, int sp_id, double* g19, double* h361) {
   Gradient_admm::local_spline_gradient(g_spline[u], g_piece_time[u], g_p_slack[u], g_t_slack[u], g_p_lambda[u], g_t_lambda[u], g_c_lists[u], g_d_lists[u], g, h, sp_id);
   memcpy(g19, g.data(), 19 * sizeof(double)); memcpy(h361, h.data(), 361 * sizeof(double));
 }
+// one segment's velocity / acceleration barrier terms (Gradient_admm.h:409-572): g[18], h[18*18] column-major, part[18]
+void ref_bound_grad(int u, int tr, double* g18, double* h324, double* gt_ht, double* part18) {
+  Eigen::VectorXd g, part; Eigen::MatrixXd h; double g_t, h_t;
+  Gradient_admm::local_bound_gradient(tr, g_spline[u], g_piece_time[u], g, h, g_t, h_t, part);
+  memcpy(g18, g.data(), 18 * sizeof(double)); memcpy(h324, h.data(), 324 * sizeof(double)); memcpy(part18, part.data(), 18 * sizeof(double));
+  gt_ht[0] = g_t; gt_ht[1] = h_t;
+}
 // assembled (3T+1) gradient and Hessian after per-piece PSD projection (Gradient_admm.h:13-65)
 void ref_global_grad(int u, double* g, double* h) {
   Eigen::VectorXd gg; Eigen::MatrixXd hh;
@@ -506,6 +513,18 @@ int ref_gjk_dcd_general(int n1, const double* A, int n2, const double* B, double
   for (int i = 0; i < n1; i++) for (int k = 0; k < 3; k++) Am(i, k) = A[3 * i + k];
   for (int i = 0; i < n2; i++) for (int k = 0; k < 3; k++) Bm(i, k) = B[3 * i + k];
   return CCD::GJKDCD(Am, Bm, d);
+}
+// The single-UAV Newton solve exactly as Optimization3D_admm.h:470-475 performs it: SimplicialLLT (AMD ordering) on the
+// sparse view of a dense symmetric matrix.  H column-major n x n.  order = permutationPinv().indices().
+int ref_sparse_llt_solve(int n, const double* H, const double* b, double* x, int* order) {
+  Eigen::MatrixXd h0 = Eigen::Map<const Eigen::MatrixXd>(H, n, n);
+  Eigen::VectorXd g0 = Eigen::Map<const Eigen::VectorXd>(b, n);
+  Eigen::SparseMatrix<double> Hs = h0.sparseView();
+  Eigen::SimplicialLLT<Eigen::SparseMatrix<double>> solver;
+  solver.compute(Hs);
+  Eigen::VectorXd xs = solver.solve(g0);
+  for (int i = 0; i < n; i++) { x[i] = xs(i); if (order) order[i] = solver.permutationPinv().indices()(i); }
+  return solver.info() == Eigen::Success;
 }
 // Broad phase known answers on the reference's own trees: prim = 1 BVH::InitPointcloud(V) + pc_tree.query, prim = 3
 // BVH::InitObstacle(V, F) + ob_tree.query (the dormant triangle path, BVH.cpp:15-51).  verts row-major [n][prim][3];

@@ -312,6 +312,68 @@ def make_bvh_kat():
     np.savez_compressed(os.path.join(HERE, "bvh_kat.npz"), **rec)
 
 
+def reduced_system(e, u=0):
+    """the (9P-2) Newton system the single-UAV driver hands to SimplicialLLT (Optimization3D_admm.h:425-441) from the
+    assembled gradient / Hessian of robot u"""
+    g, h = e.global_grad(u)
+    n = len(g) - 1; m = n - 12
+    idx = list(range(6, 6 + m)) + [n]
+    return h[np.ix_(idx, idx)].copy(), g[idx].copy()
+
+
+def hard_single():
+    return dict(pkg_scenes.hard(U=1, n_points=2500, seed=12), mode=0, ks=1e-8, name="hard-single")
+
+
+def make_single_solve():
+    """Single-UAV Newton solve: Eigen's AMD permutation and SimplicialLLT solution for the reduced systems of real runs (SCN-A
+    seed 7, the cloud-hugging `hard_single` scene: both with velocity / acceleration / plane barriers switching on and off, i.e.
+    changing sparsity patterns) and for synthetic band-arrow patterns with exact zeros; per-piece Hessian blocks before the
+    PSD shift; and the 1-ulp envelopes of three single-UAV scenes."""
+    rng = np.random.default_rng(31)
+    mats, rhs = [], []
+    lh_state, lh_blocks = [], []
+    for sc, its in ((pkg_scenes.scn_a(n_points=20000, seed=7), (0, 3, 5, 8, 12, 20, 30, 45)), (hard_single(), (0, 2, 4, 6, 9, 15, 25, 35))):
+        e = Engine("ref", sc)
+        for it in range(max(its) + 1):
+            e.stage_planes()
+            if it in its:
+                H, g = reduced_system(e); mats.append(H); rhs.append(g)
+            if it in its[2:5]:
+                st = e.get_state()
+                lh_state.append(np.concatenate([st[k].ravel() for k in ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")]))
+                lh_blocks.append(np.stack([e.local_grad(0, spc)[1] for spc in range(sc["P"])]))
+            e.stage_direction(); e.stage_steps(); e.stage_linesearch(); e.stage_slack(); e.iters += 1
+    n_real = len(mats)
+    for trial in range(40):   # synthetic: 5 pieces, random per-piece activity (dense block / axis-decoupled block / time coupling)
+        n = 43; m = 42
+        H = np.zeros((n, n))
+        for spc in range(5):
+            idx = [9 * spc + a - 6 for a in range(18) if 0 <= 9 * spc + a - 6 < m]
+            A = rng.normal(size=(len(idx), len(idx))); A = A @ A.T + len(idx) * np.eye(len(idx))
+            if rng.random() < 0.4:
+                for i, gi in enumerate(idx):
+                    for j, gj in enumerate(idx):
+                        if (gi % 3) != (gj % 3): A[i, j] = 0
+            H[np.ix_(idx, idx)] += A
+            if rng.random() < 0.5:
+                t = rng.normal(size=len(idx)) * 0.1; H[idx, m] += t; H[m, idx] += t
+        H[m, m] += 50
+        mats.append(H); rhs.append(rng.normal(size=n))
+    pr = Prims("ref")
+    order, sol = [], []
+    for H, g in zip(mats, rhs):
+        ok, x, o = pr.sparse_llt_solve(H, g)
+        assert ok
+        order.append(o); sol.append(x)
+    rec = dict(H=np.array(mats), g=np.array(rhs), order=np.array(order), x=np.array(sol), n_real=np.array(n_real),
+               lh_state=np.array(lh_state), lh_blocks=np.array(lh_blocks))
+    np.savez_compressed(os.path.join(HERE, "amd_kat.npz"), **rec)
+    make_envelope("scn_a", pkg_scenes.scn_a(), snap=(0, 2, 4, 8))
+    make_envelope("scn_a_seed7", pkg_scenes.scn_a(n_points=20000, seed=7), snap=(0, 2, 4, 8))
+    make_envelope("hard_single", hard_single(), snap=(0, 2, 4, 8))
+
+
 def ccd_order_case(seed, U=7):
     """robots of the `hard` family all heading for one point: many robot pairs collide in the same segment and share
     robots, so Step::self_step's result depends on the pair ORDER of the reference's per-segment dynamic tree"""
@@ -450,6 +512,9 @@ if __name__ == "__main__":
         make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
         make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
         sys.exit(0)
+    if "--single-only" in sys.argv:
+        make_single_solve()
+        sys.exit(0)
     if "--bvh-only" in sys.argv:
         make_bvh_kat()
         sys.exit(0)
@@ -483,4 +548,5 @@ if __name__ == "__main__":
     make_ccd_order()
     make_tri_prims()
     make_bvh_kat()
+    make_single_solve()
     print("golden vectors written to", HERE)

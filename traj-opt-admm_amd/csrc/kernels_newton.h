@@ -74,7 +74,7 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
 #pragma unroll 4
           for (int k = 0; k < n; k++) {
             const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
-            seg += (e2s[j * n + k] * dxi) * dxk;
+            seg = (dxi * dxk) * e2s[j * n + k] + seg;   // Eigen runs e2*d_x*d_x^T (dynamic d_x) as a depth-1 GEMM with alpha = e2 (Gradient_admm.h:401)
           }
         }
         Hacc += seg;
@@ -227,8 +227,9 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
         const int b = __ffs(bits) - 1;
         const double* t = bts + b * 23;
         const double dxi = t[3 + qi] * t[15 + ai], dxk = t[3 + qk] * t[15 + ak];
-        const double s = t[1] * dxi, lft = t[0] * t[15 + ai];
-        seg = (seg + s * dxk) + (lft * t[6 + 3 * qi + qk]) * t[15 + ak];
+        // hessian += e2*d_x*d_x^T + e1*A^T*h_p*A (Gradient_admm.h:504,553) as Eigen evaluates it (checked entry by entry against
+        // Eigen): the outer product as a depth-1 GEMM with alpha = e2, then ((e1*w_a)*h_p)*w_b
+        seg = ((dxi * dxk) * t[1] + seg) + ((t[0] * t[15 + ai]) * t[6 + 3 * qi + qk]) * t[15 + ak];
       }
       Hacc += seg;
     } else if (vr >= 0) {
