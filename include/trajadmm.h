@@ -170,6 +170,9 @@ typedef struct tj_stats {
                            tj_iterate returns TJ_ERR_UNSUPPORTED) -- 0 unless uav_num is in the thousands */
 } tj_stats;
 int tj_get_stats(tj_ctx* c, tj_stats* s);
+/* the obstacle BVH of the last tj_set_cloud / tj_set_mesh: device time of the build (Morton keys, radix sort, box pyramid;
+ * upload excluded) -- the counterpart of the reference's tree construction (BVH.cpp:53-93: 95 ms for 20k points) */
+int tj_get_build_info(tj_ctx* c, double* bvh_build_ms, int* built_on_device);
 
 /* ---- known-answer hooks: the device primitives of the hot path on caller-supplied batches -------
  * (host pointers; one case per GPU lane; used by the parity tests against tests/golden/) */

@@ -65,6 +65,40 @@ def test_broad_phase_candidate_sets_vs_reference_trees(pkg, scenes, prim):
     s.close()
 
 
+@pytest.mark.parametrize("prim", [1, 3])
+def test_device_bvh_build_equals_host_build(pkg, scenes, prim, monkeypatch):
+    """the BVH is built on the device (Morton keys, stable radix sort, box pyramid: kernels_bvh.h); the host build of
+    host_tables.h is its checker: same sorted order (hence the same obstacle ids in the same candidate order), same results bit
+    for bit.  Includes duplicate points (equal keys must keep their index order) and a count that is not a multiple of 8."""
+    sc = dict(scenes.hard(4, 4003))
+    sc["cloud"] = np.concatenate([sc["cloud"], sc["cloud"][:37]])          # exact duplicates -> equal Morton keys
+    if prim == 3:
+        sc = scenes.triangulate(sc, size=0.025)
+    a = pkg.Solver(sc, stop=0.0)
+    assert a.build_info()["on_device"]
+    monkeypatch.setenv("TJ_BVH_HOST", "1")
+    b = pkg.Solver(sc, stop=0.0)
+    assert not b.build_info()["on_device"]
+    rng = np.random.default_rng(3)
+    lo = rng.uniform(-4, 4, (300, 3)); boxes = np.concatenate([lo, lo + rng.uniform(0, 1.5, (300, 3))], axis=1)
+    for qa, qb in zip(a.kat_query(boxes, 0.2, sort=False), b.kat_query(boxes, 0.2, sort=False)):
+        assert np.array_equal(qa, qb)                                      # same ids in the same traversal order
+    for it in range(6):
+        a.iterate(1); b.iterate(1)
+    sa, sb = a.get_state(), b.get_state()
+    for n in STATE:
+        assert np.array_equal(sa[n], sb[n]), n
+    a.close(); b.close()
+
+
+def test_device_bvh_build_time_1m(pkg, scenes):
+    """1M primitives: the build is a few streaming passes (the reference's incremental tree takes 95 ms for 20k points)"""
+    s = pkg.Solver(scenes.scn_d_tri(), stop=0.0)
+    info = s.build_info()
+    assert info["on_device"] and 0 < info["bvh_build_ms"] < 50.0, info
+    s.close()
+
+
 @pytest.mark.parametrize("name", ["hard", "scn_b", "tiny_single", "hard_single"])
 def test_degenerate_triangles_reproduce_the_point_cloud_bitwise(pkg, scenes, name):
     """three equal vertices = the cloud point: every stage (BVH over triangle boxes, k-DOP, GJK hull-vs-triangle, CCD) must

@@ -24,7 +24,7 @@ _ip = C.POINTER(C.c_int)
 EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_set_mesh", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes", "tj_get_candidates",
-    "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_exchange_buffer",
+    "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_get_build_info", "tj_exchange_buffer",
     "tj_iterate_phase", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
 ]
@@ -357,12 +357,12 @@ class Solver:
         self._check(self.lib.tj_kat_ccd(self._ctx, C.c_int(n), *[_d(x) for x in arrs], C.c_double(d), _d(out)))
         return out
 
-    def kat_query(self, boxes, margin, cap=2048):
+    def kat_query(self, boxes, margin, cap=2048, sort=True):
         """raw broad-phase candidate SETS of caller-supplied query boxes [nq][6] (lo, hi): list of sorted id arrays"""
         boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
         nq = boxes.shape[0]; counts = np.zeros(nq, dtype=np.int32); ids = np.zeros((nq, cap), dtype=np.int32)
         self._check(self.lib.tj_kat_query(self._ctx, C.c_int(nq), _d(boxes), C.c_double(margin), C.c_int(cap), _i(counts), _i(ids)))
-        return [np.sort(ids[q, :counts[q]]) for q in range(nq)]
+        return [np.sort(ids[q, :counts[q]]) if sort else ids[q, :counts[q]].copy() for q in range(nq)]
 
     def kat_tri(self, P, D, tri, t, dist, off):
         arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (P, D, tri, t)]
@@ -375,6 +375,11 @@ class Solver:
         out = np.zeros((mats.shape[0], 2))
         self._check(self.lib.tj_kat_linalg(self._ctx, C.c_int(mats.shape[0]), C.c_int(mats.shape[1]), _d(mats), _d(out)))
         return out
+
+    def build_info(self):
+        ms, dev = C.c_double(), C.c_int()
+        self._check(self.lib.tj_get_build_info(self._ctx, C.byref(ms), C.byref(dev)))
+        return dict(bvh_build_ms=ms.value, on_device=bool(dev.value))
 
     def stats(self):
         s = TjStats()

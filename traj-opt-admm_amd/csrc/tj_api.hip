@@ -25,6 +25,7 @@
 #include "kernels_step.h"
 #include "kernels_debug.h"
 #include "kernels_plan.h"
+#include "kernels_bvh.h"
 
 using namespace tj;
 
@@ -51,6 +52,8 @@ struct tj_ctx {
   std::vector<void*> cloud_allocs;
   std::vector<int> cloud_order;   // sorted position -> index in the caller's cloud (ids of tj_get/set_obs_cache)
   double cloud_lo[3] = {0, 0, 0}, cloud_hi[3] = {0, 0, 0};   // bounding box of the cloud (planner bounds, Main/multiPathPlanning3D.cpp:211-218)
+  double bvh_build_ms = 0;   // device time of the last BVH build (tj_get_build_info)
+  int bvh_on_device = 0;
 };
 
 namespace {
@@ -445,6 +448,18 @@ void tj_destroy(tj_ctx* c) {
 }
 
 namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+};
+int to_dev(tj_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+  HIPCHK(c, hipMalloc(&b.p, std::max<size_t>(bytes, 8)));
+  if (src && bytes) return upload(c, b.p, src, bytes);
+  return TJ_OK;
+}
+}  // namespace
+
+namespace {
 // verts: [n][prim][3] in the caller's order
 int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
   QUIESCE(c);
@@ -459,28 +474,67 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
     return TJ_ERR_UNSUPPORTED;
   }
   if (n > 0) {
-    HostBvh b;
-    build_bvh(verts, n, prim, b);
-    if ((int)b.lvl_n.size() > MAX_LEVELS) { c->err = "too many obstacle primitives for MAX_LEVELS"; return TJ_ERR_UNSUPPORTED; }
-    float* boxes; int r;
-    if ((r = dalloc(c, &boxes, b.boxes.size(), &c->cloud_allocs)) || (r = upload(c, boxes, b.boxes.data(), b.boxes.size() * 4))) return r;
-    d.boxes = boxes;
-    if (prim == 1) {
-      double *px, *py, *pz;
-      if ((r = dalloc(c, &px, n, &c->cloud_allocs)) || (r = dalloc(c, &py, n, &c->cloud_allocs)) || (r = dalloc(c, &pz, n, &c->cloud_allocs)) ||
-          (r = upload(c, px, b.px.data(), (size_t)n * 8)) || (r = upload(c, py, b.py.data(), (size_t)n * 8)) || (r = upload(c, pz, b.pz.data(), (size_t)n * 8))) return r;
-      d.px = px; d.py = py; d.pz = pz;
-    } else {
-      double* tri; float* lb;
-      if ((r = dalloc(c, &tri, (size_t)n * 9, &c->cloud_allocs)) || (r = dalloc(c, &lb, (size_t)n * 6, &c->cloud_allocs)) ||
-          (r = upload(c, tri, b.tri.data(), (size_t)n * 72)) || (r = upload(c, lb, b.leafbox.data(), (size_t)n * 24))) return r;
-      d.tri = tri; d.leafbox = lb;
-    }
-    d.nlevels = (int)b.lvl_n.size();
-    c->cloud_order = b.order;
     for (int k = 0; k < 3; k++) { c->cloud_lo[k] = INFINITY; c->cloud_hi[k] = -INFINITY; }
     for (size_t i = 0; i < (size_t)n * prim; i++) for (int k = 0; k < 3; k++) { c->cloud_lo[k] = std::min(c->cloud_lo[k], verts[3 * i + k]); c->cloud_hi[k] = std::max(c->cloud_hi[k], verts[3 * i + k]); }
-    for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = b.lvl_off[i]; d.lvl_n[i] = b.lvl_n[i]; }
+    // pyramid geometry: level 0 = boxes over 8 consecutive primitives, up to a top level of <= 64 boxes
+    std::vector<int> lvl_off, lvl_n;
+    { int cnt = (n + 7) / 8, off = 0; for (;;) { lvl_off.push_back(off); lvl_n.push_back(cnt); off += cnt; if (cnt <= 64) break; cnt = (cnt + 7) / 8; } }
+    if ((int)lvl_n.size() > MAX_LEVELS) { c->err = "too many obstacle primitives for MAX_LEVELS"; return TJ_ERR_UNSUPPORTED; }
+    const size_t nbox = (size_t)lvl_off.back() + lvl_n.back();
+    float* boxes; int r;
+    if ((r = dalloc(c, &boxes, nbox * 6, &c->cloud_allocs))) return r;
+    double *px = nullptr, *py = nullptr, *pz = nullptr, *tri = nullptr; float* lb = nullptr;
+    if (prim == 1) { if ((r = dalloc(c, &px, n, &c->cloud_allocs)) || (r = dalloc(c, &py, n, &c->cloud_allocs)) || (r = dalloc(c, &pz, n, &c->cloud_allocs))) return r; }
+    else if ((r = dalloc(c, &tri, (size_t)n * 9, &c->cloud_allocs)) || (r = dalloc(c, &lb, (size_t)n * 6, &c->cloud_allocs))) return r;
+    c->cloud_order.resize(n);
+    c->bvh_on_device = getenv("TJ_BVH_HOST") ? 0 : 1;   // TJ_BVH_HOST=1: the host build of host_tables.h (the checker of the device build)
+    if (!c->bvh_on_device) {
+      HostBvh b;
+      build_bvh(verts, n, prim, b);
+      if ((r = upload(c, boxes, b.boxes.data(), b.boxes.size() * 4))) return r;
+      if (prim == 1) { if ((r = upload(c, px, b.px.data(), (size_t)n * 8)) || (r = upload(c, py, b.py.data(), (size_t)n * 8)) || (r = upload(c, pz, b.pz.data(), (size_t)n * 8))) return r; }
+      else if ((r = upload(c, tri, b.tri.data(), (size_t)n * 72)) || (r = upload(c, lb, b.leafbox.data(), (size_t)n * 24))) return r;
+      c->cloud_order = b.order;
+      c->bvh_build_ms = 0;
+    } else {
+      // device build (kernels_bvh.h): bounds -> Morton keys -> stable radix sort -> gather -> box pyramid
+      DevBuf dv, dpart, dlohi, dkA, dkB, dvA, dvB, dhist, d64a, d64b;
+      const int nb_red = std::min(1024, (n + 255) / 256), nblocks = (n + RS_TILE - 1) / RS_TILE;
+      if ((r = to_dev(c, dv, verts, (size_t)n * prim * 24)) || (r = to_dev(c, dpart, nullptr, (size_t)nb_red * 48)) || (r = to_dev(c, dlohi, nullptr, 48)) ||
+          (r = to_dev(c, dkA, nullptr, (size_t)n * 8)) || (r = to_dev(c, dkB, nullptr, (size_t)n * 8)) || (r = to_dev(c, dvA, nullptr, (size_t)n * 4)) || (r = to_dev(c, dvB, nullptr, (size_t)n * 4)) ||
+          (r = to_dev(c, dhist, nullptr, (size_t)256 * nblocks * 4)) || (r = to_dev(c, d64a, nullptr, (size_t)lvl_n[0] * 48)) || (r = to_dev(c, d64b, nullptr, (size_t)(lvl_n.size() > 1 ? lvl_n[1] : 1) * 48))) return r;
+      hipEvent_t e0, e1;
+      HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+      hipStream_t s = c->stream;
+      HIPCHK(c, hipEventRecord(e0, s));
+      const double* V = (const double*)dv.p;
+      hipLaunchKernelGGL(k_bvh_bounds, dim3(nb_red), dim3(256), 0, s, V, n, prim, (double*)dpart.p);
+      hipLaunchKernelGGL(k_bvh_bounds_final, dim3(1), dim3(64), 0, s, (const double*)dpart.p, nb_red, (double*)dlohi.p);
+      unsigned long long *kA = (unsigned long long*)dkA.p, *kB = (unsigned long long*)dkB.p; int *vA = (int*)dvA.p, *vB = (int*)dvB.p;
+      hipLaunchKernelGGL(k_bvh_keys, dim3((n + 255) / 256), dim3(256), 0, s, V, n, prim, (const double*)dlohi.p, kA, vA);
+      for (int pass = 0; pass < 8; pass++) {
+        hipLaunchKernelGGL(k_rsort_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, kA, n, 8 * pass, nblocks, (int*)dhist.p);
+        hipLaunchKernelGGL(k_rsort_scan, dim3(1), dim3(1024), 0, s, (int*)dhist.p, 256 * nblocks);
+        hipLaunchKernelGGL(k_rsort_scatter, dim3(nblocks), dim3(RS_THREADS), 0, s, kA, vA, n, 8 * pass, nblocks, (const int*)dhist.p, kB, vB);
+        std::swap(kA, kB); std::swap(vA, vB);
+      }
+      hipLaunchKernelGGL(k_bvh_gather, dim3((n + 255) / 256), dim3(256), 0, s, V, vA, n, prim, px, py, pz, tri, lb);
+      double *cur = (double*)d64a.p, *prev = (double*)d64b.p;
+      for (size_t lv = 0; lv < lvl_n.size(); lv++) {
+        const int nchild = lv == 0 ? n : lvl_n[lv - 1];
+        hipLaunchKernelGGL(k_bvh_level, dim3((lvl_n[lv] + 255) / 256), dim3(256), 0, s, (int)lv, lvl_n[lv], nchild, prim, px, py, pz, tri, prev, cur, boxes + (size_t)lvl_off[lv] * 6);
+        std::swap(cur, prev);
+      }
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(e1, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1)); c->bvh_build_ms = ms;
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      HIPCHK(c, hipMemcpy(c->cloud_order.data(), vA, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    d.boxes = boxes; d.px = px; d.py = py; d.pz = pz; d.tri = tri; d.leafbox = lb;
+    d.nlevels = (int)lvl_n.size();
+    for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = lvl_off[i]; d.lvl_n[i] = lvl_n[i]; }
   }
   c->have_cloud = true;
   return TJ_OK;
@@ -817,17 +871,6 @@ int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_ar
 }
 
 // ---- known-answer hooks ------------------------------------------------------------------------
-namespace {
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-};
-int to_dev(tj_ctx* c, DevBuf& b, const void* src, size_t bytes) {
-  HIPCHK(c, hipMalloc(&b.p, std::max<size_t>(bytes, 8)));
-  if (src && bytes) return upload(c, b.p, src, bytes);
-  return TJ_OK;
-}
-}  // namespace
 
 int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v) {
   if (!c || n < 0 || !a || !b || !v) return TJ_ERR_INVALID;
@@ -1190,6 +1233,13 @@ int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out) {
   HIPCHK(c, hipGetLastError());
   QUIESCE(c);
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)nmat * 16, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
+int tj_get_build_info(tj_ctx* c, double* bvh_build_ms, int* built_on_device) {
+  if (!c) return TJ_ERR_INVALID;
+  if (bvh_build_ms) *bvh_build_ms = c->bvh_build_ms;
+  if (built_on_device) *built_on_device = c->bvh_on_device;
   return TJ_OK;
 }
 
