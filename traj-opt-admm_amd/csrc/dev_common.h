@@ -74,6 +74,8 @@ struct Dev {
   // ---- parameters (3D.json + hard-coded constants of the mains) ----
   int mode, U, P, res, S, T, N;
   int u0, u1;  // robots owned by this rank: [u0,u1)
+  int xs_band;  // long trajectories (piece_num > 10): the Newton solve runs on band storage (k_xsolve_band) and the swept-hull
+                // cache comes from k_ccd_prep again
   int seq_tree; // k_ccd_self_seq has LDS for the reference's per-segment dynamic tree (dev_dyntree.h)
   int fuse;    // single-GPU iteration graph: k_linesearch leaves the next iteration's hull cache, so k_hullinfo is not
                // launched (the sharded schedule needs the cache for ALL robots after its all-gather and keeps the kernel;
@@ -143,6 +145,7 @@ struct Dev {
   // forward-substituted right-hand side, the raw gradient, {Schur corner, Schur rhs, g_t} contributions,
   // and the per-(round, robot, candidate) energies of the Armijo search on the summed objective
   double *xL, *xy, *xg, *xcorner, *ls_e;
+  double *xs_scr;                 // k_xsolve_band: per-robot dense scratch [owned][n*n + 4n] for the eigenvalue fallback
   int *k_obs, *k_self;            // [U] exponents: step = 0.8^k
   double *step_out;               // [U] accepted Armijo step (diagnostics)
   double *ccdinfo;                // [U][S][CCD_STRIDE] swept-hull cache of the current direction

@@ -156,6 +156,77 @@ __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int l
   return true;
 }
 
+// ---- band storage (long trajectories: piece_num > 10, where a dense n x n copy no longer fits LDS) ----------------------
+// The same arrowhead-band factorisation and solve on compact storage: Bd[m][BS] holds the band rows (m = n - 1 of them),
+// Bd[i][c] = A[i][i - (BS-1) + c], c = BS-1 the diagonal; Ar[n] holds the arrow row A[n-1][0..n-1].  Same operation order as
+// chol_arrow_lds / chol_arrow_backsolve_lds (a_ij - l_ik * l_jk, k ascending; IEEE division by the pivot's root), executed by
+// ONE wave; y rides along (y <- L^-1 y).  Returns false on a pivot <= 0.
+constexpr int BAND_BS = 18;   // half-bandwidth 17 + diagonal
+__device__ inline bool chol_band_lds(double* Bd, double* Ar, int n, int tid, double* y) {
+  __shared__ double s_colb[CHOL_MB + 2];
+  const int m = n - 1, BS = BAND_BS;
+  int er[3], ec[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int e = tid + 64 * t;
+    er[t] = -1; ec[t] = 0;
+    if (e < (BS - 1) * BS / 2) { int r = 0; while ((r + 1) * (r + 2) / 2 <= e) r++; er[t] = r; ec[t] = e - r * (r + 1) / 2; }
+  }
+  for (int k = 0; k < m; k++) {
+    blk_sync<true>();
+    const int mb = min(BS - 1, m - 1 - k);
+    const double x = Bd[k * BS + BS - 1];
+    const int myrow = k + 1 + min(tid, max(mb - 1, 0));
+    const double ci = mb > 0 ? Bd[myrow * BS + (BS - 2 - min(tid, mb - 1))] : 0.0;
+    double w[3]; int widx[3]; bool wact[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      wact[t] = er[t] >= 0 && er[t] < mb;
+      widx[t] = wact[t] ? (k + 1 + er[t]) * BS + (ec[t] - er[t] + BS - 1) : k * BS + BS - 1;
+      w[t] = Bd[widx[t]];
+    }
+    const double ak = Ar[k], ae = Ar[min(k + 1 + tid, m)], add = Ar[m];
+    const double yk_raw = y[k], yi = y[min(k + 1 + tid, m)], ylast = y[m];
+    if (x <= 0) return false;
+    const double sx = sqrt(x);
+    const double v = ci / sx, la = ak / sx, yk = yk_raw / sx;
+    blk_sync<true>();
+    if (tid == 0) { Bd[k * BS + BS - 1] = sx; Ar[k] = la; y[k] = yk; }
+    if (tid < mb) { Bd[myrow * BS + (BS - 2 - tid)] = v; s_colb[tid] = v; }
+    blk_sync<true>();
+    const double cm = s_colb[min(tid, CHOL_MB - 1)];
+#pragma unroll
+    for (int t = 0; t < 3; t++) if (wact[t]) Bd[widx[t]] = w[t] - s_colb[er[t]] * s_colb[ec[t]];
+    if (tid < mb) { Ar[k + 1 + tid] = ae - la * cm; y[k + 1 + tid] = yi - yk * cm; }
+    if (tid == 63) { Ar[m] = add - la * la; y[m] = ylast - yk * la; }
+  }
+  blk_sync<true>();
+  const double x = Ar[m];
+  if (x <= 0) return false;
+  blk_sync<true>();
+  if (tid == 0) { const double sx = sqrt(x); Ar[m] = sx; y[m] = y[m] / sx; }
+  blk_sync<true>();
+  return true;
+}
+__device__ inline void chol_band_backsolve_lds(const double* Bd, const double* Ar, int n, double* y, int tid) {
+  const int m = n - 1, BS = BAND_BS;
+  blk_sync<true>();
+  const double xl = y[m] / Ar[m];
+  blk_sync<true>();
+  if (tid == 0) y[m] = xl;
+  for (int i = tid; i < m; i += 64) y[i] -= xl * Ar[i];
+  for (int j = m - 1; j >= 0; j--) {
+    blk_sync<true>();
+    const int lo = max(0, j - (BS - 1));
+    const int i0 = min(lo + tid, j);
+    const double yj = y[j] / Bd[j * BS + BS - 1], lji = Bd[j * BS + (i0 - j + BS - 1)], yi = y[i0];
+    blk_sync<true>();
+    if (tid == 0) y[j] = yj;
+    if (lo + tid < j) y[i0] = yi - yj * lji;
+  }
+  blk_sync<true>();
+}
+
 // Generic dense variant for larger matrices (only the known-answer hook uses n > 20).
 __device__ inline bool chol_lds(double* A, int n, int tid, int nth, double* y = nullptr) {
   if (n <= CHOL_MB + 2) return chol_arrow_lds(A, n, n, tid, nth, y);  // the 19x19 / 13x13 piece systems

@@ -26,9 +26,12 @@ constexpr int LS_GSIZE = 64;   // one wave per candidate: group-private LDS need
 struct LsLayout {  // offsets in doubles into dynamic LDS
   size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, gcons, res, planes, pltr, total;
   int plane_cap;
+  int groups;   // Armijo candidates evaluated side by side (one wave each): 8 where the per-candidate hull buffers fit LDS,
+                // fewer for long trajectories (piece_num > 10); the accepted step is the same, only the rounds get shorter
 };
-__host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_budget_bytes) {
+__host__ __device__ inline LsLayout ls_layout_g(int S, int T, int P, size_t lds_budget_bytes, int G) {
   LsLayout L;
+  L.groups = G;
   size_t o = 0;
   L.basis = o; o += (size_t)S * 36;
   L.convert = o; o += (size_t)P * 36;
@@ -38,9 +41,9 @@ __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_bu
   L.tla = o; o += P;
   L.net = o; o += 3 * (size_t)T;
   L.dir = o; o += 3 * (size_t)T;
-  L.gnet = o; o += (size_t)LS_GROUPS * 3 * T;
-  L.ghull = o; o += (size_t)LS_GROUPS * S * 18;
-  L.gcons = o; o += (size_t)LS_GROUPS * 24 * P;   // per group: delta[18P], then 6 consensus/dual terms per piece
+  L.gnet = o; o += (size_t)G * 3 * T;
+  L.ghull = o; o += (size_t)G * S * 18;
+  L.gcons = o; o += (size_t)G * 24 * P;   // per group: delta[18P], then 6 consensus/dual terms per piece
   L.res = o; o += 2 * LS_GROUPS + 8;
   L.planes = o;
   const size_t used = o * 8;
@@ -50,6 +53,13 @@ __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_bu
   o += (size_t)L.plane_cap * 4;
   L.pltr = o; o += ((size_t)L.plane_cap + 1) / 2;
   L.total = o;
+  return L;
+}
+// lds_budget_bytes: soft budget that also sizes the LDS-resident plane list; hard_bytes: what one workgroup may allocate.  The
+// widest group count whose fixed part fits is taken (8 up to piece_num = 10 with the shipped res = 8).
+__host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_budget_bytes, size_t hard_bytes = 155 * 1024) {
+  LsLayout L = ls_layout_g(S, T, P, lds_budget_bytes, LS_GROUPS);
+  for (int G = LS_GROUPS / 2; G >= 1 && L.total * 8 > hard_bytes; G /= 2) L = ls_layout_g(S, T, P, lds_budget_bytes, G);
   return L;
 }
 
@@ -278,7 +288,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   __shared__ int pref[512];   // plane prefix per segment (S <= 511 checked on the host)
   __shared__ int s_accept;
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
-  const int g = tid / LS_GSIZE, gl = tid % LS_GSIZE;
+  // G = L.groups candidates per round.  With G < 8 (long trajectories) the waves beyond G shadow the last group: they compute
+  // the same candidate into the same buffers (identical values), which keeps every barrier uniform.
+  const int G = L.groups;
+  const int g = min(tid / LS_GSIZE, G - 1), gl = tid % LS_GSIZE;
+  const bool shadow = tid / LS_GSIZE >= G;
   double* net = sm + L.net; double* dir = sm + L.dir;
   double* gnet = sm + L.gnet + (size_t)g * 3 * T;
   double* ghull = sm + L.ghull + (size_t)g * S * 18;
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   int k_acc = -1, evals = 0, wg = 0;
   for (int round = 0; k_acc < 0; round++) {
     // candidate of this group: -1 = E(x) (round 0, group 0), otherwise trial index k >= 0
-    const int k = round == 0 ? g - 1 : 7 + (round - 1) * LS_GROUPS + g;
+    const int k = round == 0 ? g - 1 : (G - 1) + (round - 1) * G + g;
     double step = step0;
     for (int i = 0; i < k; i++) step *= 0.8;           // same rounding as the reference's repeated step *= 0.8
     const double pt = k < 0 ? t0 : t0 + step * t_dir;
@@ -305,12 +319,12 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 3);
     const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl);
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 4);
-    if (gl == 0) { res[g] = e; res[LS_GROUPS + g] = step; }
+    if (gl == 0 && !shadow) { res[g] = e; res[LS_GROUPS + g] = step; }
     if (tid == 0) s_accept = -1;
     __syncthreads();
     if (round == 0) e_base = res[0];
     if (tid == 0) {
-      for (int c = (round == 0 ? 1 : 0); c < LS_GROUPS; c++) {
+      for (int c = (round == 0 ? 1 : 0); c < G; c++) {
         const double st = res[LS_GROUPS + c];
         if (!(e_base - 1e-4 * wolfe * st < res[c])) { s_accept = c; break; }
       }
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     __syncthreads();
     const int acc = s_accept;
     if (acc >= 0) {
-      k_acc = round == 0 ? acc - 1 : 7 + (round - 1) * LS_GROUPS + acc;
+      k_acc = round == 0 ? acc - 1 : (G - 1) + (round - 1) * G + acc;
       step_acc = res[LS_GROUPS + acc];
       pt_acc = t0 + step_acc * t_dir;
       evals = 2 + k_acc;
@@ -326,15 +340,15 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
       wg = acc;
       const double* win = sm + L.gnet + (size_t)acc * 3 * T;
       for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
-    } else if (7 + round * LS_GROUPS >= LOOP_CAP) {
+    } else if ((G - 1) + round * G >= LOOP_CAP) {
       // no acceptable step: behave like the capped sequential loop (take the last candidate)
       if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
-      k_acc = 7 + (round - 1) * LS_GROUPS + LS_GROUPS - 1;
-      step_acc = res[2 * LS_GROUPS - 1];
+      k_acc = (G - 1) + (round - 1) * G + G - 1;
+      step_acc = res[LS_GROUPS + G - 1];
       pt_acc = t0 + step_acc * t_dir;
       evals = 2 + k_acc;
-      wg = LS_GROUPS - 1;
-      const double* win = sm + L.gnet + (size_t)(LS_GROUPS - 1) * 3 * T;
+      wg = G - 1;
+      const double* win = sm + L.gnet + (size_t)(G - 1) * 3 * T;
       for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
     }
     __syncthreads();

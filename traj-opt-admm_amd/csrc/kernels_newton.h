@@ -577,6 +577,90 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   TJ_TIC(D, K_XSOLVE, 6);
 }
 
+// ---- long trajectories (Dev::xs_band: piece_num > 10, or TJ_XS_BAND=1 for testing): the same solve on band storage ----------
+// n = 9P-2 grows past what a dense n x n copy in LDS allows (P = 11 already needs 2 x 74 KB), while the system itself is a band
+// of half-width 17 plus one arrow row: n x 18 + n doubles (26 KB at P = 20).  One workgroup per robot; the band entries are
+// gathered straight from the per-piece blocks in HBM (each is the sum of at most two of them, in piece order like the
+// reference's += sequence), wave 0 factors and solves with the band routines of dev_linalg.h -- the same operation order as
+// the dense kernels, hence the same bits (cross-checked at P <= 10 by tests with TJ_XS_BAND=1).  The PSD fallback of the
+// multi-UAV mode (LLT fails: shift by the smallest eigenvalue, Optimization3D_multi.h:703-719) needs the dense matrix; it is
+// formed in a per-robot HBM scratch (rare path).  Decoupled and single-UAV modes only.
+constexpr int XB_THREADS = 256;
+__host__ __device__ inline size_t xsolve_band_lds_doubles(int n) { return (size_t)(n - 1) * BAND_BS + 3 * (size_t)n + 64; }
+__device__ __forceinline__ double xb_entry(const double* gh, int P, int ga, int gb) {   // assembled Hessian entry; -1 = time
+  int lo = 0, hi = P - 1;
+  if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
+  if (gb >= 0) { lo = max(lo, (gb - 17 + 8) / 9); hi = min(hi, gb / 9); }
+  double acc = 0;
+  for (int sp = max(lo, 0); sp <= hi; sp++) acc += gh[(size_t)sp * 361 + (ga < 0 ? 18 : ga - 9 * sp) * 19 + (gb < 0 ? 18 : gb - 9 * sp)];
+  return acc;
+}
+__global__ __launch_bounds__(XB_THREADS) void k_xsolve_band(Dev D) {
+  if (D.ctl->done) return;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x;
+  const int T = D.T, m = 3 * (T - 4), n = m + 1, BS = BAND_BS;
+  double* Bd = sm; double* Ar = Bd + (size_t)m * BS; double* g0 = Ar + n; double* y = g0 + n;
+  const double* gh = D.lh + (size_t)u * D.P * 361;
+  const double* gg = D.lg + (size_t)u * D.P * 19;
+  auto assemble = [&]() {
+    for (int idx = tid; idx < m * BS; idx += XB_THREADS) {
+      const int i = idx / BS, c = idx % BS, j = i - (BS - 1) + c;
+      Bd[idx] = j >= 0 ? xb_entry(gh, D.P, i + 6, j + 6) : 0.0;
+    }
+    for (int j = tid; j < n; j += XB_THREADS) {
+      Ar[j] = xb_entry(gh, D.P, -1, j == m ? -1 : j + 6);
+      const int ga = j == m ? -1 : j + 6;
+      int lo = 0, hi = D.P - 1;
+      if (ga >= 0) { lo = max(lo, (ga - 17 + 8) / 9); hi = min(hi, ga / 9); }
+      double acc = 0;
+      for (int sp = max(lo, 0); sp <= hi; sp++) acc += gg[sp * 19 + (ga < 0 ? 18 : ga - 9 * sp)];
+      g0[j] = acc; y[j] = acc;
+    }
+  };
+  assemble();
+  __syncthreads();
+  __shared__ int s_ok;
+  if (tid < 64) { const bool ok = chol_band_lds(Bd, Ar, n, tid, y); if (tid == 0) s_ok = ok; }
+  __syncthreads();
+  if (!s_ok) {
+    if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
+    double shift = 0;
+    if (D.mode == 1) {   // dense copy in HBM scratch -> smallest eigenvalue -> shift the diagonal (whole block cooperates)
+      double* Hd = D.xs_scr + (size_t)blockIdx.x * ((size_t)n * n + 4 * n);
+      double* sc = Hd + (size_t)n * n;
+      for (int idx = tid; idx < n * n; idx += XB_THREADS) { const int i = idx / n, j = idx % n; Hd[idx] = xb_entry(gh, D.P, i == m ? -1 : i + 6, j == m ? -1 : j + 6); }
+      __threadfence_block();
+      __syncthreads();
+      const double ev = min_eig_lds(Hd, n, sc, sc + n, sc + 2 * n, sc + 3 * n, tid, XB_THREADS);
+      if (ev < 0) shift = -ev * 1.0 + 0.01 * 1.0;
+    }
+    __syncthreads();
+    assemble();
+    __syncthreads();
+    if (shift != 0) {
+      for (int i = tid; i < m; i += XB_THREADS) Bd[i * BS + BS - 1] = Bd[i * BS + BS - 1] + shift;   // h0 - ev*I + 0.01*I, entry by entry like the dense kernel
+      if (tid == 0) Ar[m] = Ar[m] + shift;
+    }
+    __syncthreads();
+    if (tid < 64) chol_band_lds(Bd, Ar, n, tid, y);   // like the reference, the second factorisation is not re-checked
+    __syncthreads();
+  }
+  if (tid >= 64) return;
+  chol_band_backsolve_lds(Bd, Ar, n, y, tid);
+  double* scr = Bd;   // the factor is no longer needed: [n] x.g products, [n] g.g products
+  for (int i = tid; i < n; i += 64) y[i] = -y[i];
+  blk_sync<true>();
+  for (int i = tid; i < n; i += 64) { scr[i] = y[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
+  blk_sync<true>();
+  double* dir = D.dirp(u);
+  for (int idx = tid; idx < 3 * T; idx += 64) {
+    const int row = idx % T, a = idx / T;
+    dir[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0;
+  }
+  if (tid == 0) { D.wolfe(u) = -esum(scr, n); D.gn(u) = sqrt(esum(scr + n, n)); D.tdir(u) = y[m]; }
+}
+
 // Coupled mode, second half of the arrowhead solve: one wave per robot.  The Schur corner
 // sum_u (h_t,u - y_u.y_u) and its right-hand side are summed in robot order (every block forms the
 // same bits), the corner pivot is taken, and the existing arrow back-substitution finishes the

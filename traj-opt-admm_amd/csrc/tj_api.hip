@@ -141,9 +141,12 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if (in_graph) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad, s, d);
       else hipLaunchKernelGGL((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
       return true;
-    case K_XSOLVE: hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); return true;
+    case K_XSOLVE:
+      if (d.xs_band) hipLaunchKernelGGL(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
+      else hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d);
+      return true;
     case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
-    case K_CCD_PREP: if (in_graph && d.fuse) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
+    case K_CCD_PREP: if (in_graph && d.fuse && !d.xs_band) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
       hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
     case K_CCD: if (!in_graph && !in_phase) return false;
       if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d);
@@ -376,7 +379,11 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   const int n = 9 * d.P - 2;
   d.grad_npl = std::min(d.cap_obs + d.cap_self, 96);   // what a batch of segments really carries (SCN-C: <= 40); more goes through grad_scr
   c->lds_grad = grad_lds_doubles(d.grad_npl, d.res) * sizeof(double);
-  c->lds_xs = xsolve_lds_doubles(n) * sizeof(double);
+  const size_t lds_max = 160 * 1024 - 1024;
+  // long trajectories: the dense per-robot system no longer fits LDS -> band storage (decoupled / single-UAV modes)
+  d.xs_band = (xsolve_lds_doubles(n) * sizeof(double) > lds_max || getenv("TJ_XS_BAND")) ? 1 : 0;
+  if (d.xs_band && p->mode == TJ_MODE_MULTI_COUPLED) { c->err = "coupled mode (decouple:0) supports piece_num <= 10 (the arrowhead system's per-robot factor is exchanged as a dense block)"; return TJ_ERR_UNSUPPORTED; }
+  c->lds_xs = (d.xs_band ? xsolve_band_lds_doubles(n) : xsolve_lds_doubles(n)) * sizeof(double);
   c->lds_xs2 = ((size_t)n * n + 4 * (size_t)n) * sizeof(double);
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
   c->lds_ls = c->lsl.total * sizeof(double);
@@ -385,20 +392,20 @@ int tj_create(const tj_params* p, tj_ctx** out) {
 #endif
   if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
   if (d.res > GRAD_MAXRES) { c->err = "res > 16 segments per piece is not supported by the gradient kernel"; return TJ_ERR_UNSUPPORTED; }
-  const size_t lds_max = 160 * 1024 - 1024;
   d.seq_tree = (d.mode == TJ_MODE_MULTI_DECOUPLE && seq_lds_bytes(d.U, d.S, true) <= lds_max) ? 1 : 0;
   if (getenv("TJ_NO_SEQ_TREE")) d.seq_tree = 0;  // test hook: behave like a fleet too large for the LDS-resident tree
   c->lds_seq = seq_lds_bytes(d.U, d.S, d.seq_tree != 0);
-  if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max) {
-    c->err = "problem does not fit the 160 KB LDS of one CU (piece_num <= 10 supported in this version)";
+  if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
+    c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
     return TJ_ERR_UNSUPPORTED;
   }
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
-  HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
+  if (d.xs_band) HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
+  else HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_linesearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ls_coupled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
-  HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_c2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs2));
+  if (!d.xs_band) HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_c2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs2));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ccd_self_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_seq));
 
   HostTables t;
@@ -425,7 +432,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
-      (r = dalloc(c, &d.grad_scr, (size_t)(d.u1 - d.u0) * P * 16 * (size_t)(d.cap_obs + d.cap_self)))) return r;
+      (r = dalloc(c, &d.grad_scr, (size_t)(d.u1 - d.u0) * P * 16 * (size_t)(d.cap_obs + d.cap_self))) ||
+      (r = dalloc(c, &d.xs_scr, d.xs_band ? (size_t)(d.u1 - d.u0) * ((size_t)n * n + 4 * n) : 1))) return r;
   if (d.optimal_plane) {
     const bool m0 = d.mode == 0;
     if ((r = dalloc(c, &d.kobs_id, m0 ? U * S * d.cap_obs : 1)) || (r = dalloc(c, &d.kobs_n, U * S)) || (r = dalloc(c, &d.kobs_cd, m0 ? U * S * d.cap_obs * 4 : 1)) ||
