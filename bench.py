@@ -202,7 +202,7 @@ def main():
         torch.cuda.set_stream(tstream)
         slv.set_stream(tstream.cuda_stream)
         views = []
-        for what in (0, 1):
+        for what in ((0, 1, 2, 3, 4) if args.coupled else (0, 1)):
             ptr, per, first, n = slv.exchange_buffer(what)
             full = torch.as_tensor(_DevView(ptr, per * slv.U), device=f"cuda:{local}")
             views.append((full, full[first * per:(first + n) * per]))
@@ -232,7 +232,10 @@ def main():
             return work.wait
 
         def run(n_it):
-            sharding.run_sharded(_Eng, _gather, n_it, gather_begin=_gather_begin)
+            if args.coupled:   # six phases, five small all-gathers per iteration (sharding.COUPLED_SCHEDULE)
+                sharding.run_schedule(_Eng, _gather, n_it, sharding.COUPLED_SCHEDULE)
+            else:
+                sharding.run_sharded(_Eng, _gather, n_it, gather_begin=_gather_begin)
     else:
         def run(n_it):
             slv.iterate_async(n_it)

@@ -219,13 +219,23 @@ int tj_edge_collision(tj_ctx* c, int n, const double* edges, int n_prior, const 
 int tj_plan_init(tj_ctx* c, int n_robots, const double* starts, const double* goals, double bound_scale, int nodes, int min_waypoints, int cap_waypoints, double* waypoints, int* n_waypoints);
 
 /* ---- robot sharding across GPUs (one context per rank) -------------------------------------- */
-/* Device pointers + element counts of the two buffers that must be all-gathered per iteration
- * (robot-major, so a rank's owned robots are one contiguous slice): what = 0 control points
- * (spline, 3T doubles per robot), what = 1 search directions (3T + 4 doubles per robot:
- * direction, t_direction, wolfe, |g|, pad). */
+/* Device pointers + element counts of the buffers that must be all-gathered per iteration (robot-major, so a rank's owned
+ * robots are one contiguous slice of doubles):
+ *   what = 0  control points (spline, 3T doubles per robot)
+ *   what = 1  search direction records (3T + 4: direction, t_direction, wolfe, |g|, the robot's share of the time gradient)
+ * coupled mode ("decouple":0) only:
+ *   what = 2  Schur-corner contributions of the shared piece_time (4 per robot)  -- the arrowhead system of update_spline,
+ *             Optimization3D_multi.h:519-557: every rank eliminates its robots' blocks, the corner is their sum
+ *   what = 3  obstacle CCD exponent of every robot (1)  -- Step::couple_self_step takes ONE step for all (Step.h:112-182)
+ *   what = 4  energies of the Armijo candidates (4 rounds x 8 per robot)  -- the test is on the SUM over robots (:605-636) */
 int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_robot, int* first_owned, int* n_owned);
-/* Iteration split for external collectives: phase 0 = the stop test; all-gather control points; phase 1 = planes, gradient,
- * Newton direction; all-gather directions; phase 2 = CCD clamps and line search. */
+/* Iteration split for external collectives.  Decoupled / single-UAV, 3 phases:
+ *   phase 0 stop test | gather 0 | phase 1 planes, gradient, Newton direction | gather 1 | phase 2 CCD clamps, line search
+ * coupled, 6 phases:
+ *   phase 0 | gather 0 | phase 1 planes, gradient, per-robot elimination | gather 2 | phase 2 corner pivot + back substitution |
+ *   gather 1 | phase 3 CCD clamps, shared step, gnorm | gather 3 | phase 4 Armijo candidates (all rounds) | gather 4 | phase 5 commit
+ * Results are bitwise those of one unsharded context. */
+int tj_phase_count(tj_ctx* c);
 int tj_iterate_phase(tj_ctx* c, int phase);
 
 #ifdef __cplusplus

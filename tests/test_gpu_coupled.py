@@ -75,7 +75,42 @@ def test_coupled_end_to_end_vs_reference(pkg, scenes):
     s.close()
 
 
-def test_coupled_is_single_gpu_only(pkg, scenes):
-    scene = scene_by_name(scenes, "hard_coupled")
-    with pytest.raises(pkg.TrajAdmmError):
-        pkg.Solver(scene, rank=0, world=2)
+def test_coupled_mode_sharded_equals_unsharded(pkg, scenes):
+    """"decouple":0 with the robots split over two contexts (ranks 0/2 and 1/2 on the same GPU; the five per-iteration exchanges
+    done by plain device copies -- the schedule bench.py --coupled runs over RCCL): the arrowhead system is solved by per-rank
+    elimination + the gathered Schur-corner terms, the shared CCD step and the Armijo test on the summed energy use gathered
+    exponents / energies.  State must be BITWISE equal to the single-context run."""
+    import ctypes as C
+    import importlib
+    sharding = importlib.import_module("traj-opt-admm_amd.sharding")
+    scene = dict(scenes.hard(4, 4000)); scene["mode"] = 2
+    ref = pkg.Solver(scene, stop=0.0)
+    r0 = pkg.Solver(scene, stop=0.0, rank=0, world=2)
+    r1 = pkg.Solver(scene, stop=0.0, rank=1, world=2)
+    assert r0.phase_count() == 6
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def exchange(what):
+        p0, per, f0, n0 = r0.exchange_buffer(what)
+        p1, _, f1, n1 = r1.exchange_buffer(what)
+        r0.sync(); r1.sync()
+        assert hip.hipMemcpy(p0 + f1 * per * 8, p1 + f1 * per * 8, n1 * per * 8, 3) == 0
+        assert hip.hipMemcpy(p1 + f0 * per * 8, p0 + f0 * per * 8, n0 * per * 8, 3) == 0
+
+    for it in range(8):
+        ref.iterate(1)
+        for phase, what in sharding.COUPLED_SCHEDULE:
+            r0.iterate_phase(phase); r1.iterate_phase(phase)
+            if what is not None:
+                exchange(what)
+        r0.sync(); r1.sync()
+        a = ref.get_state(); b0 = r0.get_state(); b1 = r1.get_state()
+        h = scene["U"] // 2
+        for n in STATE:
+            assert np.array_equal(a[n][:h], b0[n][:h]), (it, n)
+            assert np.array_equal(a[n][h:], b1[n][h:]), (it, n)
+    assert np.all(b0["piece_time"][:h] == b1["piece_time"][h:][0])      # one piece_time for the whole fleet
+    assert ref.stats()["error_bits"] == 0 and r0.stats()["error_bits"] == 0 and r1.stats()["error_bits"] == 0
+    for x in (ref, r0, r1):
+        x.close()

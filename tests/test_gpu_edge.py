@@ -269,7 +269,8 @@ def test_many_obstacle_candidates_per_segment(pkg, scenes):
     assert "-3" in str(ei.value)
 
 
-def test_bench_two_processes_sharded_equals_single_process(tmp_path):
+@pytest.mark.parametrize("coupled", [False, True])
+def test_bench_two_processes_sharded_equals_single_process(tmp_path, coupled):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank, robots sharded,
     two all-gathers per iteration) on a 1-GPU box: both ranks share device 0 and the gathers go through host memory
     over gloo (RCCL refuses two ranks on one device).  The owned robots' final state must be bitwise what the
@@ -277,10 +278,10 @@ def test_bench_two_processes_sharded_equals_single_process(tmp_path):
     import json
     import sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "6", "--warmup", "2", "--scene", "B", "--no-cpu", "--state-checksum"]
+    common = ["--steps", "6", "--warmup", "2", "--scene", "B", "--no-cpu", "--state-checksum"] + (["--coupled"] if coupled else [])   # coupled: 6 phases, 5 gathers
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534" if coupled else "29533",
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-gpu"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-3000:]
     j = json.loads(two.stdout[two.stdout.index('{"metric"'):].split("\n")[0])
@@ -289,7 +290,7 @@ def test_bench_two_processes_sharded_equals_single_process(tmp_path):
     import hashlib
     import importlib
     pkg = importlib.import_module("traj-opt-admm_amd")
-    s = pkg.Solver(pkg.scenes.scn_b(), stop=0.0)
+    s = pkg.Solver(dict(pkg.scenes.scn_b(), mode=2) if coupled else pkg.scenes.scn_b(), stop=0.0)
     s.iterate(2); s.reset(); s.iterate(6)            # bench: warmup, reset, K timed iterations
     st = s.get_state()
     want = {}

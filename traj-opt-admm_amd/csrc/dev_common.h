@@ -145,6 +145,7 @@ struct Dev {
   // forward-substituted right-hand side, the raw gradient, {Schur corner, Schur rhs, g_t} contributions,
   // and the per-(round, robot, candidate) energies of the Armijo search on the summed objective
   double *xL, *xy, *xg, *xcorner, *ls_e;
+  double *k_obs_f;                // coupled + sharded: every robot's obstacle CCD exponent as a double (exchange buffer 3)
   double *xs_scr;                 // k_xsolve_band: per-robot dense scratch [owned][n*n + 4n] for the eigenvalue fallback
   int *k_obs, *k_self;            // [U] exponents: step = 0.8^k
   double *step_out;               // [U] accepted Armijo step (diagnostics)

@@ -20,7 +20,7 @@
 namespace tj {
 
 constexpr int LS_THREADS = 512;
-constexpr int LS_GROUPS = 8;
+constexpr int LS_GROUPS = 8;    // 16 candidates per round (1024 threads, 128-VGPR cap) measured SLOWER: 44.7 vs 40.5 us over the first 20 iterations
 constexpr int LS_GSIZE = 64;   // one wave per candidate: group-private LDS needs only wave-local ordering
 
 struct LsLayout {  // offsets in doubles into dynamic LDS
@@ -379,13 +379,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
 // candidates (round 0: E(x) and steps 0.8^0..0.8^6, later rounds 8 more steps each) into ls_e; the next
 // launch (or k_ls_commit) first forms the totals in robot order -- every block computes the same bits --
 // and returns at once when an earlier round already holds the accepted step.
-__device__ __forceinline__ int lsc_cand_k(int round, int c) { return round == 0 ? c - 1 : 7 + (round - 1) * LS_GROUPS + c; }
+__device__ __forceinline__ int lsc_cand_k(int round, int c) { return round == 0 ? c - 1 : (LS_GROUPS - 1) + (round - 1) * LS_GROUPS + c; }
 
 // step after the CCD clamps and the t > 0 guard (Optimization3D_multi.h:586-601); wave 0 computes, all threads get it
 __device__ __forceinline__ double lsc_step0(const Dev& D, int tid, double t0, double t_dir, double* s_val) {
   if (tid < 64) {
     int kmax = D.k_self[0];
-    for (int r = tid; r < D.U; r += 64) kmax = max(kmax, D.k_obs[r]);
+    const bool sharded = D.u1 - D.u0 != D.U;   // foreign robots' exponents arrive through exchange buffer 3
+    for (int r = tid; r < D.U; r += 64) kmax = max(kmax, sharded ? (int)D.k_obs_f[r] : D.k_obs[r]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
     double step0 = D.pow08[min(LOOP_CAP, kmax)];
@@ -400,13 +401,13 @@ __device__ __forceinline__ double lsc_step0(const Dev& D, int tid, double t0, do
 // (-1 none), acc[1] = slot, accstep = its step.
 __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double step0, int lane, int* acc, double* accstep) {
   const double wolfe = D.ctl->wolfe_c;
-  const int c = lane & 7;
+  const int c = lane % LS_GROUPS;
   double e0 = 0;
   int found_r = -1, found_c = 0; double found_step = step0;
   for (int r = 0; r < nrounds && found_r < 0; r++) {
     double tot = 0, step = step0;
     if (lane < LS_GROUPS) {
-      for (int u = 0; u < D.U; u++) tot += D.ls_e[((size_t)r * D.U + u) * LS_GROUPS + c];  // e += spline_energy(i), robot order
+      for (int u = 0; u < D.U; u++) tot += D.ls_e[((size_t)u * LSC_ROUNDS + r) * LS_GROUPS + c];  // e += spline_energy(i), robot order
       const int k = lsc_cand_k(r, c);
       for (int i = 0; i < k; i++) step *= 0.8;
     }
@@ -428,7 +429,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   const int g = tid / LS_GSIZE, gl = tid % LS_GSIZE;
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
-  if (round > 0) {
+  // the early exit needs every robot's energies of the earlier rounds: a sharded context (u1 - u0 < U) only has its own until
+  // the all-gather after the last round, so it evaluates every round (same decision, taken by k_ls_commit on the gathered table)
+  if (round > 0 && D.u1 - D.u0 == D.U) {
     if (tid < 64) lsc_decide(D, round, step0, tid, s_acc, &s_accstep);
     __syncthreads();
     if (s_acc[0] >= 0) return;  // an earlier round already holds the accepted step
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
   __syncthreads();
   const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl);
-  if (gl == 0) D.ls_e[((size_t)round * D.U + u) * LS_GROUPS + g] = e;
+  if (gl == 0) D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + g] = e;
 }
 
 // commit: x_u += step d_u for every robot, the shared piece_time advances by step * t_direction

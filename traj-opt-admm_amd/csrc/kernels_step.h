@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     const int kshared = ks[0];
     __syncthreads();
     for (int i = lane; i < D.U; i += 64) { D.k_self[i] = D.coupled() ? kshared : ks[i]; seen[i] = 0; }
+    if (D.coupled()) for (int i = D.u0 + lane; i < D.u1; i += 64) D.k_obs_f[i] = (double)D.k_obs[i];   // exchange buffer 3 (sharded contexts)
   }
   // gnorm exactly as the drivers form it (Optimization3D_multi.h:57,72,750; _admm.h:499): a
   // sequential sum in robot order; the values are first pulled into LDS by all lanes

@@ -135,10 +135,10 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
       hipLaunchKernelGGL(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
-    case K_SEP_SELF_COMPACT: if (in_graph) return false;   // single-GPU chain: folded into k_grad
+    case K_SEP_SELF_COMPACT: if (in_graph || in_phase) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
       hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD:
-      if (in_graph) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad, s, d);
+      if (in_graph || in_phase) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad, s, d);
       else hipLaunchKernelGGL((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
       return true;
     case K_XSOLVE:
@@ -226,16 +226,27 @@ int flush_deferred(tj_ctx* c) {
 //   phase 0: begin (stop test)                                                            -> all-gather control points
 //   phase 1: hull cache (ALL robots), k_front {obstacle query | pair rows}, k_mid, compaction, gradient, Newton solve -> all-gather directions
 //   phase 2: swept-hull cache (ALL robots), k_ccd, sequential pair clamp + gnorm, line search
-int enqueue_body(tj_ctx* c, int which, int chain_pos = 0) {
-  if (which == 3) return enqueue_iteration(c, chain_pos);
+int enqueue_body(tj_ctx* c, int which, int chain_pos = 0, bool whole_iteration = false) {
+  if (whole_iteration) return enqueue_iteration(c, chain_pos);
   hipStream_t m = c->stream;
-  static const int ph0[] = {K_BEGIN}, ph1[] = {K_HULLINFO, K_FRONT, K_MID, K_KEEP, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE, K_XSOLVE_C2},
-                   ph2[] = {K_CCD_PREP, K_CCD, K_CCD_SELF_SEQ, K_LINESEARCH, K_LS_COUPLED, K_LS_COMMIT};
-  const int* list = which == 0 ? ph0 : (which == 1 ? ph1 : ph2);
-  const int n = which == 0 ? 1 : (which == 1 ? 8 : 6);
+  // decoupled / single: 3 phases.  coupled ("decouple":0): 6 phases -- the arrowhead system, the shared CCD step and the
+  // Armijo test on the summed energy each need something from every robot (tj_iterate_phase, trajadmm.h)
+  static const int ph0[] = {K_BEGIN}, ph1[] = {K_HULLINFO, K_FRONT, K_MID, K_KEEP, K_SEP_SELF_COMPACT, K_GRAD, K_XSOLVE},
+                   ph2[] = {K_CCD_PREP, K_CCD, K_CCD_SELF_SEQ, K_LINESEARCH},
+                   pc2[] = {K_XSOLVE_C2}, pc3[] = {K_CCD_PREP, K_CCD, K_CCD_SELF_SEQ}, pc4[] = {K_LS_COUPLED}, pc5[] = {K_LS_COMMIT};
+  const bool cpl = c->d.mode == TJ_MODE_MULTI_COUPLED;
+  const int* list = nullptr; int n = 0;
+  switch (which) {
+    case 0: list = ph0; n = 1; break;
+    case 1: list = ph1; n = 7; break;
+    case 2: if (cpl) { list = pc2; n = 1; } else { list = ph2; n = 4; } break;
+    case 3: list = pc3; n = 3; break;
+    case 4: list = pc4; n = 1; break;
+    case 5: list = pc5; n = 1; break;
+  }
   for (int i = 0; i < n; i++) launch_kernel(c, list[i], m, 0, false, true);
   HIPCHK(c, hipGetLastError());
-  if (which == 2) c->maybe_deferred = true;  // this iteration's slack/dual update is owed to the next k_mid (or the flush)
+  if (which == (cpl ? 5 : 2)) c->maybe_deferred = true;  // this iteration's slack/dual update is owed to the next k_mid (or the flush)
   return TJ_OK;
 }
 
@@ -247,7 +258,7 @@ int launch_graph_or_eager(tj_ctx* c, int which, int chain_pos = 0) {
   // hipGraph replay of the same chain measured 4 us SLOWER per iteration (~8 us between consecutive graph launches),
   // and ten iterations per graph 6 us slower still.  TJ_USE_GRAPH=1 selects the captured-graph replay.
   if (!c->use_graph) {
-    int r = enqueue_body(c, which, chain_pos);
+    int r = enqueue_body(c, which, chain_pos, which == 3);
     if (r == TJ_OK && which >= 3) c->maybe_deferred = true;
     return r;
   }
@@ -255,7 +266,7 @@ int launch_graph_or_eager(tj_ctx* c, int which, int chain_pos = 0) {
   if (!c->graph_ok[which] && !c->graph_failed[which]) {
     hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-      int r = enqueue_body(c, which);
+      int r = enqueue_body(c, which, 0, which == 3);
       hipGraph_t g = nullptr;
       e = hipStreamEndCapture(c->stream, &g);
       if (r == TJ_OK && e == hipSuccess && g && hipGraphInstantiate(&c->gexec[which], g, nullptr, nullptr, 0) == hipSuccess) { c->graph[which] = g; c->graph_ok[which] = true; }
@@ -267,7 +278,7 @@ int launch_graph_or_eager(tj_ctx* c, int which, int chain_pos = 0) {
     if (which == 3) c->maybe_deferred = true;  // a replayed iteration leaves its slack/dual update owed
     return TJ_OK;
   }
-  return enqueue_body(c, which);
+  return enqueue_body(c, which, 0, which == 3);
 }
 
 int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
@@ -355,7 +366,6 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     c->err = "invalid tj_params (need uav_num>=1, piece_num>=2, res>=1, mode 0/1/2, 0<=rank<world)";
     return TJ_ERR_INVALID;
   }
-  if (p->mode == TJ_MODE_MULTI_COUPLED && p->world != 1) { c->err = "TJ_MODE_MULTI_COUPLED is single-GPU in this version (world must be 1)"; return TJ_ERR_UNSUPPORTED; }
   if (p->mode == TJ_MODE_SINGLE && p->uav_num != 1) { c->err = "TJ_MODE_SINGLE requires uav_num == 1"; return TJ_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device available (this library has no CPU fallback)"; return TJ_ERR_DEVICE; }
@@ -442,7 +452,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   }
   if (d.mode == TJ_MODE_MULTI_COUPLED &&
       ((r = dalloc(c, &d.xL, U * (size_t)n * n)) || (r = dalloc(c, &d.xy, U * (size_t)n)) || (r = dalloc(c, &d.xg, U * (size_t)n)) ||
-       (r = dalloc(c, &d.xcorner, U * 4)) || (r = dalloc(c, &d.ls_e, (size_t)LSC_ROUNDS * U * LS_GROUPS)))) return r;
+       (r = dalloc(c, &d.xcorner, U * 4)) || (r = dalloc(c, &d.k_obs_f, U)) || (r = dalloc(c, &d.ls_e, (size_t)LSC_ROUNDS * U * LS_GROUPS)))) return r;
   return TJ_OK;
 }
 
@@ -748,8 +758,10 @@ int tj_run_stage(tj_ctx* c, int stage) {
   return check_device_errors(c);
 }
 
+int tj_phase_count(tj_ctx* c) { return c ? (c->d.mode == TJ_MODE_MULTI_COUPLED ? 6 : 3) : TJ_ERR_INVALID; }
+
 int tj_iterate_phase(tj_ctx* c, int phase) {
-  if (!c || phase < 0 || phase > 2) return TJ_ERR_INVALID;
+  if (!c || phase < 0 || phase >= tj_phase_count(c)) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
   // eager launches: measured faster than three graph replays per iteration (a replay costs ~10-16 us of host time, a
   // plain launch ~3.5 us, and a phase has only 2-7 kernels).  No flush here: the slack/dual update an iteration owes is
@@ -758,10 +770,19 @@ int tj_iterate_phase(tj_ctx* c, int phase) {
 }
 
 int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_robot, int* first_owned, int* n_owned) {
-  if (!c || what < 0 || what > 1) return TJ_ERR_INVALID;
+  if (!c || what < 0 || what > 4) return TJ_ERR_INVALID;
   const Dev& d = c->d;
-  if (dev_ptr) *dev_ptr = what == 0 ? (void*)d.spline : (void*)d.xdir;
-  if (doubles_per_robot) *doubles_per_robot = what == 0 ? 3 * d.T : d.xs;
+  if (what >= 2 && d.mode != TJ_MODE_MULTI_COUPLED) { c->err = "tj_exchange_buffer: buffers 2..4 exist in coupled mode only"; return TJ_ERR_INVALID; }
+  void* p = nullptr; int per = 0;
+  switch (what) {
+    case 0: p = d.spline; per = 3 * d.T; break;
+    case 1: p = d.xdir; per = d.xs; break;
+    case 2: p = d.xcorner; per = 4; break;                       // Schur-corner contributions of the shared piece_time
+    case 3: p = d.k_obs_f; per = 1; break;                       // obstacle CCD exponent of every robot (as a double)
+    case 4: p = d.ls_e; per = LSC_ROUNDS * LS_GROUPS; break;     // energies of the Armijo candidates
+  }
+  if (dev_ptr) *dev_ptr = p;
+  if (doubles_per_robot) *doubles_per_robot = per;
   if (first_owned) *first_owned = d.u0;
   if (n_owned) *n_owned = d.u1 - d.u0;
   return TJ_OK;

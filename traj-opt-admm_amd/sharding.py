@@ -23,6 +23,25 @@ def owned_range(n_robots, rank, world):
     return (rank * n_robots) // world, ((rank + 1) * n_robots) // world
 
 
+# Coupled mode ("decouple":0, one piece_time shared by all robots): the arrowhead Newton system, the single CCD step and the
+# Armijo test on the summed energy each need a small contribution from every robot (Optimization3D_multi.h:508-639,
+# Step.h:112-182), so an iteration has six phases and five exchanges:
+#   phase 0 stop test | gather 0 control points | phase 1 planes, gradient, per-robot elimination | gather 2 Schur-corner terms |
+#   phase 2 corner pivot + back substitution | gather 1 directions | phase 3 CCD clamps, shared step, gnorm |
+#   gather 3 obstacle CCD exponents | phase 4 Armijo candidates | gather 4 their energies | phase 5 commit
+COUPLED_SCHEDULE = ((0, 0), (1, 2), (2, 1), (3, 3), (4, 4), (5, None))
+DECOUPLED_SCHEDULE = ((0, 0), (1, 1), (2, None))
+
+
+def run_schedule(engine, gather, n_iters, schedule):
+    """(phase, what to all-gather after it) pairs, n_iters times"""
+    for _ in range(n_iters):
+        for phase, what in schedule:
+            engine.phase(phase)
+            if what is not None:
+                gather(what)
+
+
 def run_sharded(engine, gather, n_iters, gather_begin=None):
     """engine.phase(k) runs phase k for the robots this rank owns; gather(what) all-gathers buffer
     `what` (0 = control points, 1 = direction records) in place.
