@@ -85,6 +85,32 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
   const double m = D.margin;
   double part = 0, partb = 0;
   int bad = 0;
+  // velocity / acceleration barriers (Energy_admm.h:98-170); two loops so that a wave never runs
+  // both formulas
+  for (int it = gl; it < S * 5; it += LS_GSIZE) {
+    const int tr = it / 5, b = it % 5;
+    const double w = seg_weight(D, tr);
+    const double* Pp = hulls + tr * 18;
+    const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
+    const double d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
+    if (d <= 0) bad = 1;
+    else if (d < m) partb += barrier(w, d, m);
+  }
+  for (int it = gl; it < S * 4; it += LS_GSIZE) {
+    const int tr = it / 4, j = it % 4;
+    const double w = seg_weight(D, tr);
+    const double* Pp = hulls + tr * 18;
+    const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
+                 az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
+    const double d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
+    if (d <= 0) bad = 1;
+    else if (d < m) partb += barrier(w, d, m);
+  }
+  // A violated velocity / acceleration limit already makes the energy +infinity (Energy_admm.h:137-138,154-155): skip the plane
+  // terms and the consensus sums.  In the first iterations every robot backs off 10-20 times on exactly this (measured:
+  // tests/devtools/armijo_hist.py), so most candidates of those rounds end here.  The group = one wave: the decision is uniform.
+  if (__ballot(bad != 0) != 0ull) return INFINITY;
+  TJ_TIC(D, K_BEGIN, 2);
   // plane barrier (Energy_admm.h:46-96)
   const double* pl_lds = sm + L.planes;
   const int* pltr = (const int*)(sm + L.pltr);
@@ -107,28 +133,6 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
       if (d <= 0) bad = 1;
       else if (d < m) part += barrier(w, d, m);
     }
-  }
-  TJ_TIC(D, K_BEGIN, 2);
-  // velocity / acceleration barriers (Energy_admm.h:98-170); two loops so that a wave never runs
-  // both formulas
-  for (int it = gl; it < S * 5; it += LS_GSIZE) {
-    const int tr = it / 5, b = it % 5;
-    const double w = seg_weight(D, tr);
-    const double* Pp = hulls + tr * 18;
-    const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
-    const double d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
-    if (d <= 0) bad = 1;
-    else if (d < m) partb += barrier(w, d, m);
-  }
-  for (int it = gl; it < S * 4; it += LS_GSIZE) {
-    const int tr = it / 4, j = it % 4;
-    const double w = seg_weight(D, tr);
-    const double* Pp = hulls + tr * 18;
-    const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
-                 az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
-    const double d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
-    if (d <= 0) bad = 1;
-    else if (d < m) partb += barrier(w, d, m);
   }
   TJ_TIC(D, K_BEGIN, 3);
   // fixed butterfly inside the group
