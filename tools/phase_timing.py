@@ -36,7 +36,7 @@ def main():
     lib = C.CDLL(os.environ["TRAJADMM_LIB"])
     lib.tj_kernel_name.restype = C.c_char_p
     NAMES[:] = [lib.tj_kernel_name(i).decode() for i in range(lib.tj_kernel_count())]
-    out = np.zeros((len(NAMES), 4096, 8), dtype=np.int64)
+    out = np.zeros((len(NAMES), 65536, 8), dtype=np.int64)
     lib.tj_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.tj_debug_phase_times(s._ctx, out.ctypes.data) == len(NAMES)
     km = NAMES.index("k_mid")
@@ -44,7 +44,7 @@ def main():
     if live.any():
         t0 = t[live, 0].min()
         n_sl = scene["U"] * scene["P"]; n_pair = 1024 if scene["mode"] >= 1 else 0
-        for lab, lo, hi in (("slack", 0, n_sl), ("pair solve", n_sl, n_sl + n_pair), ("obstacle solve", n_sl + n_pair, 4096)):
+        for lab, lo, hi in (("slack", 0, n_sl), ("pair solve", n_sl, n_sl + n_pair), ("obstacle solve", n_sl + n_pair, 65536)):
             sel = live.copy(); sel[:lo] = False; sel[hi:] = False
             if sel.any():
                 st = (t[sel, 0] - t0) * 0.01; en = (t[sel, 1] - t0) * 0.01; du = en - st
@@ -53,7 +53,7 @@ def main():
     t = out[kf]; live = t[:, 0] != 0
     if live.any():
         t0 = t[live, 0].min(); n_obs = scene["U"] * scene["P"] * 8
-        for lab, lo, hi in (("obstacle query", 0, n_obs), ("pair rows", n_obs, 8192)):
+        for lab, lo, hi in (("obstacle query", 0, n_obs), ("pair rows", n_obs, 65536)):
             sel = live.copy(); sel[:lo] = False; sel[hi:] = False
             if sel.any():
                 st = (t[sel, 0] - t0) * 0.01; en = (t[sel, 1] - t0) * 0.01; du = en - st

@@ -37,7 +37,7 @@ struct Ctl {
   int epoch;           // bumped by every k_begin: stamp that marks this iteration's pair-plane slots as valid
   int slack_now;       // the slack/dual update of the PREVIOUS iteration is due (deferred so it overlaps the next planes)
   int slack_next;      // the iteration that k_begin just started still owes its slack/dual update
-  int any_pair;        // some robot pair is within `offset` at full step this iteration: the sequential CCD replay has work
+  int any_pair;        // robot pairs within `offset` at full step this iteration (entries of Dev::pair_list): work of the sequential CCD replay
   int order_unresolved; // segments whose pair order mattered but could not be replayed in the reference's tree order
   int ticket;          // k_linesearch blocks that have finished (the last one does the next iteration's k_begin work)
   int pad1;
@@ -63,7 +63,7 @@ constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates 
 
 // Phase stamps for kernel tuning: compiled in only by `make timing` (-DTJ_PHASE_TIMING); thread 0 of
 // a block stores the constant-rate wall clock at a phase boundary.  The product build has none.
-constexpr int TJ_TIC_BLOCKS = 4096, TJ_TIC_SLOTS = 8;
+constexpr int TJ_TIC_BLOCKS = 65536, TJ_TIC_SLOTS = 8;   // blocks per kernel that leave stamps (timing builds only)
 #ifdef TJ_PHASE_TIMING
 #define TJ_TIC(D, kid, slot) do { if (threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
 #else
@@ -150,8 +150,7 @@ struct Dev {
   int *k_obs, *k_self;            // [U] exponents: step = 0.8^k
   double *step_out;               // [U] accepted Armijo step (diagnostics)
   double *ccdinfo;                // [U][S][CCD_STRIDE] swept-hull cache of the current direction
-  int *pair_list; int *pair_count;   // [S][U][cap_row] partner indices per (segment, lower robot), [S][U]
-  int cap_row;
+  int *pair_list;                 // [ACT_CAP] inter-robot CCD: keys (segment, p0, p1) of the pairs within `offset` at full step; Ctl::any_pair counts them
   // per-(robot, segment) statistics slots {nodes_dcd, cand_dcd, nodes_ccd, cand_ccd, planes_obs, planes_self}:
   // each slot is only ever touched by the one wave that owns (robot, segment), so plain += suffices
   // (a shared counter would serialise ~10^4 atomics per iteration on one L2 word)

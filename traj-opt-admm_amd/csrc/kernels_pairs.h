@@ -51,9 +51,23 @@ __global__ __launch_bounds__(64) void k_hullinfo(Dev D) {
   }
 }
 
-// one (segment, lower robot) row = one wavefront; bid in [0, S * U)
+// one (segment, lower robot p0, chunk of 64 partners p1 > p0) = one wavefront.  With hundreds of robots a whole row per wave
+// left the rows of the middle segments (where everybody meets) as a long tail; only chunks that HAVE partners are launched:
+// chunk c exists for p0 <= U - 2 - 64c, i.e. pair_units(U) = sum_c max(0, U - 1 - 64c) units per segment (636 instead of
+// 1024 row-chunks at U = 256: workgroup dispatch is what bounds these kernels at that size).
+__host__ __device__ inline int pair_units(int U) { int n = 0; for (int c = 0; U - 1 - 64 * c > 0; c++) n += U - 1 - 64 * c; return n; }
+__host__ __device__ inline void pair_unit(int U, int bid, int& tr, int& p0, int& chunk) {
+  const int per = pair_units(U);
+  tr = bid / per;
+  int r = bid % per;
+  chunk = 0;
+  while (r >= U - 1 - 64 * chunk) { r -= U - 1 - 64 * chunk; chunk++; }
+  p0 = r;
+}
 __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid) {
-  const int tr = bid / D.U, p0 = bid % D.U, lane = lane_id();
+  int tr, p0, chunk;
+  pair_unit(D.U, bid, tr, p0, chunk);
+  const int lane = lane_id();
   const int U = D.U;
   __shared__ double A[HULL_STRIDE];   // hull, box and k-DOP intervals of robot p0
   __shared__ int todo[64];            // partner ids that passed box + k-DOP
@@ -63,7 +77,8 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid) {
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
   const bool own0 = p0 >= D.u0 && p0 < D.u1;
-  for (int c0 = p0 + 1; c0 < U; c0 += 64) {
+  {
+    const int c0 = p0 + 1 + 64 * chunk;
     // 1. lanes over partners: AABB test (12 independent loads per lane)
     const int p1 = c0 + lane;
     bool hit = false;

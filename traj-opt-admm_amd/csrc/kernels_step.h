@@ -23,6 +23,7 @@
 #include "dev_linalg.h"
 #include "kernels_sep.h"
 #include "kernels_ls.h"
+#include "kernels_pairs.h"
 #include "dev_dyntree.h"
 
 namespace tj {
@@ -114,16 +115,19 @@ __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
   ccd_obs_body<PRIM>(D, blockIdx.x);
 }
 
-// Phase A: one wave per (segment, lower robot p0); lanes over the partners p1 > p0.  Survivors are
-// written in ascending p1, so (segment, p0, p1) is a lexicographic, deterministic pair order.
+// Phase A: one wave per (segment, lower robot p0, chunk of 64 partners p1 > p0); lanes over the partners.  Acting pairs go to
+// ONE global list as sortable keys; the replay kernel sorts it, so (segment, p0, p1) is a lexicographic, deterministic order.
+constexpr int ACT_CAP = 4096;                                    // acting pairs of one iteration (all segments)
+__device__ __forceinline__ int act_key(int tr, int p0, int p1) { return (tr << 20) | (p0 << 10) | p1; }   // S < 512, U <= 1024
 __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
-  const int tr = bid / D.U, p0 = bid % D.U, lane = lane_id();
+  int tr, p0, chunk;
+  pair_unit(D.U, bid, tr, p0, chunk);
+  const int lane = lane_id();
   const int U = D.U;
+  const int c0 = p0 + 1 + 64 * chunk;
   const double off = D.offset;
   const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
-  int* out = D.pair_list + ((size_t)tr * U + p0) * D.cap_row;
-  int base = 0;
-  for (int c0 = p0 + 1; c0 < U; c0 += 64) {
+  {
     const int p1 = c0 + lane;
     bool ok = false;
     if (p1 < U) {
@@ -149,16 +153,16 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
       }
     }
     const unsigned long long mask = ballot(ok);
-    const int w = base + prefix_count(mask);
-    if (ok) {
-      if (w < D.cap_row) out[w] = p1;
-      else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
+    if (mask) {   // rare
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&D.ctl->any_pair, __popcll(mask));   // any_pair = number of acting pairs this iteration
+      base = __shfl(base, 0);
+      const int w = base + prefix_count(mask);
+      if (ok) {
+        if (w < ACT_CAP) D.pair_list[w] = act_key(tr, p0, p1);
+        else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
+      }
     }
-    base += __popcll(mask);
-  }
-  if (lane == 0) {
-    D.pair_count[tr * U + p0] = min(base, D.cap_row);
-    if (base > 0) atomicOr(&D.ctl->any_pair, 1);
   }
 }
 
@@ -178,52 +182,64 @@ constexpr int SEQ_ACT_CAP = 256;   // acting pairs of ONE segment
 constexpr int SEQ_STK_CAP = 1024;  // node-pair stack of the tree's self query
 __host__ __device__ inline size_t seq_lds_bytes(int U, int S, bool with_tree) {
   size_t b = (with_tree ? dyntree_lds_bytes(U) + 6 * (size_t)U * sizeof(double) : 0);
-  b += (2 * (size_t)U + (size_t)S * U + 3 * SEQ_ACT_CAP + (with_tree ? 2 * SEQ_STK_CAP : 0)) * sizeof(int);
+  b += (size_t)U * sizeof(double);   // gnorm staging
+  b += (2 * (size_t)U + ACT_CAP + 3 * SEQ_ACT_CAP + (with_tree ? 2 * SEQ_STK_CAP : 0)) * sizeof(int);
+  (void)S;
   return b;
 }
 __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   if (D.ctl->done) return;
   const int lane = lane_id();
   extern __shared__ double seq_sm[];
-  // doubles first (alignment): tree nodes + the segment's swept boxes, then the int arrays
+  // doubles first (alignment): tree nodes + the segment's swept boxes + gnorm staging, then the int arrays
   double* tbox = seq_sm; double* tarea = tbox + (D.seq_tree ? 12 * (size_t)D.U : 0); double* bx = tarea + (D.seq_tree ? 2 * (size_t)D.U : 0);
-  int* ti = (int*)(bx + (D.seq_tree ? 6 * (size_t)D.U : 0));   // [5][2U] parent, left, right, height, particle
+  double* gns = bx + (D.seq_tree ? 6 * (size_t)D.U : 0);        // [U]
+  int* ti = (int*)(gns + D.U);                                   // [5][2U] parent, left, right, height, particle
   int* ks = ti + (D.seq_tree ? 10 * (size_t)D.U : 0);           // [U] exponents
   int* seen = ks + D.U;                                          // [U] last segment in which the robot appeared
-  int* cnt = seen + D.U;                                         // [S*U] survivor counts, staged once so the segment loop never waits on HBM
-  int* act0 = cnt + (size_t)D.S * D.U; int* act1 = act0 + SEQ_ACT_CAP; int* ord = act1 + SEQ_ACT_CAP;
+  int* keys = seen + D.U;                                        // [ACT_CAP] acting pairs, sorted
+  int* act0 = keys + ACT_CAP; int* act1 = act0 + SEQ_ACT_CAP; int* ord = act1 + SEQ_ACT_CAP;
   int* stk = ord + SEQ_ACT_CAP;
   TJ_TIC(D, K_CCD_SELF_SEQ, 0);
   for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
-  // usually no pair is within `offset` at full step (the selection kernel raises a flag otherwise): skip staging and walk
-  const bool any_pair = D.multi() && D.ctl->any_pair != 0;
-  if (any_pair) for (int i = lane; i < D.S * D.U; i += 64) cnt[i] = D.pair_count[i];
+  // usually no pair is within `offset` at full step (any_pair counts the acting pairs the selection kernel listed)
+  const int n_act = D.multi() ? min(D.ctl->any_pair, ACT_CAP) : 0;
+  if (n_act > 0) {
+    // stage the keys and sort them ascending = (segment, p0, p1) lexicographic: bitonic network over the next power of two
+    int npow = 1; while (npow < n_act) npow <<= 1;
+    for (int i = lane; i < npow; i += 64) keys[i] = i < n_act ? D.pair_list[i] : 0x7fffffff;
+    blk_sync<true>();
+    for (int k = 2; k <= npow; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = lane; i < npow; i += 64) {
+          const int l = i ^ j;
+          if (l > i) {
+            const int x = keys[i], y = keys[l];
+            const bool up = (i & k) == 0;
+            if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+          }
+        }
+        blk_sync<true>();
+      }
+  }
   __syncthreads();
   TJ_TIC(D, K_CCD_SELF_SEQ, 1);
-  if (any_pair) {
+  if (n_act > 0) {
     const bool shared = D.coupled();  // Step::couple_self_step (Step.h:112-182): one step for all robots, held in ks[0]
     const double off2 = D.offset * D.offset;
     int ambiguous = 0, unresolved = 0;
-    for (int tr = 0; tr < D.S; tr++) {
+    for (int pos = 0; pos < n_act;) {
       // 1. this segment's acting pairs, lexicographic (p0, p1); does any robot appear twice?
+      const int tr = keys[pos] >> 20;
       int m = 0; bool share = false;
-      for (int r0 = 0; r0 < D.U; r0 += 64) {  // rows with survivors, found 64 at a time
-        unsigned long long rows = ballot(r0 + lane < D.U && cnt[tr * D.U + min(r0 + lane, D.U - 1)] > 0);
-        while (rows) {
-          const int p0 = r0 + __ffsll((long long)rows) - 1;
-          rows &= rows - 1;
-          const int n = cnt[tr * D.U + p0];
-          for (int i = 0; i < n; i++) {
-            const int p1 = D.pair_list[((size_t)tr * D.U + p0) * D.cap_row + i];
-            if (seen[p0] == tr || seen[p1] == tr) share = true;
-            blk_sync<true>();
-            if (lane == 0) { seen[p0] = tr; seen[p1] = tr; if (m < SEQ_ACT_CAP) { act0[m] = p0; act1[m] = p1; } }
-            blk_sync<true>();
-            m++;
-          }
-        }
+      while (pos < n_act && (keys[pos] >> 20) == tr) {
+        const int p0 = (keys[pos] >> 10) & 1023, p1 = keys[pos] & 1023;
+        if (seen[p0] == tr || seen[p1] == tr) share = true;
+        blk_sync<true>();
+        if (lane == 0) { seen[p0] = tr; seen[p1] = tr; if (m < SEQ_ACT_CAP) { act0[m] = p0; act1[m] = p1; } }
+        blk_sync<true>();
+        m++; pos++;
       }
-      if (m == 0) continue;
       if (m > SEQ_ACT_CAP) { if (lane == 0) atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW); m = SEQ_ACT_CAP; unresolved += share && !shared; share = false; }
       // 2. order: lexicographic unless two acting pairs share a robot, then the reference's tree order
       bool tree_order = false;
@@ -273,7 +289,6 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   }
   // gnorm exactly as the drivers form it (Optimization3D_multi.h:57,72,750; _admm.h:499): a
   // sequential sum in robot order; the values are first pulled into LDS by all lanes
-  double* gns = reinterpret_cast<double*>(cnt);  // reuse the staging area (S*U ints >= U doubles for S >= 2)
   __syncthreads();
   for (int i = lane; i < D.U; i += 64) gns[i] = D.gn(i);
   __syncthreads();

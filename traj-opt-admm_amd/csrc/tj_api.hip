@@ -115,11 +115,13 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
   const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 512 : 0;
+  const int n_rows = multi ? d.S * pair_units(d.U) : 0;   // one wave per (segment, lower robot, chunk of 64 partners)
+  const int n_front = owned * d.S + n_rows, n_ccd = n_front;
   switch (kid) {
     case K_BEGIN: if (chain_pos & 1) return false; hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
     case K_FRONT: if (!in_graph && !in_phase) return false;
-      if (tri) hipLaunchKernelGGL((k_front<3>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_front<1>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d);
+      if (tri) hipLaunchKernelGGL((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
       return true;
     case K_SEP_OBS: if (in_graph || in_phase) return false;  // stage API and sharded phase 0
       if (tri) hipLaunchKernelGGL((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d);
@@ -127,7 +129,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false;
       if (tri) hipLaunchKernelGGL((k_obs_solve<3>), dim3(n_obs_solve), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_solve<1>), dim3(n_obs_solve), dim3(64), 0, s, d);
       return true;
-    case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
+    case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d); return true;
     case K_MID: if (!in_graph && !in_phase) return false;
       if (tri) hipLaunchKernelGGL((k_mid<3>), dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else hipLaunchKernelGGL((k_mid<1>), dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
       return true;
@@ -149,12 +151,12 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_CCD_PREP: if (in_graph && d.fuse && !d.xs_band) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
       hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
     case K_CCD: if (!in_graph && !in_phase) return false;
-      if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(owned * d.S + (multi ? d.S * d.U : 0)), dim3(64), 0, s, d);
+      if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(n_ccd), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(n_ccd), dim3(64), 0, s, d);
       return true;
     case K_CCD_OBS: if (in_graph) return false;
       if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d);
       return true;
-    case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(d.S * d.U), dim3(64), 0, s, d); return true;
+    case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
     case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
@@ -383,7 +385,6 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, std::min(d.U - 1, 64));  // neighbours within offset + 2 margin of ONE segment; k_grad's LDS grows with it
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
   d.optimal_plane = p->optimal_plane ? 1 : 0;
-  d.cap_row = std::max(1, std::min(d.cap_pairs, d.U));  // partners per (segment, lower robot)
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
@@ -400,6 +401,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
 #ifdef TJ_PHASE_TIMING
   { int r_ = dalloc(c, &d.dbg, (size_t)K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS); if (r_) return r_; }
 #endif
+  if (d.U > 1024) { c->err = "more than 1024 robots are not supported (pair keys pack robot ids into 10 bits)"; return TJ_ERR_UNSUPPORTED; }
   if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
   if (d.res > GRAD_MAXRES) { c->err = "res > 16 segments per piece is not supported by the gradient kernel"; return TJ_ERR_UNSUPPORTED; }
   d.seq_tree = (d.mode == TJ_MODE_MULTI_DECOUPLE && seq_lds_bytes(d.U, d.S, true) <= lds_max) ? 1 : 0;
@@ -434,8 +436,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.splanes, U * S * d.cap_self * 4)) || (r = dalloc(c, &d.scount, U * S)) ||
       (r = dalloc(c, &d.lg, U * P * 19)) || (r = dalloc(c, &d.lh, U * P * 361)) || (r = dalloc(c, &d.xdir, U * d.xs)) ||
       (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) ||
-      (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, S * U * (size_t)d.cap_row)) ||
-      (r = dalloc(c, &d.pair_count, S * U)) || (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
+      (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, ACT_CAP)) ||
+      (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
       (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 2)) || (r = dalloc(c, &d.ctl, 1)) ||
