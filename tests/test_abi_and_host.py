@@ -127,8 +127,12 @@ def test_coupled_mode_params(pkg):
     p = pkg.TjParams()
     lib.tj_default_params(C.byref(p), 2, 8, 5)        # TJ_MODE_MULTI_COUPLED keeps the multi main's ks
     assert p.mode == 2 and p.ks == 1e-3
-    p.world, p.rank = 2, 0                            # coupled mode is single-GPU: rejected before any device work
+    p.world, p.rank = 2, 2                            # argument validation happens before any device work: rank must be < world
     ctx = C.c_void_p()
-    assert lib.tj_create(C.byref(p), C.byref(ctx)) == -5
-    assert b"COUPLED" in lib.tj_last_error(ctx)
+    assert lib.tj_create(C.byref(p), C.byref(ctx)) == -1
+    assert b"rank" in lib.tj_last_error(ctx)
+    lib.tj_destroy(ctx)
+    p.world, p.rank = 2, 0                            # coupled mode shards across ranks since round 2: on a box without a GPU the only
+    ctx = C.c_void_p()                                # possible failure is the missing device (there is no CPU fallback)
+    assert lib.tj_create(C.byref(p), C.byref(ctx)) in (0, -2)
     lib.tj_destroy(ctx)
