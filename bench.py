@@ -135,7 +135,8 @@ def cpu_baseline(scene, steps, optimal_plane=False):
     prebuilt in the dev container) if present, else this repo's CPU restatement.  Single thread --
     the reference has no threading (no `#pragma omp` anywhere in its first-party code)."""
     from oracle import pyoracle
-    kind = "reference" if pyoracle.available("ref") else "port"
+    # triangle obstacles exist in the port only: the reference's triangle path is dead code
+    kind = "reference" if pyoracle.available("ref") and scene.get("tris") is None else "port"
     eng = pyoracle.Engine("ref" if kind == "reference" else "port", scene)
     if optimal_plane:
         eng.set_optimal_plane(True)
@@ -293,7 +294,8 @@ def main():
         impl_bytes = kernel_bytes(st2, slv, K)           # this implementation's record sizes, caches included
         alg_bytes, alg_total = survey_bytes(st2, slv, K)   # the figure `achieved` is priced on
         per_launch_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
-        dom = max(per_launch_ms, key=per_launch_ms.get)
+        # dominant = largest share of the iteration (a kernel launched once per batch, like k_begin, is not a candidate)
+        dom = max((k for k, v in prof.items() if v[1] >= K), key=lambda k: prof[k][0])
         ach = alg_bytes[dom] / (per_launch_ms[dom] * 1e-3) / 1e9
         impl_total = sum(impl_bytes[k] for k, v in prof.items() if v[1])
         # PMC traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_round.sh) is only quoted when the

@@ -20,6 +20,15 @@ def source_id():
     return h.hexdigest()[:16]
 
 
+def short_name(n):
+    """tj::k_mid<1>(...) mangled as _ZN2tj5k_midILi1EEEv... -> k_mid (length-prefixed identifier after the namespace)"""
+    m = re.search(r"_ZN2tj(\d+)", n)
+    if not m:
+        return n.replace(".kd", "")
+    k = int(m.group(1)); st = m.end()
+    return n[st:st + k]
+
+
 def per_kernel(path, counter):
     db = sqlite3.connect(path); cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -29,8 +38,7 @@ def per_kernel(path, counter):
          f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id where i.name=? group by s.kernel_name")
     out = {}
     for name, n, v in cur.execute(q, (counter,)):
-        m = re.search(r"_ZN2tj\d+([a-z_0-9]+?)E", name)
-        out[m.group(1) if m else name] = (n, v)
+        out[short_name(name)] = (n, v)
     return out
 
 

@@ -5,16 +5,19 @@ import argparse, csv, sqlite3, sys
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("db"); ap.add_argument("--iter", type=int, default=12); ap.add_argument("--csv")
+    ap = argparse.ArgumentParser(); ap.add_argument("db"); ap.add_argument("--iter", type=int, default=315); ap.add_argument("--csv")
     a = ap.parse_args()
     db = sqlite3.connect(a.db); cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]; ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = list(cur.execute(f"select s.kernel_name, d.start, d.end, d.stream_id, d.queue_id from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
     import re
-    def short(n):
-        m = re.search(r"_ZN2tj\d+([a-z_0-9]+?)E", n)
-        return m.group(1) if m else n.replace(".kd", "")
+    def short(n):   # _ZN2tj5k_midILi1EEEv... -> k_mid (length-prefixed identifier after the namespace; templates included)
+        m = re.search(r"_ZN2tj(\d+)", n)
+        if not m:
+            return n.replace(".kd", "")
+        k = int(m.group(1)); st = m.end()
+        return n[st:st + k]
     st = {}
     for n, s, e, _, _ in rows:
         st.setdefault(short(n), []).append(e - s)
@@ -25,11 +28,12 @@ def main():
     for r in out: print(",".join(str(x) for x in r))
     if a.csv:
         with open(a.csv, "w", newline="") as f: csv.writer(f).writerows(out)
-    begins = [i for i, r in enumerate(rows) if short(r[0]) == "k_begin"]
+    # iterations start with k_front (k_begin runs once per batch: its work rides on the previous iteration's k_linesearch)
+    begins = [i for i, r in enumerate(rows) if short(r[0]) in ("k_front", "k_obs_query")]
     if len(begins) > a.iter + 1:
         i0, i1 = begins[a.iter], begins[a.iter + 1]
         t0 = rows[i0][1]
-        print(f"\ntimeline of iteration {a.iter} (us from its k_begin; span {1e-3 * (rows[i1][1] - t0):.1f} us):")
+        print(f"\ntimeline of iteration {a.iter} (us from its first kernel; span {1e-3 * (rows[i1][1] - t0):.1f} us):")
         for n, s, e, sid, q in rows[i0:i1]:
             print(f"  {short(n):22s} start {1e-3 * (s - t0):8.1f}  dur {1e-3 * (e - s):7.1f}  end {1e-3 * (e - t0):8.1f}  stream {sid} queue {q}")
 
