@@ -24,14 +24,16 @@ constexpr int LS_GROUPS = 8;    // 16 candidates per round (1024 threads, 128-VG
 constexpr int LS_GSIZE = 64;   // one wave per candidate: group-private LDS needs only wave-local ordering
 
 struct LsLayout {  // offsets in doubles into dynamic LDS
-  size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, gcons, res, planes, pltr, total;
+  size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, gcons, res, planes, pltr, hn, hd, total;
   int plane_cap;
+  int affine;   // hulls of a trial step come from hull(net) + step * hull(dir), both formed once per launch (see x_energy_group)
   int groups;   // Armijo candidates evaluated side by side (one wave each): 8 where the per-candidate hull buffers fit LDS,
                 // fewer for long trajectories (piece_num > 10); the accepted step is the same, only the rounds get shorter
 };
-__host__ __device__ inline LsLayout ls_layout_g(int S, int T, int P, size_t lds_budget_bytes, int G) {
+__host__ __device__ inline LsLayout ls_layout_g(int S, int T, int P, size_t lds_budget_bytes, int G, int affine = 0) {
   LsLayout L;
   L.groups = G;
+  L.affine = affine;
   size_t o = 0;
   L.basis = o; o += (size_t)S * 36;
   L.convert = o; o += (size_t)P * 36;
@@ -45,6 +47,8 @@ __host__ __device__ inline LsLayout ls_layout_g(int S, int T, int P, size_t lds_
   L.ghull = o; o += (size_t)G * S * 18;
   L.gcons = o; o += (size_t)G * 24 * P;   // per group: delta[18P], then 6 consensus/dual terms per piece
   L.res = o; o += 2 * LS_GROUPS + 8;
+  L.hn = o; o += affine ? (size_t)S * 18 : 0;
+  L.hd = o; o += affine ? (size_t)S * 18 : 0;
   L.planes = o;
   const size_t used = o * 8;
   size_t room = lds_budget_bytes > used ? (lds_budget_bytes - used) / 36 : 0;  // 32 B plane + 4 B segment id
@@ -58,7 +62,9 @@ __host__ __device__ inline LsLayout ls_layout_g(int S, int T, int P, size_t lds_
 // lds_budget_bytes: soft budget that also sizes the LDS-resident plane list; hard_bytes: what one workgroup may allocate.  The
 // widest group count whose fixed part fits is taken (8 up to piece_num = 10 with the shipped res = 8).
 __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_budget_bytes, size_t hard_bytes = 155 * 1024) {
-  LsLayout L = ls_layout_g(S, T, P, lds_budget_bytes, LS_GROUPS);
+  LsLayout L = ls_layout_g(S, T, P, lds_budget_bytes, LS_GROUPS, 1);
+  if (L.total * 8 <= hard_bytes) return L;
+  L = ls_layout_g(S, T, P, lds_budget_bytes, LS_GROUPS);
   for (int G = LS_GROUPS / 2; G >= 1 && L.total * 8 > hard_bytes; G /= 2) L = ls_layout_g(S, T, P, lds_budget_bytes, G);
   return L;
 }
@@ -66,19 +72,32 @@ __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_bu
 // E(net, pt) for robot u, evaluated by ONE group = one wave (gl = lane within the group).
 // Returns the value in every lane of the group.  Must be called by the whole workgroup (contains a
 // block barrier).
+// one control point coordinate of a segment's hull: row j of the segment's basis times the piece's 6 control points
+__device__ __forceinline__ double ls_hull_entry(const Dev& D, const double* basis, const double* net, int idx) {
+  const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
+  const double* B = basis + (size_t)tr * 36 + j * 6;
+  const double* col = net + (tr / D.res) * 3 + D.T * a;
+  double acc = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc += B[k] * col[k];
+  return acc;
+}
+
+// `trial`: 0 = the hulls are those of `net` itself (E(x)), 1 = a trial step `step` along the direction.  With L.affine the
+// trial hulls are hull(x) + step * hull(d) (the hull map is linear; the two images are formed once per launch by ls_stage)
+// instead of 6 multiply-adds per entry and candidate: the hull pass was 2.9 of the 10.4 us of an evaluation.  The values
+// differ from basis * (x + step d) by rounding (~1e-16 relative) -- far below any Armijo margin seen -- and the hulls that
+// are PUBLISHED for the next iteration are recomputed exactly from the accepted control net.
 __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, const LsLayout& L, const double* net, double pt, double* hulls,
-                                        double* cons, int M, bool planes_in_lds, const int* pref, int gl) {
+                                        double* cons, int M, bool planes_in_lds, const int* pref, int gl, int trial, double step) {
   const int S = D.S, T = D.T;
   const double* basis = sm + L.basis;
   TJ_TIC(D, K_BEGIN, 0);
-  for (int idx = gl; idx < S * 18; idx += LS_GSIZE) {
-    const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
-    const double* B = basis + (size_t)tr * 36 + j * 6;
-    const double* col = net + (tr / D.res) * 3 + T * a;
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) acc += B[k] * col[k];
-    hulls[idx] = acc;
+  if (L.affine) {
+    const double* hn = sm + L.hn; const double* hd = sm + L.hd;
+    for (int idx = gl; idx < S * 18; idx += LS_GSIZE) hulls[idx] = trial ? hn[idx] + step * hd[idx] : hn[idx];
+  } else {
+    for (int idx = gl; idx < S * 18; idx += LS_GSIZE) hulls[idx] = ls_hull_entry(D, basis, net, idx);
   }
   __syncthreads();  // all 8 groups run this function in lock step (uniform trip counts)
   TJ_TIC(D, K_BEGIN, 1);
@@ -213,6 +232,9 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
   }
   __syncthreads();
   TJ_TIC(D, K_LINESEARCH, 1);
+  if (L.affine) {   // consumed after the barrier below
+    for (int idx = tid; idx < S * 18; idx += nth) { sm[L.hn + idx] = ls_hull_entry(D, sm + L.basis, net, idx); sm[L.hd + idx] = ls_hull_entry(D, sm + L.basis, dir, idx); }
+  }
   const int M = pref[S];
   const bool in_lds = M <= L.plane_cap;
   if (in_lds) {
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
     __syncthreads();
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 3);
-    const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl);
+    const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 4);
     if (gl == 0 && !shadow) { res[g] = e; res[LS_GROUPS + g] = step; }
     if (tid == 0) s_accept = -1;
@@ -357,7 +379,15 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     }
     __syncthreads();
   }
-  if (D.fuse && D.multi()) ls_publish_hullinfo(D, u, sm + L.ghull + (size_t)wg * S * 18, tid, LS_THREADS);
+  if (D.fuse && D.multi()) {
+    double* wh = sm + L.ghull + (size_t)wg * S * 18;
+    if (L.affine) {   // the published hulls are exactly basis * (accepted control net), like k_hullinfo's
+      const double* win = sm + L.gnet + (size_t)wg * 3 * T;
+      for (int idx = tid; idx < S * 18; idx += LS_THREADS) wh[idx] = ls_hull_entry(D, sm + L.basis, win, idx);
+      __syncthreads();
+    }
+    ls_publish_hullinfo(D, u, wh, tid, LS_THREADS);
+  }
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
   if (begin_next) {
@@ -451,7 +481,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   const double pt = k < 0 ? t0 : t0 + step * t_dir;
   for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
   __syncthreads();
-  const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl);
+  const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
   if (gl == 0) D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + g] = e;
 }
 

@@ -397,6 +397,10 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   c->lds_xs = (d.xs_band ? xsolve_band_lds_doubles(n) : xsolve_lds_doubles(n)) * sizeof(double);
   c->lds_xs2 = ((size_t)n * n + 4 * (size_t)n) * sizeof(double);
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
+  if (const char* e = getenv("TJ_LS_EXACT_HULLS")) if (atoi(e)) {   // A/B hook: every trial hull as basis * (x + step d)
+    c->lsl = ls_layout_g(d.S, d.T, d.P, 120 * 1024, LS_GROUPS);
+    for (int G = LS_GROUPS / 2; G >= 1 && c->lsl.total * 8 > 155 * 1024; G /= 2) c->lsl = ls_layout_g(d.S, d.T, d.P, 120 * 1024, G);
+  }
   c->lds_ls = c->lsl.total * sizeof(double);
 #ifdef TJ_PHASE_TIMING
   { int r_ = dalloc(c, &d.dbg, (size_t)K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS); if (r_) return r_; }
