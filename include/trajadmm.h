@@ -238,6 +238,26 @@ int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_rob
 int tj_phase_count(tj_ctx* c);
 int tj_iterate_phase(tj_ctx* c, int phase);
 
+/* ---- several GPUs under one process (csrc/tj_group.h) ------------------------------------------------------------------
+ * What a maintainer of Main/multiPathPlanning3D.cpp would call instead of tj_create / tj_iterate to use N devices: the robots
+ * of the per-robot loops (Optimization3D_multi.h:29-118, :120-174) are block-partitioned over n_ranks contexts, rank r on HIP
+ * device devices[r] (NULL: device r; entries may repeat -- several ranks on one device, which is how the tests run it on a
+ * one-GPU box).  tj_group_iterate runs the phase schedule above on every rank (one host thread per rank) and exchanges the
+ * tj_exchange_buffer slices by direct peer stores + events: no collective library, no host staging.  Results are bitwise
+ * those of one context.  tj_params.rank / world / device are ignored (set per rank).  Single-UAV mode has nothing to shard
+ * (n_ranks must be 1). */
+typedef struct tj_group tj_group;
+int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_group** out);
+void tj_group_destroy(tj_group* g);
+int tj_group_size(tj_group* g);
+tj_ctx* tj_group_ctx(tj_group* g, int rank);          /* rank's context: stats, planes, caches of the robots it owns */
+const char* tj_group_last_error(tj_group* g);         /* g == NULL: why the last tj_group_create failed */
+int tj_group_set_cloud(tj_group* g, const double* xyz, int n);   /* the obstacle BVH is replicated on every device */
+int tj_group_set_mesh(tj_group* g, const double* vertices, int n_vertices, const int* faces, int n_faces);
+int tj_group_init_state(tj_group* g, const double* waypoints, double piece_time0);
+int tj_group_iterate(tj_group* g, int n_iters, double* gnorm, int* iters_total, int* converged);   /* like tj_iterate */
+int tj_group_get_state(tj_group* g, int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time);   /* from u's owner */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,79 @@
+"""tj_group: the library sharding one problem over several ranks by itself (csrc/tj_group.h) -- one context and one host
+thread per rank, peer stores + events for the exchanges.  A one-GPU box runs the ranks on the same device (the device list
+may repeat), which exercises everything but the xGMI hop: the schedule, the receive-buffer parity, the event choreography
+between the host threads."""
+import subprocess
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
+
+
+@pytest.mark.parametrize("mode,ranks", [(1, 2), (1, 3), (2, 2), (2, 4)])
+def test_group_equals_one_context_bitwise(pkg, scenes, mode, ranks):
+    """decoupled and coupled ("decouple":0) mode, 2-4 ranks, batches of different length (the exchange parity carries over
+    between tj_group_iterate calls): every robot's state bitwise equal to the unsharded run after every batch"""
+    scene = dict(scenes.hard(4, 4000)); scene["mode"] = mode
+    ref = pkg.Solver(scene, stop=0.0)
+    grp = pkg.Group(scene, [0] * ranks, stop=0.0)
+    done = 0
+    for batch in (1, 3, 2, 5):
+        g0, _, _ = ref.iterate(batch)
+        g, it, cv = grp.iterate(batch)
+        done += batch
+        assert it == done and not cv
+        a, b = ref.get_state(), grp.get_state()
+        for n in STATE:
+            assert np.array_equal(a[n], b[n]), (n, done)
+        assert g == g0
+    ref.close(); grp.close()
+
+
+def test_group_stop_test_and_uneven_partition(pkg, scenes):
+    """5 robots over 2 and 3 ranks (uneven blocks); the device stop test ends the run on every rank in the same iteration"""
+    scene = scenes.crossing(5, 3000, seed=4)
+    ref = pkg.Solver(scene)
+    g0, it0, cv0 = ref.iterate(200)
+    assert cv0
+    for ranks in (2, 3):
+        grp = pkg.Group(scene, [0] * ranks)
+        g, it, cv = grp.iterate(200)
+        assert (it, cv) == (it0, cv0) and g == g0
+        a, b = ref.get_state(), grp.get_state()
+        for n in STATE:
+            assert np.array_equal(a[n], b[n]), n
+        grp.close()
+    ref.close()
+
+
+def test_group_rejects_what_cannot_shard(pkg, scenes):
+    with pytest.raises(pkg.TrajAdmmError):
+        pkg.Group(scenes.tiny(mode=0, U=1), [0, 0])
+    with pytest.raises(pkg.TrajAdmmError):
+        pkg.Group(scenes.hard(4, 4000), [0] * 17)
+
+
+def test_cli_devices_flag_gives_the_one_device_trajectory(scenes, tmp_path):
+    """multiPathPlanning3D --devices 0,0,0 (three ranks): same iteration count and bitwise the same --dump-state file as the
+    plain run"""
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scene = scenes.scn_b()
+    mesh = "x.obj"
+    scenes.write_reference_files(scene, str(tmp_path), mesh)
+    os.makedirs(tmp_path / "Config_File", exist_ok=True)
+    (tmp_path / "Config_File" / "3D.json").write_text(
+        '{"auto":0,"init":1,"gui":0,"optimal_plane":0,"decouple":1,"res":8,"vel_limit":2,"acc_limit":2,"lambda":1e1,'
+        '"epsilon":1e-1,"margin":1e-1,"offset":1e-1,"stop":1e-2,"exit":0,"init_ob":1,"mu":0.1}')
+    exe = os.path.join(ROOT, "traj-opt-admm_amd", "multiPathPlanning3D")
+    out = []
+    for extra, name in (([], "a.txt"), (["--devices", "0,0,0"], "b.txt")):
+        r = subprocess.run([exe, mesh, "--dump-state", name, "--max-iter", "300"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out.append(open(tmp_path / name).read())
+        if extra:
+            assert "devices: 3" in r.stdout
+    assert out[0] == out[1]
+    r = subprocess.run([os.path.join(ROOT, "traj-opt-admm_amd", "admmPathPlanning3D"), mesh, "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "does not shard" in r.stderr

@@ -27,6 +27,8 @@ EXPORTS = [
     "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_get_build_info", "tj_exchange_buffer",
     "tj_iterate_phase", "tj_phase_count", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
+    "tj_group_create", "tj_group_destroy", "tj_group_size", "tj_group_ctx", "tj_group_last_error", "tj_group_set_cloud", "tj_group_set_mesh",
+    "tj_group_init_state", "tj_group_iterate", "tj_group_get_state",
 ]
 
 STAGES = dict(begin=0, planes_obs=1, planes_self=2, grad=3, xsolve=4, ccd_prep=5, ccd_obs=6, ccd_self=7, linesearch=8, slack=9, end=10)
@@ -63,6 +65,8 @@ def load_library():
         _lib = C.CDLL(LIB_PATH)
         _lib.tj_last_error.restype = C.c_char_p
         _lib.tj_stream.restype = C.c_void_p
+        _lib.tj_group_last_error.restype = C.c_char_p
+        _lib.tj_group_ctx.restype = C.c_void_p
     return _lib
 
 
@@ -393,3 +397,79 @@ class Solver:
         ptr, per, first, n = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
         self._check(self.lib.tj_exchange_buffer(self._ctx, what, C.byref(ptr), C.byref(per), C.byref(first), C.byref(n)))
         return ptr.value, per.value, first.value, n.value
+
+
+class Group:
+    """The same problem sharded over several devices by the library itself (`tj_group`, csrc/tj_group.h): one context per rank,
+    peer stores + events between them, no torch on the path.  `devices` may repeat (several ranks on one GPU)."""
+
+    def __init__(self, scene, devices, params=None, stop=None, **caps):
+        self.lib = load_library()
+        p = dict(scenes.DEFAULT_PARAMS)
+        if params:
+            p.update(params)
+        self.mode, self.U, self.P = scene["mode"], scene["U"], scene["P"]
+        self.res = p["res"]
+        self.S, self.T = self.P * self.res, 3 * self.P + 3
+        tp = TjParams()
+        self.lib.tj_default_params(C.byref(tp), self.mode, self.U, self.P)
+        tp.res = self.res
+        tp.lambda_, tp.margin, tp.offset, tp.mu = p["lam"], p["margin"], p["offset"], p["mu"]
+        tp.vel_limit, tp.acc_limit, tp.ks, tp.kt = p["vel_limit"], p["acc_limit"], scene["ks"], p["kt"]
+        tp.stop = p["stop"] if stop is None else stop
+        for k, v in caps.items():
+            setattr(tp, k, v)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self.n = len(dev)
+        self._g = C.c_void_p()
+        rc = self.lib.tj_group_create(C.byref(tp), C.c_int(self.n), _i(dev), C.byref(self._g))
+        if rc < 0:
+            raise TrajAdmmError(f"tj_group_create error {rc}: {self.lib.tj_group_last_error(None).decode()}")
+        if scene.get("tris") is not None:
+            verts = np.ascontiguousarray(scene["tris"], dtype=np.float64).reshape(-1, 3)
+            n = verts.shape[0] // 3
+            faces = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+            self._check(self.lib.tj_group_set_mesh(self._g, _d(verts), C.c_int(3 * n), _i(faces), C.c_int(n)))
+        else:
+            cloud = np.ascontiguousarray(scene["cloud"], dtype=np.float64).reshape(-1, 3)
+            self._check(self.lib.tj_group_set_cloud(self._g, _d(cloud), C.c_int(cloud.shape[0])))
+        self._wp = np.ascontiguousarray(scene["waypoints"], dtype=np.float64)
+        self._pt0 = float(p["piece_time0"])
+        self.reset()
+
+    def reset(self):
+        self._check(self.lib.tj_group_init_state(self._g, _d(self._wp), C.c_double(self._pt0)))
+
+    def _check(self, rc):
+        if rc < 0:
+            raise TrajAdmmError(f"libtrajadmm group error {rc}: {self.lib.tj_group_last_error(self._g).decode()}")
+        return rc
+
+    def iterate(self, n=1):
+        """n iterations on every rank; returns (gnorm, iterations so far, converged)"""
+        g, it, cv = C.c_double(), C.c_int(), C.c_int()
+        self._check(self.lib.tj_group_iterate(self._g, C.c_int(n), C.byref(g), C.byref(it), C.byref(cv)))
+        return g.value, it.value, bool(cv.value)
+
+    def get_state(self):
+        """every robot's state from the rank that owns it"""
+        U, P, T = self.U, self.P, self.T
+        st = dict(spline=np.zeros((U, 3, T)), p_slack=np.zeros((U, 3, 6 * P)), p_lambda=np.zeros((U, 3, 6 * P)),
+                  t_slack=np.zeros((U, P)), t_lambda=np.zeros((U, P)), piece_time=np.zeros(U))
+        for u in range(U):
+            pt = C.c_double()
+            self._check(self.lib.tj_group_get_state(self._g, u, _d(st["spline"][u]), _d(st["p_slack"][u]), _d(st["p_lambda"][u]),
+                                                    _d(st["t_slack"][u]), _d(st["t_lambda"][u]), C.byref(pt)))
+            st["piece_time"][u] = pt.value
+        return st
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            self.lib.tj_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -13,7 +13,10 @@
 // --batch N iterations per device batch (the stop test runs on the device before every iteration),
 // --triangles (or the optional key "triangles":1 in 3D.json): obstacles are the TRIANGLES of the OBJ (`f` lines, tj_set_mesh)
 // instead of its vertices as a point cloud.
+// --gpus N / --devices a,b,.. (multi-UAV main only): the robots are sharded over N devices by the library (tj_group, trajadmm.h);
+// the trajectory is bitwise the one-device one.
 #include <chrono>
+#include <sstream>
 #include "../../include/trajadmm.h"
 #include "cli_common.h"
 
@@ -24,9 +27,10 @@ static const bool kMulti = false;
 #endif
 
 int main(int argc, char** argv) {
-  if (argc < 2) { std::cerr << "Syntax: " << argv[0] << " <mesh file> [--max-iter N] [--batch N] [--dump-state FILE] [--sample-traj FILE] [--triangles]" << std::endl; return -1; }
+  if (argc < 2) { std::cerr << "Syntax: " << argv[0] << " <mesh file> [--max-iter N] [--batch N] [--dump-state FILE] [--sample-traj FILE] [--triangles] [--gpus N | --devices a,b,..]" << std::endl; return -1; }
   const std::string mesh = argv[1];
   long max_iter = 1000000; int batch = 8; std::string dump, sample_file; bool triangles = false;
+  std::vector<int> devices;   // empty: one context on device 0
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--max-iter" && i + 1 < argc) max_iter = atol(argv[++i]);
@@ -34,9 +38,13 @@ int main(int argc, char** argv) {
     else if (a == "--dump-state" && i + 1 < argc) dump = argv[++i];
     else if (a == "--sample-traj" && i + 1 < argc) sample_file = argv[++i];
     else if (a == "--triangles") triangles = true;
+    else if (a == "--gpus" && i + 1 < argc) { const int n = atoi(argv[++i]); devices.clear(); for (int k = 0; k < n; k++) devices.push_back(k); }
+    else if (a == "--devices" && i + 1 < argc) { devices.clear(); std::stringstream ss(argv[++i]); std::string t; while (std::getline(ss, t, ',')) devices.push_back(atoi(t.c_str())); }
     else { std::cerr << "unknown argument " << a << std::endl; return -1; }
   }
   tj_ctx* ctx = nullptr;
+  tj_group* grp = nullptr;
+  if (!kMulti && devices.size() > 1) { std::cerr << "error: a single UAV does not shard over devices" << std::endl; return 1; }
   try {
     auto j = tjcli::read_flat_json("Config_File/3D.json");
     const double lambda = tjcli::need(j, "lambda"), margin = tjcli::need(j, "margin"), offset = tjcli::need(j, "offset");
@@ -90,10 +98,20 @@ int main(int argc, char** argv) {
     tj_default_params(&p, kMulti ? (decouple ? TJ_MODE_MULTI_DECOUPLE : TJ_MODE_MULTI_COUPLED) : TJ_MODE_SINGLE, U, P);
     p.optimal_plane = optimal_plane ? 1 : 0;  // persistent planes refined by Optimal_plane::optimal_cd / self_optimal_cd
     p.res = res; p.lambda = lambda; p.margin = margin; p.offset = offset; p.mu = mu; p.vel_limit = vel; p.acc_limit = acc; p.stop = stop;
-    auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + tj_last_error(ctx)); };
-    chk(tj_create(&p, &ctx), "tj_create");
-    chk(set_obstacles(ctx), "tj_set_cloud / tj_set_mesh");
-    chk(tj_init_state(ctx, wp.data(), 20.0), "tj_init_state");  // piece_time = 20 (admmPathPlanning3D.cpp:482)
+    auto chk = [&](int rc, const char* what) { if (rc < 0) throw std::runtime_error(std::string(what) + ": " + (grp ? tj_group_last_error(grp) : tj_last_error(ctx))); };
+    const bool group = devices.size() > 1;
+    if (group) {
+      if (tj_group_create(&p, (int)devices.size(), devices.data(), &grp) < 0) throw std::runtime_error(std::string("tj_group_create: ") + tj_group_last_error(nullptr));
+      chk(triangles ? tj_group_set_mesh(grp, V.data(), (int)(V.size() / 3), F.data(), N) : tj_group_set_cloud(grp, V.data(), N), "tj_group_set_cloud / tj_group_set_mesh");
+      chk(tj_group_init_state(grp, wp.data(), 20.0), "tj_group_init_state");
+      std::cout << "devices: " << devices.size() << std::endl;
+    } else {
+      if (devices.size() == 1) p.device = devices[0];
+      chk(tj_create(&p, &ctx), "tj_create");
+      chk(set_obstacles(ctx), "tj_set_cloud / tj_set_mesh");
+      chk(tj_init_state(ctx, wp.data(), 20.0), "tj_init_state");  // piece_time = 20 (admmPathPlanning3D.cpp:482)
+    }
+    auto get_state = [&](int u, double* s, double* pt) { return group ? tj_group_get_state(grp, u, s, nullptr, nullptr, nullptr, nullptr, pt) : tj_get_state(ctx, u, s, nullptr, nullptr, nullptr, nullptr, pt); };
 
     std::ofstream result("result/" + mesh + (kMulti ? "_result_file_multi.txt" : "_result_file_admm.txt"));
     double whole_ms = 0, gnorm = 1;
@@ -101,7 +119,7 @@ int main(int argc, char** argv) {
     while (iter < max_iter && !converged) {
       const int n = (int)std::min<long>(batch, max_iter - iter);
       auto t0 = std::chrono::steady_clock::now();
-      chk(tj_iterate(ctx, n, &gnorm, &iter, &converged), "tj_iterate");
+      chk(group ? tj_group_iterate(grp, n, &gnorm, &iter, &converged) : tj_iterate(ctx, n, &gnorm, &iter, &converged), "tj_iterate");
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       whole_ms += ms;
       std::cout << "iter: " << iter << "\n" << "gnorm: " << gnorm << "\n" << "time:" << ms << std::endl;
@@ -124,7 +142,7 @@ int main(int argc, char** argv) {
       double whole_len = 0;
       for (int u = 0; u < U; u++) {
         double pt = 0, tt = 0, len = 0;
-        chk(tj_get_state(ctx, u, s.data(), nullptr, nullptr, nullptr, nullptr, &pt), "tj_get_state");
+        chk(get_state(u, s.data(), &pt), "tj_get_state");
         std::vector<double> smp;
         tjcli::log_data(s.data(), P, conv.data(), pt, dt, tt, len, sample_file.empty() ? nullptr : &smp);
         std::cout << "ccd time:" << tt << std::endl << "ccd len:" << len << std::endl;
@@ -140,15 +158,17 @@ int main(int argc, char** argv) {
       std::vector<double> s(3 * T); double pt = 0;
       df << "uav_num " << U << " piece_num " << P << " iter " << iter << " gnorm " << gnorm << " converged " << converged << "\n";
       for (int u = 0; u < U; u++) {
-        chk(tj_get_state(ctx, u, s.data(), nullptr, nullptr, nullptr, nullptr, &pt), "tj_get_state");
+        chk(get_state(u, s.data(), &pt), "tj_get_state");
         df << "uav " << u << " piece_time " << pt << "\n";
         for (int r = 0; r < T; r++) df << s[r] << " " << s[r + T] << " " << s[r + 2 * T] << "\n";
       }
     }
-    tj_destroy(ctx);
+    if (grp) tj_group_destroy(grp);
+    if (ctx) tj_destroy(ctx);
     return converged ? 0 : 2;
   } catch (const std::exception& e) {
     std::cerr << "error: " << e.what() << std::endl;
+    if (grp) tj_group_destroy(grp);
     if (ctx) tj_destroy(ctx);
     return 1;
   }

@@ -1297,3 +1297,5 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
 }
 
 }  // extern "C"
+
+#include "tj_group.h"
