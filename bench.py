@@ -149,6 +149,31 @@ def cpu_baseline(scene, steps, optimal_plane=False):
             "sample": f"the first {n} ADMM iterations of the same scene from the same initial trajectory (BVH build excluded)"}
 
 
+def bench_group(pkg, scene, devices, args):
+    """K iterations through tj_group (one process, one host thread per rank inside the library)"""
+    torch.cuda.set_device(devices[0])
+    grp = pkg.Group(scene, devices, stop=0.0, optimal_plane=int(args.optimal_plane))
+    K, W = args.steps, args.warmup
+    grp.iterate(300); grp.reset()          # clock ramp, like the default path
+    grp.iterate(max(W, 1)); grp.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    grp.iterate(K)                         # returns after every rank's stream has drained
+    dt = time.perf_counter() - t0
+    out = {"metric": "ADMM iterations/sec", "value": K / dt, "unit": "iters/s", "n_gpus": len(set(devices)), "steps": K, "warmup": W,
+           "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{scene['name']}: {scene['U']} UAVs, {scene['P']} pieces x res 8, {'coupled' if scene['mode'] == 2 else 'decoupled'} mode",
+                      "parallelism": f"tj_group: {len(devices)} ranks on devices {devices}, robots block-sharded, exchanges by peer stores + events inside the library",
+                      "iters_timed_from": "initial trajectory"},
+           "timed_window_ms": 1e3 * dt}
+    if args.state_checksum:
+        import hashlib
+        stt = grp.get_state()
+        print("CHECK group " + hashlib.sha256(np.ascontiguousarray(stt["spline"]).tobytes() + np.ascontiguousarray(stt["piece_time"]).tobytes()).hexdigest(), flush=True)
+    grp.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +188,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
     ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: every rank uses device 0 and the all-gathers are staged through host memory over gloo "
                                                             "(RCCL refuses two ranks on one device); exercises the multi-process schedule on a 1-GPU box")
+    ap.add_argument("--group-devices", default=None, help="ONE process drives several ranks through the library's own sharding (tj_group: peer stores + events, no torch "
+                                                          "collectives), e.g. 0,1,2,3 -- entries may repeat (0,0 = two ranks on one GPU).  `--gpus N` without torchrun selects devices 0..N-1")
     ap.add_argument("--state-checksum", action="store_true", help="each rank also prints 'CHECK <rank> <sha256 of its owned robots\' final control points and piece times>'")
     args = ap.parse_args()
 
@@ -175,9 +202,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    group_devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else None
+    if world == 1 and args.gpus > 1 and group_devices is None:
+        group_devices = list(range(args.gpus))   # not under torchrun: the library shards by itself
+    if group_devices is not None:
+        return bench_group(pkg, scene, group_devices, args)
     dist = None
     sharded = world > 1 or args.force_dist
     torch.cuda.set_device(local)   # torch initialises the HIP runtime first; the library then shares it

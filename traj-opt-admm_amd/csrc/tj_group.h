@@ -63,6 +63,7 @@ GroupExchangeInfo group_buffer(tj_ctx* c, int what) {
 int group_exchange(tj_group* g, int r, int what, long s) {
   tj_ctx* c = g->ctx[r];
   const Dev& d = c->d;
+  if (g->n == 1) return TJ_OK;   // nothing is foreign
   const int par = (int)(s & 1);
   const GroupExchangeInfo b = group_buffer(c, what);
   const size_t off = (size_t)d.u0 * b.per, cnt = (size_t)(d.u1 - d.u0) * b.per, total = (size_t)d.U * b.per;
