@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
 
 
+# observed (TJ_PRINT_OBSERVED=1): tiny_multi 80 plane entries, median 0 (bit-identical), 85 % within 1e-12, 92.5 % within 1e-10, max 3.4e-9;
+# tiny_multi_coupled 64 entries, 89 % / 94 %, same max; tiny_single stores no plane on the kept iterations
+FRAC_1E12 = dict(tiny_single=1.0, tiny_multi=0.8, tiny_multi_coupled=0.85)
+FRAC_1E10 = dict(tiny_single=1.0, tiny_multi=0.9, tiny_multi_coupled=0.9)
+
+
 def _scene(scenes, name):
     if name == "tiny_single":
         return scenes.tiny(0, n_points=3000)
@@ -60,6 +66,7 @@ def test_persistent_plane_stage_teacher_forced_vs_reference(pkg, scenes, name):
     g = gold(f"optplane_stages_{name}.npz"); scene = _scene(scenes, name)
     check_scene_matches_fixture(scene, g)
     s = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    diffs = []   # every refined plane entry's distance from the reference's, all kept iterations
     for it in g["kept"]:
         k = f"it{it}_"
         s.set_state({n: g[k + "pre_" + n] for n in STATE})
@@ -77,12 +84,26 @@ def test_persistent_plane_stage_teacher_forced_vs_reference(pkg, scenes, name):
             want = {(tr, int(i)): c for tr, (ids, cd) in enumerate(_unflat(g[k + "post_cache_n"], g[k + "post_cache_ids"], g[k + "post_cache_cd"])) for i, c in zip(ids, cd)}
             assert got.keys() == want.keys()
             assert max((np.max(np.abs(got[key] - want[key])) for key in got), default=0.0) <= 1e-7
+            diffs += [np.abs(got[key] - want[key]).ravel() for key in got]
         else:
             on, cd = s.get_pair_cache()
             assert np.array_equal(on, g[k + "post_cache_on"])
             assert maxdiff(cd, g[k + "post_cache_cd"]) <= 1e-7
+            live = np.asarray(on).astype(bool)
+            diffs.append(np.abs(np.asarray(cd)[live] - np.asarray(g[k + "post_cache_cd"])[live]).ravel())
     assert s.stats()["error_bits"] == 0
     s.close()
+    # Where the 1e-7 above comes from: not from an indexing or ordering difference -- the stored SETS are
+    # identical and the bulk of the refined planes is at rounding level; a few planes sit on the zig-zagging Newton
+    # iterations whose repaired eigenvalue (1e-8) amplifies the 1-ulp differences between the device's and glibc's
+    # log / sin / cos by up to 1e8.  Pin that distribution, so that a real defect (which would move the bulk) cannot hide
+    # under the loose maximum.
+    d = np.concatenate(diffs) if diffs else np.zeros(1)
+    d = d[np.isfinite(d)]
+    frac12, frac10 = float(np.mean(d <= 1e-12)), float(np.mean(d <= 1e-10))
+    if __import__("os").environ.get("TJ_PRINT_OBSERVED"):
+        print("OBSERVED", name, dict(n=int(d.size), max=float(d.max()), median=float(np.median(d)), frac_1e12=frac12, frac_1e10=frac10))
+    assert np.median(d) <= 1e-14 and frac12 >= FRAC_1E12[name] and frac10 >= FRAC_1E10[name], (float(np.median(d)), frac12, frac10)
 
 
 @pytest.mark.parametrize("name", ["tiny_single", "tiny_multi", "scn_b"])

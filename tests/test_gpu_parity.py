@@ -91,8 +91,11 @@ def test_device_llt_and_min_eigenvalue(katsolver):
     assert (np.abs(out[:, 1] - g["min_eig"]) <= 1e-12 * np.maximum(1.0, scale)).all()
 
 
-def _teacher_forced(pkg, scene, g, tol_dir=1e-9):
+def _teacher_forced(pkg, scene, g, tol_dir=1e-11):
+    """tolerances = ~10x the largest difference observed against the reference's vectors (TJ_PRINT_OBSERVED=1 prints them:
+    direction 7e-13 on tiny / SCN-C and 1e-11 on the ill-conditioned `hard` scene, |g| 5e-15 relative, slack/dual 7e-14)"""
     s = pkg.Solver(scene, stop=0.0)
+    seen = dict(direction=0.0, mid=0.0, gn=0.0, post=0.0)   # largest differences met (TJ_PRINT_OBSERVED=1 prints them)
     for it in g["kept"]:
         k = f"it{it}_"
         s.set_state({n: g[k + "pre_" + n] for n in STATE})
@@ -104,7 +107,9 @@ def _teacher_forced(pkg, scene, g, tol_dir=1e-9):
         assert maxdiff(canon(counts, planes), want) <= 1e-13
         s.set_planes(g[k + "counts"], g[k + "planes_raw"])       # then continue from the reference's exact lists
         d = s.stage_direction()
-        assert maxdiff(d["gn"], g[k + "gn"]) <= 1e-11 * max(1.0, np.abs(g[k + "gn"]).max())
+        assert maxdiff(d["gn"], g[k + "gn"]) <= 1e-13 * max(1.0, np.abs(g[k + "gn"]).max())
+        seen["gn"] = max(seen["gn"], maxdiff(d["gn"], g[k + "gn"]) / max(1.0, np.abs(g[k + "gn"]).max()))
+        seen["direction"] = max(seen["direction"], maxdiff(d["direction"], g[k + "direction"]), maxdiff(d["t_direction"], g[k + "t_direction"]))
         assert maxdiff(d["direction"], g[k + "direction"]) <= tol_dir
         assert maxdiff(d["t_direction"], g[k + "t_direction"]) <= tol_dir
         s_self, s_pos = s.stage_steps()
@@ -114,15 +119,19 @@ def _teacher_forced(pkg, scene, g, tol_dir=1e-9):
         if scene["mode"] == 1:
             assert maxdiff(arm, g[k + "step_armijo"]) <= 1e-12   # same number of Armijo halvings
         st = s.get_state()
+        seen["mid"] = max(seen["mid"], maxdiff(st["spline"], g[k + "mid_spline"]), maxdiff(st["piece_time"], g[k + "mid_piece_time"]))
         assert maxdiff(st["spline"], g[k + "mid_spline"]) <= tol_dir
         assert maxdiff(st["piece_time"], g[k + "mid_piece_time"]) <= tol_dir
         s.set_state({n: (g[k + "mid_" + n] if n in ("spline", "piece_time") else g[k + "pre_" + n]) for n in STATE})
         s.stage_slack()
         st = s.get_state()
         for n in STATE:
+            seen["post"] = max(seen["post"], maxdiff(st[n], g[k + "post_" + n]) / max(1.0, np.abs(g[k + "post_" + n]).max()))
             assert maxdiff(st[n], g[k + "post_" + n]) <= 1e-12 * max(1.0, np.abs(g[k + "post_" + n]).max()), (it, n)
     assert s.stats()["error_bits"] == 0
     s.close()
+    if os.environ.get("TJ_PRINT_OBSERVED"):
+        print("OBSERVED", scene.get("name"), {k: float("%.2g" % v) for k, v in seen.items()})
 
 
 @pytest.mark.parametrize("name", ["tiny_multi", "tiny_single", "hard", "scn_c"])
@@ -130,7 +139,7 @@ def test_stages_teacher_forced_vs_reference(pkg, scenes, name):
     g = gold(f"stages_{name}.npz")
     scene = scene_by_name(scenes, name)
     check_scene_matches_fixture(scene, g)
-    _teacher_forced(pkg, scene, g)
+    _teacher_forced(pkg, scene, g, tol_dir=1e-10 if name == "hard" else 1e-11)
 
 
 @pytest.mark.parametrize("name", ["hard", "scn_b"])
