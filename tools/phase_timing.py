@@ -18,7 +18,7 @@ PHASES = {
     "k_xsolve": ["load", "assemble", "chol+fwd", "backsolve", "finish", "swept-hull tail"],
     "k_linesearch": ["stage", "planes->lds", "setup", "E round0", "later rounds"],
     "k_sep_self_solve": ["load", "gjk+newton+store"],
-    "k_sep_obs": ["hull+kdop", "bvh+planes"],
+    "k_obs_query": ["hull+kdop", "walk", "leaves", "last cull", "work items"],
     "k_ccd_self_seq": ["stage counts", "segment loop", "k_self + gn stage", "gnorm"],
 }
 NAMES = []   # filled from tj_kernel_name() in main(): the library's own enumeration order
@@ -58,6 +58,12 @@ def main():
             if sel.any():
                 st = (t[sel, 0] - t0) * 0.01; en = (t[sel, 1] - t0) * 0.01; du = en - st
                 print(f"k_front {lab:15s}: {sel.sum():5d} blocks  start {st.min():6.1f}..{st.max():6.1f}  end max {en.max():6.1f}  dur mean {du.mean():6.1f} max {du.max():6.1f} us")
+                pc = np.percentile(du, [50, 90, 99, 99.9])
+                print(f"    duration percentiles 50/90/99/99.9: {pc[0]:.1f} {pc[1]:.1f} {pc[2]:.1f} {pc[3]:.1f} us; blocks > 20 us: {(du > 20).sum()}, > 50 us: {(du > 50).sum()}; sum of durations {du.sum():.0f} us")
+                idx = np.nonzero(sel)[0]
+                top = np.argsort(-du)[:8]
+                S = scene["P"] * 8
+                print("    longest: " + ", ".join(f"blk {idx[i]} (u {(idx[i] - lo) // S if lab.startswith('obst') else -1}, seg {(idx[i] - lo) % S if lab.startswith('obst') else -1}) {du[i]:.0f}us@{st[i]:.0f}" for i in top))
     for k, name in enumerate(NAMES):
         if name not in PHASES:
             continue

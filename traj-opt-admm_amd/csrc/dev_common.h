@@ -123,6 +123,7 @@ struct Dev {
   // one component of 64 partners with one coalesced load instead of 64 strided 8-byte loads
   double *hbox, *cbox;
   double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
+  int pair_rows;                   // rows per tile of the robot-pair broad phase (kernels_pairs.h)
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
   // "optimal_plane":1 -- planes that persist across iterations (the reference's is_seperate / seperate_c / seperate_d and
   // is_self_seperate / self_seperate_c / self_seperate_d tables, CCDUtils.cpp:30-36).  Obstacle planes (mode 0): a list per

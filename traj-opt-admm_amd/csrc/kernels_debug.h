@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_dbg_tri(Dev D, int n, const double* P, c
       }
       klo[k] = lo; khi[k] = up;
     }
-    o[5 + pass] = kdop_body_pass(D, klo, khi, tb, pass ? off : dist);
+    o[5 + pass] = kdop_body_pass(D.kdop, klo, khi, tb, pass ? off : dist);
   }
   const V3 v = gjk(BodySwept{p, dd, t[i]}, tb);
   o[7] = (v.x * v.x + v.y * v.y + v.z * v.z <= off * off);

@@ -90,13 +90,15 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     }
     D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
   };
-  const int nwork = min(D.pair_work_n[0], D.cap_work), nold = D.kpair_n[1];
+  __shared__ int wpre[513];
+  const int nwork = pair_work_prefix(D, wpre, lane), nold = D.kpair_n[1];
   // Few planes (up to a handful per wave of the grid): one WAVE per plane -- the 12 barrier terms of a Newton round on 12
   // lanes (opt_plane_pair_wave), a quarter of the dependent chain; the kernel is as long as its slowest plane.  Many planes
   // (hundreds of robots): one plane per LANE, the same arithmetic bit for bit, for throughput.  The switch is grid-uniform.
   if (nwork + nold <= 4 * (int)gridDim.x) {
     for (int w = blockIdx.x; w < nwork; w += gridDim.x) {    // part 1 (Optimization3D_multi.h:276-290)
-      const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+      const size_t sl = (size_t)pair_work_slot(D, wpre, w);
+      const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
       const size_t s0 = ((size_t)tr * U + p0) * U + q;
       if (D.kpair_on[s0]) continue;
       const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
   }
   // part 1 (Optimization3D_multi.h:276-290): pairs that passed box + k-DOP this iteration and have no plane yet
   for (int w = blockIdx.x * 64 + lane; w < nwork; w += gridDim.x * 64) {
-    const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+    const size_t sl = (size_t)pair_work_slot(D, wpre, w);
+    const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
     const size_t s0 = ((size_t)tr * U + p0) * U + q;
     if (D.kpair_on[s0]) continue;
     const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;

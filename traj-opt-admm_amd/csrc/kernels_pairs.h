@@ -23,6 +23,7 @@
 // (AABB.cc:131-148).
 #pragma once
 #include "dev_common.h"
+#include "dev_linalg.h"
 #include "kernels_sep.h"
 
 namespace tj {
@@ -51,90 +52,155 @@ __global__ __launch_bounds__(64) void k_hullinfo(Dev D) {
   }
 }
 
-// one (segment, lower robot p0, chunk of 64 partners p1 > p0) = one wavefront.  With hundreds of robots a whole row per wave
-// left the rows of the middle segments (where everybody meets) as a long tail; only chunks that HAVE partners are launched:
-// chunk c exists for p0 <= U - 2 - 64c, i.e. pair_units(U) = sum_c max(0, U - 1 - 64c) units per segment (636 instead of
-// 1024 row-chunks at U = 256: workgroup dispatch is what bounds these kernels at that size).
-__host__ __device__ inline int pair_units(int U) { int n = 0; for (int c = 0; U - 1 - 64 * c > 0; c++) n += U - 1 - 64 * c; return n; }
-__host__ __device__ inline void pair_unit(int U, int bid, int& tr, int& p0, int& chunk) {
-  const int per = pair_units(U);
+// One unit of the robot-pair broad phase = one wavefront = a TILE of the (lower robot p0, partner p1 > p0) triangle of one
+// segment: R consecutive rows p0 (R = Dev::pair_rows: 2, 4, 8 or 16) against one aligned block of 64 partners.  A row per wave
+// (round 1) and then a 64-partner chunk of a row per wave (35 680 one-wave workgroups per launch at 256 robots) were bound by
+// workgroup dispatch and by one memory latency per handful of box tests; a tile loads the 64 partner boxes ONCE for R rows,
+// and 25 440 units become 1 600.  Tiles of a segment: row blocks grouped by the column block g that holds their diagonal
+// (rows [64g, 64g+64)); a row block of group g meets column blocks g .. nc-1.
+__host__ __device__ inline int pair_units(int U, int R) {
+  const int nc = (U + 63) / 64;
+  int n = 0;
+  for (int g = 0; 64 * g < U - 1; g++) { const int rows = min(64 * g + 64, U - 1) - 64 * g; n += ((rows + R - 1) / R) * (nc - g); }
+  return n;
+}
+__host__ __device__ inline void pair_unit(int U, int R, int bid, int& tr, int& rb, int& cb) {
+  const int per = pair_units(U, R), nc = (U + 63) / 64;
   tr = bid / per;
   int r = bid % per;
-  chunk = 0;
-  while (r >= U - 1 - 64 * chunk) { r -= U - 1 - 64 * chunk; chunk++; }
-  p0 = r;
+  rb = 0; cb = 0;
+  for (int g = 0; 64 * g < U - 1; g++) {
+    const int rows = min(64 * g + 64, U - 1) - 64 * g;
+    const int cnt = ((rows + R - 1) / R) * (nc - g);
+    if (r < cnt) { rb = 64 * g + (r / (nc - g)) * R; cb = 64 * (g + r % (nc - g)); return; }
+    r -= cnt;
+  }
 }
-__device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid) {
-  int tr, p0, chunk;
-  pair_unit(D.U, bid, tr, p0, chunk);
+constexpr int PAIR_ROWS_MAX = 16;
+constexpr int PAIR_TILE_CAP = PAIR_ROWS_MAX * 64;
+
+// The pair work list is S sub-lists, one per segment: sub-list tr occupies slots [tr * cap_seg, (tr + 1) * cap_seg) of pair_work
+// and has its own counter pair_work_n[tr] (pair_work_n[S] is the cursor of the solve waves).  One global counter was hit by
+// ~8 000 producer waves per iteration at 256 robots, and same-address atomics serialise (each waits for its return value):
+// the plane stage of k_front was bound by that, not by its work.  Consumers index the concatenation: wprefix() leaves the
+// exclusive prefix of the (clamped) counts in LDS, wslot() maps an item number to its slot.
+__device__ __forceinline__ int pair_work_cap_seg(const Dev& D) { return D.cap_work / D.S; }
+__device__ __forceinline__ int pair_work_prefix(const Dev& D, int* pre, int lane) {   // one wave; pre[0..S]; returns the total
+  const int S = D.S, cap = pair_work_cap_seg(D);
+  int run = 0;
+  for (int base = 0; base < S; base += 64) {
+    const int tr = base + lane;
+    const int c = tr < S ? min(D.pair_work_n[tr], cap) : 0;
+    int x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (tr < S) pre[tr] = run + x - c;
+    run += __shfl(x, 63);
+  }
+  if (lane == 0) pre[S] = run;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  return run;
+}
+__device__ __forceinline__ int pair_work_slot(const Dev& D, const int* pre, int w) {
+  int lo = 0, hi = D.S;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= w) lo = mid; else hi = mid; }
+  return lo * pair_work_cap_seg(D) + (w - pre[lo]);
+}
+
+// Broad phase of one tile, shared by the plane stage (hull boxes / hull intervals) and the CCD selection (swept boxes / swept
+// intervals).  Box test: lanes over the 64 partners (their boxes in registers, loaded once), loop over the R rows (boxes
+// broadcast from LDS); hits are appended to list[] as (p0 << 16 | p1) in (p0, p1) order.  Then, per box survivor, lanes over the
+// 49 axes against both robots' interval records; the records of FOUR pairs are fetched together -- the loop is a chain of
+// memory latencies, not of arithmetic -- and the list is compacted in place.  Same comparisons as the one-pair-at-a-time
+// forms (CCD.h:535-587), hence the same decisions.  Returns the number of pairs left in list[].
+//   segbox  [6][U] lo.xyz, hi.xyz of every robot for this segment      rec(q) -> robot q's record, intervals lo at LO, hi at HI
+//   [own0, own1): robots of this rank -- a pair is skipped unless it touches one (sharded contexts; pass 0, U otherwise)
+template <class RecOf>
+__device__ __forceinline__ int pair_tile_filter(const double* segbox, int U, int rb, int R, int cb, int own0, int own1, RecOf rec, int LO, int HI, double d,
+                                                double* rowbox, int* list, int lane) {
+  for (int i = lane; i < R * 6; i += 64) rowbox[i] = segbox[(size_t)(i % 6) * U + min(rb + i / 6, U - 1)];
+  const int p1 = cb + lane;
+  const int pc = min(p1, U - 1);
+  double bv[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) bv[k] = segbox[(size_t)k * U + pc];   // independent loads, no branch between them
+  const bool own1p = p1 >= own0 && p1 < own1;
+  blk_sync<true>();
+  int n = 0;
+  for (int r = 0; r < R; r++) {
+    const int p0 = rb + r;
+    if (p0 >= U - 1) break;   // uniform
+    bool hit = p1 < U && p1 > p0 && (own1p || (p0 >= own0 && p0 < own1));
+#pragma unroll
+    for (int k = 0; k < 3; k++) hit = hit & !((bv[3 + k] + d < rowbox[6 * r + k]) | (bv[k] > rowbox[6 * r + 3 + k] + d));
+    const unsigned long long mask = ballot(hit);
+    if (hit) list[n + prefix_count(mask)] = (p0 << 16) | p1;
+    n += __popcll(mask);
+  }
+  blk_sync<true>();
+  if (n == 0) return 0;
+  const int ax = min(lane, 48);
+  int m = 0;
+  for (int base = 0; base < n; base += 4) {
+    int pr[4]; double alo[4], ahi[4], blo[4], bhi[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) pr[c] = list[min(base + c, n - 1)];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const double* a = rec(pr[c] >> 16); const double* b = rec(pr[c] & 0xffff);
+      alo[c] = a[LO + ax]; ahi[c] = a[HI + ax]; blo[c] = b[LO + ax]; bhi[c] = b[HI + ax];
+    }
+    blk_sync<true>();   // every lane has read this batch's list entries before the compaction overwrites earlier slots
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (base + c >= n) break;
+      const bool sep = lane < 49 && (bhi[c] < alo[c] - d || ahi[c] < blo[c] - d);
+      if (ballot(sep) == 0ull) {
+        if (lane == 0) list[m] = pr[c];
+        m++;
+      }
+    }
+  }
+  blk_sync<true>();
+  return m;
+}
+
+constexpr int PAIR_LDS_DOUBLES = PAIR_ROWS_MAX * 6 + PAIR_TILE_CAP / 2;   // rowbox | list
+__device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double* lds) {
+  int tr, rb, cb;
+  pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
   const int lane = lane_id();
   const int U = D.U;
-  __shared__ double A[HULL_STRIDE];   // hull, box and k-DOP intervals of robot p0
-  __shared__ int todo[64];            // partner ids that passed box + k-DOP
-  const double* a = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
-  for (int i = lane; i < HULL_STRIDE; i += 64) A[i] = a[i];
-  __syncthreads();
-  const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
-  const int epoch = D.ctl->epoch;
-  const bool own0 = p0 >= D.u0 && p0 < D.u1;
-  {
-    const int c0 = p0 + 1 + 64 * chunk;
-    // 1. lanes over partners: AABB test (12 independent loads per lane)
-    const int p1 = c0 + lane;
-    bool hit = false;
-    if (p1 < U && (own0 || (p1 >= D.u0 && p1 < D.u1))) {  // at least one robot of the pair belongs to this rank
-      const double* b = D.hbox + (size_t)tr * 6 * U + p1;   // component k of partner p1: b[k * U], coalesced over lanes
-      double bv[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) bv[k] = b[k * U];   // six independent loads, no branch between them
-      hit = true;
-#pragma unroll
-      for (int k = 0; k < 3; k++) hit = hit & !((bv[3 + k] + dist < A[18 + k]) | (bv[k] > A[21 + k] + dist));
-    }
-    unsigned long long box = ballot(hit);
-    // 2. per box survivor, wave-cooperative 49-axis interval test: lanes over AXES, two coalesced
-    //    loads per lane instead of a 49-step dependent chain per pair
-    int ntodo = 0;
-    while (box) {
-      const int l = __ffsll((long long)box) - 1;
-      box &= box - 1;
-      const int q = c0 + l;
-      const double* b = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
-      bool sep = false;
-      if (lane < 49) { const double lob = b[24 + lane], hib = b[73 + lane]; sep = hib < A[24 + lane] - dist || A[73 + lane] < lob - dist; }
-      if (ballot(sep) == 0ull) {
-        if (lane == 0) todo[ntodo] = q;
-        ntodo++;
-      }
-    }
-    __syncthreads();
-    // 3. hand the remaining pairs to k_sep_self_solve: one work item per pair.  Solving them here,
-    //    one lane per pair, serialises up to 63 divergent GJK paths in one wave where many robots
-    //    meet (measured: 87 us); one pair per wave keeps every path on its own program counter.
-    if (ntodo > 0) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(D.pair_work_n, ntodo);
-      base = __shfl(base, 0);
-      if (lane < ntodo) {
-        const int w = base + lane;
-        if (w < D.cap_work) { D.pair_work[3 * w] = tr; D.pair_work[3 * w + 1] = p0; D.pair_work[3 * w + 2] = todo[lane]; }
-        else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
-      }
-    }
-    __syncthreads();
+  double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
+  const double dist = D.offset + 2 * D.margin;
+  const int m = pair_tile_filter(D.hbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, D.u0, D.u1,
+                                 [&](int q) { return D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE; }, 24, 73, dist, rowbox, list, lane);
+  if (m == 0) return;
+  // hand the remaining pairs to the solve stage (k_mid / k_sep_self_solve): one work item per pair.  Solving them here,
+  // one lane per pair, serialises up to 63 divergent GJK paths in one wave where many robots meet (measured: 87 us).
+  int base = 0;
+  if (lane == 0) base = atomicAdd(D.pair_work_n + tr, m);   // the segment's own counter
+  base = __shfl(base, 0);
+  const int cap = pair_work_cap_seg(D);
+  for (int i = lane; i < m; i += 64) {
+    const int w = base + i;
+    if (w < cap) { const size_t sl = (size_t)tr * cap + w; D.pair_work[3 * sl] = tr; D.pair_work[3 * sl + 1] = list[i] >> 16; D.pair_work[3 * sl + 2] = list[i] & 0xffff; }
+    else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
   }
 }
 
 __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
   if (D.ctl->done) return;
-  sep_self_rows_body(D, blockIdx.x);
+  __shared__ double lds[PAIR_LDS_DOUBLES];
+  sep_self_rows_body(D, blockIdx.x, lds);
 }
 
 // one wavefront per robot pair (stride over the work list: wave bid of nwaves), solved cooperatively by its lanes (plane_pair_wave)
 __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int nwaves) {
   const int lane = lane_id();
   __shared__ double A[18], B[18];
-  const int n = min(*D.pair_work_n, D.cap_work), U = D.U;
+  __shared__ int wpre[513];
+  const int n = pair_work_prefix(D, wpre, lane), U = D.U;
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
   // Long work list (hundreds of robots): a wave per pair is the lowest LATENCY but occupies 64 lanes for one chain of
@@ -145,7 +211,8 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     for (int base = bid * 64; base < n; base += nwaves * 64) {
       const int w = base + lane;
       if (w < n) {
-        const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+        const size_t sl = (size_t)pair_work_slot(D, wpre, w);
+        const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
         const double* Ag = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
         const double* Bg = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
         double e0, e1c, e2c, dpl; bool capped; int nit = 0;
@@ -170,7 +237,8 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   for (int w = bid; w < n;) {
     const bool first = w == bid;   // phase stamps (timing build only) describe a wave's first work item
     if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
-    const int tr = D.pair_work[3 * w], p0 = D.pair_work[3 * w + 1], q = D.pair_work[3 * w + 2];
+    const size_t sl = (size_t)pair_work_slot(D, wpre, w);
+    const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
     __syncthreads();
     if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
     __syncthreads();
@@ -193,7 +261,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     }
     if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
     int nxt = 0;
-    if (lane == 0) nxt = nwaves + atomicAdd(D.pair_work_n + 1, 1);
+    if (lane == 0) nxt = nwaves + atomicAdd(D.pair_work_n + D.S, 1);
     w = __shfl(nxt, 0);
   }
 }

@@ -105,6 +105,7 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
     int* t = cur; cur = nxt; nxt = t;
     count = ncount;
   }
+  if constexpr (BQ_UNROLL == 4) TJ_TIC(D, K_SEP_OBS, 2);   // timing build: the plane query's walk is done, leaves next
   int nc = 0, found = 0;
   for (int base = 0; base < count; base += 8 * BQ_UNROLL) {
     int pts[BQ_UNROLL]; bool live[BQ_UNROLL]; double px[BQ_UNROLL], py[BQ_UNROLL], pz[BQ_UNROLL]; float lb[BQ_UNROLL][6];
@@ -161,6 +162,7 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
       }
     }
   }
+  if constexpr (BQ_UNROLL == 4) TJ_TIC(D, K_SEP_OBS, 3);
   if (nc > 0) process(lane < nc ? cand[lane] : -1);
   if (visits) *visits += nv;
   return found;
@@ -191,10 +193,19 @@ __device__ __forceinline__ bool kdop_point_pass(const Dev& D, const double* klo,
 
 // obstacle primitive (1 or 3 vertices) vs cached hull intervals: CCD::KDOPDCD / KDOPCCD with the body-2 loop over
 // _position.rows() (CCD.h:391-400; for one vertex it is kdop_point_pass)
+// One candidate per LANE.  The axes come from LDS (kax, staged by stage_kdop_axes) and all 49 are evaluated without an early
+// exit: with the axes in global memory and a `return false` per axis the loop was a chain of up to 49 dependent memory
+// round trips -- 118 us for a segment under an obstacle slab (40 candidates), the whole tail of k_front at 256 robots.
+// Same comparisons, hence the same decision.
+__device__ __forceinline__ void stage_kdop_axes(const Dev& D, double* kax, int lane) {
+  for (int i = lane; i < 147; i += 64) kax[i] = D.kdop[i];
+  __syncthreads();
+}
 template <class B>
-__device__ __forceinline__ bool kdop_body_pass(const Dev& D, const double* klo, const double* khi, const B& body, double d) {
+__device__ __forceinline__ bool kdop_body_pass(const double* kax, const double* klo, const double* khi, const B& body, double d) {
+  bool sep = false;
   for (int k = 0; k < 49; k++) {
-    const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+    const double x = kax[3 * k], y = kax[3 * k + 1], z = kax[3 * k + 2];
     double up = -INFINITY, lo = INFINITY;
 #pragma unroll
     for (int i = 0; i < B::N; i++) {
@@ -203,9 +214,9 @@ __device__ __forceinline__ bool kdop_body_pass(const Dev& D, const double* klo, 
       if (lv < lo) lo = lv;
       if (lv > up) up = lv;
     }
-    if (up < klo[k] - d || khi[k] < lo - d) return false;
+    sep = sep | (up < klo[k] - d) | (khi[k] < lo - d);
   }
-  return true;
+  return !sep;
 }
 
 // Separate::opengjk (Separate.h:18-163): plane (c,d) between a 6-point hull and one cloud point
@@ -351,13 +362,17 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
 // per round) they made a 45 us tail on a 5 us kernel.  One wave per candidate runs them all at once.
 // Plane order = candidate order = what the fused version produced, so downstream sums see the same sequence.
 constexpr int OBS_SINGLE_MAX = 16;  // candidates of a segment that still get a wave each
+// LDS of one unit, carved from a buffer the KERNEL owns: the union kernels run a different body per block, and function-local
+// __shared__ arrays of exclusive branches are not overlaid by the compiler (their sizes add up, and with them go residency).
+constexpr int OBS_LDS_DOUBLES = 264 + (2 * FRONT_CAP + 128) / 2;   // P[18] klo[49] khi[49] kax[147] | fa fb cand
 template <int PRIM>
-__device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
+__device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* lds) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
-  __shared__ double P[18];
-  __shared__ double klo[49], khi[49];
-  __shared__ int fa[FRONT_CAP], fb[FRONT_CAP], cand[128];
+  double* P = lds; double* klo = P + 18; double* khi = klo + 49;
+  double* kax = khi + 49;   // the 49 axes, staged when the first candidate shows up
+  int* fa = (int*)(lds + 264); int* fb = fa + FRONT_CAP; int* cand = fb + FRONT_CAP;
+  bool kax_ready = false;
   const double* net = D.spline + (size_t)u * 3 * D.T;
   TJ_TIC(D, K_SEP_OBS, 0);
   if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
@@ -378,8 +393,9 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   int base = 0;
   unsigned long long visits = 0;
   const int found = bvh_query<4, PRIM>(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
+    if (!kax_ready) { stage_kdop_axes(D, kax, lane); kax_ready = true; }   // wave-uniform
     bool ok = false;
-    if (pt >= 0) ok = kdop_body_pass(D, klo, khi, PrimOf<PRIM>::load(D, pt), dist);
+    if (pt >= 0) ok = kdop_body_pass(kax, klo, khi, PrimOf<PRIM>::load(D, pt), dist);
     const unsigned long long mask = ballot(ok);
     const int idx = base + prefix_count(mask);
     if (ok) {
@@ -388,7 +404,7 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
     }
     base += __popcll(mask);
   });
-  TJ_TIC(D, K_SEP_OBS, 2);
+  TJ_TIC(D, K_SEP_OBS, 4);
   const int cnt = min(base, D.cap_obs);
   if (lane < 18) D.ohull[seg * 18 + lane] = P[lane];
   // Work items: a segment with few candidates hands each one to its own wave (cooperative GJK, lowest latency); a
@@ -400,11 +416,12 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid) {
   if (lane == 0) {
     D.ocand_n[seg] = cnt;
     if (items > 0) w0 = atomicAdd(D.obs_work_n, items);
-    unsigned long long* st = D.seg_stats + seg * 6;
-    st[0] += visits; st[1] += (unsigned long long)found;
+    unsigned long long* st = D.seg_stats + seg * 6;   // fire-and-forget atomics instead of a read-modify-write round trip
+    atomicAdd(&st[0], visits); atomicAdd(&st[1], (unsigned long long)found);
   }
   w0 = __shfl(w0, 0);
   for (int i = lane; i < items; i += 64) { D.obs_work[2 * (size_t)(w0 + i)] = (int)seg; D.obs_work[2 * (size_t)(w0 + i) + 1] = batched ? -(i * 64) - 1 : i; }
+  TJ_TIC(D, K_SEP_OBS, 5);
 }
 
 // Separate::opengjk (Separate.h:18-163) for one candidate, by one wave
@@ -441,7 +458,8 @@ __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_query(Dev D) {
   if (D.ctl->done) return;
-  obs_query_body<PRIM>(D, blockIdx.x);
+  __shared__ double lds[OBS_LDS_DOUBLES];
+  obs_query_body<PRIM>(D, blockIdx.x, lds);
 }
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_solve(Dev D) {

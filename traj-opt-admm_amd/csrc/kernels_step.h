@@ -74,12 +74,15 @@ __global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
   ccd_prep_segment(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane_id(), sh);
 }
 
+constexpr int CCD_LDS_DOUBLES = 294 + (2 * FRONT_CAP + 128) / 2;   // info[146] kax[147] | fa fb cand
 template <int PRIM>
-__device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
+__device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
-  __shared__ double info[CCD_STRIDE];
-  __shared__ int fa[FRONT_CAP], fb[FRONT_CAP], cand[128];
+  double* info = lds;
+  double* kax = info + CCD_STRIDE;   // the 49 axes, staged when the first candidate shows up
+  int* fa = (int*)(lds + 294); int* fb = fa + FRONT_CAP; int* cand = fb + FRONT_CAP;
+  bool kax_ready = false;
   const double* src = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
   for (int i = lane; i < CCD_STRIDE; i += 64) info[i] = src[i];
   __syncthreads();
@@ -89,9 +92,10 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
   unsigned long long visits = 0;
   int kmax = 0;
   const int found = bvh_query<1, PRIM>(D, q, off, fa, fb, cand, &visits, [&](int pt) {
+    if (!kax_ready) { stage_kdop_axes(D, kax, lane); kax_ready = true; }   // wave-uniform
     if (pt >= 0) {
       const typename PrimOf<PRIM>::Body qb = PrimOf<PRIM>::load(D, pt);
-      if (kdop_body_pass(D, info + 48, info + 97, qb, off)) {
+      if (kdop_body_pass(kax, info + 48, info + 97, qb, off)) {
         int k = max(kmax, atomicAdd(&D.k_obs[u], 0));  // any earlier value is a valid lower bound
         while (k < LOOP_CAP) {
           const V3 v = gjk(BodySwept{info, info + 18, D.pow08[k]}, qb);
@@ -103,54 +107,47 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid) {
       }
     }
   });
-  if (lane == 0) {
+  if (lane == 0) {   // fire-and-forget atomics: a read-modify-write would keep the wave alive for another memory round trip
     unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;
-    st[2] += visits; st[3] += (unsigned long long)found;
+    atomicAdd(&st[2], visits); atomicAdd(&st[3], (unsigned long long)found);
   }
 }
 
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
   if (D.ctl->done) return;
-  ccd_obs_body<PRIM>(D, blockIdx.x);
+  __shared__ double lds[CCD_LDS_DOUBLES];
+  ccd_obs_body<PRIM>(D, blockIdx.x, lds);
 }
 
 // Phase A: one wave per (segment, lower robot p0, chunk of 64 partners p1 > p0); lanes over the partners.  Acting pairs go to
 // ONE global list as sortable keys; the replay kernel sorts it, so (segment, p0, p1) is a lexicographic, deterministic order.
 constexpr int ACT_CAP = 4096;                                    // acting pairs of one iteration (all segments)
 __device__ __forceinline__ int act_key(int tr, int p0, int p1) { return (tr << 20) | (p0 << 10) | p1; }   // S < 512, U <= 1024
-__device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
-  int tr, p0, chunk;
-  pair_unit(D.U, bid, tr, p0, chunk);
+__device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid, double* lds) {
+  int tr, rb, cb;
+  pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
   const int lane = lane_id();
   const int U = D.U;
-  const int c0 = p0 + 1 + 64 * chunk;
   const double off = D.offset;
-  const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
-  {
-    const int p1 = c0 + lane;
+  double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
+  // swept boxes (lanes over partners), then swept 49-axis intervals (lanes over axes): BVH::SelfCCDCollision + CCD::SelfKDOPCCD
+  const int m = pair_tile_filter(D.cbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, 0, U,
+                                 [&](int q) { return D.ccdinfo + ((size_t)q * D.S + tr) * CCD_STRIDE; }, 48, 97, off, rowbox, list, lane);
+  if (m == 0) return;
+  // A pair can only ever ACT in the sequential replay if its swept hulls are within `offset` at FULL step: hulls are
+  // nested in the step (conv{P, P+tD} shrinks with t), and the replay evaluates them at steps <= 1.  Deciding that
+  // here, in parallel over all tiles (one surviving pair per lane), leaves the one-wave replay kernel with the (rare)
+  // colliding pairs only.
+  for (int i0 = 0; i0 < m; i0 += 64) {
     bool ok = false;
-    if (p1 < U) {
+    int p0 = 0, p1 = 0;
+    if (i0 + lane < m) {
+      p0 = list[i0 + lane] >> 16; p1 = list[i0 + lane] & 0xffff;
+      const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
       const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
-      const double* bb = D.cbox + (size_t)tr * 6 * U + p1;   // swept pair box of partner p1, coalesced over lanes
-      double bv[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) bv[k] = bb[k * U];   // six independent loads, no branch between them
-      bool hit = true;
-#pragma unroll
-      for (int k = 0; k < 3; k++) hit = hit & !((a[45 + k] + off < bv[k]) | (a[42 + k] > bv[3 + k] + off));
-      if (hit) {
-        bool pass = true;
-        for (int k = 0; k < 49 && pass; k++) if (b[97 + k] < a[48 + k] - off || a[97 + k] < b[48 + k] - off) pass = false;
-        ok = pass;
-      }
-      // A pair can only ever ACT in the sequential replay if its swept hulls are within `offset` at FULL step: hulls are
-      // nested in the step (conv{P, P+tD} shrinks with t), and the replay evaluates them at steps <= 1.  Deciding that
-      // here, in parallel over all rows, leaves the one-wave replay kernel with the (rare) colliding pairs only.
-      if (ok) {
-        const V3 v = gjk(BodySwept{a, a + 18, D.pow08[0]}, BodySwept{b, b + 18, D.pow08[0]});
-        ok = v.x * v.x + v.y * v.y + v.z * v.z <= off * off;
-      }
+      const V3 v = gjk(BodySwept{a, a + 18, D.pow08[0]}, BodySwept{b, b + 18, D.pow08[0]});
+      ok = v.x * v.x + v.y * v.y + v.z * v.z <= off * off;
     }
     const unsigned long long mask = ballot(ok);
     if (mask) {   // rare
@@ -168,7 +165,8 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid) {
 
 __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
   if (D.ctl->done) return;
-  ccd_self_pairs_body(D, blockIdx.x);
+  __shared__ double lds[PAIR_LDS_DOUBLES];
+  ccd_self_pairs_body(D, blockIdx.x, lds);
 }
 
 // Phase B + gnorm.  One workgroup of one wave; control flow is wave uniform.
@@ -469,8 +467,9 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   if (D.ctl->done) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
-  if ((int)blockIdx.x < n_obs) obs_query_body<PRIM>(D, blockIdx.x);
-  else sep_self_rows_body(D, blockIdx.x - n_obs);
+  __shared__ double lds[OBS_LDS_DOUBLES > PAIR_LDS_DOUBLES ? OBS_LDS_DOUBLES : PAIR_LDS_DOUBLES];   // one buffer for whichever body this block runs
+  if ((int)blockIdx.x < n_obs) obs_query_body<PRIM>(D, blockIdx.x, lds);
+  else sep_self_rows_body(D, blockIdx.x - n_obs, lds);
   TJ_TIC(D, K_FRONT, 1);
 }
 // two waves per SIMD (<= 256 VGPRs): all 320 + 1024 + 512 blocks of SCN-C are resident at once; at the natural 340 VGPRs a
@@ -490,8 +489,9 @@ template <int PRIM>
 __global__ __launch_bounds__(64) void k_ccd(Dev D) {
   if (D.ctl->done) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
-  if ((int)blockIdx.x < n_obs) ccd_obs_body<PRIM>(D, blockIdx.x);
-  else ccd_self_pairs_body(D, blockIdx.x - n_obs);
+  __shared__ double lds[CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES];
+  if ((int)blockIdx.x < n_obs) ccd_obs_body<PRIM>(D, blockIdx.x, lds);
+  else ccd_self_pairs_body(D, blockIdx.x - n_obs, lds);
 }
 
 // ---- iteration bookkeeping ---------------------------------------------------------------------

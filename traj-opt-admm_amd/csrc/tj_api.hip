@@ -47,6 +47,7 @@ struct tj_ctx {
   bool graph_ok[4] = {false, false, false, false};
   bool graph_failed[4] = {false, false, false, false};
   size_t lds_grad = 0, lds_xs = 0, lds_xs2 = 0, lds_ls = 0, lds_seq = 0;
+  bool split_unions = false;   // k_front / k_ccd as two launches each (hundreds of robots), see launch_kernel
   LsLayout lsl;
   // cloud-dependent allocations (rebuilt by tj_set_cloud)
   std::vector<void*> cloud_allocs;
@@ -115,12 +116,19 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
   const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 512 : 0;
-  const int n_rows = multi ? d.S * pair_units(d.U) : 0;   // one wave per (segment, lower robot, chunk of 64 partners)
+  const int n_rows = multi ? d.S * pair_units(d.U, d.pair_rows) : 0;   // one wave per (segment, tile of pair_rows lower robots x 64 partners)
   const int n_front = owned * d.S + n_rows, n_ccd = n_front;
   switch (kid) {
     case K_BEGIN: if (chain_pos & 1) return false; hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
     case K_FRONT: if (!in_graph && !in_phase) return false;
+      if (c->split_unions && multi) {
+        // hundreds of robots: the union is bound by how many one-wave blocks are resident (LDS of the BVH frontier: 14 per CU), and
+        // the pair rows need none of that LDS -- two launches, the second one at full occupancy, beat one boundary saved
+        if (owned * d.S > 0) { if (tri) hipLaunchKernelGGL((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d); }
+        hipLaunchKernelGGL(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d);
+        return true;
+      }
       if (tri) hipLaunchKernelGGL((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
       return true;
     case K_SEP_OBS: if (in_graph || in_phase) return false;  // stage API and sharded phase 0
@@ -151,6 +159,11 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_CCD_PREP: if (in_graph && d.fuse && !d.xs_band) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
       hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
     case K_CCD: if (!in_graph && !in_phase) return false;
+      if (c->split_unions && multi) {
+        if (owned * d.S > 0) { if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d); }
+        hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d);
+        return true;
+      }
       if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(n_ccd), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(n_ccd), dim3(64), 0, s, d);
       return true;
     case K_CCD_OBS: if (in_graph) return false;
@@ -385,6 +398,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, std::min(d.U - 1, 64));  // neighbours within offset + 2 margin of ONE segment; k_grad's LDS grows with it
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
   d.optimal_plane = p->optimal_plane ? 1 : 0;
+  d.pair_rows = 16;   // measured best at 64 and at 256 robots (2, 4, 8 are within 10 %)
+  if (const char* e = getenv("TJ_PAIR_ROWS")) { const int r = atoi(e); if (r == 2 || r == 4 || r == 8 || r == 16) d.pair_rows = r; }
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
@@ -411,6 +426,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.seq_tree = (d.mode == TJ_MODE_MULTI_DECOUPLE && seq_lds_bytes(d.U, d.S, true) <= lds_max) ? 1 : 0;
   if (getenv("TJ_NO_SEQ_TREE")) d.seq_tree = 0;  // test hook: behave like a fleet too large for the LDS-resident tree
   c->lds_seq = seq_lds_bytes(d.U, d.S, d.seq_tree != 0);
+  c->split_unions = false;
+  if (const char* e = getenv("TJ_SPLIT_UNIONS")) c->split_unions = atoi(e) != 0;
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
     return TJ_ERR_UNSUPPORTED;
@@ -444,7 +461,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
-      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, 2)) || (r = dalloc(c, &d.ctl, 1)) ||
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.ctl, 1)) ||
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
