@@ -47,6 +47,7 @@ struct tj_ctx {
   bool graph_ok[4] = {false, false, false, false};
   bool graph_failed[4] = {false, false, false, false};
   size_t lds_grad = 0, lds_xs = 0, lds_xs2 = 0, lds_ls = 0, lds_seq = 0;
+  bool grad_fold = true;       // k_grad compacts its own segments (one launch less); TJ_GRAD_FOLD=0 keeps k_sep_self_compact + the 192-thread k_grad
   bool split_unions = false;   // k_front / k_ccd as two launches each (hundreds of robots), see launch_kernel
   LsLayout lsl;
   // cloud-dependent allocations (rebuilt by tj_set_cloud)
@@ -145,10 +146,10 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
       hipLaunchKernelGGL(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
-    case K_SEP_SELF_COMPACT: if (in_graph || in_phase) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
+    case K_SEP_SELF_COMPACT: if ((in_graph || in_phase) && c->grad_fold) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
       hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD:
-      if (in_graph || in_phase) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad, s, d);
+      if ((in_graph || in_phase) && c->grad_fold) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad, s, d);
       else hipLaunchKernelGGL((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
       return true;
     case K_XSOLVE:
@@ -403,7 +404,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
-  d.grad_npl = std::min(d.cap_obs + d.cap_self, 96);   // what a batch of segments really carries (SCN-C: <= 40); more goes through grad_scr
+  d.grad_npl = std::min(d.cap_obs + d.cap_self, 64);   // what a batch of segments really carries (SCN-C: <= 40); more goes through grad_scr.  64: five workgroups per CU (96: four)
+  if (const char* e = getenv("TJ_GRAD_NPL")) { const int r = atoi(e); if (r >= 8 && r <= 4096) d.grad_npl = std::min(d.cap_obs + d.cap_self, r); }
   c->lds_grad = grad_lds_doubles(d.grad_npl, d.res) * sizeof(double);
   const size_t lds_max = 160 * 1024 - 1024;
   // long trajectories: the dense per-robot system no longer fits LDS -> band storage (decoupled / single-UAV modes)
@@ -427,6 +429,10 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if (getenv("TJ_NO_SEQ_TREE")) d.seq_tree = 0;  // test hook: behave like a fleet too large for the LDS-resident tree
   c->lds_seq = seq_lds_bytes(d.U, d.S, d.seq_tree != 0);
   c->split_unions = false;
+  // hundreds of robots: the 512-thread folded k_grad is limited to ~2 workgroups per CU by wave slots; the 192-thread one (5 per CU)
+  // plus a separate compaction launch is faster once there are more pieces than that (SCN-D: k_grad 109 -> 72 + 14 us)
+  c->grad_fold = (d.u1 - d.u0) * d.P <= 512;
+  if (const char* e = getenv("TJ_GRAD_FOLD")) c->grad_fold = atoi(e) != 0;
   if (const char* e = getenv("TJ_SPLIT_UNIONS")) c->split_unions = atoi(e) != 0;
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
