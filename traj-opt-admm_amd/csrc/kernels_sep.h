@@ -17,6 +17,7 @@
 // is evaluated here in fp64 on the primitives themselves (a point, or the exact box of a triangle's three vertices).
 #pragma once
 #include "dev_common.h"
+#include "dev_linalg.h"
 
 namespace tj {
 
@@ -219,6 +220,28 @@ __device__ __forceinline__ bool kdop_body_pass(const double* kax, const double* 
   return !sep;
 }
 
+// The same cull for up to 64 candidates held one per LANE (lanes [0, n)), done by the whole wave: lanes over the 49 AXES
+// (axis and the hull's interval in registers), candidates one after the other with their vertices broadcast by v_readlane.
+// ~20 instructions per point candidate instead of a 49-step loop per lane; returns this lane's verdict.  Same products and
+// sums as kdop_body_pass, hence the same decision.  axv = this lane's axis (x, y, z), lo_ax / hi_ax = hull interval on it.
+template <class B>
+__device__ __forceinline__ bool kdop_cull_wave(const B& body, int n, const V3& axv, double lo_ax, double hi_ax, double d, int lane) {
+  unsigned long long pass = 0ull;
+  for (int i = 0; i < n; i++) {   // wave-uniform
+    double up = -INFINITY, lo = INFINITY;
+#pragma unroll
+    for (int v = 0; v < B::N; v++) {
+      const V3 p = body.get(v);
+      const double lv = axv.x * readlane_f64(p.x, i) + axv.y * readlane_f64(p.y, i) + axv.z * readlane_f64(p.z, i);
+      if (lv < lo) lo = lv;
+      if (lv > up) up = lv;
+    }
+    const bool sep = lane < 49 && ((up < lo_ax - d) | (hi_ax < lo - d));
+    if (ballot(sep) == 0ull) pass |= 1ull << i;
+  }
+  return (pass >> lane) & 1ull;
+}
+
 // Separate::opengjk (Separate.h:18-163): plane (c,d) between a 6-point hull and one cloud point
 // plane (c,d) from the GJK witness vector v of hull - point (Separate.h:107-151): rejected if |v| > dist
 __device__ __forceinline__ bool plane_from_witness(const V3& v, const V3& qp, double dist, double offset, double& c0, double& c1, double& c2, double& dd) {
@@ -370,9 +393,9 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   double* P = lds; double* klo = P + 18; double* khi = klo + 49;
-  double* kax = khi + 49;   // the 49 axes, staged when the first candidate shows up
   int* fa = (int*)(lds + 264); int* fb = fa + FRONT_CAP; int* cand = fb + FRONT_CAP;
   bool kax_ready = false;
+  V3 axv{0, 0, 0}; double lo_ax = 0, hi_ax = 0;
   const double* net = D.spline + (size_t)u * 3 * D.T;
   TJ_TIC(D, K_SEP_OBS, 0);
   if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
@@ -393,9 +416,13 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
   int base = 0;
   unsigned long long visits = 0;
   const int found = bvh_query<4, PRIM>(D, q, dist, fa, fb, cand, &visits, [&](int pt) {
-    if (!kax_ready) { stage_kdop_axes(D, kax, lane); kax_ready = true; }   // wave-uniform
-    bool ok = false;
-    if (pt >= 0) ok = kdop_body_pass(kax, klo, khi, PrimOf<PRIM>::load(D, pt), dist);
+    if (!kax_ready) {   // wave-uniform: this lane's axis and the hull's interval on it, kept in registers from the first candidate on
+      const int ax = min(lane, 48);
+      axv = V3{D.kdop[3 * ax], D.kdop[3 * ax + 1], D.kdop[3 * ax + 2]}; lo_ax = klo[ax]; hi_ax = khi[ax];
+      kax_ready = true;
+    }
+    const int ncand = __popcll(ballot(pt >= 0));   // candidates sit in lanes [0, ncand)
+    const bool ok = kdop_cull_wave(PrimOf<PRIM>::load(D, max(pt, 0)), ncand, axv, lo_ax, hi_ax, dist, lane) && pt >= 0;
     const unsigned long long mask = ballot(ok);
     const int idx = base + prefix_count(mask);
     if (ok) {

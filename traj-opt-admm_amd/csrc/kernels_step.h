@@ -80,9 +80,9 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   double* info = lds;
-  double* kax = info + CCD_STRIDE;   // the 49 axes, staged when the first candidate shows up
   int* fa = (int*)(lds + 294); int* fb = fa + FRONT_CAP; int* cand = fb + FRONT_CAP;
   bool kax_ready = false;
+  V3 axv{0, 0, 0}; double lo_ax = 0, hi_ax = 0;
   const double* src = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
   for (int i = lane; i < CCD_STRIDE; i += 64) info[i] = src[i];
   __syncthreads();
@@ -92,10 +92,16 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
   unsigned long long visits = 0;
   int kmax = 0;
   const int found = bvh_query<1, PRIM>(D, q, off, fa, fb, cand, &visits, [&](int pt) {
-    if (!kax_ready) { stage_kdop_axes(D, kax, lane); kax_ready = true; }   // wave-uniform
+    if (!kax_ready) {   // wave-uniform: this lane's axis and the swept hull's interval on it
+      const int ax = min(lane, 48);
+      axv = V3{D.kdop[3 * ax], D.kdop[3 * ax + 1], D.kdop[3 * ax + 2]}; lo_ax = info[48 + ax]; hi_ax = info[97 + ax];
+      kax_ready = true;
+    }
+    const int ncand = __popcll(ballot(pt >= 0));   // candidates sit in lanes [0, ncand)
+    const typename PrimOf<PRIM>::Body qb = PrimOf<PRIM>::load(D, max(pt, 0));
+    const bool pass = kdop_cull_wave(qb, ncand, axv, lo_ax, hi_ax, off, lane);
     if (pt >= 0) {
-      const typename PrimOf<PRIM>::Body qb = PrimOf<PRIM>::load(D, pt);
-      if (kdop_body_pass(kax, info + 48, info + 97, qb, off)) {
+      if (pass) {
         int k = max(kmax, atomicAdd(&D.k_obs[u], 0));  // any earlier value is a valid lower bound
         while (k < LOOP_CAP) {
           const V3 v = gjk(BodySwept{info, info + 18, D.pow08[k]}, qb);
