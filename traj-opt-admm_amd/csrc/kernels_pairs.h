@@ -272,11 +272,39 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
 
 // per (owned robot, segment): obstacle planes from the stamped candidate slots (slot order), then -- multi-robot modes --
 // the robot-pair planes from the stamped partner slots (ascending partner): deterministic lists, no atomics
+// The loads are ordered so that the chain is three memory latencies long, not six: epoch, candidate count and the first 256
+// partner stamps go out together; then the candidate stamps and the stamped partners' planes; then the candidates' planes.
 __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int lane) {   // one wave
   const int U = D.U, epoch = D.ctl->epoch;
   const size_t seg = (size_t)u * D.S + tr;
-  if (!(D.optimal_plane && !D.multi())) {  // single-UAV "optimal_plane":1 -- k_keep wrote the obstacle plane list itself
-    const int n = D.ocand_n[seg];
+  const bool obs_part = !(D.optimal_plane && !D.multi());  // single-UAV "optimal_plane":1 -- k_keep wrote the obstacle plane list itself
+  const bool pair_part = D.multi();
+  const int n = obs_part ? D.ocand_n[seg] : 0;
+  // partner stamps of the first four chunks (all of them up to 256 robots)
+  int pst[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int q = 64 * c + lane;
+    pst[c] = (pair_part && q < U) ? D.pairstamp[((size_t)tr * U + u) * U + q] : 0;
+  }
+  double* outp = D.splanes + seg * D.cap_self * 4;
+  int pbase = 0;
+  if (pair_part) {
+    for (int q0 = 0; q0 < U; q0 += 64) {
+      const int q = q0 + lane;
+      const size_t slot = ((size_t)tr * U + u) * U + min(q, U - 1);
+      const int st = q0 < 256 ? pst[q0 >> 6] : (q < U ? D.pairstamp[slot] : 0);
+      const bool ok = q < U && q != u && st == epoch;
+      const unsigned long long mask = ballot(ok);
+      const int idx = pbase + prefix_count(mask);
+      if (ok) {
+        if (idx < D.cap_self) { const double* p = D.pairplane + 4 * slot; outp[4 * idx] = p[0]; outp[4 * idx + 1] = p[1]; outp[4 * idx + 2] = p[2]; outp[4 * idx + 3] = p[3]; }
+        else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
+      }
+      pbase += __popcll(mask);
+    }
+  }
+  if (obs_part) {
     double* out = D.oplanes + seg * D.cap_obs * 4;
     int base = 0;
     for (int s0 = 0; s0 < n; s0 += 64) {
@@ -287,26 +315,11 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
       if (ok) { const double* p = D.oraw + (seg * D.cap_obs + sl) * 4; out[4 * idx] = p[0]; out[4 * idx + 1] = p[1]; out[4 * idx + 2] = p[2]; out[4 * idx + 3] = p[3]; }
       base += __popcll(mask);
     }
-    if (lane == 0) { D.ocount[seg] = base; D.seg_stats[seg * 6 + 4] += (unsigned long long)base; }
+    if (lane == 0) { D.ocount[seg] = base; atomicAdd(&D.seg_stats[seg * 6 + 4], (unsigned long long)base); }   // fire-and-forget
   }
-  if (!D.multi()) return;
-  double* out = D.splanes + seg * D.cap_self * 4;
-  int base = 0;
-  for (int q0 = 0; q0 < U; q0 += 64) {
-    const int q = q0 + lane;
-    const size_t slot = ((size_t)tr * U + u) * U + min(q, U - 1);
-    const bool ok = q < U && q != u && D.pairstamp[slot] == epoch;
-    const unsigned long long mask = ballot(ok);
-    const int idx = base + prefix_count(mask);
-    if (ok) {
-      if (idx < D.cap_self) { const double* p = D.pairplane + 4 * slot; out[4 * idx] = p[0]; out[4 * idx + 1] = p[1]; out[4 * idx + 2] = p[2]; out[4 * idx + 3] = p[3]; }
-      else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
-    }
-    base += __popcll(mask);
-  }
-  if (lane == 0) {
-    D.scount[seg] = min(base, D.cap_self);
-    D.seg_stats[seg * 6 + 5] += (unsigned long long)base;
+  if (pair_part && lane == 0) {
+    D.scount[seg] = min(pbase, D.cap_self);
+    atomicAdd(&D.seg_stats[seg * 6 + 5], (unsigned long long)pbase);
   }
 }
 __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
