@@ -410,3 +410,32 @@ def test_more_scenes_end_to_end_vs_oracle(pkg, scenes, which):
     assert rel(a["spline"], b["spline"]) <= 1e-7 and rel(a["piece_time"], b["piece_time"]) <= 1e-7
     assert s.stats()["error_bits"] == 0
     s.close()
+
+
+@pytest.mark.parametrize("U,rows", [(5, None), (13, None), (70, None), (130, None), (70, 2), (130, 4)])
+def test_ragged_fleet_sizes_pair_tiles_vs_oracle(pkg, scenes, U, rows, monkeypatch):
+    """robot counts that are no multiple of the pair tile (16 rows x 64 partners): ragged last row block, ragged last partner
+    block, a diagonal tile that is mostly empty; also other tile heights (TJ_PAIR_ROWS).  Plane COUNTS per (robot, segment)
+    equal the oracle's -- the pair set is exact -- and three whole iterations agree like the full-size scenes do."""
+    from oracle.pyoracle import Engine
+    if rows is not None:
+        monkeypatch.setenv("TJ_PAIR_ROWS", str(rows))
+    scene = scenes.crossing(U, 4000, seed=21 + U)
+    o = Engine("port", scene)
+    o2 = Engine("port", scene)          # plane stage only (the stage calls and whole iterations are not mixed on one engine)
+    s = pkg.Solver(scene, stop=0.0)
+    for it in range(3):
+        st0 = o.get_state()
+        s.set_state(st0); o2.set_state(st0)
+        co, _ = o2.stage_planes()
+        go = o.iterate()
+        gg, _, _ = s.iterate(1)
+        cg, _ = s.get_planes()          # the lists the iteration just used
+        assert np.array_equal(co, cg), f"it{it}: plane counts differ"
+        a, b = s.get_state(), o.get_state()
+        assert abs(gg - go) <= 1e-10 * max(1.0, go), (it, gg, go)
+        for n in STATE:
+            assert maxdiff(a[n], b[n]) <= 1e-9 * max(1.0, np.abs(b[n]).max()), (it, n, maxdiff(a[n], b[n]))
+    st = s.stats()
+    assert st["error_bits"] == 0 and st["order_unresolved"] == 0
+    s.close()
