@@ -278,7 +278,10 @@ def main():
 
     # clock ramp: a freshly started process finds the GPU at its idle clock (543 MHz sclk on the bench box); ~60 ms of the same
     # work, untimed and before the W warm-up steps, lets the power management settle so that K short steps are not timed on the ramp
-    run(300)
+    if sharded:
+        run(300)
+    else:
+        slv.iterate(300)   # the synchronous call: it is also where the library looks at its counters and picks kernel builds for what follows
     barrier()
     slv.reset()
     # warmup (also instantiates the hipGraph), then restart from the initial trajectory

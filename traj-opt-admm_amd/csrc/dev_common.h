@@ -123,6 +123,8 @@ struct Dev {
   // one component of 64 partners with one coalesced load instead of 64 strided 8-byte loads
   double *hbox, *cbox;
   double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
+  int* ccd_found;                  // [64] obstacle primitives the CCD stage found inside swept boxes, cumulative, spread over 64 counters (block & 63) so that no
+                                   // address is hot; the host sums them when it reads the control block and picks k_ccd's build from the rate
   int pair_rows;                   // rows per tile of the robot-pair broad phase (kernels_pairs.h)
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
   // "optimal_plane":1 -- planes that persist across iterations (the reference's is_seperate / seperate_c / seperate_d and

@@ -116,6 +116,7 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
   if (lane == 0) {   // fire-and-forget atomics: a read-modify-write would keep the wave alive for another memory round trip
     unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;
     atomicAdd(&st[2], visits); atomicAdd(&st[3], (unsigned long long)found);
+    if (found > 0) atomicAdd(&D.ccd_found[blockIdx.x & 63], found);
   }
 }
 
@@ -492,12 +493,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   TJ_TIC(D, K_MID, 1);
 }
 template <int PRIM>
-__global__ __launch_bounds__(64) void k_ccd(Dev D) {
-  if (D.ctl->done) return;
+__device__ __forceinline__ void ccd_union_body(const Dev& D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   __shared__ double lds[CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES];
   if ((int)blockIdx.x < n_obs) ccd_obs_body<PRIM>(D, blockIdx.x, lds);
   else ccd_self_pairs_body(D, blockIdx.x - n_obs, lds);
+}
+// Two builds of the same code.  The per-lane swept-hull GJK needs ~240 VGPRs, which leaves 2 waves per SIMD -- fewer slots
+// (2 048) than SCN-C has units (2 720), although almost none of them ever reaches the GJK there.  k_ccd_lean is compiled
+// for 3 waves per SIMD (168 VGPRs, the GJK spills ~215 registers): 3 us faster where the swept boxes meet (next to) no
+// obstacle, 3 % slower where thousands of candidates per iteration go through the GJK (SCN-E).  The host picks by the
+// candidate rate the device counted during the previous batch (Dev::ccd_found); both give the same bits.
+template <int PRIM>
+__global__ __launch_bounds__(64) void k_ccd(Dev D) {
+  if (D.ctl->done) return;
+  ccd_union_body<PRIM>(D);
+}
+template <int PRIM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ccd_lean(Dev D) {
+  if (D.ctl->done) return;
+  ccd_union_body<PRIM>(D);
 }
 
 // ---- iteration bookkeeping ---------------------------------------------------------------------

@@ -47,6 +47,8 @@ struct tj_ctx {
   bool graph_ok[4] = {false, false, false, false};
   bool graph_failed[4] = {false, false, false, false};
   size_t lds_grad = 0, lds_xs = 0, lds_xs2 = 0, lds_ls = 0, lds_seq = 0;
+  bool ccd_lean = true;        // which build of k_ccd the chain launches (kernels_step.h); re-decided whenever the control block is read
+  unsigned ccd_found_seen = 0; long long iters_enqueued = 0, iters_seen = 0;
   bool grad_fold = true;       // k_grad compacts its own segments (one launch less); TJ_GRAD_FOLD=0 keeps k_sep_self_compact + the 192-thread k_grad
   bool split_unions = false;   // k_front / k_ccd as two launches each (hundreds of robots), see launch_kernel
   LsLayout lsl;
@@ -165,7 +167,8 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
         hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
-      if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(n_ccd), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(n_ccd), dim3(64), 0, s, d);
+      if (c->ccd_lean) { if (tri) hipLaunchKernelGGL((k_ccd_lean<3>), dim3(n_ccd), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_lean<1>), dim3(n_ccd), dim3(64), 0, s, d); }
+      else { if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(n_ccd), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(n_ccd), dim3(64), 0, s, d); }
       return true;
     case K_CCD_OBS: if (in_graph) return false;
       if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d);
@@ -297,11 +300,22 @@ int launch_graph_or_eager(tj_ctx* c, int which, int chain_pos = 0) {
   return enqueue_body(c, which, 0, which == 3);
 }
 
+// obstacle-CCD candidates per iteration since the last look -> build of k_ccd for what comes next (kernels_step.h)
+void choose_builds(tj_ctx* c, const int* found64) {
+  unsigned tot = 0;
+  for (int i = 0; i < 64; i++) tot += (unsigned)found64[i];
+  const long long di = c->iters_enqueued - c->iters_seen;
+  if (di > 0 && !getenv("TJ_CCD_LEAN")) c->ccd_lean = (long long)(unsigned)(tot - c->ccd_found_seen) < 2048 * di;
+  c->ccd_found_seen = tot; c->iters_seen = c->iters_enqueued;
+}
+
 int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
-  Ctl h;
+  Ctl h; int found64[64];
   HIPCHK(c, hipMemcpyAsync(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(found64, c->d.ccd_found, sizeof(found64), hipMemcpyDeviceToHost, c->stream));
   QUIESCE(c);
   if (out) *out = h;
+  choose_builds(c, found64);
   if (h.error & (ERR_PLANE_OVERFLOW | ERR_FRONT_OVERFLOW | ERR_PAIR_OVERFLOW)) {
     c->err = "device list overflow (error bits " + std::to_string(h.error) + "): raise cap_obs/cap_self/cap_pairs";
     return TJ_ERR_CAPACITY;
@@ -429,6 +443,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if (getenv("TJ_NO_SEQ_TREE")) d.seq_tree = 0;  // test hook: behave like a fleet too large for the LDS-resident tree
   c->lds_seq = seq_lds_bytes(d.U, d.S, d.seq_tree != 0);
   c->split_unions = false;
+  if (const char* e = getenv("TJ_CCD_LEAN")) c->ccd_lean = atoi(e) != 0;
   // hundreds of robots: the 512-thread folded k_grad is limited to ~2 workgroups per CU by wave slots; the 192-thread one (5 per CU)
   // plus a separate compaction launch is faster once there are more pieces than that (SCN-D: k_grad 109 -> 72 + 14 us)
   c->grad_fold = (d.u1 - d.u0) * d.P <= 512;
@@ -467,7 +482,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.seg_stats, U * S * 6)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
-      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.ctl, 1)) ||
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
@@ -707,6 +722,7 @@ int tj_iterate_async(tj_ctx* c, int n_iters) {
     const int pos = chain ? ((i > 0 ? 1 : 0) | (i + 1 < n_iters ? 2 : 0)) : 0;
     int r = launch_graph_or_eager(c, 3, pos); if (r) return r;
   }
+  c->iters_enqueued += n_iters;
   return TJ_OK;
 }
 
