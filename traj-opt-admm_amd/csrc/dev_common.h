@@ -28,6 +28,11 @@ enum : int {
   ERR_PLANE_REFINE = 64,     // "optimal_plane":1 -- a plane's Newton refinement hit PLANE_NEWTON_CAP / PLANE_BACKOFF_CAP
 };
 
+#ifdef TJ_NO_DONE_CHECK
+#define TJ_DONE(D) false
+#else
+#define TJ_DONE(D) ((D).ctl->done)
+#endif
 struct Ctl {
   int iter;            // completed iterations (reference global `iter`)
   int done;            // stop test fired: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)

@@ -22,7 +22,7 @@
 namespace tj {
 
 __global__ __launch_bounds__(64) void k_keep(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   const int lane = lane_id();
   const int epoch = D.ctl->epoch;
   if (!D.multi()) {

@@ -306,7 +306,7 @@ __device__ __forceinline__ void begin_body(const Dev& D) {
 // begin_next = 1: the last block to finish also starts the NEXT iteration (begin_body): the stop test and the counter resets
 // need every block of this kernel to be done, which the ticket establishes; the host then omits the k_begin launch.
 __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, int begin_next) {
-  if (D.ctl->done) {
+  if (TJ_DONE(D)) {
     // converged: the only begin work left for the next iteration is to retire the slack/dual update that k_mid has just paid
     if (begin_next && blockIdx.x == 0 && threadIdx.x == 0) { D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0; }
     return;
@@ -455,7 +455,7 @@ __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double ste
 }
 
 __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   extern __shared__ double sm[];
   __shared__ int pref[512];
   __shared__ int s_acc[2];
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
 
 // commit: x_u += step d_u for every robot, the shared piece_time advances by step * t_direction
 __global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   __shared__ int s_acc[2];
   __shared__ double s_step0, s_accstep;
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, T = D.T;

@@ -95,7 +95,7 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
 // k_sep_self_compact, one wave per segment), so that kernel -- and its boundary -- drops out of the single-GPU chain.
 template <bool FOLD>
 __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   if constexpr (FOLD) {
     const int u_ = D.u0 + blockIdx.x / D.P, sp_ = blockIdx.x % D.P;
     for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64) compact_segment(D, u_, sp_ * D.res + i, threadIdx.x & 63);
@@ -455,7 +455,7 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
 }
 
 __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
   const int u = D.u0 + blockIdx.x;
@@ -596,7 +596,7 @@ __device__ __forceinline__ double xb_entry(const double* gh, int P, int ga, int 
   return acc;
 }
 __global__ __launch_bounds__(XB_THREADS) void k_xsolve_band(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   extern __shared__ double sm[];
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x;
   const int T = D.T, m = 3 * (T - 4), n = m + 1, BS = BAND_BS;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(XB_THREADS) void k_xsolve_band(Dev D) {
 // robot's block: x_u = L_u^-T (w_u - y_u t).  Per robot it leaves direction, t_direction and the
 // partial sums of wolfe = -x0.G and |G|^2 (completed by k_ccd_self_seq in robot order).
 __global__ __launch_bounds__(XS_THREADS) void k_xsolve_c2(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   extern __shared__ double sm[];
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x;
   const int T = D.T, m = 3 * (T - 4), n = m + 1;

@@ -31,7 +31,7 @@ namespace tj {
 constexpr int HULL_STRIDE = 18 + 6 + 98;  // P[6][3], lo[3], hi[3], kdop lo[49], kdop hi[49]
 
 __global__ __launch_bounds__(64) void k_hullinfo(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   const int u = blockIdx.x / D.S, tr = blockIdx.x % D.S, lane = lane_id();
   __shared__ double P[18];
   if (lane < 18) P[lane] = hull_entry(D, D.spline + (size_t)u * 3 * D.T, tr, lane / 3, lane % 3);
@@ -190,7 +190,7 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
 }
 
 __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   __shared__ double lds[PAIR_LDS_DOUBLES];
   sep_self_rows_body(D, blockIdx.x, lds);
 }
@@ -266,7 +266,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   }
 }
 __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   sep_self_solve_body(D, blockIdx.x, gridDim.x);
 }
 
@@ -323,7 +323,7 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
   }
 }
 __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   compact_segment(D, D.u0 + blockIdx.x / D.S, blockIdx.x % D.S, lane_id());
 }
 

@@ -484,13 +484,13 @@ __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves
 
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_query(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   __shared__ double lds[OBS_LDS_DOUBLES];
   obs_query_body<PRIM>(D, blockIdx.x, lds);
 }
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_solve(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   obs_solve_body<PRIM>(D, blockIdx.x, gridDim.x);
 }
 

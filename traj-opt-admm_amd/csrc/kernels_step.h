@@ -68,7 +68,7 @@ __device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net
 }
 
 __global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   const int u = blockIdx.x / D.S, tr = blockIdx.x % D.S;  // ALL robots: the pair clamp is replicated per rank
   __shared__ double sh[18 * 3 + 18];
   ccd_prep_segment(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane_id(), sh);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
 
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   __shared__ double lds[CCD_LDS_DOUBLES];
   ccd_obs_body<PRIM>(D, blockIdx.x, lds);
 }
@@ -171,7 +171,7 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid, doubl
 }
 
 __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   __shared__ double lds[PAIR_LDS_DOUBLES];
   ccd_self_pairs_body(D, blockIdx.x, lds);
 }
@@ -193,7 +193,7 @@ __host__ __device__ inline size_t seq_lds_bytes(int U, int S, bool with_tree) {
   return b;
 }
 __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   const int lane = lane_id();
   extern __shared__ double seq_sm[];
   // doubles first (alignment): tree nodes + the segment's swept boxes + gnorm staging, then the int arrays
@@ -456,7 +456,7 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
   }
 }
 __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
-  if (deferred ? !D.ctl->slack_now : D.ctl->done) return;
+  if (deferred ? !D.ctl->slack_now : TJ_DONE(D)) return;
   slack_body(D, blockIdx.x, deferred);
 }
 
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
 //   k_ccd    obstacle CCD clamp (owned * S)  |  robot-pair CCD selection (S * U)
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_front(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
   __shared__ double lds[OBS_LDS_DOUBLES > PAIR_LDS_DOUBLES ? OBS_LDS_DOUBLES : PAIR_LDS_DOUBLES];   // one buffer for whichever body this block runs
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int b = blockIdx.x;
   TJ_TIC(D, K_MID, 0);
   if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
-  else if (D.ctl->done) return;
+  else if (TJ_DONE(D)) return;
   else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves);
   else obs_solve_body<PRIM>(D, b - n_slack - n_pair_waves, n_obs_waves);
   TJ_TIC(D, K_MID, 1);
@@ -506,12 +506,12 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
 // candidate rate the device counted during the previous batch (Dev::ccd_found); both give the same bits.
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_ccd(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   ccd_union_body<PRIM>(D);
 }
 template <int PRIM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ccd_lean(Dev D) {
-  if (D.ctl->done) return;
+  if (TJ_DONE(D)) return;
   ccd_union_body<PRIM>(D);
 }
 
