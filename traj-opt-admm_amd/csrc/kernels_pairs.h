@@ -28,7 +28,7 @@
 
 namespace tj {
 
-constexpr int HULL_STRIDE = 18 + 6 + 98;  // P[6][3], lo[3], hi[3], kdop lo[49], kdop hi[49]
+constexpr int HULL_STRIDE = HULL_INFO_STRIDE;  // P[6][3], lo[3], hi[3], kdop lo[49], kdop hi[49]
 
 __global__ __launch_bounds__(64) void k_hullinfo(Dev D) {
   if (TJ_DONE(D)) return;

@@ -22,6 +22,7 @@
 namespace tj {
 
 struct QBox { double lo[3], hi[3]; };
+constexpr int HULL_INFO_STRIDE = 18 + 6 + 98;   // record of Dev::hullinfo (kernels_pairs.h HULL_STRIDE): hull, box lo/hi, 49 intervals lo/hi
 
 __device__ __forceinline__ bool box_hit(const float* b, const QBox& q, double m) {
   // query.overlaps(node): reject if node.hi + m < q.lo or node.lo > q.hi + m on any axis
@@ -65,6 +66,7 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
     count = __popcll(mask);
     nv += n;
   }
+  if (count == 0) { if (visits) *visits += nv; return 0; }   // wave-uniform: nothing of the obstacle set is near this box (the common case)
   __syncthreads();
   int* cur = fa; int* nxt = fb;
   // Each step of the walk is a dependent global load (~0.7 us).  BQ_UNROLL chunks of 8 frontier nodes are therefore
@@ -388,8 +390,11 @@ constexpr int OBS_SINGLE_MAX = 16;  // candidates of a segment that still get a 
 // LDS of one unit, carved from a buffer the KERNEL owns: the union kernels run a different body per block, and function-local
 // __shared__ arrays of exclusive branches are not overlaid by the compiler (their sizes add up, and with them go residency).
 constexpr int OBS_LDS_DOUBLES = 264 + (2 * FRONT_CAP + 128) / 2;   // P[18] klo[49] khi[49] kax[147] | fa fb cand
+// use_cache: the hull cache (hullinfo: hull, box, 49 intervals -- the same expressions, written by k_linesearch / k_hullinfo) is
+// valid for this robot; taking the record from there is ONE memory latency where recomputing costs two plus the projections.
+// True in the iteration chains of the multi-robot modes, false in the stage API (the cache is rebuilt after this stage there).
 template <int PRIM>
-__device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* lds) {
+__device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* lds, bool use_cache) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   double* P = lds; double* klo = P + 18; double* khi = klo + 49;
@@ -398,15 +403,23 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
   V3 axv{0, 0, 0}; double lo_ax = 0, hi_ax = 0;
   const double* net = D.spline + (size_t)u * 3 * D.T;
   TJ_TIC(D, K_SEP_OBS, 0);
-  if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
-  __syncthreads();
-  kdop_intervals(D, P, 6, klo, khi);
   QBox q;
+  if (use_cache && D.multi()) {
+    const double* h = D.hullinfo + ((size_t)u * D.S + tr) * HULL_INFO_STRIDE;
+    if (lane < 18) P[lane] = h[lane];
+    if (lane < 49) { klo[lane] = h[24 + lane]; khi[lane] = h[73 + lane]; }
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double lo = INFINITY, hi = -INFINITY;
-    for (int j = 0; j < 6; j++) { const double v = P[3 * j + k]; if (v < lo) lo = v; if (v > hi) hi = v; }
-    q.lo[k] = lo; q.hi[k] = hi;
+    for (int k = 0; k < 3; k++) { q.lo[k] = h[18 + k]; q.hi[k] = h[21 + k]; }
+  } else {
+    if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
+    __syncthreads();
+    kdop_intervals(D, P, 6, klo, khi);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double lo = INFINITY, hi = -INFINITY;
+      for (int j = 0; j < 6; j++) { const double v = P[3 * j + k]; if (v < lo) lo = v; if (v > hi) hi = v; }
+      q.lo[k] = lo; q.hi[k] = hi;
+    }
   }
   __syncthreads();
   TJ_TIC(D, K_SEP_OBS, 1);
@@ -433,7 +446,7 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
   });
   TJ_TIC(D, K_SEP_OBS, 4);
   const int cnt = min(base, D.cap_obs);
-  if (lane < 18) D.ohull[seg * 18 + lane] = P[lane];
+  if (cnt > 0 && lane < 18) D.ohull[seg * 18 + lane] = P[lane];   // read by the solve waves of this segment's candidates only
   // Work items: a segment with few candidates hands each one to its own wave (cooperative GJK, lowest latency); a
   // segment in a dense part of the cloud hands them over in batches of up to 64, one candidate per lane (per-lane GJK,
   // highest throughput).  slot >= 0: single candidate; slot < 0: batch starting at candidate -(slot + 1).
@@ -486,7 +499,7 @@ template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_query(Dev D) {
   if (TJ_DONE(D)) return;
   __shared__ double lds[OBS_LDS_DOUBLES];
-  obs_query_body<PRIM>(D, blockIdx.x, lds);
+  obs_query_body<PRIM>(D, blockIdx.x, lds, false);
 }
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_obs_solve(Dev D) {

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
   __shared__ double lds[OBS_LDS_DOUBLES > PAIR_LDS_DOUBLES ? OBS_LDS_DOUBLES : PAIR_LDS_DOUBLES];   // one buffer for whichever body this block runs
-  if ((int)blockIdx.x < n_obs) obs_query_body<PRIM>(D, blockIdx.x, lds);
+  if ((int)blockIdx.x < n_obs) obs_query_body<PRIM>(D, blockIdx.x, lds, true);
   else sep_self_rows_body(D, blockIdx.x - n_obs, lds);
   TJ_TIC(D, K_FRONT, 1);
 }
