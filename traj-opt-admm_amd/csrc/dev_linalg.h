@@ -30,6 +30,22 @@ __device__ __forceinline__ void blk_sync() {
 
 constexpr int CHOL_MB = 18;  // max band rows below a pivot handled by the wave kernel (bw <= 18, dense n <= 20)
 
+// FAST forms of the factorisations below (the x-update's per-robot Newton systems, which are one dependent chain of up to
+// 9P-2 pivots on a single wave): the pivot's RECIPROCAL root comes from v_rsq_f64 + two Newton steps (rounding level) and
+// multiplies the column, the right-hand side and -- stored on the factor's diagonal -- the back substitution, so the IEEE
+// sqrt and the divisions (~60 dependent instructions per pivot) leave the chain; the trailing update is one fma per entry.
+// Entries differ from the exact form by an ulp or so, which is what Eigen's blocked LLT differs by anyway (the reference
+// factors these n >= 43 systems panel-wise); all FAST variants (registers, LDS, band) perform the same operations in the same
+// order and agree bit for bit.  The exact forms stay where a pass/fail decision is pinned to Eigen's unblocked LLT (per-piece
+// 19x19 check, slack system, known-answer hook).
+__device__ __forceinline__ double pivot_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  double e = fma(-(x * r), r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-(x * r), r, 1.0);
+  return fma(0.5 * r, e, r);
+}
+
 // In-place lower Cholesky of the row-major n x n matrix A (lower triangle is read and written).
 // Pattern: half-bandwidth bw (bw >= n-1 means dense) plus a dense last row.  Returns false as soon as
 // a pivot is <= 0 (Eigen LLT.h:320-323; NaN pivots pass, like Eigen).  If y != nullptr, y <- L^-1 y.
@@ -37,7 +53,7 @@ constexpr int CHOL_MB = 18;  // max band rows below a pivot handled by the wave 
 // npiv < n stops after npiv pivots: with npiv = n-1 the last diagonal entry is left as the Schur
 // complement a_nn - sum l_nk^2 and y[n-1] as the matching reduced right-hand side (coupled mode:
 // the shared-time corner is completed across robots before its pivot can be taken).
-template <bool ONE_WAVE = false>
+template <bool ONE_WAVE = false, bool FAST = false>
 __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth, double* y = nullptr, int npiv = -1) {
   if (npiv < 0) npiv = n;
   __shared__ double s_col[CHOL_MB + 2];  // scaled pivot column: [0..mb) band rows, [CHOL_MB] arrow row
@@ -77,9 +93,9 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
     double yk_raw = 0, yi = 0, ylast = 0;
     if (y) { yk_raw = y[k]; yi = y[min(k + 1 + tid, last)]; ylast = y[last]; }
     if (x <= 0) return false;  // uniform: every thread read the same LDS word
-    const double sx = sqrt(x);
-    const double v = ci / sx;
-    const double yk = yk_raw / sx;
+    const double sx = FAST ? pivot_rsqrt(x) : sqrt(x);   // FAST: the diagonal holds 1 / l_kk
+    const double v = FAST ? ci * sx : ci / sx;
+    const double yk = FAST ? yk_raw * sx : yk_raw / sx;
     blk_sync<ONE_WAVE>();
     if (tid == 0) A[k * n + k] = sx;
     if (tid < mb) { A[myrow * n + k] = v; s_col[tid] = v; }
@@ -92,14 +108,14 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
 #pragma unroll
       for (int t = 0; t < 3; t++) { cr[t] = s_col[max(er[t], 0)]; cc[t] = s_col[ec[t]]; }
 #pragma unroll
-      for (int t = 0; t < 3; t++) if (wact[t]) A[widx[t]] = w[t] - cr[t] * cc[t];
+      for (int t = 0; t < 3; t++) if (wact[t]) A[widx[t]] = FAST ? fma(-cr[t], cc[t], w[t]) : w[t] - cr[t] * cc[t];
       if (arrow) {
-        if (tid < mb) A[aidx] = ae - la * cm;
-        if (tid == CHOL_MB + 1) A[last * n + last] = add - la * la;
+        if (tid < mb) A[aidx] = FAST ? fma(-la, cm, ae) : ae - la * cm;
+        if (tid == CHOL_MB + 1) A[last * n + last] = FAST ? fma(-la, la, add) : add - la * la;
       }
       if (y) {
-        if (tid < mb) y[k + 1 + tid] = yi - yk * cm;
-        else if (tid == mb && arrow) y[last] = ylast - yk * la;
+        if (tid < mb) y[k + 1 + tid] = FAST ? fma(-yk, cm, yi) : yi - yk * cm;
+        else if (tid == mb && arrow) y[last] = FAST ? fma(-yk, la, ylast) : ylast - yk * la;
         if (tid == 63) y[k] = yk;
       }
     }
@@ -130,10 +146,10 @@ __device__ __forceinline__ bool chol_check_wave(double (&r)[N]) {
 
 // Arrowhead-band Cholesky of an N x N system (N <= 64) entirely in the registers of ONE wave: lane i holds
 // the full row i (r[j] = A[i][j], both triangles), the right-hand side rides along in y (lane i = y_i).
-// Same operation order as chol_arrow_lds (a_ij - l_ik * l_jk with k ascending; column scaled by IEEE
-// division), so pivots, factor and forward-substituted rhs are bit-identical to it -- but a pivot is
-// ~150 straight-line instructions (v_readlane broadcasts, no LDS round trip, no barrier) instead of three
-// LDS round trips.  Pattern: half-bandwidth BW plus a dense last row.  npiv = N - 1 leaves the Schur
+// Same operations in the same order as chol_arrow_lds<.., FAST = true> (fma(-l_ik, l_jk, a_ij) with k ascending; column
+// scaled by the refined reciprocal root, which is what the diagonal keeps), so factor and forward-substituted rhs are
+// bit-identical to it -- but a pivot is ~75 straight-line instructions (v_readlane broadcasts, no LDS round trip, no
+// barrier) instead of three LDS round trips.  Pattern: half-bandwidth BW plus a dense last row.  npiv = N - 1 leaves the Schur
 // complement of the last diagonal entry in lane N-1 (see chol_arrow_lds).  Returns false on a pivot <= 0.
 template <int N, int BW>
 __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int lane, int npiv) {
@@ -142,16 +158,16 @@ __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int l
     if (k == N - 1 && npiv < N) break;
     const double x = readlane_f64(r[k], k);
     if (x <= 0) return false;
-    const double sx = sqrt(x);
-    const double lik = r[k] / sx;
-    const double yk = readlane_f64(y, k) / sx;
-    r[k] = lane == k ? sx : lik;
+    const double rs = pivot_rsqrt(x);
+    const double lik = r[k] * rs;
+    const double yk = readlane_f64(y, k) * rs;
+    r[k] = lane == k ? rs : lik;
     constexpr int LAST = N - 1;
     const int jhi = (k + BW < LAST - 1) ? k + BW : LAST - 1;
 #pragma unroll
-    for (int j = k + 1; j <= jhi; j++) r[j] = r[j] - lik * readlane_f64(lik, j);
-    if (k < LAST) r[LAST] = r[LAST] - lik * readlane_f64(lik, LAST);
-    y = lane == k ? yk : (lane > k ? y - yk * lik : y);
+    for (int j = k + 1; j <= jhi; j++) r[j] = fma(-lik, readlane_f64(lik, j), r[j]);
+    if (k < LAST) r[LAST] = fma(-lik, readlane_f64(lik, LAST), r[LAST]);
+    y = lane == k ? yk : (lane > k ? fma(-yk, lik, y) : y);
   }
   return true;
 }
@@ -159,7 +175,7 @@ __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int l
 // ---- band storage (long trajectories: piece_num > 10, where a dense n x n copy no longer fits LDS) ----------------------
 // The same arrowhead-band factorisation and solve on compact storage: Bd[m][BS] holds the band rows (m = n - 1 of them),
 // Bd[i][c] = A[i][i - (BS-1) + c], c = BS-1 the diagonal; Ar[n] holds the arrow row A[n-1][0..n-1].  Same operation order as
-// chol_arrow_lds / chol_arrow_backsolve_lds (a_ij - l_ik * l_jk, k ascending; IEEE division by the pivot's root), executed by
+// the FAST chol_arrow_lds / chol_arrow_backsolve_lds (fma(-l_ik, l_jk, a_ij), k ascending; reciprocal root on the diagonal), executed by
 // ONE wave; y rides along (y <- L^-1 y).  Returns false on a pivot <= 0.
 constexpr int BAND_BS = 18;   // half-bandwidth 17 + diagonal
 __device__ inline bool chol_band_lds(double* Bd, double* Ar, int n, int tid, double* y) {
@@ -188,41 +204,41 @@ __device__ inline bool chol_band_lds(double* Bd, double* Ar, int n, int tid, dou
     const double ak = Ar[k], ae = Ar[min(k + 1 + tid, m)], add = Ar[m];
     const double yk_raw = y[k], yi = y[min(k + 1 + tid, m)], ylast = y[m];
     if (x <= 0) return false;
-    const double sx = sqrt(x);
-    const double v = ci / sx, la = ak / sx, yk = yk_raw / sx;
+    const double sx = pivot_rsqrt(x);   // FAST form: reciprocal root, kept on the diagonal
+    const double v = ci * sx, la = ak * sx, yk = yk_raw * sx;
     blk_sync<true>();
     if (tid == 0) { Bd[k * BS + BS - 1] = sx; Ar[k] = la; y[k] = yk; }
     if (tid < mb) { Bd[myrow * BS + (BS - 2 - tid)] = v; s_colb[tid] = v; }
     blk_sync<true>();
     const double cm = s_colb[min(tid, CHOL_MB - 1)];
 #pragma unroll
-    for (int t = 0; t < 3; t++) if (wact[t]) Bd[widx[t]] = w[t] - s_colb[er[t]] * s_colb[ec[t]];
-    if (tid < mb) { Ar[k + 1 + tid] = ae - la * cm; y[k + 1 + tid] = yi - yk * cm; }
-    if (tid == 63) { Ar[m] = add - la * la; y[m] = ylast - yk * la; }
+    for (int t = 0; t < 3; t++) if (wact[t]) Bd[widx[t]] = fma(-s_colb[er[t]], s_colb[ec[t]], w[t]);
+    if (tid < mb) { Ar[k + 1 + tid] = fma(-la, cm, ae); y[k + 1 + tid] = fma(-yk, cm, yi); }
+    if (tid == 63) { Ar[m] = fma(-la, la, add); y[m] = fma(-yk, la, ylast); }
   }
   blk_sync<true>();
   const double x = Ar[m];
   if (x <= 0) return false;
   blk_sync<true>();
-  if (tid == 0) { const double sx = sqrt(x); Ar[m] = sx; y[m] = y[m] / sx; }
+  if (tid == 0) { const double sx = pivot_rsqrt(x); Ar[m] = sx; y[m] = y[m] * sx; }
   blk_sync<true>();
   return true;
 }
 __device__ inline void chol_band_backsolve_lds(const double* Bd, const double* Ar, int n, double* y, int tid) {
   const int m = n - 1, BS = BAND_BS;
   blk_sync<true>();
-  const double xl = y[m] / Ar[m];
+  const double xl = y[m] * Ar[m];
   blk_sync<true>();
   if (tid == 0) y[m] = xl;
-  for (int i = tid; i < m; i += 64) y[i] -= xl * Ar[i];
+  for (int i = tid; i < m; i += 64) y[i] = fma(-xl, Ar[i], y[i]);
   for (int j = m - 1; j >= 0; j--) {
     blk_sync<true>();
     const int lo = max(0, j - (BS - 1));
     const int i0 = min(lo + tid, j);
-    const double yj = y[j] / Bd[j * BS + BS - 1], lji = Bd[j * BS + (i0 - j + BS - 1)], yi = y[i0];
+    const double yj = y[j] * Bd[j * BS + BS - 1], lji = Bd[j * BS + (i0 - j + BS - 1)], yi = y[i0];
     blk_sync<true>();
     if (tid == 0) y[j] = yj;
-    if (lo + tid < j) y[i0] = yi - yj * lji;
+    if (lo + tid < j) y[i0] = fma(-yj, lji, yi);
   }
   blk_sync<true>();
 }
@@ -252,7 +268,7 @@ __device__ inline bool chol_lds(double* A, int n, int tid, int nth, double* y = 
 }
 
 // x = L^-T y in place (column oriented; row j of L is dense only for the arrow row)
-template <bool ONE_WAVE = false>
+template <bool ONE_WAVE = false, bool FAST = false>
 __device__ inline void chol_arrow_backsolve_lds(const double* L, int n, int bw, double* y, int tid, int nth) {
   const int last = n - 1;
   for (int j = n - 1; j >= 0; j--) {
@@ -260,24 +276,35 @@ __device__ inline void chol_arrow_backsolve_lds(const double* L, int n, int bw, 
     const int lo = (j == last) ? 0 : max(0, j - bw);
     const int i0 = min(lo + tid, j);                 // first element of this lane (clamped: load is unconditional)
     const double yj_raw = y[j], ljj = L[j * n + j], lji = L[j * n + i0], yi = y[i0];
-    const double yj = yj_raw / ljj;                  // every thread computes it; one publishes it
+    const double yj = FAST ? yj_raw * ljj : yj_raw / ljj;   // every thread computes it; one publishes it (FAST: the diagonal holds 1 / l_jj)
     blk_sync<ONE_WAVE>();
     if (tid == 0) y[j] = yj;
-    if (lo + tid < j) y[i0] = yi - yj * lji;
-    for (int i = lo + tid + nth; i < j; i += nth) y[i] -= yj * L[j * n + i];   // only the arrow row of large systems
+    if (lo + tid < j) y[i0] = FAST ? fma(-yj, lji, yi) : yi - yj * lji;
+    for (int i = lo + tid + nth; i < j; i += nth) y[i] = FAST ? fma(-yj, L[j * n + i], y[i]) : y[i] - yj * L[j * n + i];   // only the arrow row of large systems
   }
   blk_sync<ONE_WAVE>();
 }
 
-// a / q for the Sturm recurrence: reciprocal estimate + two Newton steps (~1 ulp) instead of the
-// IEEE division sequence -- the recurrence is a chain of n dependent divisions per trial shift and
-// only the SIGN of each q is used.  |q| is first kept away from zero (LAPACK dstebz's pivmin).
-__device__ __forceinline__ double sturm_div(double a, double& q) {
-  if (fabs(q) < 1e-300) q = q < 0 ? -1e-300 : 1e-300;
-  double r = __builtin_amdgcn_rcp(q);
-  r = fma(r, fma(-q, r, 1.0), r);
-  r = fma(r, fma(-q, r, 1.0), r);
-  return a * r;
+// Sturm test "does the symmetric tridiagonal T (diagonal d, squared off-diagonals e2) have an eigenvalue <= x": T - xI is positive
+// definite iff all its leading principal minors p_i = (d_i - x) p_{i-1} - e2_i p_{i-2} are > 0.  The minors are carried in PRODUCT
+// form: two multiplications and a subtraction on the dependent chain per row, where the quotient form q_i = p_i / p_{i-1}
+// (LAPACK dstebz) costs a division -- ~100 cycles of a chain of 18 x 9 steps that sets k_grad's duration when a block is
+// repaired.  Both forms evaluate the same recurrence with O(eps) relative error per step.  Entries are scaled by a power of
+// two (exact) so that a step grows a minor at most 3x, and every third step the pair is renormalised by the exponent of the
+// current minor (v_frexp_exp / v_ldexp, exact), so graded spectra cannot underflow to a false zero.
+struct SturmScale { double is, is2; };   // 2^-k and 2^-2k with 2^k > max(|lo|, |hi|) of the Gershgorin interval
+__device__ __forceinline__ SturmScale sturm_scale(double lo, double hi) {
+  const double s = fmax(fabs(lo), fabs(hi));
+  const int k = (s > 0 && s < 1e300) ? __builtin_amdgcn_frexp_exp(s) : 0;
+  return SturmScale{__builtin_ldexp(1.0, -k), __builtin_ldexp(1.0, -2 * k)};
+}
+__device__ __forceinline__ void sturm_first(double d0, double x, const SturmScale sc, double& p0, double& p1, bool& below) {
+  p0 = 1.0; p1 = (d0 - x) * sc.is; below = !(p1 > 0);
+}
+__device__ __forceinline__ void sturm_next(double di, double e2, double x, const SturmScale sc, int i, double& p0, double& p1, bool& below) {
+  const double pn = ((di - x) * sc.is) * p1 - (e2 * sc.is2) * p0;
+  p0 = p1; p1 = pn; below = below || !(pn > 0);
+  if (i % 3 == 0) { const int ex = __builtin_amdgcn_frexp_exp(p1); p0 = __builtin_ldexp(p0, -ex); p1 = __builtin_ldexp(p1, -ex); }
 }
 constexpr int STURM_ROUNDS = 9;   // 64-way multisection: 65^9 > 2^54 subdivisions of the Gershgorin interval (its width is a few times the
                                   // matrix norm, so the result is good to ~1e-16 of the norm; the parity bar is 1e-12 of it)
@@ -342,18 +369,16 @@ __device__ inline double min_eig_lds(double* A, int n, double* d, double* e, dou
   }
   __syncthreads();
   // multisection on the Sturm count "#eigenvalues < x >= 1"; lanes 0..63 of the first wave
+  const SturmScale sc = sturm_scale(s_scal[0], s_scal[1]);
   for (int round = 0; round < STURM_ROUNDS; round++) {
     const double lo = s_scal[0], hi = s_scal[1];
     __syncthreads();
     if (tid < 64) {
       const double x = lo + (hi - lo) * (double(tid + 1) / 65.0);
-      double q = d[0] - x;
-      int cnt = q < 0;
-      for (int i = 1; i < n; i++) {
-        q = d[i] - x - sturm_div(e[i - 1] * e[i - 1], q);
-        cnt += q < 0;
-      }
-      const unsigned long long mask = __ballot(cnt >= 1);
+      double p0, p1; bool below;
+      sturm_first(d[0], x, sc, p0, p1, below);
+      for (int i = 1; i < n; i++) sturm_next(d[i], e[i - 1] * e[i - 1], x, sc, i, p0, p1, below);
+      const unsigned long long mask = __ballot(below);
       if (tid == 0) {
         if (mask == 0) { s_scal[0] = lo + (hi - lo) * (64.0 / 65.0); }
         else {
@@ -417,13 +442,14 @@ __device__ __forceinline__ double min_eig_wave(double (&r)[N], int lane, const v
   double e2[N];
 #pragma unroll
   for (int i = 1; i < N; i++) e2[i] = e[i - 1] * e[i - 1];
+  const SturmScale sc = sturm_scale(lo, hi);
   for (int round = 0; round < STURM_ROUNDS; round++) {
     const double x = lo + (hi - lo) * (double(lane + 1) / 65.0);
-    double q = d[0] - x;
-    int cnt = q < 0;
+    double p0, p1; bool below;
+    sturm_first(d[0], x, sc, p0, p1, below);
 #pragma unroll
-    for (int i = 1; i < N; i++) { q = d[i] - x - sturm_div(e2[i], q); cnt += q < 0; }
-    const unsigned long long mask = __ballot(cnt >= 1);
+    for (int i = 1; i < N; i++) sturm_next(d[i], e2[i], x, sc, i, p0, p1, below);
+    const unsigned long long mask = __ballot(below);
     if (mask == 0) lo = lo + (hi - lo) * (64.0 / 65.0);
     else {
       const int f = __ffsll((long long)mask) - 1;

@@ -32,133 +32,11 @@ __host__ __device__ inline size_t grad_lds_doubles(int npl, int res) {  // sized
   return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 23 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
 }
 
-// One batch of segments [sb, se) of a piece: planes -> staging buffer, barrier derivatives, accumulation into this
-// thread's Hessian / gradient entry.  The staging buffer is LDS (the common case) or the block's HBM scratch (a segment
-// with more planes than the LDS buffer holds); one instantiation per address space, same summation order.
-struct GradRole { int tid, hi, ai, qi, ak, qk, vr, av, qv; };
-__device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
-                                                 const double* Pall, const double* Ball, const int* segn, int* sego, const GradRole R, double Hacc, double gacc, double& Hacc_out, double& gacc_out) {   // running sums in, running sums out
-  const int tid = R.tid, hi_ = R.hi, ai = R.ai, qi = R.qi, ak = R.ak, qk = R.qk, vr = R.vr, av = R.av, qv = R.qv;
-    __syncthreads();
-    if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
-    __syncthreads();
-    // planes of the batch: obstacle list first, then inter-robot list, per segment
-    for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
-      const int w = it >> 2, c = it & 3;
-      int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
-      const int tr = sp * res + i, k = w - sego[i], no = D.ocount[u * D.S + tr];
-      pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
-                      : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
-    }
-    __syncthreads();
-    // barrier derivatives for every (plane, control point) of the batch, stored [segment][j][k]
-    for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
-      int i = sb; while (i + 1 < se && 6 * sego[i + 1] <= it) i++;
-      const int n = segn[i], loc = it - 6 * sego[i], j = loc / n, k = loc % n;
-      const double* P = Pall + i * 18; const double* pl = pcb + 4 * (sego[i] + k);
-      const double d = P[3 * j] * pl[0] + P[3 * j + 1] * pl[1] + P[3 * j + 2] * pl[2] + pl[3];
-      double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
-      if (d < m) barrier_d(seg_weight(D, sp * res + i), d, m, e1, e2);
-      E1b[it] = e1; E2b[it] = e2;
-    }
-    __syncthreads();
-    for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
-      const int n = segn[i];
-      if (n == 0) continue;
-      const double* Bs = Ball + i * 36; const double* pls = pcb + 4 * sego[i];
-      const double* e1s = E1b + 6 * sego[i]; const double* e2s = E2b + 6 * sego[i];
-      if (hi_ >= 0) {
-        double seg = 0;
-        for (int j = 0; j < 6; j++) {
-          const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
-#pragma unroll 4
-          for (int k = 0; k < n; k++) {
-            const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
-            seg = (dxi * dxk) * e2s[j * n + k] + seg;   // Eigen runs e2*d_x*d_x^T (dynamic d_x) as a depth-1 GEMM with alpha = e2 (Gradient_admm.h:401)
-          }
-        }
-        Hacc += seg;
-      } else if (vr >= 0) {
-        double seg = 0;
-        for (int j = 0; j < 6; j++) {
-          const double bv = Bs[j * 6 + av];
-#pragma unroll 4
-          for (int k = 0; k < n; k++) seg += e1s[j * n + k] * (bv * pls[4 * k + qv]);
-        }
-        gacc += seg;
-      }
-    }
-  Hacc_out = Hacc; gacc_out = gacc;
-}
-
-// FOLD: the block first turns the stamped candidate / partner slots of ITS OWN segments into plane lists (the work of
-// k_sep_self_compact, one wave per segment), so that kernel -- and its boundary -- drops out of the single-GPU chain.
-template <bool FOLD>
-__global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
-  if (TJ_DONE(D)) return;
-  if constexpr (FOLD) {
-    const int u_ = D.u0 + blockIdx.x / D.P, sp_ = blockIdx.x % D.P;
-    for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64) compact_segment(D, u_, sp_ * D.res + i, threadIdx.x & 63);
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x >= GRAD_THREADS) return;   // the remaining barriers count surviving waves only
-  }
-  extern __shared__ double sm[];
-  const int npl = D.grad_npl;
-  double* Pall = sm;                          // [res][18] hulls of the piece's segments, row-major [6][3]
-  double* Ball = Pall + D.res * 18;           // [res][36] their bases
-  double* pc = Ball + D.res * 36;             // [npl][4] planes of the current batch of segments
-  double* E1 = pc + 4 * npl;                  // [6 * planes] barrier derivatives (0 when inactive)
-  double* E2 = E1 + 6 * npl;
-  double* bt = E2 + 6 * npl;                  // [res][9] bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
-  double* H = bt + D.res * 9 * 23;            // [361]
-  double* g = H + 361;                        // [19]
-  double* scr = g + 19;                       // [4*19] d,e,v,p
-  int* segn = (int*)(scr + 4 * 19);           // [res] planes per segment, [res+1] offsets inside the batch
-  int* sego = segn + GRAD_MAXRES;
-  unsigned long long* amask = (unsigned long long*)(sego + GRAD_MAXRES);  // [3] active vel/acc records
-
-  const int tid = threadIdx.x;
-  const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
-  const double* net = D.spline + (size_t)u * 3 * D.T;
-  const double m = D.margin, pt = D.piece_time[u];
-  const int res = D.res;
-
-  // role of this thread
-  int hi_ = -1, hk_ = -1;  // Hessian entry (row >= col) for tid < 171
-  if (tid < 171) { int i = 0; while ((i + 1) * (i + 2) / 2 <= tid) i++; hi_ = i; hk_ = tid - i * (i + 1) / 2; }
-  const int vr = (tid >= 171 && tid < 189) ? tid - 171 : -1;  // gradient / time-column entry
-  const bool scal = tid == 189;
-  const int ai = hi_ >= 0 ? hi_ / 3 : 0, qi = hi_ >= 0 ? hi_ % 3 : 0, ak = hk_ >= 0 ? hk_ / 3 : 0, qk = hk_ >= 0 ? hk_ % 3 : 0;
-  const int av = vr >= 0 ? vr / 3 : 0, qv = vr >= 0 ? vr % 3 : 0;
-  double Hacc = 0, gacc = 0, pacc = 0, gt = 0, ht = 0;
-
-  TJ_TIC(D, K_GRAD, 0);
-  // ---- stage every segment of the piece once: hull, basis, plane counts ----
-  for (int idx = tid; idx < res * 18; idx += GRAD_THREADS) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
-  for (int idx = tid; idx < res * 36; idx += GRAD_THREADS) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
-  if (tid < res) segn[tid] = D.ocount[u * D.S + sp * res + tid] + (D.multi() ? D.scount[u * D.S + sp * res + tid] : 0);
-  __syncthreads();
-
-  TJ_TIC(D, K_GRAD, 1);
-  // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
-  // The buffer holds `npl` planes (16 doubles each: plane, e1[6], e2[6]) -- sized for what segments really carry, not for the
-  // configured capacity, so that several blocks share a CU when there are hundreds of robots.  A segment with more planes
-  // than that (a robot inside a dense obstacle slab) is staged through a per-block HBM scratch buffer instead: same code,
-  // same summation order, instantiated once per address space.
-  const GradRole role{tid, hi_, ai, qi, ak, qk, vr, av, qv};
-  for (int sb = 0; sb < res;) {
-    int se = sb, tot = 0;
-    while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
-    if (tot > 0) {
-      if (tot <= npl) grad_plane_batch(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, Hacc, gacc, Hacc, gacc);
-      else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, Hacc, gacc, Hacc, gacc); }
-    }
-    sb = se;
-  }
-
-  TJ_TIC(D, K_GRAD, 2);
-  // ---- velocity / acceleration barrier terms (Gradient_admm.h:107-129, :409-572): all res*9 records at once ----
+// Velocity / acceleration barrier terms of a piece (Gradient_admm.h:107-129, :409-572).  grad_velacc_records: one thread per
+// (segment, record) -- 5 velocity and 4 acceleration records per segment -- writes the 23 values the accumulation needs and a
+// bitmask of the active records (most are inactive: the limits bind on few segments).
+struct GradRole { int tid, hi, ai, qi, ak, qk, vr, av, qv; bool scal; };
+__device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int sp, int res, double m, double pt, const double* Pall, const double* Ball, double* bt, unsigned long long* amask) {
   bool rec_act = false;
   if (tid < res * 9) {
     const int i = tid / 9, b = tid % 9;
@@ -208,13 +86,15 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       t[21] = tg; t[22] = th;
     }
   }
-  {  // bitmask of active records (most are inactive: the limits bind on few segments)
-    const unsigned long long bal = __ballot(rec_act);
-    if ((tid & 63) == 0) amask[tid >> 6] = bal;
-  }
-  __syncthreads();
+  const unsigned long long bal = __ballot(rec_act);
+  if ((tid & 63) == 0) amask[tid >> 6] = bal;
+}
+// ... and their accumulation into this thread's entry: per segment partial sums, added in segment order; an all-inactive
+// segment adds an exact +0.  a0: Hessian entry / gradient entry / time gradient, a1: time-column entry / time Hessian.
+__device__ __forceinline__ void grad_velacc_accumulate(const GradRole R, int res, const double* bt, const unsigned long long* amask, double& a0, double& a1) {
   const unsigned long long am[3] = {amask[0], amask[1], amask[2]};
-  for (int i = 0; i < res; i++) {  // per segment partial sums, added in segment order; an all-inactive segment adds an exact +0
+  const int hi_ = R.hi, ai = R.ai, qi = R.qi, ak = R.ak, qk = R.qk, vr = R.vr, av = R.av, qv = R.qv;
+  for (int i = 0; i < res; i++) {
     const double* bts = bt + i * 9 * 23;
     const int base = i * 9, aw = base >> 6, ao = base & 63;
     unsigned long long av9 = am[aw] >> ao;
@@ -231,7 +111,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
         // Eigen): the outer product as a depth-1 GEMM with alpha = e2, then ((e1*w_a)*h_p)*w_b
         seg = ((dxi * dxk) * t[1] + seg) + ((t[0] * t[15 + ai]) * t[6 + 3 * qi + qk]) * t[15 + ak];
       }
-      Hacc += seg;
+      a0 += seg;
     } else if (vr >= 0) {
       double sg = 0, spp = 0;
       for (unsigned bits = bits0; bits; bits &= bits - 1) {
@@ -240,14 +120,168 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
         const double dx = t[3 + qv] * t[15 + av];
         sg += t[0] * dx; spp += t[2] * dx;
       }
-      gacc += sg; pacc += spp;
-    } else if (scal) {
+      a0 += sg; a1 += spp;
+    } else if (R.scal) {
       double sg = 0, sh = 0;
       for (unsigned bits = bits0; bits; bits &= bits - 1) { const int b = __ffs(bits) - 1; sg += bts[b * 23 + 21]; sh += bts[b * 23 + 22]; }
-      gt += sg; ht += sh;
+      a0 += sg; a1 += sh;
     }
   }
+}
+
+// One batch of segments [sb, se) of a piece: planes -> staging buffer, barrier derivatives, accumulation into this
+// thread's Hessian / gradient entry.  The staging buffer is LDS (the common case) or the block's HBM scratch (a segment
+// with more planes than the LDS buffer holds); one instantiation per address space, same summation order.
+// grpB: this thread belongs to the block's second wave group (folded launch only), which takes part in the barriers but not in
+// the plane work; during the FIRST batch's accumulation it accumulates the velocity / acceleration records instead (vb0/vb1).
+__device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
+                                                 const double* Pall, const double* Ball, const int* segn, int* sego, const GradRole R, bool grpB, bool velacc_now,
+                                                 const double* bt, const unsigned long long* amask, double& Hacc, double& gacc, double& vb0, double& vb1) {
+  const int tid = R.tid, hi_ = R.hi, ai = R.ai, qi = R.qi, ak = R.ak, qk = R.qk, vr = R.vr, av = R.av, qv = R.qv;
+    __syncthreads();
+    if (threadIdx.x == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
+    __syncthreads();
+    // planes of the batch: obstacle list first, then inter-robot list, per segment
+    if (!grpB) for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
+      const int w = it >> 2, c = it & 3;
+      int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
+      const int tr = sp * res + i, k = w - sego[i], no = D.ocount[u * D.S + tr];
+      pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
+                      : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
+    }
+    __syncthreads();
+    // barrier derivatives for every (plane, control point) of the batch, stored [segment][j][k]
+    if (!grpB) for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
+      int i = sb; while (i + 1 < se && 6 * sego[i + 1] <= it) i++;
+      const int n = segn[i], loc = it - 6 * sego[i], j = loc / n, k = loc % n;
+      const double* P = Pall + i * 18; const double* pl = pcb + 4 * (sego[i] + k);
+      const double d = P[3 * j] * pl[0] + P[3 * j + 1] * pl[1] + P[3 * j + 2] * pl[2] + pl[3];
+      double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
+      if (d < m) barrier_d(seg_weight(D, sp * res + i), d, m, e1, e2);
+      E1b[it] = e1; E2b[it] = e2;
+    }
+    __syncthreads();
+    if (grpB) { if (velacc_now) grad_velacc_accumulate(R, res, bt, amask, vb0, vb1); return; }
+    for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
+      const int n = segn[i];
+      if (n == 0) continue;
+      const double* Bs = Ball + i * 36; const double* pls = pcb + 4 * sego[i];
+      const double* e1s = E1b + 6 * sego[i]; const double* e2s = E2b + 6 * sego[i];
+      if (hi_ >= 0) {
+        double seg = 0;
+        for (int j = 0; j < 6; j++) {
+          const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
+#pragma unroll 4
+          for (int k = 0; k < n; k++) {
+            const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
+            seg = (dxi * dxk) * e2s[j * n + k] + seg;   // Eigen runs e2*d_x*d_x^T (dynamic d_x) as a depth-1 GEMM with alpha = e2 (Gradient_admm.h:401)
+          }
+        }
+        Hacc += seg;
+      } else if (vr >= 0) {
+        double seg = 0;
+        for (int j = 0; j < 6; j++) {
+          const double bv = Bs[j * 6 + av];
+#pragma unroll 4
+          for (int k = 0; k < n; k++) seg += e1s[j * n + k] * (bv * pls[4 * k + qv]);
+        }
+        gacc += seg;
+      }
+    }
+}
+
+// FOLD: the block first turns the stamped candidate / partner slots of ITS OWN segments into plane lists (the work of
+// k_sep_self_compact, one wave per segment), so that kernel -- and its boundary -- drops out of the single-GPU chain.
+// The folded launch also keeps a SECOND group of three waves (B) alive: the plane terms (group A) and the velocity /
+// acceleration terms (group B) of a piece are independent sums over the same 190 entries, each a serial walk per thread, and
+// they were two thirds of the kernel's critical path one after the other.  B computes its records while A stages planes and
+// takes the barrier logarithms, accumulates while A accumulates, hands its sums over through LDS and retires.  Both launch
+// forms add (sum over plane segments) + (sum over velocity/acceleration segments), so they agree bit for bit.
+template <bool FOLD>
+__global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
+  if (TJ_DONE(D)) return;
+  if constexpr (FOLD) {
+    const int u_ = D.u0 + blockIdx.x / D.P, sp_ = blockIdx.x % D.P;
+    for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64) compact_segment(D, u_, sp_ * D.res + i, threadIdx.x & 63);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x >= 2 * GRAD_THREADS) return;   // the remaining barriers count surviving waves only
+  }
+  extern __shared__ double sm[];
+  const int npl = D.grad_npl;
+  double* Pall = sm;                          // [res][18] hulls of the piece's segments, row-major [6][3]
+  double* Ball = Pall + D.res * 18;           // [res][36] their bases
+  double* pc = Ball + D.res * 36;             // [npl][4] planes of the current batch of segments
+  double* E1 = pc + 4 * npl;                  // [6 * planes] barrier derivatives (0 when inactive)
+  double* E2 = E1 + 6 * npl;
+  double* bt = E2 + 6 * npl;                  // [res][9] bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
+  double* H = bt + D.res * 9 * 23;            // [361]
+  double* g = H + 361;                        // [19]
+  double* scr = g + 19;                       // [4*19] d,e,v,p
+  int* segn = (int*)(scr + 4 * 19);           // [res] planes per segment, [res+1] offsets inside the batch
+  int* sego = segn + GRAD_MAXRES;
+  unsigned long long* amask = (unsigned long long*)(sego + GRAD_MAXRES);  // [3] active vel/acc records
+
+  const bool grpB = FOLD && threadIdx.x >= GRAD_THREADS;
+  const int tid = grpB ? threadIdx.x - GRAD_THREADS : threadIdx.x;   // position inside the wave group
+  constexpr int NTH = FOLD ? 2 * GRAD_THREADS : GRAD_THREADS;
+  const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
+  const double* net = D.spline + (size_t)u * 3 * D.T;
+  const double m = D.margin, pt = D.piece_time[u];
+  const int res = D.res;
+
+  // role of this thread
+  int hi_ = -1, hk_ = -1;  // Hessian entry (row >= col) for tid < 171
+  if (tid < 171) { int i = 0; while ((i + 1) * (i + 2) / 2 <= tid) i++; hi_ = i; hk_ = tid - i * (i + 1) / 2; }
+  const int vr = (tid >= 171 && tid < 189) ? tid - 171 : -1;  // gradient / time-column entry
+  const bool scal = tid == 189;
+  const int ai = hi_ >= 0 ? hi_ / 3 : 0, qi = hi_ >= 0 ? hi_ % 3 : 0, ak = hk_ >= 0 ? hk_ / 3 : 0, qk = hk_ >= 0 ? hk_ % 3 : 0;
+  const int av = vr >= 0 ? vr / 3 : 0, qv = vr >= 0 ? vr % 3 : 0;
+  double Hacc = 0, gacc = 0, vb0 = 0, vb1 = 0;
+
+  TJ_TIC(D, K_GRAD, 0);
+  // ---- stage every segment of the piece once: hull, basis, plane counts ----
+  for (int idx = threadIdx.x; idx < res * 18; idx += NTH) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
+  for (int idx = threadIdx.x; idx < res * 36; idx += NTH) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
+  if (threadIdx.x < res) segn[threadIdx.x] = D.ocount[u * D.S + sp * res + threadIdx.x] + (D.multi() ? D.scount[u * D.S + sp * res + threadIdx.x] : 0);
   __syncthreads();
+
+  TJ_TIC(D, K_GRAD, 1);
+  // ---- velocity / acceleration records: group B (folded launch), else everyone before the plane terms ----
+  if (!FOLD || grpB) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, bt, amask);
+
+  // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
+  // The buffer holds `npl` planes (16 doubles each: plane, e1[6], e2[6]) -- sized for what segments really carry, not for the
+  // configured capacity, so that several blocks share a CU when there are hundreds of robots.  A segment with more planes
+  // than that (a robot inside a dense obstacle slab) is staged through a per-block HBM scratch buffer instead: same code,
+  // same summation order, instantiated once per address space.
+  const GradRole role{tid, hi_, ai, qi, ak, qk, vr, av, qv, scal};
+  bool velacc_pending = true;   // uniform
+  for (int sb = 0; sb < res;) {
+    int se = sb, tot = 0;
+    while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
+    if (tot > 0) {
+      const bool now = FOLD && velacc_pending;
+      if (tot <= npl) grad_plane_batch(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, grpB, now, bt, amask, Hacc, gacc, vb0, vb1);
+      else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, grpB, now, bt, amask, Hacc, gacc, vb0, vb1); }
+      if (FOLD) velacc_pending = false;
+    }
+    sb = se;
+  }
+  TJ_TIC(D, K_GRAD, 2);
+  if (velacc_pending) {   // no plane batch at all (folded), or the one-group launch: records are complete after this barrier
+    __syncthreads();
+    if (!FOLD || grpB) grad_velacc_accumulate(role, res, bt, amask, vb0, vb1);
+  }
+  if constexpr (FOLD) {   // hand over B's sums: H / g are not in use yet
+    if (grpB) { H[tid] = vb0; if (tid >= 171 && tid < 190) g[tid - 171] = vb1; }
+    __syncthreads();
+    if (grpB) return;
+    vb0 = H[tid]; if (tid >= 171 && tid < 190) vb1 = g[tid - 171];
+  }
+  __syncthreads();
+  Hacc += vb0; gacc += vb0;
+  const double pacc = vb1, gt = vb0, ht = vb1;
 
   TJ_TIC(D, K_GRAD, 3);
   // ---- scale by lambda, add consensus + dual terms (Gradient_admm.h:132-163) ----
@@ -285,7 +319,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
 
   TJ_TIC(D, K_GRAD, 4);
   // ---- PSD repair: only if LLT fails and lambda_min < 0 (Gradient_admm.h:38-53) ----
-  // Wave 0 runs the LLT check (~4 us) while wave 1 already works on the smallest eigenvalue (~15 us) of the same block, both in
+  // Wave 0 runs the LLT check (~4 us) while wave 1 already works on the smallest eigenvalue of the same block, both in
   // registers, one row per lane.  A successful check stops the eigenvalue wave at its next Householder step; a failed one
   // finds the eigenvalue 4 us further along than if it had been started afterwards -- and it is the repaired blocks
   // (a third of them in the early iterations) that set the kernel's duration.
@@ -366,22 +400,22 @@ __device__ __forceinline__ bool xs_factor_regs(double* L, double* x0, int n, int
   return false;
 }
 // x = L^-T y for the arrowhead-band factor in LDS (row-major n x n), by ONE wave with y in registers (lane i = y_i, n <= 64).
-// Same operations as chol_arrow_backsolve_lds (x_j = y_j / l_jj, then y_i -= x_j * l_ji), but the row of L needed by the next
+// Same operations as the FAST chol_arrow_backsolve_lds (x_j = y_j * (1/l_jj), then y_i = fma(-x_j, l_ji, y_i)), but the row of L needed by the next
 // step is fetched while the current division runs, x_j travels by v_readlane, and there is no LDS round trip or barrier on
 // the dependent chain: ~0.1 us per unknown instead of ~0.19.
 __device__ __forceinline__ double backsolve_wave(const double* L, int n, int bw, double y, int lane) {
   const int last = n - 1;
   {  // the arrow row is dense
     const double lrow = L[last * n + min(lane, last)];
-    const double xl = readlane_f64(y, last) / readlane_f64(lrow, last);
-    y = lane == last ? xl : (lane < last ? y - xl * lrow : y);
+    const double xl = readlane_f64(y, last) * readlane_f64(lrow, last);   // the diagonal holds 1 / l_jj (FAST factor)
+    y = lane == last ? xl : (lane < last ? fma(-xl, lrow, y) : y);
   }
   double lrow = L[max(last - 1, 0) * n + min(lane, last)];
 #pragma unroll 1
   for (int j = last - 1; j >= 0; j--) {
     const double nxt = L[max(j - 1, 0) * n + min(lane, last)];   // next step's row: independent of the chain
-    const double xj = readlane_f64(y, j) / readlane_f64(lrow, j);
-    y = lane == j ? xj : ((lane < j && lane + bw >= j) ? y - xj * lrow : y);
+    const double xj = readlane_f64(y, j) * readlane_f64(lrow, j);
+    y = lane == j ? xj : ((lane < j && lane + bw >= j) ? fma(-xj, lrow, y) : y);
     lrow = nxt;
   }
   return y;
@@ -392,7 +426,7 @@ __device__ __forceinline__ bool xs_factor(double* L, double* x0, int n, int tid,
   bool handled;
   const bool ok = xs_factor_regs(L, x0, n, tid, npiv, handled);
   if (handled) return ok;
-  return chol_arrow_lds<true>(L, n, XS_BAND, tid, XS_THREADS, x0, npiv);
+  return chol_arrow_lds<true, true>(L, n, XS_BAND, tid, XS_THREADS, x0, npiv);
 }
 
 // wave 0 of k_xsolve: factor, solve, direction record (all sync points are wave-local)
@@ -436,7 +470,7 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     blk_sync<true>();
     if (tid < n) x0[tid] = yv;
     blk_sync<true>();
-  } else chol_arrow_backsolve_lds<true>(L, n, XS_BAND, x0, tid, XS_THREADS);
+  } else chol_arrow_backsolve_lds<true, true>(L, n, XS_BAND, x0, tid, XS_THREADS);
   TJ_TIC(D, K_XSOLVE, 4);
   for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
   blk_sync<true>();
@@ -684,10 +718,10 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve_c2(Dev D) {
   blk_sync<true>();
   const double corner = s_red[0], rhs = s_red[1];
   if (!(corner > 0) && tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_NOT_SPD);
-  const double lc = sqrt(corner);
-  if (tid == 0) { L[m * n + m] = lc; y[m] = rhs / lc; }
+  const double lc = pivot_rsqrt(corner);   // reciprocal root, like the rest of the FAST factor's diagonal
+  if (tid == 0) { L[m * n + m] = lc; y[m] = rhs * lc; }
   blk_sync<true>();
-  chol_arrow_backsolve_lds<true>(L, n, XS_BAND, y, tid, XS_THREADS);
+  chol_arrow_backsolve_lds<true, true>(L, n, XS_BAND, y, tid, XS_THREADS);
   for (int i = tid; i < n; i += XS_THREADS) y[i] = -y[i];
   blk_sync<true>();
   for (int i = tid; i < m; i += XS_THREADS) { scr[i] = y[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
