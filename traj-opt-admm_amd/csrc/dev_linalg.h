@@ -28,6 +28,16 @@ __device__ __forceinline__ void blk_sync() {
 }
 
 
+// Barrier among SOME of a block's waves (the others are busy or gone, so s_barrier cannot be used): arrivals are counted in an
+// LDS word that starts at 0; `target` is the caller's running total (nwaves more per barrier).  Every wave of the group must call it.
+__device__ __forceinline__ void group_barrier(int* cnt, int& target, int nwaves) {
+  target += nwaves;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 constexpr int CHOL_MB = 18;  // max band rows below a pivot handled by the wave kernel (bw <= 18, dense n <= 20)
 
 // FAST forms of the factorisations below (the x-update's per-robot Newton systems, which are one dependent chain of up to

@@ -359,6 +359,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
 constexpr int XS_THREADS = 64;   // the factorisation runs in one wave per robot: its sync points are wave-local
 constexpr int XS_LOAD_THREADS = 512;  // the whole block streams the piece blocks in and assembles; waves 1..7 then retire, or (Dev::fuse) wait for the solve and share the swept-hull tail
 constexpr int XS_BAND = 17;      // pieces couple reduced coordinates at most 17 apart
+constexpr int XS_HELP = XS_LOAD_THREADS - XS_THREADS;   // helper threads (waves 1..7)
+constexpr int XS_KPT = 6;        // (segment, axis) interval pairs a helper thread carries across the solve (S <= 54)
 // n = 9P-2.  Layout: H[n*n] L[n*n] g0[n] x0[n] scr[6n] lhu[P*361] lgu[P*19] | tail: net[3T] dir[3T].  The swept-hull tail
 // (Dev::fuse) reuses the front of the buffer for its S x 54 hull values, so the front part is at least that large.
 __host__ __device__ inline size_t xsolve_front_doubles(int n) {
@@ -421,6 +423,51 @@ __device__ __forceinline__ double backsolve_wave(const double* L, int n, int bw,
   return y;
 }
 
+// The same back substitution with the size known at compile time: lane indices of the broadcasts are immediates and the rows of L
+// are fetched ahead of the chain by the scheduler (the generic loop above pays the SGPR-lane-select hazards 4 x per unknown).
+template <int N>
+__device__ __noinline__ double backsolve_wave_n(const double* L, double y, int lane) {
+  constexpr int last = N - 1;
+  const int col = min(lane, last);
+  {
+    const double lrow = L[last * N + col];
+    const double xl = readlane_f64(y, last) * readlane_f64(lrow, last);
+    y = lane == last ? xl : (lane < last ? fma(-xl, lrow, y) : y);
+  }
+#pragma unroll
+  for (int j = last - 1; j >= 0; j--) {
+    const double lrow = L[j * N + col];
+    const double xj = readlane_f64(y, j) * readlane_f64(lrow, j);
+    y = lane == j ? xj : ((lane < j && lane + XS_BAND >= j) ? fma(-xj, lrow, y) : y);
+  }
+  return y;
+}
+__device__ __forceinline__ double xs_backsolve(const double* L, int n, double y, int lane) {
+  switch (n) {
+    case 16: return backsolve_wave_n<16>(L, y, lane);
+    case 25: return backsolve_wave_n<25>(L, y, lane);
+    case 34: return backsolve_wave_n<34>(L, y, lane);
+    case 43: return backsolve_wave_n<43>(L, y, lane);
+    case 52: return backsolve_wave_n<52>(L, y, lane);
+    case 61: return backsolve_wave_n<61>(L, y, lane);
+  }
+  return backsolve_wave(L, n, XS_BAND, y, lane);
+}
+// esum() by one wave: the four running sums of Eigen's unrolled 2-wide reduction advance on four lanes at once (lane c adds
+// e[c], e[c+4], ...) and are then combined exactly as esum combines them -- same association, a quarter of the dependent adds.
+__device__ __forceinline__ double esum_wave(const double* e, int n, int lane) {
+  if (n < 8) return esum(e, n);
+  const int a2 = (n / 4) * 4, a1 = (n / 2) * 2, c = lane & 3;
+  double acc = e[c];
+  for (int i = 4 + c; i < a2; i += 4) acc += e[i];
+  double r0a = readlane_f64(acc, 0), r0b = readlane_f64(acc, 1);
+  r0a += readlane_f64(acc, 2); r0b += readlane_f64(acc, 3);
+  if (a1 > a2) { r0a += e[a2]; r0b += e[a2 + 1]; }
+  double r = r0a + r0b;
+  for (int i = a1; i < n; i++) r += e[i];
+  return r;
+}
+
 // one factorisation attempt: registers when the size allows, LDS otherwise
 __device__ __forceinline__ bool xs_factor(double* L, double* x0, int n, int tid, int npiv) {
   bool handled;
@@ -466,7 +513,7 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
   TJ_TIC(D, K_XSOLVE, 3);
   if (n <= 64) {
     double yv = x0[min(tid, n - 1)];
-    yv = backsolve_wave(L, n, XS_BAND, yv, tid);
+    yv = xs_backsolve(L, n, yv, tid);
     blk_sync<true>();
     if (tid < n) x0[tid] = yv;
     blk_sync<true>();
@@ -481,9 +528,10 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     const int row = idx % T, a = idx / T;
     dir[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0;
   }
+  const double w_ = esum_wave(scr, n, tid), g_ = esum_wave(scr + n, n, tid);
   if (tid == 0) {
-    D.wolfe(u) = -esum(scr, n);
-    D.gn(u) = sqrt(esum(scr + n, n));
+    D.wolfe(u) = -w_;
+    D.gn(u) = sqrt(g_);
     D.tdir(u) = x0[m];
   }
 }
@@ -508,6 +556,8 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   // piece blocks first go to LDS with one streaming copy (independent loads, many in flight); the
   // scatter below then never waits on HBM/L2
   TJ_TIC(D, K_XSOLVE, 0);
+  __shared__ int s_grp;               // arrival counter of the helper waves' private barrier
+  if (tid == 0) s_grp = 0;
   double* lhu = scr + 6 * n;          // [P*361]
   double* lgu = lhu + D.P * 361;      // [P*19]
   {
@@ -548,9 +598,48 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   __syncthreads();
   // From here on wave 0 works alone (its sync points are wave-local: blk_sync<true>).  Without the swept-hull tail the other
   // waves retire (s_barrier counts surviving waves only); with it (Dev::fuse) they wait at the barrier below.
+  // While wave 0 factors and solves (10-14 us), the seven helper waves already prepare the part of the swept-hull tail that does
+  // not depend on the direction: the control net in LDS, the hull of every segment, and -- carried in registers across the
+  // wait -- the k-DOP intervals of the current hull for the (segment, axis) pairs each helper thread will finish afterwards.
+  // The helpers synchronise among themselves through an LDS counter (wave 0 is busy and must not be waited for).
   const bool tail = D.fuse != 0;
   if (tid >= XS_THREADS && !tail) return;
+  const int S = D.S;
+  double* netl = sm + xsolve_front_doubles(n);   // [3T] control net, [3T] direction (rows 0,1,T-2,T-1 are zero)
+  double* dl = netl + 3 * T;
+  double* php = lhu;                             // [S][18] hull of the current net (the piece blocks are assembled: lhu is free)
+  const double* gnet = D.spline + (size_t)u * 3 * T;
+  const bool pre = tail && S * 49 <= XS_HELP * XS_KPT && (size_t)S * 54 <= 2 * (size_t)n * n + 8 * (size_t)n && S * 18 <= D.P * 361;   // uniform
+  double klo[XS_KPT], kup[XS_KPT];
+  const int ht = tid - XS_THREADS;
   if (tid < XS_THREADS) xs_wave0(D, u, tid, n, m, H, L, g0, x0, scr);
+  else if (pre) {
+    int target = 0;
+    for (int idx = ht; idx < 3 * T; idx += XS_HELP) netl[idx] = gnet[idx];
+    group_barrier(&s_grp, target, XS_HELP / 64);
+    for (int idx = ht; idx < S * 18; idx += XS_HELP) {
+      const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
+      const double* B = D.basis + (size_t)tr * 36 + j * 6;
+      const int r0 = (tr / D.res) * 3 + T * a;
+      double p = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) p += B[k] * netl[r0 + k];
+      php[idx] = p;
+    }
+    group_barrier(&s_grp, target, XS_HELP / 64);
+#pragma unroll
+    for (int q_ = 0; q_ < XS_KPT; q_++) {
+      const int idx = ht + q_ * XS_HELP;
+      double up = -INFINITY, lo = INFINITY;
+      if (idx < S * 49) {
+        const int tr = idx / 49, k = idx % 49;
+        const double* q = php + tr * 18;
+        const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+        for (int i = 0; i < 6; i++) { const double lv = x * q[3 * i] + y * q[3 * i + 1] + z * q[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+      }
+      klo[q_] = lo; kup[q_] = up;
+    }
+  }
   if (!tail) return;
   __syncthreads();
   TJ_TIC(D, K_XSOLVE, 5);
@@ -559,13 +648,9 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   // Flat over the whole block: 54 hull values per segment into LDS (the front of the buffer is free now), then boxes and the
   // 49 x S interval pairs.  Folding this into the solve kernel removes one kernel boundary from the chain.
   {
-    const int S = D.S;
-    double* netl = sm + xsolve_front_doubles(n);   // [3T] control net, [3T] direction (rows 0,1,T-2,T-1 are zero)
-    double* dl = netl + 3 * T;
-    const double* gnet = D.spline + (size_t)u * 3 * T;
     for (int idx = tid; idx < 3 * T; idx += XS_LOAD_THREADS) {
       const int row = idx % T, a = idx / T;
-      netl[idx] = gnet[idx];
+      if (!pre) netl[idx] = gnet[idx];
       dl[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0;
     }
     __syncthreads();
@@ -597,7 +682,25 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
       o[36 + a] = lo; o[39 + a] = hi; o[42 + a] = lo2; o[45 + a] = hi2;
       D.cbox[((size_t)tr * 6 + a) * D.U + u] = lo2; D.cbox[((size_t)tr * 6 + 3 + a) * D.U + u] = hi2;
     }
-    for (int idx = tid; idx < S * 49; idx += XS_LOAD_THREADS) {   // 49-axis intervals of the swept hull at step 1
+    // 49-axis intervals of the swept hull at step 1: min / max over the 6 hull points and the 6 points P + Dh.  With the
+    // hull's part already known (helpers), only the second half is left -- min and max do not depend on the order.
+    if (pre) {
+      if (tid >= XS_THREADS) {
+#pragma unroll
+        for (int q_ = 0; q_ < XS_KPT; q_++) {
+          const int idx = ht + q_ * XS_HELP;
+          if (idx < S * 49) {
+            const int tr = idx / 49, k = idx % 49;
+            const double* q = Ph + tr * 54;
+            const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
+            double up = kup[q_], lo = klo[q_];
+            for (int i = 0; i < 6; i++) { const double lv = x * (q[3 * i] + q[18 + 3 * i]) + y * (q[3 * i + 1] + q[18 + 3 * i + 1]) + z * (q[3 * i + 2] + q[18 + 3 * i + 2]); if (lv < lo) lo = lv; if (lv > up) up = lv; }
+            double* o = D.ccdinfo + ((size_t)u * S + tr) * CCD_STRIDE;
+            o[48 + k] = lo; o[97 + k] = up;
+          }
+        }
+      }
+    } else for (int idx = tid; idx < S * 49; idx += XS_LOAD_THREADS) {
       const int tr = idx / 49, k = idx % 49;
       const double* q = Ph + tr * 54;
       const double x = D.kdop[3 * k], y = D.kdop[3 * k + 1], z = D.kdop[3 * k + 2];
