@@ -132,26 +132,29 @@ __device__ __forceinline__ void grad_velacc_accumulate(const GradRole R, int res
 // One batch of segments [sb, se) of a piece: planes -> staging buffer, barrier derivatives, accumulation into this
 // thread's Hessian / gradient entry.  The staging buffer is LDS (the common case) or the block's HBM scratch (a segment
 // with more planes than the LDS buffer holds); one instantiation per address space, same summation order.
-// grpB: this thread belongs to the block's second wave group (folded launch only), which takes part in the barriers but not in
-// the plane work; during the FIRST batch's accumulation it accumulates the velocity / acceleration records instead (vb0/vb1).
+// GSYNC: barrier among the three waves that do the plane work -- the whole block in the one-group launch, an LDS-counter
+// barrier in the folded launch, whose second wave group works on the velocity / acceleration terms at its own pace.
+struct GradSync { int* cnt; int target; };
+template <bool GSYNC>
+__device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, GRAD_THREADS / 64); else __syncthreads(); }
+template <bool GSYNC>
 __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
-                                                 const double* Pall, const double* Ball, const int* segn, int* sego, const GradRole R, bool grpB, bool velacc_now,
-                                                 const double* bt, const unsigned long long* amask, double& Hacc, double& gacc, double& vb0, double& vb1) {
+                                                 const double* Pall, const double* Ball, const int* segn, int* sego, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
   const int tid = R.tid, hi_ = R.hi, ai = R.ai, qi = R.qi, ak = R.ak, qk = R.qk, vr = R.vr, av = R.av, qv = R.qv;
-    __syncthreads();
-    if (threadIdx.x == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
-    __syncthreads();
+    grad_sync<GSYNC>(gs);
+    if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
+    grad_sync<GSYNC>(gs);
     // planes of the batch: obstacle list first, then inter-robot list, per segment
-    if (!grpB) for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
+    for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
       const int w = it >> 2, c = it & 3;
       int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
       const int tr = sp * res + i, k = w - sego[i], no = D.ocount[u * D.S + tr];
       pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
                       : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
     }
-    __syncthreads();
+    grad_sync<GSYNC>(gs);
     // barrier derivatives for every (plane, control point) of the batch, stored [segment][j][k]
-    if (!grpB) for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
+    for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
       int i = sb; while (i + 1 < se && 6 * sego[i + 1] <= it) i++;
       const int n = segn[i], loc = it - 6 * sego[i], j = loc / n, k = loc % n;
       const double* P = Pall + i * 18; const double* pl = pcb + 4 * (sego[i] + k);
@@ -160,8 +163,7 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
       if (d < m) barrier_d(seg_weight(D, sp * res + i), d, m, e1, e2);
       E1b[it] = e1; E2b[it] = e2;
     }
-    __syncthreads();
-    if (grpB) { if (velacc_now) grad_velacc_accumulate(R, res, bt, amask, vb0, vb1); return; }
+    grad_sync<GSYNC>(gs);
     for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
       const int n = segn[i];
       if (n == 0) continue;
@@ -194,9 +196,9 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
 // k_sep_self_compact, one wave per segment), so that kernel -- and its boundary -- drops out of the single-GPU chain.
 // The folded launch also keeps a SECOND group of three waves (B) alive: the plane terms (group A) and the velocity /
 // acceleration terms (group B) of a piece are independent sums over the same 190 entries, each a serial walk per thread, and
-// they were two thirds of the kernel's critical path one after the other.  B computes its records while A stages planes and
-// takes the barrier logarithms, accumulates while A accumulates, hands its sums over through LDS and retires.  Both launch
-// forms add (sum over plane segments) + (sum over velocity/acceleration segments), so they agree bit for bit.
+// they were two thirds of the kernel's critical path one after the other.  Each group synchronises within itself through an
+// LDS counter (group_barrier), so neither waits for the other before the hand-over: B leaves its sums in LDS and retires.
+// Both launch forms add (sum over plane segments) + (sum over velocity/acceleration segments), so they agree bit for bit.
 template <bool FOLD>
 __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
   if (TJ_DONE(D)) return;
@@ -240,6 +242,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   double Hacc = 0, gacc = 0, vb0 = 0, vb1 = 0;
 
   TJ_TIC(D, K_GRAD, 0);
+  __shared__ int s_gsync[2];   // arrival counters of the two wave groups' private barriers (folded launch)
+  if (threadIdx.x < 2) s_gsync[threadIdx.x] = 0;
   // ---- stage every segment of the piece once: hull, basis, plane counts ----
   for (int idx = threadIdx.x; idx < res * 18; idx += NTH) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
   for (int idx = threadIdx.x; idx < res * 36; idx += NTH) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
@@ -247,34 +251,35 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   __syncthreads();
 
   TJ_TIC(D, K_GRAD, 1);
-  // ---- velocity / acceleration records: group B (folded launch), else everyone before the plane terms ----
-  if (!FOLD || grpB) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, bt, amask);
-
-  // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
-  // The buffer holds `npl` planes (16 doubles each: plane, e1[6], e2[6]) -- sized for what segments really carry, not for the
-  // configured capacity, so that several blocks share a CU when there are hundreds of robots.  A segment with more planes
-  // than that (a robot inside a dense obstacle slab) is staged through a per-block HBM scratch buffer instead: same code,
-  // same summation order, instantiated once per address space.
   const GradRole role{tid, hi_, ai, qi, ak, qk, vr, av, qv, scal};
-  bool velacc_pending = true;   // uniform
-  for (int sb = 0; sb < res;) {
-    int se = sb, tot = 0;
-    while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
-    if (tot > 0) {
-      const bool now = FOLD && velacc_pending;
-      if (tot <= npl) grad_plane_batch(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, grpB, now, bt, amask, Hacc, gacc, vb0, vb1);
-      else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, grpB, now, bt, amask, Hacc, gacc, vb0, vb1); }
-      if (FOLD) velacc_pending = false;
+  if (grpB) {
+    // ---- group B (folded launch): velocity / acceleration records, then their accumulation, at its own pace ----
+    GradSync gb{&s_gsync[1], 0};
+    grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, bt, amask);
+    grad_sync<true>(gb);
+    grad_velacc_accumulate(role, res, bt, amask, vb0, vb1);
+    H[tid] = vb0; if (tid >= 171 && tid < 190) g[tid - 171] = vb1;   // hand-over: H / g are not in use yet
+  } else {
+    if (!FOLD) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, bt, amask);
+    // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
+    // The buffer holds `npl` planes (16 doubles each: plane, e1[6], e2[6]) -- sized for what segments really carry, not for the
+    // configured capacity, so that several blocks share a CU when there are hundreds of robots.  A segment with more planes
+    // than that (a robot inside a dense obstacle slab) is staged through a per-block HBM scratch buffer instead: same code,
+    // same summation order, instantiated once per address space.
+    GradSync ga{&s_gsync[0], 0};
+    for (int sb = 0; sb < res;) {
+      int se = sb, tot = 0;
+      while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
+      if (tot > 0) {
+        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, ga, Hacc, gacc);
+        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, ga, Hacc, gacc); }
+      }
+      sb = se;
     }
-    sb = se;
+    TJ_TIC(D, K_GRAD, 2);
+    if (!FOLD) { __syncthreads(); grad_velacc_accumulate(role, res, bt, amask, vb0, vb1); }
   }
-  TJ_TIC(D, K_GRAD, 2);
-  if (velacc_pending) {   // no plane batch at all (folded), or the one-group launch: records are complete after this barrier
-    __syncthreads();
-    if (!FOLD || grpB) grad_velacc_accumulate(role, res, bt, amask, vb0, vb1);
-  }
-  if constexpr (FOLD) {   // hand over B's sums: H / g are not in use yet
-    if (grpB) { H[tid] = vb0; if (tid >= 171 && tid < 190) g[tid - 171] = vb1; }
+  if constexpr (FOLD) {
     __syncthreads();
     if (grpB) return;
     vb0 = H[tid]; if (tid >= 171 && tid < 190) vb1 = g[tid - 171];
