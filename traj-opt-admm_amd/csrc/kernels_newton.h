@@ -29,20 +29,23 @@ constexpr int GRAD_FOLD_THREADS = 512;   // FOLD: 8 waves compact the piece's se
 // dynamic LDS layout of k_grad, in doubles; npl = cap_obs + cap_self (capacity of one plane batch)
 constexpr int GRAD_MAXRES = 16;  // segments per piece staged at once ("res" of 3D.json, shipped value 8)
 __host__ __device__ inline size_t grad_lds_doubles(int npl, int res) {  // sized by the actual res: 2 blocks must fit one CU
-  return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 23 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
+  return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 20 + (size_t)res * 54 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
 }
 
 // Velocity / acceleration barrier terms of a piece (Gradient_admm.h:107-129, :409-572).  grad_velacc_records: one thread per
-// (segment, record) -- 5 velocity and 4 acceleration records per segment -- writes the 23 values the accumulation needs and a
-// bitmask of the active records (most are inactive: the limits bind on few segments).
-struct GradRole { int tid, hi, ai, qi, ak, qk, vr, av, qv; bool scal; };
+// (segment, record) -- 5 velocity and 4 acceleration records per segment -- writes the GRAD_REC values the accumulation needs and
+// a bitmask of the active records (most are inactive: the limits bind on few segments).  A record's contribution to Hessian
+// entry ((a,q),(a',q')) is w_a w_a' (e2 dp_q dp_q' + e1 hp_qq') with w the record's 6-vector of basis differences: the 3x3 matrix
+// N = e2 dp dp^T + e1 hp (symmetric, 6 values) is formed ONCE per record here instead of once per entry in the accumulation.
+constexpr int GRAD_REC = 20;   // N[6] (00,10,11,20,21,22), e1*dp[3], e3*dp[3], w[6], time gradient, time Hessian
+struct GradRole { int tid, hi, ai, qi, ak, qk, vr, av, qv, cq; bool scal; };   // cq: index of the symmetric pair (qi, qk) in {00,10,11,20,21,22}
 __device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int sp, int res, double m, double pt, const double* Pall, const double* Ball, double* bt, unsigned long long* amask) {
   bool rec_act = false;
   if (tid < res * 9) {
     const int i = tid / 9, b = tid % 9;
     const double w = seg_weight(D, sp * res + i);
     const double* P = Pall + i * 18; const double* Bs = Ball + i * 36;
-    double* t = bt + tid * 23;
+    double* t = bt + tid * GRAD_REC;
     double Dv[3], len, d, coef = 0, e1 = 0, e2 = 0, e3 = 0, tg = 0, th = 0;
     bool act;
     if (b < 5) {
@@ -58,7 +61,7 @@ __device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int s
         th = -2 * e1 * v / pow3(pt) + e2 * v * v / pow4(pt);
         coef = -5 / (w * pt);
         e3 = -e1 / pt + e2 * (D.vel_limit - d) / pt;
-        for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 1) * 6 + a] - Bs[j * 6 + a];
+        for (int a = 0; a < 6; a++) t[12 + a] = Bs[(j + 1) * 6 + a] - Bs[j * 6 + a];
       }
     } else {
       const int j = b - 5;
@@ -74,16 +77,20 @@ __device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int s
         const double wp = w * pt;
         coef = -20 / (wp * wp);
         e3 = -2 * e1 / pt + 2 * e2 * (D.acc_limit - d) / pt;
-        for (int a = 0; a < 6; a++) t[15 + a] = Bs[(j + 2) * 6 + a] - 2 * Bs[(j + 1) * 6 + a] + Bs[j * 6 + a];
+        for (int a = 0; a < 6; a++) t[12 + a] = Bs[(j + 2) * 6 + a] - 2 * Bs[(j + 1) * 6 + a] + Bs[j * 6 + a];
       }
     }
     rec_act = act;
     if (act) {
       const double len3 = pow3(len);
-      t[0] = e1; t[1] = e2; t[2] = e3;
-      for (int q = 0; q < 3; q++) t[3 + q] = coef * Dv[q] / len;
-      for (int q = 0; q < 3; q++) for (int s = 0; s < 3; s++) t[6 + 3 * q + s] = coef * ((q == s ? 1.0 : 0.0) / len - Dv[q] * Dv[s] / len3);
-      t[21] = tg; t[22] = th;
+      double dp[3];
+      for (int q = 0; q < 3; q++) dp[q] = coef * Dv[q] / len;
+      for (int q = 0, c = 0; q < 3; q++) for (int s = 0; s <= q; s++, c++) {
+        const double hp = coef * ((q == s ? 1.0 : 0.0) / len - Dv[q] * Dv[s] / len3);
+        t[c] = e2 * (dp[q] * dp[s]) + e1 * hp;
+      }
+      for (int q = 0; q < 3; q++) { t[6 + q] = e1 * dp[q]; t[9 + q] = e3 * dp[q]; }
+      t[18] = tg; t[19] = th;
     }
   }
   const unsigned long long bal = __ballot(rec_act);
@@ -93,37 +100,33 @@ __device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int s
 // segment adds an exact +0.  a0: Hessian entry / gradient entry / time gradient, a1: time-column entry / time Hessian.
 __device__ __forceinline__ void grad_velacc_accumulate(const GradRole R, int res, const double* bt, const unsigned long long* amask, double& a0, double& a1) {
   const unsigned long long am[3] = {amask[0], amask[1], amask[2]};
-  const int hi_ = R.hi, ai = R.ai, qi = R.qi, ak = R.ak, qk = R.qk, vr = R.vr, av = R.av, qv = R.qv;
+  const int hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv, cq = R.cq;
   for (int i = 0; i < res; i++) {
-    const double* bts = bt + i * 9 * 23;
+    const double* bts = bt + i * 9 * GRAD_REC;
     const int base = i * 9, aw = base >> 6, ao = base & 63;
     unsigned long long av9 = am[aw] >> ao;
     if (ao > 55 && aw < 2) av9 |= am[aw + 1] << (64 - ao);
     const unsigned bits0 = (unsigned)av9 & 0x1ffu;
     if (!bits0) continue;
     if (hi_ >= 0) {
-      double seg = 0;
+      double seg = 0;   // hessian += e2*d_x*d_x^T + e1*A^T*h_p*A (Gradient_admm.h:504,553), with d_x = w (x) dp
       for (unsigned bits = bits0; bits; bits &= bits - 1) {
         const int b = __ffs(bits) - 1;
-        const double* t = bts + b * 23;
-        const double dxi = t[3 + qi] * t[15 + ai], dxk = t[3 + qk] * t[15 + ak];
-        // hessian += e2*d_x*d_x^T + e1*A^T*h_p*A (Gradient_admm.h:504,553) as Eigen evaluates it (checked entry by entry against
-        // Eigen): the outer product as a depth-1 GEMM with alpha = e2, then ((e1*w_a)*h_p)*w_b
-        seg = ((dxi * dxk) * t[1] + seg) + ((t[0] * t[15 + ai]) * t[6 + 3 * qi + qk]) * t[15 + ak];
+        const double* t = bts + b * GRAD_REC;
+        seg += (t[12 + ai] * t[12 + ak]) * t[cq];
       }
       a0 += seg;
     } else if (vr >= 0) {
       double sg = 0, spp = 0;
       for (unsigned bits = bits0; bits; bits &= bits - 1) {
         const int b = __ffs(bits) - 1;
-        const double* t = bts + b * 23;
-        const double dx = t[3 + qv] * t[15 + av];
-        sg += t[0] * dx; spp += t[2] * dx;
+        const double* t = bts + b * GRAD_REC;
+        sg += t[6 + qv] * t[12 + av]; spp += t[9 + qv] * t[12 + av];
       }
       a0 += sg; a1 += spp;
     } else if (R.scal) {
       double sg = 0, sh = 0;
-      for (unsigned bits = bits0; bits; bits &= bits - 1) { const int b = __ffs(bits) - 1; sg += bts[b * 23 + 21]; sh += bts[b * 23 + 22]; }
+      for (unsigned bits = bits0; bits; bits &= bits - 1) { const int b = __ffs(bits) - 1; sg += bts[b * GRAD_REC + 18]; sh += bts[b * GRAD_REC + 19]; }
       a0 += sg; a1 += sh;
     }
   }
@@ -139,8 +142,8 @@ template <bool GSYNC>
 __device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, GRAD_THREADS / 64); else __syncthreads(); }
 template <bool GSYNC>
 __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
-                                                 const double* Pall, const double* Ball, const int* segn, int* sego, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
-  const int tid = R.tid, hi_ = R.hi, ai = R.ai, qi = R.qi, ak = R.ak, qk = R.qk, vr = R.vr, av = R.av, qv = R.qv;
+                                                 const double* Pall, const double* Ball, const int* segn, int* sego, double* Mv, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
+  const int tid = R.tid, hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv;
     grad_sync<GSYNC>(gs);
     if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
     grad_sync<GSYNC>(gs);
@@ -164,29 +167,40 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
       E1b[it] = e1; E2b[it] = e2;
     }
     grad_sync<GSYNC>(gs);
+    // The planes of a segment meet a control point j of its hull only through M_j = sum_k e2[j][k] n_k n_k^T (3x3 symmetric) and
+    // v_j = sum_k e1[j][k] n_k: Hessian entry ((a,q),(a',q')) = sum_j B[j][a] B[j][a'] M_j[q][q'], gradient entry (a,q) =
+    // sum_j B[j][a] v_j[q] (Gradient_admm.h:331-407 written out).  54 sums over the planes per segment (6 control points x
+    // {6 + 3}) by as many threads, then 6 terms per entry -- instead of every one of the 190 entries walking all 6 n products
+    // itself, which was LDS-bandwidth bound and up to 15 us for a piece next to an obstacle.
+    for (int idx = tid; idx < (se - sb) * 54; idx += GRAD_THREADS) {
+      const int i = sb + idx / 54, r = idx % 54, j = r / 9, c = r % 9, n = segn[i];
+      const double* pls = pcb + 4 * sego[i];
+      double acc = 0;
+      if (c < 6) {
+        const int q = c < 1 ? 0 : (c < 3 ? 1 : 2), q2 = c - q * (q + 1) / 2;
+        const double* e2s = E2b + 6 * sego[i] + j * n;
+#pragma unroll 4
+        for (int k = 0; k < n; k++) acc += (pls[4 * k + q] * pls[4 * k + q2]) * e2s[k];
+      } else {
+        const double* e1s = E1b + 6 * sego[i] + j * n;
+#pragma unroll 4
+        for (int k = 0; k < n; k++) acc += e1s[k] * pls[4 * k + (c - 6)];
+      }
+      Mv[i * 54 + r] = acc;
+    }
+    grad_sync<GSYNC>(gs);
     for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
-      const int n = segn[i];
-      if (n == 0) continue;
-      const double* Bs = Ball + i * 36; const double* pls = pcb + 4 * sego[i];
-      const double* e1s = E1b + 6 * sego[i]; const double* e2s = E2b + 6 * sego[i];
+      if (segn[i] == 0) continue;
+      const double* Bs = Ball + i * 36; const double* Ms = Mv + i * 54;
       if (hi_ >= 0) {
         double seg = 0;
-        for (int j = 0; j < 6; j++) {
-          const double bi = Bs[j * 6 + ai], bk = Bs[j * 6 + ak];
-#pragma unroll 4
-          for (int k = 0; k < n; k++) {
-            const double dxi = bi * pls[4 * k + qi], dxk = bk * pls[4 * k + qk];
-            seg = (dxi * dxk) * e2s[j * n + k] + seg;   // Eigen runs e2*d_x*d_x^T (dynamic d_x) as a depth-1 GEMM with alpha = e2 (Gradient_admm.h:401)
-          }
-        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) seg += (Bs[j * 6 + ai] * Bs[j * 6 + ak]) * Ms[j * 9 + R.cq];
         Hacc += seg;
       } else if (vr >= 0) {
         double seg = 0;
-        for (int j = 0; j < 6; j++) {
-          const double bv = Bs[j * 6 + av];
-#pragma unroll 4
-          for (int k = 0; k < n; k++) seg += e1s[j * n + k] * (bv * pls[4 * k + qv]);
-        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) seg += Bs[j * 6 + av] * Ms[j * 9 + 6 + qv];
         gacc += seg;
       }
     }
@@ -216,8 +230,9 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   double* pc = Ball + D.res * 36;             // [npl][4] planes of the current batch of segments
   double* E1 = pc + 4 * npl;                  // [6 * planes] barrier derivatives (0 when inactive)
   double* E2 = E1 + 6 * npl;
-  double* bt = E2 + 6 * npl;                  // [res][9] bound terms x {e1,e2,e3, dp[3], hp[9], wa[6], gt, ht}
-  double* H = bt + D.res * 9 * 23;            // [361]
+  double* bt = E2 + 6 * npl;                  // [res][9] velocity / acceleration records x GRAD_REC
+  double* Mv = bt + D.res * 9 * GRAD_REC;     // [res][6][9] per segment and control point: M (6) and v (3) of the plane terms
+  double* H = Mv + D.res * 54;                // [361]
   double* g = H + 361;                        // [19]
   double* scr = g + 19;                       // [4*19] d,e,v,p
   int* segn = (int*)(scr + 4 * 19);           // [res] planes per segment, [res+1] offsets inside the batch
@@ -251,7 +266,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   __syncthreads();
 
   TJ_TIC(D, K_GRAD, 1);
-  const GradRole role{tid, hi_, ai, qi, ak, qk, vr, av, qv, scal};
+  const int qhi = max(qi, qk), qlo = min(qi, qk);
+  const GradRole role{tid, hi_, ai, qi, ak, qk, vr, av, qv, qhi * (qhi + 1) / 2 + qlo, scal};
   if (grpB) {
     // ---- group B (folded launch): velocity / acceleration records, then their accumulation, at its own pace ----
     GradSync gb{&s_gsync[1], 0};
@@ -271,8 +287,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       int se = sb, tot = 0;
       while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
       if (tot > 0) {
-        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, ga, Hacc, gacc);
-        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, role, ga, Hacc, gacc); }
+        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, Mv, role, ga, Hacc, gacc);
+        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, Mv, role, ga, Hacc, gacc); }
       }
       sb = se;
     }
