@@ -133,17 +133,23 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
   // plane barrier (Energy_admm.h:46-96)
   const double* pl_lds = sm + L.planes;
   const int* pltr = (const int*)(sm + L.pltr);
-  for (int it = gl; it < M; it += LS_GSIZE) {
-    int tr; double c0, c1, c2, dk;
-    if (planes_in_lds) { tr = pltr[it]; c0 = pl_lds[4 * it]; c1 = pl_lds[4 * it + 1]; c2 = pl_lds[4 * it + 2]; dk = pl_lds[4 * it + 3]; }
-    else {
-      int lo = 0, hi = S;
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
-      tr = lo;
-      const int k = it - pref[tr], no = D.ocount[u * S + tr];
-      const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
-      c0 = pl[0]; c1 = pl[1]; c2 = pl[2]; dk = pl[3];
+  if (planes_in_lds) {
+    // one (plane, hull point) term per lane and pass: a robot of the headline scene carries ~30 planes, so a lane per PLANE left
+    // half the wave idle while the others took six logarithms one after the other
+    for (int it = gl; it < 6 * M; it += LS_GSIZE) {
+      const int ip = it / 6, j = it - 6 * ip, tr = pltr[ip];
+      const double* Pp = hulls + tr * 18 + 3 * j; const double* pl = pl_lds + 4 * ip;
+      const double d = Pp[0] * pl[0] + Pp[1] * pl[1] + Pp[2] * pl[2] + pl[3];
+      if (d <= 0) bad = 1;
+      else if (d < m) part += barrier(seg_weight(D, tr), d, m);
     }
+  } else for (int it = gl; it < M; it += LS_GSIZE) {
+    int lo = 0, hi = S;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
+    const int tr = lo;
+    const int k = it - pref[tr], no = D.ocount[u * S + tr];
+    const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
+    const double c0 = pl[0], c1 = pl[1], c2 = pl[2], dk = pl[3];
     const double w = seg_weight(D, tr);
     const double* Pp = hulls + tr * 18;
 #pragma unroll
@@ -325,12 +331,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   double* ghull = sm + L.ghull + (size_t)g * S * 18;
   double* res = sm + L.res;
   double* gspline = D.spline + (size_t)u * 3 * T;
-  bool in_lds;
-  const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
-  TJ_TIC(D, K_LINESEARCH, 2);
+  // scalars of the search first: two dependent global round trips that now overlap the staging below
   const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   double step0 = D.pow08[min(LOOP_CAP, max(D.k_obs[u], D.k_self[u]))];
+  bool in_lds;
+  const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
+  TJ_TIC(D, K_LINESEARCH, 2);
   if (t0 + step0 * t_dir <= 0) step0 = -0.95 * t0 / t_dir;
 
   double e_base = 0, step_acc = step0, pt_acc = t0;
