@@ -24,7 +24,7 @@ constexpr int LS_GROUPS = 8;    // 16 candidates per round (1024 threads, 128-VG
 constexpr int LS_GSIZE = 64;   // one wave per candidate: group-private LDS needs only wave-local ordering
 
 struct LsLayout {  // offsets in doubles into dynamic LDS
-  size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, gcons, res, planes, pltr, hn, hd, total;
+  size_t basis, convert, slack, lambda, tsl, tla, net, dir, gnet, ghull, gcons, res, planes, pltr, hn, hd, wseg, total;
   int plane_cap;
   int affine;   // hulls of a trial step come from hull(net) + step * hull(dir), both formed once per launch (see x_energy_group)
   int groups;   // Armijo candidates evaluated side by side (one wave each): 8 where the per-candidate hull buffers fit LDS,
@@ -49,6 +49,7 @@ __host__ __device__ inline LsLayout ls_layout_g(int S, int T, int P, size_t lds_
   L.res = o; o += 2 * LS_GROUPS + 8;
   L.hn = o; o += affine ? (size_t)S * 18 : 0;
   L.hd = o; o += affine ? (size_t)S * 18 : 0;
+  L.wseg = o; o += S;   // seg_weight per segment (two divisions and a modulo per use otherwise)
   L.planes = o;
   const size_t used = o * 8;
   size_t room = lds_budget_bytes > used ? (lds_budget_bytes - used) / 36 : 0;  // 32 B plane + 4 B segment id
@@ -92,6 +93,7 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
                                         double* cons, int M, bool planes_in_lds, const int* pref, int gl, int trial, double step) {
   const int S = D.S, T = D.T;
   const double* basis = sm + L.basis;
+  const double* wsg = sm + L.wseg;
   TJ_TIC(D, K_BEGIN, 0);
   if (L.affine) {
     const double* hn = sm + L.hn; const double* hd = sm + L.hd;
@@ -108,7 +110,7 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
   // both formulas
   for (int it = gl; it < S * 5; it += LS_GSIZE) {
     const int tr = it / 5, b = it % 5;
-    const double w = seg_weight(D, tr);
+    const double w = wsg[tr];
     const double* Pp = hulls + tr * 18;
     const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
     const double d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
@@ -117,7 +119,7 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
   }
   for (int it = gl; it < S * 4; it += LS_GSIZE) {
     const int tr = it / 4, j = it % 4;
-    const double w = seg_weight(D, tr);
+    const double w = wsg[tr];
     const double* Pp = hulls + tr * 18;
     const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
                  az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
@@ -141,7 +143,7 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
       const double* Pp = hulls + tr * 18 + 3 * j; const double* pl = pl_lds + 4 * ip;
       const double d = Pp[0] * pl[0] + Pp[1] * pl[1] + Pp[2] * pl[2] + pl[3];
       if (d <= 0) bad = 1;
-      else if (d < m) part += barrier(seg_weight(D, tr), d, m);
+      else if (d < m) part += barrier(wsg[tr], d, m);
     }
   } else for (int it = gl; it < M; it += LS_GSIZE) {
     int lo = 0, hi = S;
@@ -150,7 +152,7 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
     const int k = it - pref[tr], no = D.ocount[u * S + tr];
     const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
     const double c0 = pl[0], c1 = pl[1], c2 = pl[2], dk = pl[3];
-    const double w = seg_weight(D, tr);
+    const double w = wsg[tr];
     const double* Pp = hulls + tr * 18;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -223,6 +225,7 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
   for (int i = tid; i < 18 * P; i += nth) { sm[L.slack + i] = D.p_slack[(size_t)u * 3 * P6 + i]; sm[L.lambda + i] = D.p_lambda[(size_t)u * 3 * P6 + i]; }
   for (int i = tid; i < P; i += nth) { sm[L.tsl + i] = D.t_slack[u * P + i]; sm[L.tla + i] = D.t_lambda[u * P + i]; }
   for (int i = tid; i < 3 * T; i += nth) { net[i] = gspline[i]; dir[i] = D.dirp(u)[i]; }
+  for (int i = tid; i < S; i += nth) sm[L.wseg + i] = seg_weight(D, i);
   if (tid < 64) {  // plane-count prefix over the segments: lanes load, wave scan (a one-thread loop was 2S dependent loads, ~4 us)
     int run = 0;
     for (int base = 0; base < S; base += 64) {
