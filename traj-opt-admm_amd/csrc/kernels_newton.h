@@ -39,11 +39,11 @@ __host__ __device__ inline size_t grad_lds_doubles(int npl, int res) {  // sized
 // N = e2 dp dp^T + e1 hp (symmetric, 6 values) is formed ONCE per record here instead of once per entry in the accumulation.
 constexpr int GRAD_REC = 20;   // N[6] (00,10,11,20,21,22), e1*dp[3], e3*dp[3], w[6], time gradient, time Hessian
 struct GradRole { int tid, hi, ai, qi, ak, qk, vr, av, qv, cq; bool scal; };   // cq: index of the symmetric pair (qi, qk) in {00,10,11,20,21,22}
-__device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int sp, int res, double m, double pt, const double* Pall, const double* Ball, double* bt, unsigned long long* amask) {
+__device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int sp, int res, double m, double pt, const double* Pall, const double* Ball, const double* wseg, double* bt, unsigned long long* amask) {
   bool rec_act = false;
   if (tid < res * 9) {
     const int i = tid / 9, b = tid % 9;
-    const double w = seg_weight(D, sp * res + i);
+    const double w = wseg[i];
     const double* P = Pall + i * 18; const double* Bs = Ball + i * 36;
     double* t = bt + tid * GRAD_REC;
     double Dv[3], len, d, coef = 0, e1 = 0, e2 = 0, e3 = 0, tg = 0, th = 0;
@@ -142,7 +142,7 @@ template <bool GSYNC>
 __device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, GRAD_THREADS / 64); else __syncthreads(); }
 template <bool GSYNC>
 __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
-                                                 const double* Pall, const double* Ball, const int* segn, int* sego, double* Mv, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
+                                                 const double* Pall, const double* Ball, const double* wseg, const int* segn, int* sego, double* Mv, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
   const int tid = R.tid, hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv;
     grad_sync<GSYNC>(gs);
     if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
@@ -163,7 +163,7 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
       const double* P = Pall + i * 18; const double* pl = pcb + 4 * (sego[i] + k);
       const double d = P[3 * j] * pl[0] + P[3 * j + 1] * pl[1] + P[3 * j + 2] * pl[2] + pl[3];
       double e1 = 0, e2 = 0;  // inactive terms contribute an exact +0
-      if (d < m) barrier_d(seg_weight(D, sp * res + i), d, m, e1, e2);
+      if (d < m) barrier_d(wseg[i], d, m, e1, e2);
       E1b[it] = e1; E2b[it] = e2;
     }
     grad_sync<GSYNC>(gs);
@@ -259,6 +259,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   TJ_TIC(D, K_GRAD, 0);
   __shared__ int s_gsync[2];   // arrival counters of the two wave groups' private barriers (folded launch)
   if (threadIdx.x < 2) s_gsync[threadIdx.x] = 0;
+  __shared__ double s_wseg[GRAD_MAXRES];   // seg_weight of the piece's segments (two divisions and a modulo per use otherwise)
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + res) s_wseg[threadIdx.x - 64] = seg_weight(D, sp * res + threadIdx.x - 64);
   // ---- stage every segment of the piece once: hull, basis, plane counts ----
   for (int idx = threadIdx.x; idx < res * 18; idx += NTH) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
   for (int idx = threadIdx.x; idx < res * 36; idx += NTH) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
@@ -271,12 +273,12 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   if (grpB) {
     // ---- group B (folded launch): velocity / acceleration records, then their accumulation, at its own pace ----
     GradSync gb{&s_gsync[1], 0};
-    grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, bt, amask);
+    grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, s_wseg, bt, amask);
     grad_sync<true>(gb);
     grad_velacc_accumulate(role, res, bt, amask, vb0, vb1);
     H[tid] = vb0; if (tid >= 171 && tid < 190) g[tid - 171] = vb1;   // hand-over: H / g are not in use yet
   } else {
-    if (!FOLD) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, bt, amask);
+    if (!FOLD) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, s_wseg, bt, amask);
     // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
     // The buffer holds `npl` planes (16 doubles each: plane, e1[6], e2[6]) -- sized for what segments really carry, not for the
     // configured capacity, so that several blocks share a CU when there are hundreds of robots.  A segment with more planes
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       int se = sb, tot = 0;
       while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
       if (tot > 0) {
-        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, Mv, role, ga, Hacc, gacc);
-        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, segn, sego, Mv, role, ga, Hacc, gacc); }
+        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, sego, Mv, role, ga, Hacc, gacc);
+        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, sego, Mv, role, ga, Hacc, gacc); }
       }
       sb = se;
     }
