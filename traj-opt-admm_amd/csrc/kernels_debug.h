@@ -176,7 +176,11 @@ __global__ __launch_bounds__(64) void k_dbg_linalg(int nmat, int n, const double
     for (int c = 0; c < 19; c++) r[c] = A[row * 19 + c];
   }
   const double ev = min_eig_lds(A, n, scr, scr + n, scr + 2 * n, scr + 3 * n, tid, 64);
-  if (n == 19) agree = agree && min_eig_wave<19>(r, tid) == ev;
+  if (n == 19) {   // the register copy fuses its products: same algorithm, agreement to rounding level of the matrix norm
+    double nrm = 0;
+    for (int i = 0; i < 361; i++) nrm = fmax(nrm, fabs(src[i]));
+    agree = agree && fabs(min_eig_wave<19>(r, tid) - ev) <= 1e-13 * fmax(nrm, 1e-300);
+  }
   if (tid == 0) { out[2 * blockIdx.x] = !agree ? 2.0 : ok ? 0.0 : 1.0; out[2 * blockIdx.x + 1] = ev; }
 }
 
