@@ -14,7 +14,8 @@ os.environ["TRAJADMM_LIB"] = os.path.join(ROOT, "traj-opt-admm_amd", "libtrajadm
 
 PHASES = {
     "k_begin": ["hull", "planes", "velacc", "reduce", "consensus"],
-    "k_grad": ["stage", "planes", "vel/acc", "consensus", "psd", "store"],
+    "k_grad": ["stage", "planes", "wait for B", "consensus", "psd", "store"],
+    "k_sep_self_compact": ["(k_grad group B) records", "barrier", "accumulate"],
     "k_xsolve": ["load", "assemble", "chol+fwd", "backsolve", "finish", "swept-hull tail"],
     "k_linesearch": ["stage", "planes->lds", "setup", "E round0", "later rounds"],
     "k_sep_self_solve": ["load", "gjk+newton+store"],

@@ -70,9 +70,13 @@ constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates 
 // a block stores the constant-rate wall clock at a phase boundary.  The product build has none.
 constexpr int TJ_TIC_BLOCKS = 65536, TJ_TIC_SLOTS = 8;   // blocks per kernel that leave stamps (timing builds only)
 #ifdef TJ_PHASE_TIMING
+#define TJ_TICB(D, kid, slot) do { if (threadIdx.x == 192 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)   /* first thread of k_grad's second wave group */
+#define TJ_ORDER(v) asm volatile("" :: "v"(v))   /* the value is computed before the next stamp is taken */
 #define TJ_TIC(D, kid, slot) do { if (threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
 #else
 #define TJ_TIC(D, kid, slot) do {} while (0)
+#define TJ_TICB(D, kid, slot) do {} while (0)
+#define TJ_ORDER(v) do {} while (0)
 #endif
 
 struct Dev {

@@ -156,6 +156,7 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
                       : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
     }
     grad_sync<GSYNC>(gs);
+    TJ_TIC(D, K_SEP_SELF_COMPACT, 4);
     // barrier derivatives for every (plane, control point) of the batch, stored [segment][j][k]
     for (int it = tid; it < 6 * tot; it += GRAD_THREADS) {
       int i = sb; while (i + 1 < se && 6 * sego[i + 1] <= it) i++;
@@ -167,6 +168,7 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
       E1b[it] = e1; E2b[it] = e2;
     }
     grad_sync<GSYNC>(gs);
+    TJ_TIC(D, K_SEP_SELF_COMPACT, 5);
     // The planes of a segment meet a control point j of its hull only through M_j = sum_k e2[j][k] n_k n_k^T (3x3 symmetric) and
     // v_j = sum_k e1[j][k] n_k: Hessian entry ((a,q),(a',q')) = sum_j B[j][a] B[j][a'] M_j[q][q'], gradient entry (a,q) =
     // sum_j B[j][a] v_j[q] (Gradient_admm.h:331-407 written out).  54 sums over the planes per segment (6 control points x
@@ -189,6 +191,7 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
       Mv[i * 54 + r] = acc;
     }
     grad_sync<GSYNC>(gs);
+    TJ_TIC(D, K_SEP_SELF_COMPACT, 6);
     for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
       if (segn[i] == 0) continue;
       const double* Bs = Ball + i * 36; const double* Ms = Mv + i * 54;
@@ -273,10 +276,14 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   if (grpB) {
     // ---- group B (folded launch): velocity / acceleration records, then their accumulation, at its own pace ----
     GradSync gb{&s_gsync[1], 0};
+    TJ_TICB(D, K_SEP_SELF_COMPACT, 0);
     grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, s_wseg, bt, amask);
+    TJ_TICB(D, K_SEP_SELF_COMPACT, 1);
     grad_sync<true>(gb);
+    TJ_TICB(D, K_SEP_SELF_COMPACT, 2);
     grad_velacc_accumulate(role, res, bt, amask, vb0, vb1);
     H[tid] = vb0; if (tid >= 171 && tid < 190) g[tid - 171] = vb1;   // hand-over: H / g are not in use yet
+    TJ_TICB(D, K_SEP_SELF_COMPACT, 3);
   } else {
     if (!FOLD) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, s_wseg, bt, amask);
     // ---- plane barrier terms (Gradient_admm.h:85-105, :331-407), segments in batches that fit the LDS plane buffer ----
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       }
       sb = se;
     }
+    TJ_ORDER(Hacc); TJ_ORDER(gacc);
     TJ_TIC(D, K_GRAD, 2);
     if (!FOLD) { __syncthreads(); grad_velacc_accumulate(role, res, bt, amask, vb0, vb1); }
   }
