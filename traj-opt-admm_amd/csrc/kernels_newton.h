@@ -142,16 +142,18 @@ template <bool GSYNC>
 __device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, GRAD_THREADS / 64); else __syncthreads(); }
 template <bool GSYNC>
 __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
-                                                 const double* Pall, const double* Ball, const double* wseg, const int* segn, int* sego, double* Mv, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
+                                                 const double* Pall, const double* Ball, const double* wseg, const int* segn, const int* segno, int* sego, double* Mv, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
   const int tid = R.tid, hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv;
-    grad_sync<GSYNC>(gs);
-    if (tid == 0) { int o = 0; for (int i = sb; i < se; i++) { sego[i] = o; o += segn[i]; } }
-    grad_sync<GSYNC>(gs);
+    // offsets of the batch's segments: every wave writes the same values itself (lanes over segments), so only wave-local
+    // ordering is needed -- no barrier, no serial loop on one thread
+    if (sb > 0) grad_sync<GSYNC>(gs);   // a previous batch's readers are done with sego
+    if ((tid & 63) >= sb && (tid & 63) < se) { int o = 0; for (int i = sb; i < (tid & 63); i++) o += segn[i]; sego[tid & 63] = o; }
+    blk_sync<true>();
     // planes of the batch: obstacle list first, then inter-robot list, per segment
     for (int it = tid; it < 4 * tot; it += GRAD_THREADS) {
       const int w = it >> 2, c = it & 3;
       int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
-      const int tr = sp * res + i, k = w - sego[i], no = D.ocount[u * D.S + tr];
+      const int tr = sp * res + i, k = w - sego[i], no = segno[i];
       pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
                       : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
     }
@@ -267,7 +269,12 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   // ---- stage every segment of the piece once: hull, basis, plane counts ----
   for (int idx = threadIdx.x; idx < res * 18; idx += NTH) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
   for (int idx = threadIdx.x; idx < res * 36; idx += NTH) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
-  if (threadIdx.x < res) segn[threadIdx.x] = D.ocount[u * D.S + sp * res + threadIdx.x] + (D.multi() ? D.scount[u * D.S + sp * res + threadIdx.x] : 0);
+  __shared__ int s_no[GRAD_MAXRES];   // obstacle planes per segment (the plane lists are read without a second trip for the count)
+  if (threadIdx.x < res) {
+    const int no = D.ocount[u * D.S + sp * res + threadIdx.x];
+    s_no[threadIdx.x] = no;
+    segn[threadIdx.x] = no + (D.multi() ? D.scount[u * D.S + sp * res + threadIdx.x] : 0);
+  }
   __syncthreads();
 
   TJ_TIC(D, K_GRAD, 1);
@@ -296,8 +303,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       int se = sb, tot = 0;
       while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
       if (tot > 0) {
-        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, sego, Mv, role, ga, Hacc, gacc);
-        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, sego, Mv, role, ga, Hacc, gacc); }
+        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, Hacc, gacc);
+        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, Hacc, gacc); }
       }
       sb = se;
     }
