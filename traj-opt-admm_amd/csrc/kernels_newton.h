@@ -98,14 +98,16 @@ __device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int s
 }
 // ... and their accumulation into this thread's entry: per segment partial sums, added in segment order; an all-inactive
 // segment adds an exact +0.  a0: Hessian entry / gradient entry / time gradient, a1: time-column entry / time Hessian.
-__device__ __forceinline__ void grad_velacc_accumulate(const GradRole R, int res, const double* bt, const unsigned long long* amask, double& a0, double& a1) {
-  const unsigned long long am[3] = {amask[0], amask[1], amask[2]};
+struct GradAcc { double a0, a1; };   // returned by value: accumulators handed around by reference ended up as an indexed array in scratch memory
+__device__ __forceinline__ GradAcc grad_velacc_accumulate(const GradRole R, int res, const double* bt, const unsigned long long* amask) {
+  double a0 = 0, a1 = 0;
+  const unsigned long long am0 = amask[0], am1 = amask[1], am2 = amask[2];   // selected by compares: an indexed array would live in scratch memory
   const int hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv, cq = R.cq;
   for (int i = 0; i < res; i++) {
     const double* bts = bt + i * 9 * GRAD_REC;
     const int base = i * 9, aw = base >> 6, ao = base & 63;
-    unsigned long long av9 = am[aw] >> ao;
-    if (ao > 55 && aw < 2) av9 |= am[aw + 1] << (64 - ao);
+    unsigned long long av9 = (aw == 0 ? am0 : (aw == 1 ? am1 : am2)) >> ao;
+    if (ao > 55 && aw < 2) av9 |= (aw == 0 ? am1 : am2) << (64 - ao);
     const unsigned bits0 = (unsigned)av9 & 0x1ffu;
     if (!bits0) continue;
     if (hi_ >= 0) {
@@ -130,6 +132,7 @@ __device__ __forceinline__ void grad_velacc_accumulate(const GradRole R, int res
       a0 += sg; a1 += sh;
     }
   }
+  return GradAcc{a0, a1};
 }
 
 // One batch of segments [sb, se) of a piece: planes -> staging buffer, barrier derivatives, accumulation into this
@@ -141,8 +144,8 @@ struct GradSync { int* cnt; int target; };
 template <bool GSYNC>
 __device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, GRAD_THREADS / 64); else __syncthreads(); }
 template <bool GSYNC>
-__device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
-                                                 const double* Pall, const double* Ball, const double* wseg, const int* segn, const int* segno, int* sego, double* Mv, const GradRole R, GradSync& gs, double& Hacc, double& gacc) {
+__device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
+                                                 const double* Pall, const double* Ball, const double* wseg, const int* segn, const int* segno, int* sego, double* Mv, const GradRole R, GradSync& gs, double run) {   // run: this thread's running sum (Hessian or gradient entry) in, updated sum out
   const int tid = R.tid, hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv;
     // offsets of the batch's segments: every wave writes the same values itself (lanes over segments), so only wave-local
     // ordering is needed -- no barrier, no serial loop on one thread
@@ -201,14 +204,15 @@ __device__ __forceinline__ void grad_plane_batch(const Dev& D, double* pcb, doub
         double seg = 0;
 #pragma unroll
         for (int j = 0; j < 6; j++) seg += (Bs[j * 6 + ai] * Bs[j * 6 + ak]) * Ms[j * 9 + R.cq];
-        Hacc += seg;
+        run += seg;
       } else if (vr >= 0) {
         double seg = 0;
 #pragma unroll
         for (int j = 0; j < 6; j++) seg += Bs[j * 6 + av] * Ms[j * 9 + 6 + qv];
-        gacc += seg;
+        run += seg;
       }
     }
+    return run;
 }
 
 // FOLD: the block first turns the stamped candidate / partner slots of ITS OWN segments into plane lists (the work of
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   const bool scal = tid == 189;
   const int ai = hi_ >= 0 ? hi_ / 3 : 0, qi = hi_ >= 0 ? hi_ % 3 : 0, ak = hk_ >= 0 ? hk_ / 3 : 0, qk = hk_ >= 0 ? hk_ % 3 : 0;
   const int av = vr >= 0 ? vr / 3 : 0, qv = vr >= 0 ? vr % 3 : 0;
-  double Hacc = 0, gacc = 0, vb0 = 0, vb1 = 0;
+  double pacc_ = 0, vb0 = 0, vb1 = 0;   // plane terms of this thread's entry; velocity / acceleration terms
 
   TJ_TIC(D, K_GRAD, 0);
   __shared__ int s_gsync[2];   // arrival counters of the two wave groups' private barriers (folded launch)
@@ -288,8 +292,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     TJ_TICB(D, K_SEP_SELF_COMPACT, 1);
     grad_sync<true>(gb);
     TJ_TICB(D, K_SEP_SELF_COMPACT, 2);
-    grad_velacc_accumulate(role, res, bt, amask, vb0, vb1);
-    H[tid] = vb0; if (tid >= 171 && tid < 190) g[tid - 171] = vb1;   // hand-over: H / g are not in use yet
+    const GradAcc vb = grad_velacc_accumulate(role, res, bt, amask);
+    H[tid] = vb.a0; if (tid >= 171 && tid < 190) g[tid - 171] = vb.a1;   // hand-over: H / g are not in use yet
     TJ_TICB(D, K_SEP_SELF_COMPACT, 3);
   } else {
     if (!FOLD) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, s_wseg, bt, amask);
@@ -303,14 +307,14 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       int se = sb, tot = 0;
       while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
       if (tot > 0) {
-        if (tot <= npl) grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, Hacc, gacc);
-        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, Hacc, gacc); }
+        if (tot <= npl) pacc_ = grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_);
+        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); pacc_ = grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_); }
       }
       sb = se;
     }
-    TJ_ORDER(Hacc); TJ_ORDER(gacc);
+    TJ_ORDER(pacc_);
     TJ_TIC(D, K_GRAD, 2);
-    if (!FOLD) { __syncthreads(); grad_velacc_accumulate(role, res, bt, amask, vb0, vb1); }
+    if (!FOLD) { __syncthreads(); const GradAcc vb = grad_velacc_accumulate(role, res, bt, amask); vb0 = vb.a0; vb1 = vb.a1; }
   }
   if constexpr (FOLD) {
     __syncthreads();
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     vb0 = H[tid]; if (tid >= 171 && tid < 190) vb1 = g[tid - 171];
   }
   __syncthreads();
-  Hacc += vb0; gacc += vb0;
+  const double Hacc = pacc_ + vb0, gacc = Hacc;   // (sum over plane segments) + (sum over velocity / acceleration segments)
   const double pacc = vb1, gt = vb0, ht = vb1;
 
   TJ_TIC(D, K_GRAD, 3);
