@@ -149,7 +149,7 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
     int lo = 0, hi = S;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
     const int tr = lo;
-    const int k = it - pref[tr], no = D.ocount[u * S + tr];
+    const int k = it - pref[tr], no = pref[512 + tr];
     const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
     const double c0 = pl[0], c1 = pl[1], c2 = pl[2], dk = pl[3];
     const double w = wsg[tr];
@@ -230,7 +230,9 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
     int run = 0;
     for (int base = 0; base < S; base += 64) {
       const int tr = base + tid;
-      const int c = tr < S ? D.ocount[u * S + tr] + (D.multi() ? D.scount[u * S + tr] : 0) : 0;
+      const int no_ = tr < S ? D.ocount[u * S + tr] : 0;
+      const int c = tr < S ? no_ + (D.multi() ? D.scount[u * S + tr] : 0) : 0;
+      if (tr < S) pref[512 + tr] = no_;   // obstacle planes of the segment: the plane gather below needs no second trip for it
       int x = c;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (tid >= off) x += y; }
@@ -251,7 +253,7 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
     for (int it = tid; it < M; it += nth) {
       int lo = 0, hi = S;
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= it) lo = mid; else hi = mid; }
-      const int tr = lo, k = it - pref[tr], no = D.ocount[u * S + tr];
+      const int tr = lo, k = it - pref[tr], no = pref[512 + tr];
       const double* pl = k < no ? D.oplanes + (((size_t)u * S + tr) * D.cap_obs + k) * 4 : D.splanes + (((size_t)u * S + tr) * D.cap_self + (k - no)) * 4;
       pltr[it] = tr;
       sm[L.planes + 4 * it] = pl[0]; sm[L.planes + 4 * it + 1] = pl[1]; sm[L.planes + 4 * it + 2] = pl[2]; sm[L.planes + 4 * it + 3] = pl[3];
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     return;
   }
   extern __shared__ double sm[];
-  __shared__ int pref[512];   // plane prefix per segment (S <= 511 checked on the host)
+  __shared__ int pref[1024];   // plane prefix per segment (S <= 511 checked on the host); [512 + tr]: obstacle planes of segment tr
   __shared__ int s_accept;
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
   // G = L.groups candidates per round.  With G < 8 (long trajectories) the waves beyond G shadow the last group: they compute
@@ -467,7 +469,7 @@ __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double ste
 __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round) {
   if (TJ_DONE(D)) return;
   extern __shared__ double sm[];
-  __shared__ int pref[512];
+  __shared__ int pref[1024];
   __shared__ int s_acc[2];
   __shared__ double s_step0, s_accstep;
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
