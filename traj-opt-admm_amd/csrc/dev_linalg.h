@@ -141,6 +141,21 @@ __device__ inline bool chol_arrow_lds(double* A, int n, int bw, int tid, int nth
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// esum() by one wave: the four running sums of Eigen's unrolled 2-wide reduction advance on four lanes at once (lane c adds
+// e[c], e[c+4], ...) and are then combined exactly as esum combines them -- same association, a quarter of the dependent adds.
+__device__ __forceinline__ double esum_wave(const double* e, int n, int lane) {
+  if (n < 8) return esum(e, n);
+  const int a2 = (n / 4) * 4, a1 = (n / 2) * 2, c = lane & 3;
+  double acc = e[c];
+  for (int i = 4 + c; i < a2; i += 4) acc += e[i];
+  double r0a = readlane_f64(acc, 0), r0b = readlane_f64(acc, 1);
+  r0a += readlane_f64(acc, 2); r0b += readlane_f64(acc, 3);
+  if (a1 > a2) { r0a += e[a2]; r0b += e[a2 + 1]; }
+  double r = r0a + r0b;
+  for (int i = a1; i < n; i++) r += e[i];
+  return r;
+}
+
 template <int N>
 __device__ __forceinline__ bool chol_check_wave(double (&r)[N]) {
 #pragma unroll

@@ -495,21 +495,6 @@ __device__ __forceinline__ double xs_backsolve(const double* L, int n, double y,
   }
   return backsolve_wave(L, n, XS_BAND, y, lane);
 }
-// esum() by one wave: the four running sums of Eigen's unrolled 2-wide reduction advance on four lanes at once (lane c adds
-// e[c], e[c+4], ...) and are then combined exactly as esum combines them -- same association, a quarter of the dependent adds.
-__device__ __forceinline__ double esum_wave(const double* e, int n, int lane) {
-  if (n < 8) return esum(e, n);
-  const int a2 = (n / 4) * 4, a1 = (n / 2) * 2, c = lane & 3;
-  double acc = e[c];
-  for (int i = 4 + c; i < a2; i += 4) acc += e[i];
-  double r0a = readlane_f64(acc, 0), r0b = readlane_f64(acc, 1);
-  r0a += readlane_f64(acc, 2); r0b += readlane_f64(acc, 3);
-  if (a1 > a2) { r0a += e[a2]; r0b += e[a2 + 1]; }
-  double r = r0a + r0b;
-  for (int i = a1; i < n; i++) r += e[i];
-  return r;
-}
-
 // one factorisation attempt: registers when the size allows, LDS otherwise
 __device__ __forceinline__ bool xs_factor(double* L, double* x0, int n, int tid, int npiv) {
   bool handled;

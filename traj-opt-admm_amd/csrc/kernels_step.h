@@ -335,15 +335,91 @@ __device__ inline double z_energy(const Dev& D, const double* cx, double pt, con
   return e;
 }
 
+// ---- register forms of the slack system's factorisation (EXACT: IEEE sqrt / division, unfused a - l*l -- the same operations
+// in the same order as chol_lds / chol_arrow_backsolve_lds, whose pass/fail decision is pinned to Eigen's unblocked LLT) ----
+template <int N>
+__device__ __forceinline__ bool slack_chol_wave(double (&r)[N], double& y, int lane) {   // lane i: row i of the dense N x N system, y_i
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const double x = readlane_f64(r[k], k);
+    if (x <= 0) return false;
+    const double sx = sqrt(x);
+    const double lik = r[k] / sx;
+    const double yk = readlane_f64(y, k) / sx;
+    r[k] = lane == k ? sx : lik;
+#pragma unroll
+    for (int j = k + 1; j < N; j++) r[j] = r[j] - lik * readlane_f64(lik, j);
+    y = lane == k ? yk : (lane > k ? y - yk * lik : y);
+  }
+  return true;
+}
+// factor + forward substitution from the LDS copy (L untouched on failure); on success the factor's lower triangle and L^-1 g
+// go back to LDS and the back substitution x = L^-T y runs with y in registers, rows of L fetched ahead of the chain
+template <int N>
+__device__ __noinline__ bool slack_solve_wave(double* L, double* x0, int lane) {
+  double r[N];
+  const int row = min(lane, N - 1);
+#pragma unroll
+  for (int j = 0; j < N; j++) r[j] = L[row * N + j];
+  double y = x0[row];
+  if (!slack_chol_wave<N>(r, y, lane)) return false;
+  blk_sync<true>();
+#pragma unroll
+  for (int j = 0; j < N; j++) if (lane < N && j <= lane) L[lane * N + j] = r[j];
+  blk_sync<true>();
+#pragma unroll
+  for (int j = N - 1; j >= 0; j--) {
+    const double lrow = L[j * N + row];
+    const double xj = readlane_f64(y, j) / readlane_f64(lrow, j);
+    y = lane == j ? xj : (lane < j ? y - xj * lrow : y);
+  }
+  if (lane < N) x0[lane] = y;
+  blk_sync<true>();
+  return true;
+}
+
+// z_energy by one wave: the same sums in the same order, the independent pieces side by side on the lanes.  pw = pow(t, 1.1)
+// (taken by the caller, several arguments per pass on different lanes); w18: LDS scratch [36].  Uniform result.
+__device__ __forceinline__ double z_energy_wave(const Dev& D, const double* md, const double* cx, double pt, const double* z, double t, const double* lam, double tl,
+                                                double pw, double* w18, int lane) {
+  const double s = D.ks / pow5(t) * 0.5;
+  const int a = min(lane, 17) / 6, j = min(lane, 17) % 6;
+  double y = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) y += (s * z[k + 6 * a]) * md[k * 6 + j];      // lane (a, j): y_j of axis a
+  const double delta = cx[min(lane, 17)] - z[min(lane, 17)];
+  blk_sync<true>();
+  if (lane < 18) { w18[lane] = delta * delta; w18[18 + lane] = lam[lane] * delta; }
+  double e = 0;
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++) {
+    double q = 0;
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++) q += readlane_f64(y, 6 * ax + jj) * z[jj + 6 * ax];
+    e += q;
+  }
+  e = e + D.kt * pw;
+  blk_sync<true>();
+  e += D.mu / 2.0 * esum_wave(w18, 18, lane);
+  e += D.mu / 2.0 * (pt - t) * (pt - t);
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++) e += esum(w18 + 18 + 6 * ax, 6);
+  e += tl * (pt - t);
+  return e;
+}
+
 // deferred = 1: this launch belongs to the NEXT iteration's graph (or to a flush) and performs the
 // update the previous iteration still owes, concurrently with the next iteration's plane kernels
 // (they only read the control points).  deferred = 0: stage API, update of the current iteration.
+// One wave per piece, and a chain of dependent steps: Newton system in LDS -> factorisation and solve in REGISTERS (one row
+// per lane, v_readlane broadcasts: the LDS form pays three barriers per pivot) -> Armijo search with the objective evaluated by
+// the whole wave (z_energy_wave) and every pow() of a pass taken on different lanes at once (the scalar loop on one lane was
+// a third of the 27 us this body took; it is the whole of k_mid for one or a few robots).
 __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) {
   const int tid = threadIdx.x;
   const int u = D.u0 + bid / D.P, sp = bid % D.P;
   const int P6 = 6 * D.P, T = D.T;
-  __shared__ double cx[18], z[18], lam[18], zt[18], dirz[18], g[19], H[361], L[361], g0[19], x0[19], scr[4 * 19];
-  __shared__ double s_t, s_step;
+  __shared__ double cx[18], z[18], lam[18], zt[18], dirz[18], g[19], H[361], L[361], g0[19], x0[19], scr[4 * 19], md[36], w18[36];
   const double* net = D.spline + (size_t)u * 3 * T;
   const double* C = D.convert + (size_t)sp * 36;
   const double pt = D.piece_time[u];
@@ -357,38 +433,46 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
     z[tid] = D.p_slack[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
     lam[tid] = D.p_lambda[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
   }
+  if (tid < 36) md[tid] = D.mdyn[tid];
   for (int i = tid; i < 361; i += 64) H[i] = 0;
+  // the three powers of t this update needs, one pass: lane 0 t^0.1, lane 1 t^-0.9, lane 2 t^1.1
+  const double pwl = pow(t, tid == 0 ? 0.1 : (tid == 1 ? -0.9 : 1.1));
+  const double pw01 = readlane_f64(pwl, 0), pwm09 = readlane_f64(pwl, 1), pw11 = readlane_f64(pwl, 2);
   __syncthreads();
   // Gradient_admm::slack_gradient / dynamic_gradient (Gradient_admm.h:574-671)
   const double sc = D.ks / pow5(t);
   if (tid < 18) {
     const int k = tid / 3, a = tid % 3;
     double mz = 0;
-    for (int j = 0; j < 6; j++) mz += D.mdyn[k * 6 + j] * z[j + 6 * a];
+    for (int j = 0; j < 6; j++) mz += md[k * 6 + j] * z[j + 6 * a];
     const double g1 = sc * mz;
     const double g2 = D.mu * (z[k + 6 * a] - cx[k + 6 * a]) - lam[k + 6 * a];
     g[tid] = g1 + g2;
     const double pg = -5 * g1 / t;
     H[tid * 19 + 18] = pg; H[18 * 19 + tid] = pg;
-    for (int b = 0; b < 6; b++) H[tid * 19 + 3 * b + a] = sc * D.mdyn[k * 6 + b] + (k == b ? D.mu : 0.0);
+    for (int b = 0; b < 6; b++) H[tid * 19 + 3 * b + a] = sc * md[k * 6 + b] + (k == b ? D.mu : 0.0);
   }
-  if (tid == 32) {
-    double dyn = 0;
+  {  // time entries: the quadratic form z^T M z per axis on lanes (a, j) like z_energy_wave, combined uniformly
     const double s = sc * 0.5;
-    for (int a = 0; a < 3; a++) {
-      double rrow[6], y[6];
-      for (int k = 0; k < 6; k++) rrow[k] = s * z[k + 6 * a];
-      for (int j = 0; j < 6; j++) { double acc = 0; for (int k = 0; k < 6; k++) acc += rrow[k] * D.mdyn[k * 6 + j]; y[j] = acc; }
-      double q = 0; for (int j = 0; j < 6; j++) q += y[j] * z[j + 6 * a];
+    const int a = min(tid, 17) / 6, j = min(tid, 17) % 6;
+    double y = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) y += (s * z[k + 6 * a]) * md[k * 6 + j];
+    double dyn = 0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      double q = 0;
+#pragma unroll
+      for (int jj = 0; jj < 6; jj++) q += readlane_f64(y, 6 * ax + jj) * z[jj + 6 * ax];
       dyn += q;
     }
     double g_t = -5 * dyn / t;
-    g_t += D.kt * 1.1 * pow(t, 0.1);
+    g_t += D.kt * 1.1 * pw01;
     double h_t = 30 * dyn / (t * t);
-    h_t += D.kt * 0.11 * pow(t, -0.9);
+    h_t += D.kt * 0.11 * pwm09;
     g_t += D.mu * (t - pt) - tl;
     h_t += D.mu;
-    g[18] = g_t; H[18 * 19 + 18] = h_t;
+    if (tid == 32) { g[18] = g_t; H[18 * 19 + 18] = h_t; }
   }
   __syncthreads();
   // boundary pieces keep two control points fixed (Optimization3D_multi.h:374-420)
@@ -399,11 +483,9 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
   for (int idx = tid; idx < n * n; idx += 64) { const int i = idx / n, j = idx % n; L[idx] = H[mapi(i) * 19 + mapi(j)]; }
   if (tid < n) { g0[tid] = g[mapi(tid)]; x0[tid] = g[mapi(tid)]; }
   __syncthreads();
-  for (int idx = tid; idx < n * n; idx += 64) H[idx] = L[idx];  // H now holds the reduced system (n x n)
-  __syncthreads();
-  if (!chol_lds(L, n, tid, 64, x0)) {  // forward substitution fused: x0 <- L^-1 g0
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += 64) L[idx] = H[idx];
+  const bool solved = n == 19 ? slack_solve_wave<19>(L, x0, tid) : slack_solve_wave<13>(L, x0, tid);   // x0 <- (L L^T)^-1 g0
+  if (!solved) {  // LLT failed (L and x0 untouched): eigen-shift like the reference, everything in LDS -- rare
+    for (int idx = tid; idx < n * n; idx += 64) H[idx] = L[idx];  // H now holds the reduced system (n x n)
     __syncthreads();
     const double ev = min_eig_lds(L, n, scr, scr + 19, scr + 38, scr + 57, tid, 64);
     if (ev < 0 && tid < n) H[tid * n + tid] = H[tid * n + tid] - ev * 1.0 + 0.01 * 1.0;
@@ -413,35 +495,37 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
     __syncthreads();
     chol_lds(L, n, tid, 64, x0);
     __syncthreads();
+    chol_arrow_backsolve_lds(L, n, n, x0, tid, 64);
   }
-  chol_arrow_backsolve_lds(L, n, n, x0, tid, 64);
   if (tid < n) x0[tid] = -x0[tid];
   if (tid < 18) dirz[tid] = 0;
   __syncthreads();
   if (tid < 3 * tn) { const int i = tid / 3, a = tid % 3; dirz[(lo + i) + 6 * a] = x0[tid]; }
+  if (tid < 19) scr[tid] = tid < n ? x0[tid] * g0[tid] : 0.0;
   __syncthreads();
-  if (tid == 0) {  // scalar Armijo loop: the objective is ~300 flops
-    double pr[19];  // constant trip counts below: the array stays in registers (a run-time n sends it to scratch memory)
-#pragma unroll
-    for (int i = 0; i < 19; i++) pr[i] = i < n ? x0[i] * g0[i] : 0.0;
-    const double wolfe = -(n == 19 ? esum(pr, 19) : esum(pr, 13));
-    const double t_dir = x0[3 * tn];
-    double step = 1.0;
-    if (t + step * t_dir <= 0) step = -0.95 * t / t_dir;
-    const double e = z_energy(D, cx, pt, z, t, lam, tl);
-    const double t_init = t;
-    double tt = t_init + step * t_dir;
-    int guard = 0;
-    for (;;) {
-      for (int i = 0; i < 18; i++) zt[i] = z[i] + step * dirz[i];
-      const double en = z_energy(D, cx, pt, zt, tt, lam, tl);
-      if (!(e - 1e-4 * wolfe * step < en)) break;
-      if (++guard >= LOOP_CAP) { atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_SLACK_ARMIJO); break; }
-      step *= 0.8;
-      tt = t_init + step * t_dir;
-    }
-    s_t = tt; s_step = step;
+  // Armijo loop (update_slack_lambda): uniform on the wave
+  const double wolfe = -(n == 19 ? esum(scr, 19) : esum(scr, 13));
+  const double t_dir = x0[3 * tn];
+  double step = 1.0;
+  if (t + step * t_dir <= 0) step = -0.95 * t / t_dir;
+  const double t_init = t;
+  double tt = t_init + step * t_dir;
+  const double pwt = pow(tt, 1.1);
+  const double e = z_energy_wave(D, md, cx, pt, z, t, lam, tl, pw11, w18, tid);
+  double pwc = pwt;
+  int guard = 0;
+  for (;;) {
+    blk_sync<true>();
+    if (tid < 18) zt[tid] = z[tid] + step * dirz[tid];
+    blk_sync<true>();
+    const double en = z_energy_wave(D, md, cx, pt, zt, tt, lam, tl, pwc, w18, tid);
+    if (!(e - 1e-4 * wolfe * step < en)) break;
+    if (++guard >= LOOP_CAP) { if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_SLACK_ARMIJO); break; }
+    step *= 0.8;
+    tt = t_init + step * t_dir;
+    pwc = pow(tt, 1.1);
   }
+  const double s_t = tt;
   __syncthreads();
   if (tid < 18) {
     const int j = tid % 6, a = tid / 6;
