@@ -260,6 +260,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
       }
     }
     if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
+    if (n <= nwaves) break;   // every item had its own wave (SCN-C): no cursor to ask -- its return value was a memory round trip at the end of every wave
     int nxt = 0;
     if (lane == 0) nxt = nwaves + atomicAdd(D.pair_work_n + D.S, 1);
     w = __shfl(nxt, 0);
