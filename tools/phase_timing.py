@@ -19,6 +19,7 @@ PHASES = {
     "k_xsolve": ["load", "assemble", "chol+fwd", "backsolve", "finish", "swept-hull tail"],
     "k_linesearch": ["stage", "planes->lds", "setup", "E round0", "later rounds"],
     "k_sep_self_solve": ["load", "gjk+newton+store"],
+    "k_sep_self_solve_inner": ["gjk", "normal+offsets", "newton"],
     "k_obs_query": ["hull+kdop", "walk", "leaves", "last cull", "work items"],
     "k_ccd_self_seq": ["stage counts", "segment loop", "k_self + gn stage", "gnorm"],
 }
@@ -88,6 +89,14 @@ def main():
             print("   corr(total us, gjk iters) =", np.corrcoef(tot, gk)[0, 1], " corr(total us, newton) =", np.corrcoef(tot, np.maximum(nit, 0))[0, 1])
             o = np.argsort(-tot)[:8]
             print("   slowest:", [(round(float(tot[i]), 1), int(gk[i]), int(nit[i])) for i in o])
+        if name == "k_sep_self_solve":
+            acc = (t[:, 3] >= t[:, 1]) & (t[:, 4] >= t[:, 3]) & (t[:, 5] >= t[:, 4]) & (t[:, 2] >= t[:, 5])   # stamps of THIS iteration (rejected pairs leave older ones)
+            if acc.any():
+                a = t[acc]
+                print(f"   accepted pairs ({acc.sum()}): gjk {((a[:,3]-a[:,1])*0.01).mean():.2f} (max {((a[:,3]-a[:,1])*0.01).max():.2f})  normal+offsets {((a[:,4]-a[:,3])*0.01).mean():.2f}  newton {((a[:,5]-a[:,4])*0.01).mean():.2f} (max {((a[:,5]-a[:,4])*0.01).max():.2f})  store+end {((a[:,2]-a[:,5])*0.01).mean():.2f} us")
+                one = acc & (gk == 1); two = acc & (gk == 2)
+                for lab, sel in (("1 GJK iteration", one), ("2 GJK iterations", two)):
+                    if sel.any(): print(f"   {lab}: {sel.sum()} pairs, gjk phase {((t[sel,3]-t[sel,1])*0.01).mean():.2f} us")
         if name == "k_grad":
             llt = (t[:, 7] - t[:, 4]) * 0.01; rest = (t[:, 5] - t[:, 7]) * 0.01
             failed = rest > 2.0

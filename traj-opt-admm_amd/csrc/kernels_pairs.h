@@ -245,7 +245,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
     {
       double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
-      const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk);  // whole wave, uniform result
+      const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk, first ? &D : nullptr);  // whole wave, uniform result
 #ifdef TJ_PHASE_TIMING
       if (lane == 0 && first && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
 #endif

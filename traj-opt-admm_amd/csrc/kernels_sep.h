@@ -336,9 +336,11 @@ __device__ inline bool plane_pair(const double* A, const double* Bq, double dist
 // transcendental work) evaluated by 12 lanes and summed in the reference's order.  Same expressions, same
 // summation order as plane_pair => identical results.
 __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double dist, double m, double off, int lane, double& e0, double& e1c, double& e2c, double& dpl,
-                                       bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr) {
+                                       bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr, const Dev* tic = nullptr) {
   capped = false;
   const V3 v = gjk_wave(BodyHull{A}, BodyHull{Bq}, lane, gjk_iters);
+  TJ_ORDER(v.x);
+  if (tic) TJ_TIC(*tic, K_SEP_SELF_SOLVE, 3);
   const double cn = norm3(v.x, v.y, v.z);
   if (cn > dist) return false;
   e0 = v.x / cn; e1c = v.y / cn; e2c = v.z / cn;
@@ -346,6 +348,8 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
   for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, Bq + 3 * i); if (d0 > t) d0 = t; }
   for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, A + 3 * i); if (d1 < t) d1 = t; }
   dpl = 0.5 * (d0 + d1);
+  TJ_ORDER(dpl);
+  if (tic) TJ_TIC(*tic, K_SEP_SELF_SOLVE, 4);
   const int j = lane < 6 ? lane : (lane < 12 ? lane - 6 : 0);
   const double* pt = lane < 6 ? A + 3 * j : Bq + 3 * j;
   const double px = pt[0], py = pt[1], pz = pt[2];
@@ -374,6 +378,8 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
   }
   capped = it == LOOP_CAP;
   if (newton_iters) *newton_iters = it + 1;
+  TJ_ORDER(dpl);
+  if (tic) TJ_TIC(*tic, K_SEP_SELF_SOLVE, 5);
   return true;
 }
 
