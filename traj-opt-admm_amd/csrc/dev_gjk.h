@@ -433,47 +433,51 @@ __device__ __forceinline__ void gjk_tet_wave(Simplex& s, int lane) {
     r.l0 = gjk_rl(mine.l0, jj); r.l1 = gjk_rl(mine.l1, jj); r.l2 = gjk_rl(mine.l2, jj);
     r.w0 = __builtin_amdgcn_readlane(mine.w0, jj); r.w1 = __builtin_amdgcn_readlane(mine.w1, jj); r.w2 = __builtin_amdgcn_readlane(mine.w2, jj);
   };
+  // every job's lane forms the squared length of ITS candidate point itself; only the three numbers travel, the comparisons
+  // run in the reference's order on wave-uniform values, and only the winner's simplex is fetched (a fetch is 28 v_readlane)
+  const V3 vm_ = sx_point(mine);
+  const double dd_m = dot(vm_, vm_);
   Simplex cur;
   cur.v3 = V3{0, 0, 0}; cur.l3 = 0; cur.w3 = 0;
   if (facing == 0) {
-    int id0 = 0, id1 = 0, id2 = 0, nbest = 0;
-    double lb0 = 0, lb1 = 0, lb2 = 0, best = 0;
-#pragma unroll 1
-    for (int jj = 0; jj < 3; ++jj) {
-      fetch(jj, cur);
-      const V3 vt = sx_point(cur);
-      const double dd = dot(vt, vt);
-      if (jj == 0 || dd < best) {
-        best = dd; nbest = cur.n;
-        id0 = tri_lut(jj + cur.w0 * 3); lb0 = cur.l0;
-        if (nbest > 1) { id1 = tri_lut(jj + cur.w1 * 3); lb1 = cur.l1; }
-        if (nbest > 2) { id2 = tri_lut(jj + cur.w2 * 3); lb2 = cur.l2; }
-      }
-    }
+    const double dd0 = gjk_rl(dd_m, 0), dd1 = gjk_rl(dd_m, 1), dd2 = gjk_rl(dd_m, 2);
+    int jb = 0; double best = dd0;
+    if (dd1 < best) { best = dd1; jb = 1; }
+    if (dd2 < best) { best = dd2; jb = 2; }
+    const int nbest = __builtin_amdgcn_readlane(mine.n, jb);
+    const int cw0 = __builtin_amdgcn_readlane(mine.w0, jb), cw1 = __builtin_amdgcn_readlane(mine.w1, jb), cw2 = __builtin_amdgcn_readlane(mine.w2, jb);
+    const double lb0 = gjk_rl(mine.l0, jb), lb1 = gjk_rl(mine.l1, jb), lb2 = gjk_rl(mine.l2, jb);
+    const int id0 = tri_lut(jb + cw0 * 3), id1 = tri_lut(jb + cw1 * 3), id2 = tri_lut(jb + cw2 * 3);
     s.n = nbest;
     sx_set_v(s, nbest - 1, pick4(id0, d, c, b, a)); s.l0 = lb0; sx_set_w(s, nbest - 1, id0);
     if (nbest > 1) { sx_set_v(s, nbest - 2, pick4(id1, d, c, b, a)); s.l1 = lb1; sx_set_w(s, nbest - 2, id1); }
     if (nbest > 2) { sx_set_v(s, nbest - 3, pick4(id2, d, c, b, a)); s.l2 = lb2; sx_set_w(s, nbest - 3, id2); }
     return;
   }
-  fetch(njobs - 1, cur);  // the (last) visited face becomes the simplex
-  s.n = cur.n; s.v0 = cur.v0; s.v1 = cur.v1; s.v2 = cur.v2;
-  s.l0 = cur.l0; s.l1 = cur.l1; s.l2 = cur.l2; s.w0 = cur.w0; s.w1 = cur.w1; s.w2 = cur.w2;
-  if (facing == 1) {
-    Simplex aux;
-    aux.v3 = V3{0, 0, 0}; aux.l3 = 0; aux.w3 = 0;
-    fetch(0, aux);
-    const V3 vt = sx_point(aux);
-    const double best = dot(vt, vt);
-    const V3 v = sx_point(s);
-    if (dot(v, v) < best) {
+  if (facing == 1) {   // two faces: job 0 is the reference's auxiliary simplex, job 1 the one left in place; the closer one stays
+    const double best = gjk_rl(dd_m, 0), dcur = gjk_rl(dd_m, 1);
+    if (dcur < best) {
+      fetch(1, cur);
+      s.n = cur.n; s.v0 = cur.v0; s.v1 = cur.v1; s.v2 = cur.v2;
+      s.l0 = cur.l0; s.l1 = cur.l1; s.l2 = cur.l2; s.w0 = cur.w0; s.w1 = cur.w1; s.w2 = cur.w2;
       for (int i = 0; i < s.n; ++i) sx_set_w(s, s.n - 1 - i, tri_lut(second + sx_w(s, i) * 3));  // in place, as the reference
     } else {
+      Simplex aux;
+      aux.v3 = V3{0, 0, 0}; aux.l3 = 0; aux.w3 = 0;
+      fetch(0, aux);
       s.n = aux.n; s.v0 = aux.v0; s.v1 = aux.v1; s.v2 = aux.v2;
       s.l0 = aux.l0; s.l1 = aux.l1; s.l2 = aux.l2;
+      // the labels the reference leaves behind are those of the in-place simplex beyond aux.n ... it rewrites aux.n of them
+      const int pw0 = __builtin_amdgcn_readlane(mine.w0, 1), pw1 = __builtin_amdgcn_readlane(mine.w1, 1), pw2 = __builtin_amdgcn_readlane(mine.w2, 1);
+      s.w0 = pw0; s.w1 = pw1; s.w2 = pw2;
       for (int i = 0; i < s.n; ++i) sx_set_w(s, aux.n - 1 - i, tri_lut(first + sx_w(aux, i) * 3));
     }
-  } else if (facing == 2) {
+    return;
+  }
+  fetch(njobs - 1, cur);  // the visited face becomes the simplex
+  s.n = cur.n; s.v0 = cur.v0; s.v1 = cur.v1; s.v2 = cur.v2;
+  s.l0 = cur.l0; s.l1 = cur.l1; s.l2 = cur.l2; s.w0 = cur.w0; s.w1 = cur.w1; s.w2 = cur.w2;
+  if (facing == 2) {
     if (single == 1 && s.n > 2) s.w2 = s.w2 + 1;
   } else {
     s.w0 = s.w0 + 1;
