@@ -51,7 +51,7 @@ struct Ctl {
   // statistics for the algorithmic-byte model; accumulated over iterations
   unsigned long long llt_fail_piece, llt_fail_robot;  // PSD repairs taken (per-piece 19x19, per-robot reduced system)
   unsigned long long energy_evals;
-  unsigned long long newton_iters, pair_solves;  // Optimal_plane::optimal_d iterations / robot pairs solved
+  unsigned long long newton_iters, pair_solves;  // unused since the counters moved to Dev::pair_stats (kept for the layout)
   double wolfe_c;      // coupled mode: the global `wolfe` of update_spline (Optimization3D_multi.h:558)
 };
 
@@ -167,6 +167,7 @@ struct Dev {
   // each slot is only ever touched by the one wave that owns (robot, segment), so plain += suffices
   // (a shared counter would serialise ~10^4 atomics per iteration on one L2 word)
   unsigned long long* seg_stats;
+  unsigned long long* pair_stats;   // [U*S][2] Optimal_plane::optimal_d iterations / robot pairs solved, spread over (lower robot, segment)
   Ctl* ctl;
   long long* dbg;  // phase stamps (TJ_PHASE_TIMING builds only, else null)
 };

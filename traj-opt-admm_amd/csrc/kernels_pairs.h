@@ -227,7 +227,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
       }
     }
     for (int o = 32; o > 0; o >>= 1) { nit_sum += __shfl_xor(nit_sum, o); solved += __shfl_xor(solved, o); }
-    if (lane == 0 && solved) { atomicAdd(&D.ctl->newton_iters, nit_sum); atomicAdd(&D.ctl->pair_solves, solved); }
+    if (lane == 0 && solved) { unsigned long long* ps = D.pair_stats + 2 * (size_t)(bid % (D.U * D.S)); atomicAdd(ps, nit_sum); atomicAdd(ps + 1, solved); }
     if (any_capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
     return;
   }
@@ -250,7 +250,10 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
       if (lane == 0 && first && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
 #endif
       if (okp && lane == 0) {
-        atomicAdd(&D.ctl->newton_iters, (unsigned long long)nit); atomicAdd(&D.ctl->pair_solves, 1ull);
+        // statistics per (robot, segment): ~900 waves adding to ONE word of the control block serialise there (~13 ns each) and
+        // the stores below wait for it
+        unsigned long long* ps = D.pair_stats + 2 * ((size_t)p0 * D.S + tr);
+        atomicAdd(ps, (unsigned long long)nit); atomicAdd(ps + 1, 1ull);
         if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
         const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
         double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
