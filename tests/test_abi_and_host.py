@@ -136,3 +136,33 @@ def test_coupled_mode_params(pkg):
     ctx = C.c_void_p()                                # possible failure is the missing device (there is no CPU fallback)
     assert lib.tj_create(C.byref(p), C.byref(ctx)) in (0, -2)
     lib.tj_destroy(ctx)
+
+
+def test_hot_kernels_use_no_scratch_memory(pkg, tmp_path):
+    """The kernels of the iteration chain whose critical path is a per-item dependent chain must not touch scratch (private)
+    memory: every access is a global-memory round trip on that chain.  (Round 2 found k_grad's running sums there -- handed
+    around by reference, the compiler had turned them into an indexed array: 1.5 us and 4 MB of writes per launch -- and the
+    slack body's scalar Armijo loop reloading 35 spilled registers per trial.)  Read from the code object's own metadata;
+    k_ccd_lean spills by design (its occupancy cap), the debug / planner hooks are not on the path."""
+    readelf, objdump = "/opt/rocm/lib/llvm/bin/llvm-readelf", "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(readelf) and os.path.exists(objdump)):
+        pytest.skip("LLVM binutils of the ROCm image not found")
+    so = tmp_path / "lib.so"
+    so.write_bytes(open(pkg.LIB_PATH, "rb").read())
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    cos = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert cos, "no gfx950 code object embedded in libtrajadmm.so"
+    notes = subprocess.run([readelf, "--notes", str(tmp_path / cos[0])], check=True, capture_output=True, text=True).stdout
+    name = None
+    seen = {}
+    for line in notes.splitlines():
+        m = re.search(r"\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
+        if m and name:
+            seen[name] = int(m.group(1))
+    hot = [k for k in seen if re.search(r"tj\d+(k_grad|k_xsolve|k_xsolve_band|k_linesearch|k_front|k_mid|k_slack)(I|E)", k)]
+    assert len(hot) >= 8, f"expected the chain's kernels in the metadata, found {sorted(seen)[:5]}..."
+    bad = {k: seen[k] for k in hot if seen[k] != 0}
+    assert not bad, f"scratch memory in hot kernels: {bad}"
