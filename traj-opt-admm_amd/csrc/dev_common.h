@@ -167,6 +167,7 @@ struct Dev {
   // each slot is only ever touched by the one wave that owns (robot, segment), so plain += suffices
   // (a shared counter would serialise ~10^4 atomics per iteration on one L2 word)
   unsigned long long* seg_stats;
+  unsigned long long* blk_stats;    // [U*P] PSD repairs per piece (k_grad), then [U] energy evaluations per robot (line search): single-writer words, no atomics
   unsigned long long* pair_stats;   // [U*S][2] Optimal_plane::optimal_d iterations / robot pairs solved, spread over (lower robot, segment)
   Ctl* ctl;
   long long* dbg;  // phase stamps (TJ_PHASE_TIMING builds only, else null)

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     ls_publish_hullinfo(D, u, wh, tid, LS_THREADS);
   }
   TJ_TIC(D, K_LINESEARCH, 5);
-  if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; atomicAdd(&D.ctl->energy_evals, (unsigned long long)evals); }
+  if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)evals; }   // per robot: one writer, no atomic in front of the ticket
   if (begin_next) {
     // No fence: nothing another block of THIS kernel writes is read here (gnorm and the counters come from earlier kernels;
     // what begin_body resets was consumed by every block before its ticket), and what is written here is read by later
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
   double* gspline = D.spline + (size_t)u * 3 * T;
   const double* dir = D.dirp(u);
   for (int i = tid; i < 3 * T; i += 64) gspline[i] = gspline[i] + step * dir[i];
-  if (tid == 0) { D.piece_time[u] = t0 + step * t_dir; D.step_out[u] = step; atomicAdd(&D.ctl->energy_evals, (unsigned long long)(2 + kacc)); }
+  if (tid == 0) { D.piece_time[u] = t0 + step * t_dir; D.step_out[u] = step; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)(2 + kacc); }
 }
 
 }  // namespace tj

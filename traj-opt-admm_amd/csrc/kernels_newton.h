@@ -376,7 +376,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     for (int c = 0; c < 19; c++) r[c] = H[row * 19 + c];
     if (tid < 64) {
       const bool llt_ok = chol_check_wave<19>(r);
-      if (tid == 0) { s_llt = llt_ok ? 1 : 0; if (!llt_ok) atomicAdd(&D.ctl->llt_fail_piece, 1ull); }
+      if (tid == 0) s_llt = llt_ok ? 1 : 0;   // (the statistic is taken at the very end: an atomic here would be waited for by the next barrier, on the repair path)
       TJ_TIC(D, K_GRAD, 7);
     } else {
       const double ev = min_eig_wave<19>(r, tid & 63, &s_llt);
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   double* oh = D.lh + ((size_t)u * D.P + sp) * 361;
   if (tid < 19) og[tid] = g[tid];
   for (int idx = tid; idx < 361; idx += GRAD_THREADS) oh[idx] = H[idx];
+  if (tid == 0 && s_llt == 0) D.blk_stats[(size_t)u * D.P + sp] += 1ull;   // PSD repairs of this piece: only this block writes the word
   TJ_TIC(D, K_GRAD, 6);
 }
 

@@ -479,7 +479,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.lg, U * P * 19)) || (r = dalloc(c, &d.lh, U * P * 361)) || (r = dalloc(c, &d.xdir, U * d.xs)) ||
       (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) ||
       (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, ACT_CAP)) ||
-      (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) ||
+      (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) || (r = dalloc(c, &d.blk_stats, U * P + U)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
       (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
@@ -678,6 +678,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemsetAsync(d.ostamp, 0, (size_t)U * d.S * d.cap_obs * 4, c->stream));  // epochs restart at 1
   HIPCHK(c, hipMemsetAsync(d.seg_stats, 0, (size_t)U * d.S * 6 * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(d.pair_stats, 0, (size_t)U * d.S * 2 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(d.blk_stats, 0, ((size_t)U * d.P + U) * 8, c->stream));
   if (d.mode >= 1) HIPCHK(c, hipMemsetAsync(d.pairstamp, 0, (size_t)d.S * U * U * 4, c->stream));  // epochs restart at 1
   c->have_state = true;
   return TJ_OK;
@@ -1334,7 +1335,12 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   HIPCHK(c, hipMemcpy(ps.data(), d.pair_stats, ps.size() * 8, hipMemcpyDeviceToHost));
   unsigned long long pt[2] = {0, 0};
   for (size_t i = 0; i < ps.size(); i++) pt[i % 2] += ps[i];
-  s->energy_evals = h.energy_evals; s->llt_fail_piece = h.llt_fail_piece; s->llt_fail_robot = h.llt_fail_robot; s->newton_iters = pt[0]; s->pair_solves = pt[1];
+  std::vector<unsigned long long> bs((size_t)d.U * d.P + d.U);
+  HIPCHK(c, hipMemcpy(bs.data(), d.blk_stats, bs.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long fails = 0, evals = 0;
+  for (size_t i = 0; i < (size_t)d.U * d.P; i++) fails += bs[i];
+  for (size_t i = (size_t)d.U * d.P; i < bs.size(); i++) evals += bs[i];
+  s->energy_evals = evals; s->llt_fail_piece = fails; s->llt_fail_robot = h.llt_fail_robot; s->newton_iters = pt[0]; s->pair_solves = pt[1];
   s->pair_tests = d.mode >= 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
   s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error; s->order_unresolved = h.order_unresolved;
   return TJ_OK;
