@@ -293,8 +293,10 @@ __device__ __forceinline__ void support(const Body& body, const V3& dir, V3& cur
 }
 
 // witness vector of conv(b1) - conv(b2) (openGJK.c:754-852)
+// kmax < 50 / cut: stop after kmax iterations; *cut tells whether the loop was cut short (the witness vector is then not final --
+// the caller hands the query to a wave-cooperative solve that starts over and reaches the same bits as the uncut loop)
 template <class B1, class B2>
-__device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2, int* iters_out = nullptr) {
+__device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2, int* iters_out = nullptr, int kmax = 50, bool* cut = nullptr) {
   const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
   Simplex s;
   V3 s1 = b1.get(0), s2 = b2.get(0);
@@ -304,14 +306,15 @@ __device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2, int* iters_out = n
   s.w0 = s.w1 = s.w2 = s.w3 = 0; s.l0 = s.l1 = s.l2 = s.l3 = 0;
   double wmax2 = 0;
   int k = 0;
+  bool fin = false;
   do {
     k++;
     const V3 vm{-v.x, -v.y, -v.z};
     support(b1, vm, s1);
     support(b2, v, s2);
     const V3 w{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
-    if ((sq(v) - dot(v, w)) <= eps_rel2 * sq(v)) break;
-    if (sq(v) < eps_rel2) break;
+    if ((sq(v) - dot(v, w)) <= eps_rel2 * sq(v)) { fin = true; break; }
+    if (sq(v) < eps_rel2) { fin = true; break; }
     sx_set_v(s, s.n, w);
     s.n++;
     if (s.n == 4) gjk_tet(s); else if (s.n == 3) gjk_tri(s); else gjk_seg(s);
@@ -320,9 +323,10 @@ __device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2, int* iters_out = n
     if (s.n > 1) { double t = sq(s.v1); if (t > wmax2) wmax2 = t; }
     if (s.n > 2) { double t = sq(s.v2); if (t > wmax2) wmax2 = t; }
     if (s.n > 3) { double t = sq(s.v3); if (t > wmax2) wmax2 = t; }
-    if (sq(v) <= (eps_tot * eps_tot * wmax2)) break;
-  } while ((s.n != 4) && (k != 50));
+    if (sq(v) <= (eps_tot * eps_tot * wmax2)) { fin = true; break; }
+  } while ((s.n != 4) && (k != kmax));
   if (iters_out) *iters_out = k;
+  if (cut) *cut = !fin && s.n != 4 && kmax < 50;
   return v;
 }
 

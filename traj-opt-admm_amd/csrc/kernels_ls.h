@@ -311,6 +311,7 @@ __device__ __forceinline__ void begin_body(const Dev& D) {
   for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
   if (D.multi()) for (int i = threadIdx.x; i <= D.S; i += blockDim.x) D.pair_work_n[i] = 0;   // per-segment counts, [S] = cursor of the pair-solve waves
   if (threadIdx.x == 0) *D.obs_work_n = 0;
+  if (threadIdx.x < 3 && D.multi()) D.pair_ovf[threadIdx.x] = 0;
   if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
 }
 

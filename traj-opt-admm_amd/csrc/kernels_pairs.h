@@ -76,6 +76,9 @@ __host__ __device__ inline void pair_unit(int U, int R, int bid, int& tr, int& r
     r -= cnt;
   }
 }
+constexpr int PAIR_CONSUMERS_MAX = 4096;            // bound on the waves that wait for passed-on pairs (all idle pair waves do: with 512 of them k_mid took 74 us on SCN-D, with 864 65)
+constexpr unsigned long long PAIR_OVF_STOP = 1ull << 31;   // entry flag: the list ends here
+constexpr int PAIR_LANE_GJK_CAP = 3;   // GJK iterations a lane spends on its pair before passing it on (large fleets, see sep_self_solve_body; 2 .. 4 measured alike, 8 slower)
 constexpr int PAIR_ROWS_MAX = 16;
 constexpr int PAIR_TILE_CAP = PAIR_ROWS_MAX * 64;
 
@@ -207,7 +210,57 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   // dependent steps; with thousands of pairs THROUGHPUT decides, and one pair per LANE (per-lane GJK + Newton, the same
   // arithmetic: plane_pair == plane_pair_wave bit for bit) is ~20x cheaper per pair.  The switch is wave-uniform.
   if (n > 4 * nwaves) {
+    // Almost every pair is through after one or two GJK iterations, a few dozen per iteration need 10-16 (measured on the
+    // 256-robot scene: 98 % <= 2, 0.2 % >= 10) -- and a wave is as slow as its slowest lane, at ~2.8 us per per-lane iteration:
+    // 45 us of a lone lane with the rest of the machine idle.  When the list leaves at least half of the launched waves
+    // without a chunk, the lanes stop after PAIR_LANE_GJK_CAP iterations and pass an unfinished pair on (one 64-bit word
+    // tagged with the iteration's epoch, appended to a device-wide list); the idle waves take these pairs one each and solve
+    // them from the start with the wave-cooperative form, which reaches the same bits (plane_pair == plane_pair_wave).
+    // Cross-wave traffic is agent-scope atomics only, and every waiting wave polls a word of its OWN (consumer c takes the
+    // entries c, c + nc, ...): ~900 waves polling shared counters serialise at the memory side (~13 ns per access to one
+    // address) and starve the producers -- measured.  The producer that counts itself done last writes nc STOP entries behind
+    // the list, so every consumer's next word turns valid.  An append's returning add has been performed before its wave
+    // counts itself done; no fence (= no L2 write-back) is needed anywhere.
+    const int np = min(nwaves, (n + 63) / 64);            // waves that own a chunk of the list ("producers")
+    const int nc = min(nwaves - np, PAIR_CONSUMERS_MAX);
+    const bool pass_on = 2 * np <= nwaves;
+    const int kcap = pass_on ? PAIR_LANE_GJK_CAP : 50;
+    if (pass_on && bid >= np) {   // ---- consumer: the long solves, one per wave ----
+      if (bid - np >= nc) return;
+      TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
+      const long long t_end = wall_clock64() + 500000;   // 5 ms: a logic error must not hang the device
+      for (int i = bid - np;; i += nc) {
+        unsigned long long e = 0;
+        bool have = false;
+        if (i >= D.cap_work + PAIR_CONSUMERS_MAX) return;
+        for (;;) {
+          e = __hip_atomic_load(&D.pair_ovf_list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(e >> 32) == epoch) { have = true; break; }
+          if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP); break; }
+          __builtin_amdgcn_s_sleep(16);
+        }
+        if (!have || (e & PAIR_OVF_STOP)) { TJ_TIC(D, K_SEP_SELF_SOLVE, 2); return; }
+        if (i == bid - np) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
+        const int tr = (int)(e & 0x1ff), p0 = (int)((e >> 9) & 0x3ff), q = (int)((e >> 19) & 0x3ff);
+        __syncthreads();
+        if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
+        __syncthreads();
+        double e0, e1c, e2c, dpl; bool capped; int nit = 0;
+        const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit);
+        if (okp && lane == 0) {
+          unsigned long long* ps = D.pair_stats + 2 * ((size_t)p0 * D.S + tr);
+          atomicAdd(ps, (unsigned long long)nit); atomicAdd(ps + 1, 1ull);
+          if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+          const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
+          double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
+          q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
+          q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
+          D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+        }
+      }
+    }
     unsigned long long nit_sum = 0, solved = 0; bool any_capped = false;
+    TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
     for (int base = bid * 64; base < n; base += nwaves * 64) {
       const int w = base + lane;
       if (w < n) {
@@ -216,7 +269,17 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         const double* Ag = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
         const double* Bg = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
         double e0, e1c, e2c, dpl; bool capped; int nit = 0;
-        if (plane_pair(Ag, Bg, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
+        int gkl = 0; bool cut = false;
+        const V3 vw = gjk(BodyHull{Ag}, BodyHull{Bg}, &gkl, kcap, &cut);
+#ifdef TJ_PHASE_TIMING
+        if (!cut) atomicAdd((unsigned long long*)&D.dbg[((size_t)K_SEP_SELF_ROWS * TJ_TIC_BLOCKS + min(gkl, 63)) * TJ_TIC_SLOTS], 1ull);   // histogram of GJK iterations per pair (lane path)
+#endif
+        TJ_ORDER(vw.x); TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
+        if (cut) {   // pass the pair on NOW (the consumers start while this wave's other lanes refine their offsets): slot from a returning add, then the tagged entry
+          const int slot = atomicAdd(&D.pair_ovf[0], 1);
+          if (slot < D.cap_work) __hip_atomic_store(&D.pair_ovf_list[slot], ((unsigned long long)(unsigned)epoch << 32) | (unsigned long long)(tr | (p0 << 9) | (q << 19)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!cut && plane_pair_finish(vw, Ag, Bg, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
           nit_sum += (unsigned long long)nit; solved++; any_capped = any_capped || capped;
           const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
           double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
@@ -224,6 +287,15 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
           q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
           D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
         }
+      }
+    }
+    TJ_TIC(D, K_SEP_SELF_SOLVE, 3);
+    if (pass_on) {   // this producer's appends have all been performed (their adds returned); the last producer closes the list
+      int last = 0;
+      if (lane == 0) last = atomicAdd(&D.pair_ovf[1], 1) == np - 1;
+      if (__shfl(last, 0)) {
+        const int cnt = min(__hip_atomic_load(&D.pair_ovf[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), D.cap_work);
+        for (int j = lane; j < nc; j += 64) __hip_atomic_store(&D.pair_ovf_list[cnt + j], ((unsigned long long)(unsigned)epoch << 32) | PAIR_OVF_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     for (int o = 32; o > 0; o >>= 1) { nit_sum += __shfl_xor(nit_sum, o); solved += __shfl_xor(solved, o); }

@@ -292,9 +292,14 @@ __device__ inline bool kdop_hulls_pass(const Dev& D, const double* A, const doub
 // Separate::selfgjk (Separate.h:165-304) + Optimal_plane::optimal_d (Optimal_plane.h:13-71).
 // A is the hull of the lower robot index.  Returns false if the hulls are farther than dist.
 // capped = true when the Newton loop hit LOOP_CAP.
+// second half of plane_pair: from the GJK witness vector to the plane (separate so that a caller can act between the halves)
+__device__ inline bool plane_pair_finish(const V3& v, const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters = nullptr);
 __device__ inline bool plane_pair(const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr) {
-  capped = false;
   const V3 v = gjk(BodyHull{A}, BodyHull{Bq}, gjk_iters);
+  return plane_pair_finish(v, A, Bq, dist, m, off, refine, e0, e1c, e2c, dpl, capped, newton_iters);
+}
+__device__ inline bool plane_pair_finish(const V3& v, const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters) {
+  capped = false;
   const double cn = norm3(v.x, v.y, v.z);
   if (cn > dist) return false;
   e0 = v.x / cn; e1c = v.y / cn; e2c = v.z / cn;

@@ -117,7 +117,9 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   // Waves striding over the two device-built work lists.  k_mid holds ~1 wave per SIMD (VGPR bound), i.e. 1024 resident
   // waves: a larger grid adds no parallelism, only dispatch time for blocks that find no work (measured: with
   // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
-  const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
+  // Large fleets (one pair per lane, long solves passed on to idle waves -- sep_self_solve_body): half as many waves again, they
+  // are the consumers of the passed-on pairs (SCN-D: k_mid 62 us with 1024, 58 with 1536, 62 with 2048).
+  const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, d.U >= 192 ? 1536 : 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 512 : 0;
   const int n_rows = multi ? d.S * pair_units(d.U, d.pair_rows) : 0;   // one wave per (segment, tile of pair_rows lower robots x 64 partners)
   const int n_front = owned * d.S + n_rows, n_ccd = n_front;
@@ -482,7 +484,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) || (r = dalloc(c, &d.blk_stats, U * P + U)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
-      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.pair_ovf, 4)) || (r = dalloc(c, &d.pair_ovf_list, (size_t)d.cap_work + PAIR_CONSUMERS_MAX)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
@@ -680,6 +682,8 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemsetAsync(d.pair_stats, 0, (size_t)U * d.S * 2 * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(d.blk_stats, 0, ((size_t)U * d.P + U) * 8, c->stream));
   if (d.mode >= 1) HIPCHK(c, hipMemsetAsync(d.pairstamp, 0, (size_t)d.S * U * U * 4, c->stream));  // epochs restart at 1
+  HIPCHK(c, hipMemsetAsync(d.pair_ovf_list, 0, ((size_t)d.cap_work + PAIR_CONSUMERS_MAX) * 8, c->stream));                  // (entries are tagged with the epoch)
+  HIPCHK(c, hipMemsetAsync(d.pair_ovf, 0, 16, c->stream));
   c->have_state = true;
   return TJ_OK;
 }
