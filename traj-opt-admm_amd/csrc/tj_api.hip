@@ -120,7 +120,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   // Large fleets (one pair per lane, long solves passed on to idle waves -- sep_self_solve_body): half as many waves again, they
   // are the consumers of the passed-on pairs (SCN-D: k_mid 62 us with 1024, 58 with 1536, 62 with 2048).
   const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, d.U >= 192 ? 1536 : 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
-  const int n_obs_solve = d.N > 0 ? 512 : 0;
+  const int n_obs_solve = d.N > 0 ? 1024 : 0;   // (512: SCN-E's k_mid 43.7 us, 1024: 38.3, 2048: 37.8; SCN-C indifferent)
   const int n_rows = multi ? d.S * pair_units(d.U, d.pair_rows) : 0;   // one wave per (segment, tile of pair_rows lower robots x 64 partners)
   const int n_front = owned * d.S + n_rows, n_ccd = n_front;
   switch (kid) {
