@@ -493,7 +493,7 @@ __device__ __forceinline__ void gjk_tet_wave(Simplex& s, int lane) {
 // witness vector of conv(b1) - conv(b2), computed by the whole wave; all lanes must call it with the same bodies
 // and all lanes return the same vector
 template <class B1, class B2>
-__device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int* iters_out = nullptr) {
+__device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int* iters_out = nullptr, long long* prof = nullptr) {   // prof (timing builds): [0] support, [1..3] segment / triangle / tetrahedron steps (100 MHz ticks), [4..6] their counts
   const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
   Simplex s;
   V3 s1 = b1.get(0), s2 = b2.get(0);
@@ -506,14 +506,25 @@ __device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int
   do {
     k++;
     const V3 vm{-v.x, -v.y, -v.z};
+#ifdef TJ_PHASE_TIMING
+    const long long tp0 = prof ? wall_clock64() : 0;
+#endif
     support_wave(b1, b2, vm, v, s1, s2, lane);
     const V3 w{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
     if ((sq(v) - dot(v, w)) <= eps_rel2 * sq(v)) break;
     if (sq(v) < eps_rel2) break;
     sx_set_v(s, s.n, w);
     s.n++;
+#ifdef TJ_PHASE_TIMING
+    const int kind = s.n - 1;
+    asm volatile("" :: "v"(s.v0.x), "v"(s.v1.x));
+    const long long tp1 = prof ? wall_clock64() : 0;
+#endif
     if (s.n == 4) gjk_tet_wave(s, lane); else if (s.n == 3) gjk_tri(s); else gjk_seg(s);
     v = sx_point(s);
+#ifdef TJ_PHASE_TIMING
+    if (prof) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z)); const long long tp2 = wall_clock64(); prof[0] += tp1 - tp0; prof[kind] += tp2 - tp1; prof[3 + kind] += 1; }
+#endif
     { double t = sq(s.v0); if (t > wmax2) wmax2 = t; }
     if (s.n > 1) { double t = sq(s.v1); if (t > wmax2) wmax2 = t; }
     if (s.n > 2) { double t = sq(s.v2); if (t > wmax2) wmax2 = t; }

@@ -343,7 +343,13 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
 __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double dist, double m, double off, int lane, double& e0, double& e1c, double& e2c, double& dpl,
                                        bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr, const Dev* tic = nullptr) {
   capped = false;
+#ifdef TJ_PHASE_TIMING
+  long long prof[7] = {0, 0, 0, 0, 0, 0, 0};
+  const V3 v = gjk_wave(BodyHull{A}, BodyHull{Bq}, lane, gjk_iters, tic ? prof : nullptr);
+  if (tic && threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) for (int i = 0; i < 7; i++) tic->dbg[((size_t)K_OBS_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + i] = prof[i];
+#else
   const V3 v = gjk_wave(BodyHull{A}, BodyHull{Bq}, lane, gjk_iters);
+#endif
   TJ_ORDER(v.x);
   if (tic) TJ_TIC(*tic, K_SEP_SELF_SOLVE, 3);
   const double cn = norm3(v.x, v.y, v.z);
