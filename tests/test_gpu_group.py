@@ -77,3 +77,24 @@ def test_cli_devices_flag_gives_the_one_device_trajectory(scenes, tmp_path):
     assert out[0] == out[1]
     r = subprocess.run([os.path.join(ROOT, "traj-opt-admm_amd", "admmPathPlanning3D"), mesh, "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "does not shard" in r.stderr
+
+
+@pytest.mark.gpu
+def test_passing_long_pair_solves_on_changes_no_bit(pkg, scenes, monkeypatch):
+    """Large fleets: a lane stops its pair's GJK after 3 iterations and idle waves finish the pair with the wave-cooperative form
+    (sep_self_solve_body).  Which wave solves a pair must not matter: the state after several iterations is bitwise the one
+    of the run that keeps every pair on its lane (TJ_PAIR_PASS_ON=0), and the pairs counted as solved are the same."""
+    scene = scenes.crossing(256, 20000, seed=31, name="crossing-U256-pass-on")
+    monkeypatch.setenv("TJ_PAIR_PASS_ON", "0")
+    a = pkg.Solver(scene, stop=0.0)
+    monkeypatch.setenv("TJ_PAIR_PASS_ON", "1")
+    b = pkg.Solver(scene, stop=0.0)
+    a.iterate(5); b.iterate(5)
+    sa, sb = a.get_state(), b.get_state()
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), f"{n} differs when long pair solves are passed on"
+    ta, tb = a.stats(), b.stats()
+    assert ta["pair_solves"] == tb["pair_solves"] and ta["newton_iters"] == tb["newton_iters"]
+    assert ta["error_bits"] == 0 and tb["error_bits"] == 0
+    assert ta["pair_solves"] / 5 > 4096, "the scene must be in the one-pair-per-lane regime"
+    a.close(); b.close()

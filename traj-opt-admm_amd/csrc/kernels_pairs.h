@@ -223,7 +223,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     // counts itself done; no fence (= no L2 write-back) is needed anywhere.
     const int np = min(nwaves, (n + 63) / 64);            // waves that own a chunk of the list ("producers")
     const int nc = min(nwaves - np, PAIR_CONSUMERS_MAX);
-    const bool pass_on = 2 * np <= nwaves;
+    const bool pass_on = D.pair_pass_on && 2 * np <= nwaves;
     const int kcap = pass_on ? PAIR_LANE_GJK_CAP : 50;
     if (pass_on && bid >= np) {   // ---- consumer: the long solves, one per wave ----
       if (bid - np >= nc) return;

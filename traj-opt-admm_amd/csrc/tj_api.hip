@@ -450,6 +450,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   // plus a separate compaction launch is faster once there are more pieces than that (SCN-D: k_grad 109 -> 72 + 14 us)
   c->grad_fold = (d.u1 - d.u0) * d.P <= 512;
   if (const char* e = getenv("TJ_GRAD_FOLD")) c->grad_fold = atoi(e) != 0;
+  d.pair_pass_on = 1;
+  if (const char* e = getenv("TJ_PAIR_PASS_ON")) d.pair_pass_on = atoi(e) != 0;
   if (const char* e = getenv("TJ_SPLIT_UNIONS")) c->split_unions = atoi(e) != 0;
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
