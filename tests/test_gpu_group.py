@@ -98,3 +98,26 @@ def test_passing_long_pair_solves_on_changes_no_bit(pkg, scenes, monkeypatch):
     assert ta["error_bits"] == 0 and tb["error_bits"] == 0
     assert ta["pair_solves"] / 5 > 4096, "the scene must be in the one-pair-per-lane regime"
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}],
+                         ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
+    """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state
+    after several iterations is bitwise the default's.  (TJ_GRAD_NPL=8 forces k_grad's plane batches through several rounds and
+    its HBM staging path, TJ_GRAD_FOLD=0 the one-group k_grad behind a separate compaction.)"""
+    scene = scenes.crossing(24, 6000, seed=17, name="crossing-U24-switches")
+    for k in env:
+        monkeypatch.delenv(k, raising=False)
+    a = pkg.Solver(scene, stop=0.0)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    b = pkg.Solver(scene, stop=0.0)
+    a.iterate(6); b.iterate(6)
+    sa, sb = a.get_state(), b.get_state()
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), f"{n} differs with {env}"
+    assert a.stats()["error_bits"] == 0 and b.stats()["error_bits"] == 0
+    a.close(); b.close()
