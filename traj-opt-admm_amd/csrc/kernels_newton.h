@@ -561,6 +561,7 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     D.wolfe(u) = -w_;
     D.gn(u) = sqrt(g_);
     D.tdir(u) = x0[m];
+    if (!D.multi()) D.ctl->gnorm = sqrt(g_);   // single UAV (Optimization3D_admm.h:499): what k_ccd_self_seq would copy; the chain skips that launch
   }
 }
 
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(XB_THREADS) void k_xsolve_band(Dev D) {
     const int row = idx % T, a = idx / T;
     dir[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0;
   }
-  if (tid == 0) { D.wolfe(u) = -esum(scr, n); D.gn(u) = sqrt(esum(scr + n, n)); D.tdir(u) = y[m]; }
+  if (tid == 0) { D.wolfe(u) = -esum(scr, n); const double gnv = sqrt(esum(scr + n, n)); D.gn(u) = gnv; D.tdir(u) = y[m]; if (!D.multi()) D.ctl->gnorm = gnv; }
 }
 
 // Coupled mode, second half of the arrowhead solve: one wave per robot.  The Schur corner

@@ -176,7 +176,9 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d);
       return true;
     case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d); return true;
-    case K_CCD_SELF_SEQ: hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
+    case K_CCD_SELF_SEQ:
+      if (!multi && in_graph) return false;   // single UAV: no pairs to replay, and k_xsolve has left gnorm = |g| itself -- one launch less in the chain
+      hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
     case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED: if (coupled) for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r); return coupled;
