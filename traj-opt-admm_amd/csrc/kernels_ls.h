@@ -446,23 +446,31 @@ __device__ __forceinline__ double lsc_step0(const Dev& D, int tid, double t0, do
 }
 
 // wave 0 only: first acceptable candidate among rounds [0, nrounds), in the reference's order.  acc[0] = round
-// (-1 none), acc[1] = slot, accstep = its step.
-__device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double step0, int lane, int* acc, double* accstep) {
+// (-1 none), acc[1] = slot, accstep = its step.  stage: LDS scratch of 64 * LSC_ROUNDS * LS_GROUPS doubles.
+// The energies of 64 robots (all rounds: they are contiguous per robot) come in with ONE coalesced pass per chunk, then lane
+// (round, candidate) adds its column in robot order out of LDS -- the sum the reference forms (e += spline_energy(i)); one
+// lane per candidate walking the robots through global memory was 64 dependent round trips per round, in every block of four
+// launches per iteration.
+__device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double step0, int lane, int* acc, double* accstep, double* stage) {
   const double wolfe = D.ctl->wolfe_c;
-  const int c = lane % LS_GROUPS;
-  double e0 = 0;
+  constexpr int RC = LSC_ROUNDS * LS_GROUPS;   // 32 columns
+  const int r_l = lane / LS_GROUPS, c = lane % LS_GROUPS;
+  double tot = 0;
+  for (int u0 = 0; u0 < D.U; u0 += 64) {
+    const int nu = min(64, D.U - u0), nval = nu * RC;
+    blk_sync<true>();
+    for (int i = lane; i < nval; i += 64) stage[i] = D.ls_e[(size_t)u0 * RC + i];
+    blk_sync<true>();
+    if (lane < RC) for (int j = 0; j < nu; j++) tot += stage[j * RC + lane];
+  }
+  double step = step0;
+  if (lane < RC) { const int k = lsc_cand_k(r_l, c); for (int i = 0; i < k; i++) step *= 0.8; }
+  const double e0 = __shfl(tot, 0);
   int found_r = -1, found_c = 0; double found_step = step0;
   for (int r = 0; r < nrounds && found_r < 0; r++) {
-    double tot = 0, step = step0;
-    if (lane < LS_GROUPS) {
-      for (int u = 0; u < D.U; u++) tot += D.ls_e[((size_t)u * LSC_ROUNDS + r) * LS_GROUPS + c];  // e += spline_energy(i), robot order
-      const int k = lsc_cand_k(r, c);
-      for (int i = 0; i < k; i++) step *= 0.8;
-    }
-    if (r == 0) e0 = __shfl(tot, 0);
-    const bool ok = lane < LS_GROUPS && !(r == 0 && c == 0) && !(e0 - 1e-4 * wolfe * step < tot);
+    const bool ok = r_l == r && lane < RC && !(r == 0 && c == 0) && !(e0 - 1e-4 * wolfe * step < tot);
     const unsigned long long mask = __ballot(ok);
-    if (mask) { found_r = r; found_c = __ffsll((long long)mask) - 1; found_step = __shfl(step, found_c); }
+    if (mask) { const int l = __ffsll((long long)mask) - 1; found_r = r; found_c = l - r * LS_GROUPS; found_step = __shfl(step, l); }
   }
   if (lane == 0) { acc[0] = found_r; acc[1] = found_c; *accstep = found_step; }
 }
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   // the early exit needs every robot's energies of the earlier rounds: a sharded context (u1 - u0 < U) only has its own until
   // the all-gather after the last round, so it evaluates every round (same decision, taken by k_ls_commit on the gathered table)
   if (round > 0 && D.u1 - D.u0 == D.U) {
-    if (tid < 64) lsc_decide(D, round, step0, tid, s_acc, &s_accstep);
+    if (tid < 64) lsc_decide(D, round, step0, tid, s_acc, &s_accstep, sm);   // the dynamic LDS is not in use yet
     __syncthreads();
     if (s_acc[0] >= 0) return;  // an earlier round already holds the accepted step
   }
@@ -507,7 +515,8 @@ __global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, T = D.T;
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
-  lsc_decide(D, LSC_ROUNDS, step0, tid, s_acc, &s_accstep);
+  __shared__ double s_stage[64 * LSC_ROUNDS * LS_GROUPS];
+  lsc_decide(D, LSC_ROUNDS, step0, tid, s_acc, &s_accstep, s_stage);
   __syncthreads();
   double step = s_accstep;
   int kacc = s_acc[0] >= 0 ? lsc_cand_k(s_acc[0], s_acc[1]) : lsc_cand_k(LSC_ROUNDS - 1, LS_GROUPS - 1);
