@@ -53,6 +53,9 @@ struct Ctl {
   unsigned long long energy_evals;
   unsigned long long newton_iters, pair_solves;  // unused since the counters moved to Dev::pair_stats (kept for the layout)
   double wolfe_c;      // coupled mode: the global `wolfe` of update_spline (Optimization3D_multi.h:558)
+  // coupled mode, one context: the Armijo decision, taken once by the last block of an evaluation round (kernels_ls.h)
+  int lsf_epoch, lsf_r, lsf_c, ls_ticket;   // epoch it belongs to / accepted round and slot / arrival counter of the round's blocks
+  double lsf_step;
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)

@@ -451,6 +451,7 @@ __device__ __forceinline__ double lsc_step0(const Dev& D, int tid, double t0, do
 // (round, candidate) adds its column in robot order out of LDS -- the sum the reference forms (e += spline_energy(i)); one
 // lane per candidate walking the robots through global memory was 64 dependent round trips per round, in every block of four
 // launches per iteration.
+template <bool FRESH = false>   // FRESH: the table is being written by other blocks of THIS launch (agent-scope stores): read it past the caches
 __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double step0, int lane, int* acc, double* accstep, double* stage) {
   const double wolfe = D.ctl->wolfe_c;
   constexpr int RC = LSC_ROUNDS * LS_GROUPS;   // 32 columns
@@ -459,7 +460,7 @@ __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double ste
   for (int u0 = 0; u0 < D.U; u0 += 64) {
     const int nu = min(64, D.U - u0), nval = nu * RC;
     blk_sync<true>();
-    for (int i = lane; i < nval; i += 64) stage[i] = D.ls_e[(size_t)u0 * RC + i];
+    for (int i = lane; i < nval; i += 64) stage[i] = FRESH ? __hip_atomic_load(&D.ls_e[(size_t)u0 * RC + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : D.ls_e[(size_t)u0 * RC + i];
     blk_sync<true>();
     if (lane < RC) for (int j = 0; j < nu; j++) tot += stage[j * RC + lane];
   }
@@ -483,15 +484,15 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   __shared__ double s_step0, s_accstep;
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
   const int g = tid / LS_GSIZE, gl = tid % LS_GSIZE;
-  const double t_dir = D.tdir(u), t0 = D.piece_time[u];
-  const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
   // the early exit needs every robot's energies of the earlier rounds: a sharded context (u1 - u0 < U) only has its own until
   // the all-gather after the last round, so it evaluates every round (same decision, taken by k_ls_commit on the gathered table)
-  if (round > 0 && D.u1 - D.u0 == D.U) {
-    if (tid < 64) lsc_decide(D, round, step0, tid, s_acc, &s_accstep, sm);   // the dynamic LDS is not in use yet
-    __syncthreads();
-    if (s_acc[0] >= 0) return;  // an earlier round already holds the accepted step
-  }
+  // One context: the LAST block of a round to finish takes the decision over the rounds evaluated so far and leaves it in the
+  // control block; the launches of the later rounds (and the commit) read one word instead of every block re-deriving it.
+  const bool one_ctx = D.u1 - D.u0 == D.U;
+  const int epoch = D.ctl->epoch;
+  if (round > 0 && one_ctx && D.ctl->lsf_epoch == epoch) return;  // an earlier round already holds the accepted step
+  const double t_dir = D.tdir(u), t0 = D.piece_time[u];
+  const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
   bool in_lds;
   const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
   double* net = sm + L.net; double* dir = sm + L.dir;
@@ -504,7 +505,20 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
   __syncthreads();
   const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
-  if (gl == 0) D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + g] = e;
+  if (!one_ctx) { if (gl == 0) D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + g] = e; return; }
+  // write-through store, performed before this wave arrives at the barrier; then the block's ticket
+  if (gl == 0) __hip_atomic_store(&D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + g], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0);
+  __shared__ int s_last;
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&D.ctl->ls_ticket, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) D.ctl->ls_ticket = 0;
+  if (tid < 64) {
+    lsc_decide<true>(D, round + 1, step0, tid, s_acc, &s_accstep, sm);   // sm: the evaluation is over
+    if (tid == 0 && s_acc[0] >= 0) { D.ctl->lsf_r = s_acc[0]; D.ctl->lsf_c = s_acc[1]; D.ctl->lsf_step = s_accstep; D.ctl->lsf_epoch = epoch; }   // read by LATER kernels only
+  }
 }
 
 // commit: x_u += step d_u for every robot, the shared piece_time advances by step * t_direction
@@ -516,7 +530,9 @@ __global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
   __shared__ double s_stage[64 * LSC_ROUNDS * LS_GROUPS];
-  lsc_decide(D, LSC_ROUNDS, step0, tid, s_acc, &s_accstep, s_stage);
+  if (D.u1 - D.u0 == D.U) {   // one context: the last block of the deciding round left the decision (or none was acceptable)
+    if (tid == 0) { const bool f = D.ctl->lsf_epoch == D.ctl->epoch; s_acc[0] = f ? D.ctl->lsf_r : -1; s_acc[1] = f ? D.ctl->lsf_c : 0; s_accstep = f ? D.ctl->lsf_step : step0; }
+  } else lsc_decide(D, LSC_ROUNDS, step0, tid, s_acc, &s_accstep, s_stage);
   __syncthreads();
   double step = s_accstep;
   int kacc = s_acc[0] >= 0 ? lsc_cand_k(s_acc[0], s_acc[1]) : lsc_cand_k(LSC_ROUNDS - 1, LS_GROUPS - 1);
