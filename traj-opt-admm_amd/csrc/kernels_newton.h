@@ -842,10 +842,18 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve_c2(Dev D) {
   const double* gL = D.xL + (size_t)u * n * n;
   for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = gL[idx];
   for (int i = tid; i < n; i += XS_THREADS) { y[i] = D.xy[(size_t)u * n + i]; g0[i] = D.xg[(size_t)u * n + i]; }
-  if (tid < 3) {  // lane 0: corner, lane 1: rhs, lane 2: G_t -- sequential sums in robot order
+  {  // lane 0: corner, lane 1: rhs, lane 2: G_t -- sequential sums in robot order; the terms of 64 robots come in with one
+     // coalesced pass and are added out of LDS (one lane walking global memory was 64 dependent round trips)
+    __shared__ double s_cstage[256];
     double acc = 0;
-    for (int r = 0; r < D.U; r++) acc += D.xcorner[(size_t)r * 4 + tid];
-    s_red[tid] = acc;
+    for (int r0 = 0; r0 < D.U; r0 += 64) {
+      const int nr = min(64, D.U - r0);
+      blk_sync<true>();
+      for (int i = tid; i < 4 * nr; i += XS_THREADS) s_cstage[i] = D.xcorner[(size_t)r0 * 4 + i];
+      blk_sync<true>();
+      if (tid < 3) for (int r = 0; r < nr; r++) acc += s_cstage[4 * r + tid];
+    }
+    if (tid < 3) s_red[tid] = acc;
   }
   blk_sync<true>();
   const double corner = s_red[0], rhs = s_red[1];
@@ -853,7 +861,13 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve_c2(Dev D) {
   const double lc = pivot_rsqrt(corner);   // reciprocal root, like the rest of the FAST factor's diagonal
   if (tid == 0) { L[m * n + m] = lc; y[m] = rhs * lc; }
   blk_sync<true>();
-  chol_arrow_backsolve_lds<true, true>(L, n, XS_BAND, y, tid, XS_THREADS);
+  if (n <= 64) {   // the unrolled register form of k_xsolve (same operations as the LDS form)
+    double yv = y[min(tid, n - 1)];
+    yv = xs_backsolve(L, n, yv, tid);
+    blk_sync<true>();
+    if (tid < n) y[tid] = yv;
+    blk_sync<true>();
+  } else chol_arrow_backsolve_lds<true, true>(L, n, XS_BAND, y, tid, XS_THREADS);
   for (int i = tid; i < n; i += XS_THREADS) y[i] = -y[i];
   blk_sync<true>();
   for (int i = tid; i < m; i += XS_THREADS) { scr[i] = y[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
