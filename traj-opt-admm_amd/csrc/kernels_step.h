@@ -298,14 +298,23 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   for (int i = lane; i < D.U; i += 64) gns[i] = D.gn(i);
   __syncthreads();
   TJ_TIC(D, K_CCD_SELF_SEQ, 3);
+  double gt = 0, xg = 0;
+  if (D.coupled()) {   // per-robot terms of G_t and x0.G: fetched by the lanes (one round trip per 64 robots), added by lane 0 in robot order
+    __shared__ double s_cp[2][64];
+    for (int u0 = 0; u0 < D.U; u0 += 64) {
+      const int nu = min(64, D.U - u0);
+      __syncthreads();
+      if (lane < nu) { s_cp[0][lane] = D.xdir[(size_t)(u0 + lane) * D.xs + 3 * D.T + 3]; s_cp[1][lane] = D.wolfe(u0 + lane); }
+      __syncthreads();
+      if (lane == 0) for (int j = 0; j < nu; j++) { gt += s_cp[0][j]; xg += s_cp[1][j]; }
+    }
+  }
   if (lane == 0) {
     double gsum = 0;
     for (int u = 0; u < D.U; u++) gsum += gns[u];
     if (D.coupled()) {
       // gnorm = |G| / uav_num and wolfe = -x0.G over the whole arrowhead system (Optimization3D_multi.h:558,580);
       // k_xsolve_c2 left per-robot partial sums, the shared-time entries are added here
-      double gt = 0, xg = 0;
-      for (int u = 0; u < D.U; u++) { gt += D.xdir[(size_t)u * D.xs + 3 * D.T + 3]; xg += D.wolfe(u); }
       D.ctl->gnorm = sqrt(gsum + gt * gt) / double(D.U);
       D.ctl->wolfe_c = -(xg + D.tdir(0) * gt);
     } else D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : gns[0];
