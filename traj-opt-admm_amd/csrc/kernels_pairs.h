@@ -278,6 +278,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         if (cut) {   // pass the pair on NOW (the consumers start while this wave's other lanes refine their offsets): slot from a returning add, then the tagged entry
           const int slot = atomicAdd(&D.pair_ovf[0], 1);
           if (slot < D.cap_work) __hip_atomic_store(&D.pair_ovf_list[slot], ((unsigned long long)(unsigned)epoch << 32) | (unsigned long long)(tr | (p0 << 9) | (q << 19)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);   // cannot happen (the list holds cap_work entries and there are at most that many pairs); never drop a pair silently
         }
         if (!cut && plane_pair_finish(vw, Ag, Bg, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
           nit_sum += (unsigned long long)nit; solved++; any_capped = any_capped || capped;
