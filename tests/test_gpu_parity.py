@@ -439,3 +439,33 @@ def test_ragged_fleet_sizes_pair_tiles_vs_oracle(pkg, scenes, U, rows, monkeypat
     st = s.stats()
     assert st["error_bits"] == 0 and st["order_unresolved"] == 0
     s.close()
+
+
+@pytest.mark.gpu
+def test_min_eigenvalue_of_graded_and_clustered_matrices(katsolver):
+    """The Sturm test runs in PRODUCT form (leading principal minors, rescaled by exponents): matrices whose spectrum spans many
+    orders of magnitude, is clustered, or has exactly repeated eigenvalues must neither underflow to a false 'not positive
+    definite' nor lose the smallest eigenvalue.  Against numpy's eigvalsh, 1e-12 of the norm (the bar of the golden set); the
+    register and the LDS routine are both behind the hook (out[:, 0] == 2 flags a disagreement between them)."""
+    rng = np.random.default_rng(2024)
+    mats = []
+    for k in range(96):
+        q, _ = np.linalg.qr(rng.standard_normal((19, 19)))
+        kind = k % 6
+        if kind == 0:   ev = 10.0 ** rng.uniform(-12, 6, 19)                              # graded, positive
+        elif kind == 1: ev = np.concatenate([-10.0 ** rng.uniform(-9, 2, 3), 10.0 ** rng.uniform(-6, 8, 16)])   # a few negative ones
+        elif kind == 2: ev = np.concatenate([[1.0] * 9, [1.0 + 1e-13] * 9, [-3e-7]])       # clusters
+        elif kind == 3: ev = np.concatenate([[2.5] * 18, [2.5]])                           # scalar matrix
+        elif kind == 4: ev = 1e12 * (1.0 + 1e-10 * rng.standard_normal(19))                # huge and nearly equal
+        else:           ev = np.concatenate([[0.0] * 5, 10.0 ** rng.uniform(-3, 3, 14)])   # singular
+        a = (q * ev) @ q.T
+        mats.append(0.5 * (a + a.T))
+    mats.append(np.diag(10.0 ** np.linspace(-150, 150, 19)))      # already diagonal, 300 orders of magnitude
+    mats.append(np.zeros((19, 19)))
+    mats = np.array(mats)
+    out = katsolver.kat_linalg(mats)
+    want = np.array([np.linalg.eigvalsh(m)[0] for m in mats])
+    scale = np.abs(mats).max(axis=(1, 2))
+    assert (out[:, 0] != 2.0).all(), "register and LDS eigenvalue routines disagree"
+    err = np.abs(out[:, 1] - want)
+    assert (err <= 1e-12 * np.maximum(scale, 1e-300) + 1e-300).all(), (int(np.argmax(err / np.maximum(scale, 1e-300))), err.max())
