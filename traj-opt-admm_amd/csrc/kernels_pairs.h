@@ -79,6 +79,7 @@ __host__ __device__ inline void pair_unit(int U, int R, int bid, int& tr, int& r
 constexpr int PAIR_CONSUMERS_MAX = 4096;            // bound on the waves that wait for passed-on pairs (all idle pair waves do: with 512 of them k_mid took 74 us on SCN-D, with 864 65)
 constexpr unsigned long long PAIR_OVF_STOP = 1ull << 31;   // entry flag: the list ends here
 constexpr int PAIR_LANE_GJK_CAP = 3;   // GJK iterations a lane spends on its pair before passing it on (large fleets, see sep_self_solve_body; 2 .. 4 measured alike, 8 slower)
+constexpr int PT_FLIGHT = 8;   // pairs whose interval records a tile fetches together
 constexpr int PAIR_ROWS_MAX = 16;
 constexpr int PAIR_TILE_CAP = PAIR_ROWS_MAX * 64;
 
@@ -144,18 +145,18 @@ __device__ __forceinline__ int pair_tile_filter(const double* segbox, int U, int
   if (n == 0) return 0;
   const int ax = min(lane, 48);
   int m = 0;
-  for (int base = 0; base < n; base += 4) {
-    int pr[4]; double alo[4], ahi[4], blo[4], bhi[4];
+  for (int base = 0; base < n; base += PT_FLIGHT) {
+    int pr[PT_FLIGHT]; double alo[PT_FLIGHT], ahi[PT_FLIGHT], blo[PT_FLIGHT], bhi[PT_FLIGHT];
 #pragma unroll
-    for (int c = 0; c < 4; c++) pr[c] = list[min(base + c, n - 1)];
+    for (int c = 0; c < PT_FLIGHT; c++) pr[c] = list[min(base + c, n - 1)];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < PT_FLIGHT; c++) {
       const double* a = rec(pr[c] >> 16); const double* b = rec(pr[c] & 0xffff);
       alo[c] = a[LO + ax]; ahi[c] = a[HI + ax]; blo[c] = b[LO + ax]; bhi[c] = b[HI + ax];
     }
     blk_sync<true>();   // every lane has read this batch's list entries before the compaction overwrites earlier slots
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < PT_FLIGHT; c++) {
       if (base + c >= n) break;
       const bool sep = lane < 49 && (bhi[c] < alo[c] - d || ahi[c] < blo[c] - d);
       if (ballot(sep) == 0ull) {
