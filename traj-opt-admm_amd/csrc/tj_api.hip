@@ -417,7 +417,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_self = p->cap_self > 0 ? p->cap_self : std::max(1, std::min(d.U - 1, 64));  // neighbours within offset + 2 margin of ONE segment; k_grad's LDS grows with it
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
   d.optimal_plane = p->optimal_plane ? 1 : 0;
-  d.pair_rows = 16;   // measured best at 64 and at 256 robots (2, 4, 8 are within 10 %)
+  d.pair_rows = d.U <= 128 ? 8 : 16;   // tile height: 64 robots -- 8 rows: k_front 13.3 -> 12.5 us, k_ccd 9.6 -> 8.7 (with eight interval records in flight); 256 robots -- 16 rows (8: +1.3 us, 4: +13)
   if (const char* e = getenv("TJ_PAIR_ROWS")) { const int r = atoi(e); if (r == 2 || r == 4 || r == 8 || r == 16) d.pair_rows = r; }
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
