@@ -11,8 +11,10 @@
 // instruction count per pivot, not parallel width: each lane owns a fixed handful of positions of
 // the (bw+1)^2/2 update window, the scaled pivot column is exchanged through a 19-word LDS vector,
 // and the right-hand side rides along as one more row so that the forward substitution costs no
-// extra dependent steps.  Every entry sees exactly the subtraction sequence of the scalar
-// left-looking loop (CPU oracle / Eigen's unblocked LLT), i.e. results are bit-identical to it.
+// extra dependent steps.  Two arithmetic forms (template flag FAST): the EXACT one (IEEE sqrt / division, unfused a - l*l)
+// gives every entry the subtraction sequence of the scalar left-looking loop -- bit-identical to the CPU oracle / Eigen's
+// unblocked LLT, kept wherever a pass/fail decision is pinned to it -- and the FAST one of the x-update's big systems
+// (reciprocal root, fma; see pivot_rsqrt), whose register, LDS and band variants agree with each other bit for bit.
 #pragma once
 #include "dev_common.h"
 

@@ -10,12 +10,13 @@
 //             fallback, solve, wolfe and |g|.  Replaces spline_descent_direction
 //             (Optimization3D_multi.h:659-752, Optimization3D_admm.h:400-503).
 //
-// GPU shape: one thread owns one lower-triangle Hessian entry and walks the (control point,
-// plane) terms in the reference's order, so every entry is accumulated in exactly the sequence
-// the reference uses -- no atomics, no reduction trees, bitwise reproducible.  Barrier
-// derivatives (the only transcendental work) are computed once per (plane, control point) by
-// the whole block and staged through LDS.  The Kronecker selector matrices A_list / A_vel_list /
-// A_acc_list of the reference are never formed: A[tr][j] * c == basis(j,:)^T (x) c.
+// GPU shape: one thread owns one lower-triangle Hessian entry (or gradient entry); no atomics, no reduction trees, so a
+// result is a function of the inputs alone (bitwise reproducible, and identical in both launch forms).  Barrier derivatives
+// (the only transcendental work) are computed once per (plane, control point) by the whole block and staged through LDS; the
+// planes of a segment then enter an entry only through the per-control-point sums M_j = sum_k e2 n n^T and v_j = sum_k e1 n
+// (grad_plane_batch), the velocity / acceleration terms through one 3x3 matrix per record (grad_velacc_records) -- the
+// reference's double sums with the inner sum taken first.  The Kronecker selector matrices A_list / A_vel_list / A_acc_list
+// of the reference are never formed: A[tr][j] * c == basis(j,:)^T (x) c.
 #pragma once
 #include "dev_common.h"
 #include "dev_linalg.h"
