@@ -572,8 +572,10 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   else sep_self_rows_body(D, blockIdx.x - n_obs, lds);
   TJ_TIC(D, K_FRONT, 1);
 }
-// two waves per SIMD (<= 256 VGPRs): all 320 + 1024 + 512 blocks of SCN-C are resident at once; at the natural 340 VGPRs a
-// third of them started only when an earlier block had finished, 18-33 us into the kernel
+// two waves per SIMD (<= 256 VGPRs; 244 used, no spills since the slack body was rewritten): 2 048 one-wave blocks are resident
+// at once -- on SCN-C the 320 slack blocks, the 1 024 pair waves and the first 704 of the 1 024 obstacle-solve waves (its ~250
+// candidates all fall to those); the rest follow as slack blocks retire after ~13 us.  At the natural 340 VGPRs of round 1 a
+// third of the blocks started only when an earlier one had finished, 18-33 us into the kernel.
 template <int PRIM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
   const int n_slack = (D.u1 - D.u0) * D.P;
