@@ -328,18 +328,13 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
 
   TJ_TIC(D, K_GRAD, 3);
   // ---- scale by lambda, add consensus + dual terms (Gradient_admm.h:132-163) ----
+  // The Hessian first: it needs nothing from the slack / dual blocks, and the LLT check and the eigenvalue wave wait for it.
+  // The gradient's consensus and dual terms (two global round trips for z and Lambda) are formed by wave 2 -- which holds all
+  // gradient entries -- WHILE waves 0 and 1 run the check and the eigenvalue.
   const double* C = D.convert + (size_t)sp * 36;
   const int P6 = 6 * D.P;
-  double* delta = scr;          // [18] col-major 6x3: C x - z   (scr reused later)
+  double* delta = scr;          // [18] col-major 6x3: C x - z
   double* lamb = scr + 18;      // [18]
-  if (tid < 18) {
-    const int j = tid % 6, a = tid / 6;
-    double acc = 0;
-    for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + D.T * a];
-    delta[j + 6 * a] = acc - D.p_slack[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
-    lamb[j + 6 * a] = D.p_lambda[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
-  }
-  __syncthreads();
   if (hi_ >= 0) {
     double h = Hacc * D.lambda;
     if (qi == qk) {
@@ -349,16 +344,11 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     }
     H[hi_ * 19 + hk_] = h; H[hk_ * 19 + hi_] = h;
   } else if (vr >= 0) {
-    double x1 = 0, x2 = 0;
-    for (int j = 0; j < 6; j++) { x1 += C[j * 6 + av] * delta[j + 6 * qv]; x2 += C[j * 6 + av] * lamb[j + 6 * qv]; }
-    g[vr] = gacc * D.lambda + (D.mu * x1 + x2);
     const double pc_ = pacc * D.lambda;
     H[vr * 19 + 18] = pc_; H[18 * 19 + vr] = pc_;
   } else if (scal) {
-    g[18] = gt * D.lambda + (D.mu * (pt - D.t_slack[u * D.P + sp]) + D.t_lambda[u * D.P + sp]);
     H[18 * 19 + 18] = ht * D.lambda + D.mu;
   }
-  __syncthreads();
 
   TJ_TIC(D, K_GRAD, 4);
   // ---- PSD repair: only if LLT fails and lambda_min < 0 (Gradient_admm.h:38-53) ----
@@ -370,6 +360,24 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   __shared__ double s_ev;
   if (tid == 0) s_llt = -1;
   __syncthreads();
+  if (tid >= 128) {   // wave 2: gradient entries 171..189 live here
+    const int t2 = tid - 128;
+    if (t2 < 18) {
+      const int j = t2 % 6, a = t2 / 6;
+      double acc = 0;
+      for (int k = 0; k < 6; k++) acc += C[j * 6 + k] * net[sp * 3 + k + D.T * a];
+      delta[j + 6 * a] = acc - D.p_slack[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
+      lamb[j + 6 * a] = D.p_lambda[(size_t)u * 3 * P6 + sp * 6 + j + P6 * a];
+    }
+    blk_sync<true>();
+    if (vr >= 0) {
+      double x1 = 0, x2 = 0;
+      for (int j = 0; j < 6; j++) { x1 += C[j * 6 + av] * delta[j + 6 * qv]; x2 += C[j * 6 + av] * lamb[j + 6 * qv]; }
+      g[vr] = gacc * D.lambda + (D.mu * x1 + x2);
+    } else if (scal) {
+      g[18] = gt * D.lambda + (D.mu * (pt - D.t_slack[u * D.P + sp]) + D.t_lambda[u * D.P + sp]);
+    }
+  }
   if (tid < 128) {
     double r[19];
     const int row = min(tid & 63, 18);
