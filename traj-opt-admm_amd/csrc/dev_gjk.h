@@ -490,14 +490,125 @@ __device__ __forceinline__ void gjk_tet_wave(Simplex& s, int lane) {
   }
 }
 
+// ---- wave-UNIFORM control -----------------------------------------------------------------------------------------------
+// One wave issues one instruction every 4-5 cycles whatever its lanes do, so a query that owns a wave is bound by its
+// instruction COUNT.  The per-lane routines above, called with wave-uniform operands, still pay for divergence the compiler has
+// to assume: exec-mask bookkeeping around every branch, whole-simplex copies at every merge, select chains instead of moves
+// (a triangle step that ends on an edge was ~700 issued instructions, 1.5 us).  The routines below take every decision on a
+// scalar condition (`uni`: ballot != 0), specialise the projection plane of a triangle step by a scalar switch, move vertices
+// only on the path that needs it, track the sticky supports as LANE INDICES (no base dot products, no value selects), and
+// solve the three edges a triangle step may fall back to speculatively on three lanes of ONE straight-line instruction stream
+// (seg_core) next to the cofactor / normal chain.  Every floating-point expression is the one gjk_seg / gjk_tri evaluate, on
+// the same operands, in the same association -- the witness vector is bit-identical (tests/golden/gjk_kat.npz, tri_kat.npz).
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }   // c is wave-uniform: make it a scalar condition
+__device__ __forceinline__ double flip_sign(double x, unsigned sgn) { return __hiloint2double(__double2hiint(x) ^ (int)sgn, __double2loint(x)); }
+
+// gjk_seg (openGJK.c:82-163) as straight-line code on per-lane operands {v0 = B = X, v1 = A = Y}:
+//   ec = 0: both vertices stay, weights (l0, l1);  ec = 1: only A supports (v0 = v1, weight 1);  ec = 2: only B (weight 1)
+__device__ __forceinline__ void seg_core(const V3& b, const V3& a, int& ec, double& l0, double& l1) {
+  const V3 t{b.x - a.x, b.y - a.y, b.z - a.z};
+  const double f0 = fabs(t.x), f1 = fabs(t.y), f2 = fabs(t.z);
+  const bool g01 = f0 > f1, l01 = f0 < f1;
+  const bool is0 = g01 && (f0 > f2);
+  const bool is2 = (g01 && !(f0 > f2)) || (!g01 && l01 && !(f1 > f2)) || (!g01 && !l01 && ((f0 < f2) || (f1 < f2)));
+  const double aI = is0 ? a.x : (is2 ? a.z : a.y), bI = is0 ? b.x : (is2 ? b.z : b.y), tI = is0 ? t.x : (is2 ? t.z : t.y);
+  const double pt = dot(b, t) / dot(t, t) * (aI - bI) + bI;
+  const double det_ap = aI - pt, det_pb = pt - bI;
+  const bool F0 = same_sign(tI, -1 * det_ap), F1 = same_sign(tI, -1 * det_pb);
+  const double q = det_ap * -1.0 / tI;
+  ec = (F0 && F1) ? 0 : (!F0 ? 1 : 2);
+  l0 = (F0 && F1) ? q : 1.0;
+  l1 = 1 - q;
+}
+
+// triangle {v0 = C, v1 = B, v2 = A} (openGJK.c:168-393) on wave-uniform operands; labels are not kept (nothing above the
+// sub-algorithm reads them)
+__device__ __forceinline__ void gjk_tri_uni(Simplex& s, int lane) {
+  const V3 c = s.v0, b = s.v1, a = s.v2;
+  // the three edges, one per lane (lane & 3 = 0: {B,A}, 1: {C,A}, 2 and 3: {C,B}); consumed only if the origin is outside the face
+  const int e = lane & 3;
+  int ec; double eq0, eq1;
+  seg_core(sel3(e == 0, b, c), sel3(e >= 2, b, a), ec, eq0, eq1);
+  const V3 s21{b.x - a.x, b.y - a.y, b.z - a.z}, s31{c.x - a.x, c.y - a.y, c.z - a.z};
+  const double nu0 = 1.0 * (b.y * c.z + a.y * b.z + c.y * a.z - b.y * a.z - c.y * b.z - a.y * c.z);
+  const double nu1 = -1.0 * (b.z * c.x + a.z * b.x + c.z * a.x - b.z * a.x - c.z * b.x - a.z * c.x);
+  const double nu2 = 1.0 * (b.x * c.y + a.x * b.y + c.x * a.y - b.x * a.y - c.x * b.y - a.x * c.y);
+  const double f0 = fabs(nu0), f1 = fabs(nu1), f2 = fabs(nu2);
+  // projection plane: 0 = drop x (J = y,z), 1 = drop y (J = x,z), 2 = drop z (J = x,y), 3 = the reference's fall-through
+  // (I = 1 with J0 = -1, an out-of-bounds read that yields 0 -- oracle/orc_gjk.cpp -- and J1 = 0)
+  int proj;
+  if (uni(f0 > f1)) proj = uni(f0 > f2) ? 0 : 2;
+  else if (uni(f0 < f1)) proj = uni(f1 > f2) ? 1 : 2;
+  else proj = uni(f0 < f2) ? 2 : 3;
+  const double nu_max = proj == 0 ? nu0 : (proj == 2 ? nu2 : nu1);
+  V3 n;
+  double nn = 0;
+  n.x = s21.y * s31.z - s21.z * s31.y; nn += n.x * n.x;
+  n.y = s21.z * s31.x - s21.x * s31.z; nn += n.y * n.y;
+  n.z = s21.x * s31.y - s21.y * s31.x; nn += n.z * n.z;
+  const double inv_len = 1 / sqrt(nn);
+  n.x = n.x * inv_len; n.y = n.y * inv_len; n.z = n.z * inv_len;
+  const double dna = dot(n, a);
+  double B0, B1, B2;
+  auto Bs = [&](double nJ0, double nJ1, double sa0, double sa1, double sb0, double sb1, double sc0, double sc1) {
+    const double pp0 = dna * nJ0, pp1 = dna * nJ1;
+    B0 = pp0 * sb1 + pp1 * sc0 + sb0 * sc1 - pp0 * sc1 - pp1 * sb0 - sc0 * sb1;
+    B1 = pp0 * sc1 + pp1 * sa0 + sc0 * sa1 - pp0 * sa1 - pp1 * sc0 - sa0 * sc1;
+    B2 = pp0 * sa1 + pp1 * sb0 + sa0 * sb1 - pp0 * sb1 - pp1 * sa0 - sb0 * sa1;
+  };
+  if (proj == 0) Bs(n.y, n.z, a.y, a.z, b.y, b.z, c.y, c.z);
+  else if (proj == 1) Bs(n.x, n.z, a.x, a.z, b.x, b.z, c.x, c.z);
+  else if (proj == 2) Bs(n.x, n.y, a.x, a.y, b.x, b.y, c.x, c.y);
+  else Bs(0.0, n.x, 0.0, a.x, 0.0, b.x, 0.0, c.x);
+  const bool pos = uni(nu_max > 0);
+  const int F0 = uni(B0 > 0) == pos, F1 = uni(B1 > 0) == pos, F2 = uni(B2 > 0) == pos;
+  const bool both = F1 + F2 == 0 || uni(isnan(n.x));
+  if (!both && F0 + F1 + F2 == 3) {
+    const double inv = 1 / nu_max;
+    s.l0 = B2 * inv; s.l1 = B1 * inv; s.l2 = 1 - s.l0 - s.l1;
+    s.n = 3;
+    return;
+  }
+  // edge that becomes the simplex: {B,A} if only F2 failed; {C,A} if F1 failed (or, `both`, after {B,A} went to the auxiliary
+  // simplex); {C,B} otherwise
+  const int lane_cur = both ? 1 : (F2 == 0 ? 0 : (F1 == 0 ? 1 : 2));
+  const int cc = __builtin_amdgcn_readlane(ec, lane_cur);
+  const double q0 = gjk_rl(eq0, lane_cur), q1 = gjk_rl(eq1, lane_cur);
+  if (lane_cur == 0) { s.v0 = b; s.v1 = a; } else if (lane_cur == 1) s.v1 = a;   // {C,B} is in place
+  if (cc == 1) s.v0 = s.v1;
+  s.n = cc == 0 ? 2 : 1; s.l0 = q0; s.l1 = q1;
+  if (both) {   // keep the closer of the two edges' points; if the auxiliary one wins, its count and weights are taken but the vertices stay (reference quirk)
+    const int ca = __builtin_amdgcn_readlane(ec, 0);
+    const double a0 = gjk_rl(eq0, 0), a1 = gjk_rl(eq1, 0);
+    const V3 av0 = ca == 1 ? a : b;
+    V3 vt{0, 0, 0};
+    vt.x += a0 * av0.x; vt.y += a0 * av0.y; vt.z += a0 * av0.z;
+    if (ca == 0) { vt.x += a1 * a.x; vt.y += a1 * a.y; vt.z += a1 * a.z; }
+    const V3 v = sx_point(s);
+    if (!uni(dot(v, v) < dot(vt, vt))) { s.n = ca == 0 ? 2 : 1; s.l0 = a0; if (ca == 0) s.l1 = a1; }
+  }
+}
+
 // witness vector of conv(b1) - conv(b2), computed by the whole wave; all lanes must call it with the same bodies
 // and all lanes return the same vector
 template <class B1, class B2>
 __device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int* iters_out = nullptr, long long* prof = nullptr) {   // prof (timing builds): [0] support, [1..3] segment / triangle / tetrahedron steps (100 MHz ticks), [4..6] their counts
+  static_assert(B1::N <= 16 && B2::N <= 16, "one body per row of 16 lanes");
   const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
+  // lanes 0..15 hold the vertices of body 1, lanes 16..31 those of body 2, once for the whole query
+  const bool row1 = lane < 16, row2 = lane >= 16 && lane < 32;
+  const int idx = lane & 15;
+  const bool valid = (row1 && idx < B1::N) || (row2 && idx < B2::N);
+  V3 p{0, 0, 0};
+  if (row1 && idx < B1::N) p = b1.get(idx);
+  if (row2 && idx < B2::N) p = b2.get(idx);
+  const unsigned sgn = row1 ? 0x80000000u : 0u;   // body 1 is searched along -v, body 2 along v
+  // the sticky supports as lane indices: a support is always a vertex of its body, and dot(vertex, dir) of the kept one is
+  // bit for bit the `best` the reference starts its scan with -- so "some vertex is strictly better" == "the kept lane is not
+  // among the lanes that attain the row maximum", and then the FIRST such lane wins (openGJK.c:714-737)
+  int c1 = 0, c2 = 16;
   Simplex s;
-  V3 s1 = b1.get(0), s2 = b2.get(0);
-  V3 v{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
+  V3 v{gjk_rl(p.x, 0) - gjk_rl(p.x, 16), gjk_rl(p.y, 0) - gjk_rl(p.y, 16), gjk_rl(p.z, 0) - gjk_rl(p.z, 16)};
   s.n = 1; s.v0 = v;
   s.v1 = s.v2 = s.v3 = V3{0, 0, 0};
   s.w0 = s.w1 = s.w2 = s.w3 = 0; s.l0 = s.l1 = s.l2 = s.l3 = 0;
@@ -505,31 +616,48 @@ __device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int
   int k = 0;
   do {
     k++;
-    const V3 vm{-v.x, -v.y, -v.z};
 #ifdef TJ_PHASE_TIMING
     const long long tp0 = prof ? wall_clock64() : 0;
 #endif
-    support_wave(b1, b2, vm, v, s1, s2, lane);
-    const V3 w{s1.x - s2.x, s1.y - s2.y, s1.z - s2.z};
-    if ((sq(v) - dot(v, w)) <= eps_rel2 * sq(v)) break;
-    if (sq(v) < eps_rel2) break;
-    sx_set_v(s, s.n, w);
-    s.n++;
+    const double sd0 = p.x * flip_sign(v.x, sgn) + p.y * flip_sign(v.y, sgn) + p.z * flip_sign(v.z, sgn);
+    const double sd = valid ? sd0 : -INFINITY;
+    const double m = gjk_row_max(sd);
+    const unsigned long long hit = __ballot(valid && sd == m);
+    const unsigned h1 = (unsigned)(hit & 0xFFFFull), h2 = (unsigned)((hit >> 16) & 0xFFFFull);
+    if (h1 && !((h1 >> c1) & 1u)) c1 = __ffs(h1) - 1;
+    if (h2 && !((h2 >> (c2 - 16)) & 1u)) c2 = 16 + __ffs(h2) - 1;
+    const V3 w{gjk_rl(p.x, c1) - gjk_rl(p.x, c2), gjk_rl(p.y, c1) - gjk_rl(p.y, c2), gjk_rl(p.z, c1) - gjk_rl(p.z, c2)};
+    if (uni((sq(v) - dot(v, w)) <= eps_rel2 * sq(v))) break;
+    if (uni(sq(v) < eps_rel2)) break;
 #ifdef TJ_PHASE_TIMING
-    const int kind = s.n - 1;
-    asm volatile("" :: "v"(s.v0.x), "v"(s.v1.x));
+    const int kind = s.n;
+    asm volatile("" :: "v"(w.x), "v"(w.y));
     const long long tp1 = prof ? wall_clock64() : 0;
 #endif
-    if (s.n == 4) gjk_tet_wave(s, lane); else if (s.n == 3) gjk_tri(s); else gjk_seg(s);
+    if (s.n == 1) {
+      s.v1 = w;
+      int ec; double q0, q1;
+      seg_core(s.v0, s.v1, ec, q0, q1);
+      const int cc = __builtin_amdgcn_readfirstlane(ec);
+      if (cc == 1) s.v0 = s.v1;
+      s.n = cc == 0 ? 2 : 1; s.l0 = q0; s.l1 = q1;
+    } else if (s.n == 2) {
+      s.v2 = w;
+      gjk_tri_uni(s, lane);
+    } else {
+      s.v3 = w; s.n = 4;
+      gjk_tet_wave(s, lane);
+      s.n = __builtin_amdgcn_readfirstlane(s.n);
+    }
     v = sx_point(s);
 #ifdef TJ_PHASE_TIMING
     if (prof) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z)); const long long tp2 = wall_clock64(); prof[0] += tp1 - tp0; prof[kind] += tp2 - tp1; prof[3 + kind] += 1; }
 #endif
-    { double t = sq(s.v0); if (t > wmax2) wmax2 = t; }
-    if (s.n > 1) { double t = sq(s.v1); if (t > wmax2) wmax2 = t; }
-    if (s.n > 2) { double t = sq(s.v2); if (t > wmax2) wmax2 = t; }
-    if (s.n > 3) { double t = sq(s.v3); if (t > wmax2) wmax2 = t; }
-    if (sq(v) <= (eps_tot * eps_tot * wmax2)) break;
+    { double t = sq(s.v0); if (uni(t > wmax2)) wmax2 = t; }
+    if (s.n > 1) { double t = sq(s.v1); if (uni(t > wmax2)) wmax2 = t; }
+    if (s.n > 2) { double t = sq(s.v2); if (uni(t > wmax2)) wmax2 = t; }
+    if (s.n > 3) { double t = sq(s.v3); if (uni(t > wmax2)) wmax2 = t; }
+    if (uni(sq(v) <= (eps_tot * eps_tot * wmax2))) break;
   } while ((s.n != 4) && (k != 50));
   if (iters_out) *iters_out = k;
   return v;
