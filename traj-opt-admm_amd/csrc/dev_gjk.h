@@ -353,11 +353,19 @@ __device__ __forceinline__ double gjk_dpp(double v) {
   return __hiloint2double(hi, lo);
 }
 // maximum over each row of 16 lanes, left in every lane of the row (NaNs are ignored like the `>` test does)
+// Every lane of a row is a valid DPP source for these controls, so the moves need no `old` operand (no copy in front of them),
+// and the maximum is the bare instruction: fmax() would first quiet a signalling NaN of the shuffled operand -- one more
+// v_max_f64 per step on a chain of four.
+template <int CTRL>
+__device__ __forceinline__ double gjk_dpp_mov(double v) {
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false), __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double gjk_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double gjk_row_max(double v) {
-  v = fmax(v, gjk_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = fmax(v, gjk_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = fmax(v, gjk_dpp<0x124>(v));  // row_ror:4
-  v = fmax(v, gjk_dpp<0x128>(v));  // row_ror:8
+  v = gjk_vmax(v, gjk_dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = gjk_vmax(v, gjk_dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = gjk_vmax(v, gjk_dpp_mov<0x124>(v));  // row_ror:4
+  v = gjk_vmax(v, gjk_dpp_mov<0x128>(v));  // row_ror:8
   return v;
 }
 
@@ -508,16 +516,16 @@ __device__ __forceinline__ double flip_sign(double x, unsigned sgn) { return __h
 __device__ __forceinline__ void seg_core(const V3& b, const V3& a, int& ec, double& l0, double& l1) {
   const V3 t{b.x - a.x, b.y - a.y, b.z - a.z};
   const double f0 = fabs(t.x), f1 = fabs(t.y), f2 = fabs(t.z);
-  const bool g01 = f0 > f1, l01 = f0 < f1;
-  const bool is0 = g01 && (f0 > f2);
-  const bool is2 = (g01 && !(f0 > f2)) || (!g01 && l01 && !(f1 > f2)) || (!g01 && !l01 && ((f0 < f2) || (f1 < f2)));
+  const bool g01 = f0 > f1, l01 = f0 < f1, g02 = f0 > f2, g12 = f1 > f2, l02 = f0 < f2, l12 = f1 < f2;   // mask arithmetic, no branches
+  const bool is0 = g01 & g02;
+  const bool is2 = (g01 & !g02) | (!g01 & l01 & !g12) | (!g01 & !l01 & (l02 | l12));
   const double aI = is0 ? a.x : (is2 ? a.z : a.y), bI = is0 ? b.x : (is2 ? b.z : b.y), tI = is0 ? t.x : (is2 ? t.z : t.y);
   const double pt = dot(b, t) / dot(t, t) * (aI - bI) + bI;
   const double det_ap = aI - pt, det_pb = pt - bI;
   const bool F0 = same_sign(tI, -1 * det_ap), F1 = same_sign(tI, -1 * det_pb);
   const double q = det_ap * -1.0 / tI;
-  ec = (F0 && F1) ? 0 : (!F0 ? 1 : 2);
-  l0 = (F0 && F1) ? q : 1.0;
+  ec = (F0 & F1) ? 0 : (!F0 ? 1 : 2);
+  l0 = (F0 & F1) ? q : 1.0;
   l1 = 1 - q;
 }
 

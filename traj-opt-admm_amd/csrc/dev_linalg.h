@@ -178,7 +178,11 @@ __device__ __forceinline__ bool chol_check_wave(double (&r)[N]) {
 // bit-identical to it -- but a pivot is ~75 straight-line instructions (v_readlane broadcasts, no LDS round trip, no
 // barrier) instead of three LDS round trips.  Pattern: half-bandwidth BW plus a dense last row.  npiv = N - 1 leaves the Schur
 // complement of the last diagonal entry in lane N-1 (see chol_arrow_lds).  Returns false on a pivot <= 0.
-template <int N, int BW>
+// PIECES: the system is the x-update's (k_xsolve): band row i is reduced coordinate i + 6 of a chain of 18-coordinate piece
+// blocks that overlap by 9, so column k meets rows up to 9 * ((k + 6) / 9) + 11 only -- 17 - (k + 6) % 9 of them, 13 on
+// average, not BW = 17.  The entries beyond are structural zeros (never filled); their updates fma(-0 * x, ., a) are skipped,
+// which leaves every stored value unchanged (up to the sign of an exact zero).
+template <int N, int BW, bool PIECES = false>
 __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int lane, int npiv) {
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -190,7 +194,9 @@ __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int l
     const double yk = readlane_f64(y, k) * rs;
     r[k] = lane == k ? rs : lik;
     constexpr int LAST = N - 1;
-    const int jhi = (k + BW < LAST - 1) ? k + BW : LAST - 1;
+    const int jband = (k + BW < LAST - 1) ? k + BW : LAST - 1;
+    const int jreach = 9 * ((k + 6) / 9) + 11;
+    const int jhi = (PIECES && jreach < jband) ? jreach : jband;
 #pragma unroll
     for (int j = k + 1; j <= jhi; j++) r[j] = fma(-lik, readlane_f64(lik, j), r[j]);
     if (k < LAST) r[LAST] = fma(-lik, readlane_f64(lik, LAST), r[LAST]);

@@ -432,7 +432,7 @@ __device__ __noinline__ bool xs_factor_regs_n(double* L, double* x0, int tid, in
 #pragma unroll
   for (int j = 0; j < N; j++) r[j] = tid < N ? L[row * N + j] : 0.0;
   double y = tid < N ? x0[row] : 0.0;
-  if (!chol_arrow_wave<N, XS_BAND>(r, y, tid, npiv)) return false;
+  if (!chol_arrow_wave<N, XS_BAND, true>(r, y, tid, npiv)) return false;
 #pragma unroll
   for (int j = 0; j < N; j++)
     if (tid < N && j <= tid && (j + XS_BAND >= tid || tid == N - 1)) L[tid * N + j] = r[j];
