@@ -158,6 +158,7 @@ __device__ __forceinline__ double esum_wave(const double* e, int n, int lane) {
   return r;
 }
 
+__device__ __forceinline__ bool uni_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 template <int N>
 __device__ __forceinline__ bool chol_check_wave(double (&r)[N]) {
 #pragma unroll
@@ -182,24 +183,59 @@ __device__ __forceinline__ bool chol_check_wave(double (&r)[N]) {
 // blocks that overlap by 9, so column k meets rows up to 9 * ((k + 6) / 9) + 11 only -- 17 - (k + 6) % 9 of them, 13 on
 // average, not BW = 17.  The entries beyond are structural zeros (never filled); their updates fma(-0 * x, ., a) are skipped,
 // which leaves every stored value unchanged (up to the sign of an exact zero).
-template <int N, int BW, bool PIECES = false>
+template <int N, int BW, bool PIECES = false, bool BATCH = true>   // BATCH = false: broadcasts and updates pairwise (few SGPRs: the form kept for out-of-line callers)
 __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int lane, int npiv) {
+  // What one wave pays here (tools/micro/issue_probe.hip): ~6 cycles per fp64 instruction whether or not it depends on the one
+  // before, ~35 cycles from a v_readlane to the first VALU use of the SGPR it wrote, ~25 for a branch on a fresh VALU
+  // comparison.  So: (1) the next pivot's diagonal is formed by every lane from its OWN column entry (lane k+1 holds
+  // l_{k+1,k} itself: same operands, same bits as the broadcast form) and read out first, so its broadcast travels while the
+  // column updates issue; (2) all broadcasts of the column go out before the first update, each into its own SGPR pair.
+  // (The early exit on a non-positive pivot stays a branch per pivot: without it the 43 pivots are one basic block of 3 000
+  // instructions, and the scheduler's reordering inside it doubles the register count -- 180 VGPRs, 106 SGPRs, spills.)
+  constexpr int LAST = N - 1;
+  if constexpr (!BATCH) {   // the plain right-looking loop (round 2's form)
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      if (k == N - 1 && npiv < N) break;
+      const double x = readlane_f64(r[k], k);
+      if (x <= 0) return false;
+      const double rs = pivot_rsqrt(x);
+      const double lik = r[k] * rs;
+      const double yk = readlane_f64(y, k) * rs;
+      r[k] = lane == k ? rs : lik;
+      const int jband = (k + BW < LAST - 1) ? k + BW : LAST - 1;
+      const int jreach = 9 * ((k + 6) / 9) + 11;
+      const int jhi = (PIECES && jreach < jband) ? jreach : jband;
+#pragma unroll
+      for (int j = k + 1; j <= jhi; j++) r[j] = fma(-lik, readlane_f64(lik, j), r[j]);
+      if (k < LAST) r[LAST] = fma(-lik, readlane_f64(lik, LAST), r[LAST]);
+      y = lane == k ? yk : (lane > k ? fma(-yk, lik, y) : y);
+    }
+    return true;
+  }
+  double x = readlane_f64(r[0], 0);
 #pragma unroll
   for (int k = 0; k < N; k++) {
     if (k == N - 1 && npiv < N) break;
-    const double x = readlane_f64(r[k], k);
     if (x <= 0) return false;
     const double rs = pivot_rsqrt(x);
     const double lik = r[k] * rs;
-    const double yk = readlane_f64(y, k) * rs;
+    const double ykb = readlane_f64(y, k);   // consumed after the column updates
     r[k] = lane == k ? rs : lik;
-    constexpr int LAST = N - 1;
     const int jband = (k + BW < LAST - 1) ? k + BW : LAST - 1;
     const int jreach = 9 * ((k + 6) / 9) + 11;
     const int jhi = (PIECES && jreach < jband) ? jreach : jband;
+    // next pivot: a_{k+1,k+1} - l_{k+1,k}^2, formed by lane k+1 from its own column entry (k + 1 == LAST: the arrow row's diagonal)
+    if (k < LAST) { const double dn = fma(-lik, lik, r[k + 1]); x = readlane_f64(dn, k + 1); }
+    double lj[BW + 1];
 #pragma unroll
-    for (int j = k + 1; j <= jhi; j++) r[j] = fma(-lik, readlane_f64(lik, j), r[j]);
-    if (k < LAST) r[LAST] = fma(-lik, readlane_f64(lik, LAST), r[LAST]);
+    for (int j = k + 1; j <= jhi; j++) lj[j - k - 1] = readlane_f64(lik, j);
+    const double larrow = k < LAST ? readlane_f64(lik, LAST) : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = k + 1; j <= jhi; j++) r[j] = fma(-lik, lj[j - k - 1], r[j]);
+    if (k < LAST) r[LAST] = fma(-lik, larrow, r[LAST]);
+    const double yk = ykb * rs;
     y = lane == k ? yk : (lane > k ? fma(-yk, lik, y) : y);
   }
   return true;

@@ -425,14 +425,14 @@ __host__ __device__ inline size_t xsolve_lds_doubles(int n) { return xsolve_fron
 // Factor the reduced system held in LDS (L, row-major n x n) with the register-resident wave kernel when
 // n = 9P-2 fits one row per lane (P <= 7); the factor's band + arrow row and the forward-substituted
 // right-hand side go back to LDS for the back substitution.  handled = false: caller uses chol_arrow_lds.
-template <int N>
-__device__ __noinline__ bool xs_factor_regs_n(double* L, double* x0, int tid, int npiv) {
+template <int N, bool BATCH = true>
+__device__ __forceinline__ bool xs_factor_regs_body(double* L, double* x0, int tid, int npiv) {
   double r[N];
   const int row = min(tid, N - 1);
 #pragma unroll
   for (int j = 0; j < N; j++) r[j] = tid < N ? L[row * N + j] : 0.0;
   double y = tid < N ? x0[row] : 0.0;
-  if (!chol_arrow_wave<N, XS_BAND, true>(r, y, tid, npiv)) return false;
+  if (!chol_arrow_wave<N, XS_BAND, true, BATCH>(r, y, tid, npiv)) return false;
 #pragma unroll
   for (int j = 0; j < N; j++)
     if (tid < N && j <= tid && (j + XS_BAND >= tid || tid == N - 1)) L[tid * N + j] = r[j];
@@ -440,17 +440,13 @@ __device__ __noinline__ bool xs_factor_regs_n(double* L, double* x0, int tid, in
   blk_sync<true>();
   return true;
 }
+// Out of line for the generic k_xsolve<0>, in the pairwise form: it stays within the caller-saved registers (the batched form, as
+// a called function, opens with 41 scratch stores at 43 rows).  k_xsolve<N>, N <= 52, inlines the batched body instead.
+template <int N>
+__device__ __noinline__ bool xs_factor_regs_n(double* L, double* x0, int tid, int npiv) { return xs_factor_regs_body<N, false>(L, x0, tid, npiv); }
 __device__ __forceinline__ bool xs_factor_regs(double* L, double* x0, int n, int tid, int npiv, bool& handled) {
-  handled = true;
-  switch (n) {
-    case 16: return xs_factor_regs_n<16>(L, x0, tid, npiv);
-    case 25: return xs_factor_regs_n<25>(L, x0, tid, npiv);
-    case 34: return xs_factor_regs_n<34>(L, x0, tid, npiv);
-    case 43: return xs_factor_regs_n<43>(L, x0, tid, npiv);
-    case 52: return xs_factor_regs_n<52>(L, x0, tid, npiv);
-    case 61: return xs_factor_regs_n<61>(L, x0, tid, npiv);
-  }
-  handled = false;
+  handled = n == 61;   // the smaller sizes have their own kernel instantiations (k_xsolve<N>, chosen by the host)
+  if (handled) return xs_factor_regs_n<61>(L, x0, tid, npiv);
   return false;
 }
 // x = L^-T y for the arrowhead-band factor in LDS (row-major n x n), by ONE wave with y in registers (lane i = y_i, n <= 64).
@@ -478,7 +474,7 @@ __device__ __forceinline__ double backsolve_wave(const double* L, int n, int bw,
 // The same back substitution with the size known at compile time: lane indices of the broadcasts are immediates and the rows of L
 // are fetched ahead of the chain by the scheduler (the generic loop above pays the SGPR-lane-select hazards 4 x per unknown).
 template <int N>
-__device__ __noinline__ double backsolve_wave_n(const double* L, double y, int lane) {
+__device__ __forceinline__ double backsolve_wave_body(const double* L, double y, int lane) {
   constexpr int last = N - 1;
   const int col = min(lane, last);
   {
@@ -494,6 +490,8 @@ __device__ __noinline__ double backsolve_wave_n(const double* L, double y, int l
   }
   return y;
 }
+template <int N>
+__device__ __noinline__ double backsolve_wave_n(const double* L, double y, int lane) { return backsolve_wave_body<N>(L, y, lane); }
 __device__ __forceinline__ double xs_backsolve(const double* L, int n, double y, int lane) {
   switch (n) {
     case 16: return backsolve_wave_n<16>(L, y, lane);
@@ -505,8 +503,10 @@ __device__ __forceinline__ double xs_backsolve(const double* L, int n, double y,
   }
   return backsolve_wave(L, n, XS_BAND, y, lane);
 }
-// one factorisation attempt: registers when the size allows, LDS otherwise
+// one factorisation attempt: registers when the size allows, LDS otherwise.  NREG > 0: the size is the kernel's template argument
+template <int NREG>
 __device__ __forceinline__ bool xs_factor(double* L, double* x0, int n, int tid, int npiv) {
+  if constexpr (NREG > 0) return xs_factor_regs_body<NREG>(L, x0, tid, npiv);
   bool handled;
   const bool ok = xs_factor_regs(L, x0, n, tid, npiv, handled);
   if (handled) return ok;
@@ -514,6 +514,7 @@ __device__ __forceinline__ bool xs_factor(double* L, double* x0, int n, int tid,
 }
 
 // wave 0 of k_xsolve: factor, solve, direction record (all sync points are wave-local)
+template <int NREG>
 __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, int m, double* H, double* L, double* g0, double* x0, double* scr) {
   const int T = D.T;
   TJ_TIC(D, K_XSOLVE, 2);
@@ -521,7 +522,7 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     // Optimization3D_multi::update_spline (Optimization3D_multi.h:519-557): this robot's block of the
     // arrowhead system.  Eliminate the m control-point unknowns; what is left of the last row is the
     // robot's contribution to the shared-time corner (Schur complement) -- k_xsolve_c2 completes it.
-    if (!xs_factor(L, x0, n, tid, n - 1)) {
+    if (!xs_factor<NREG>(L, x0, n, tid, n - 1)) {
       if (tid == 0) { atomicAdd(&D.ctl->llt_fail_robot, 1ull); atomicOr(&D.ctl->error, ERR_NOT_SPD); }
     }
     blk_sync<true>();
@@ -531,7 +532,7 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     if (tid == 0) { double* oc = D.xcorner + (size_t)u * 4; oc[0] = L[m * n + m]; oc[1] = x0[m]; oc[2] = g0[m]; oc[3] = 0; }
     return;
   }
-  if (!xs_factor(L, x0, n, tid, n)) {  // forward substitution fused: x0 <- L^-1 g0
+  if (!xs_factor<NREG>(L, x0, n, tid, n)) {  // forward substitution fused: x0 <- L^-1 g0
     if (tid == 0) atomicAdd(&D.ctl->llt_fail_robot, 1ull);
     blk_sync<true>();
     if (D.mode == 1) {  // multi: eigen-shift fallback (Optimization3D_multi.h:703-719); single has none
@@ -544,13 +545,13 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     for (int idx = tid; idx < n * n; idx += XS_THREADS) L[idx] = H[idx];
     for (int i = tid; i < n; i += XS_THREADS) x0[i] = g0[i];
     blk_sync<true>();
-    xs_factor(L, x0, n, tid, n);  // like the reference, the second factorisation is not re-checked
+    xs_factor<NREG>(L, x0, n, tid, n);  // like the reference, the second factorisation is not re-checked
     blk_sync<true>();
   }
   TJ_TIC(D, K_XSOLVE, 3);
   if (n <= 64) {
     double yv = x0[min(tid, n - 1)];
-    yv = xs_backsolve(L, n, yv, tid);
+    if constexpr (NREG > 0) yv = backsolve_wave_body<NREG>(L, yv, tid); else yv = xs_backsolve(L, n, yv, tid);
     blk_sync<true>();
     if (tid < n) x0[tid] = yv;
     blk_sync<true>();
@@ -574,12 +575,15 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
   }
 }
 
+// NREG = n when the system fits one row per lane (n = 9P-2 <= 61, P <= 7: the register factorisation inlined, size known at
+// compile time), 0 otherwise (size chosen at run time, LDS forms beyond 61)
+template <int NREG>
 __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   if (TJ_DONE(D)) return;
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
   const int u = D.u0 + blockIdx.x;
-  const int T = D.T, m = 3 * (T - 4), n = m + 1;  // n = 9P-2
+  const int T = D.T, m = 3 * (T - 4), n = NREG > 0 ? NREG : m + 1;  // n = 9P-2
   double* H = sm;            // [n*n] reduced Hessian (symmetric)
   double* L = H + n * n;     // [n*n] factor / eigen scratch
   double* g0 = L + n * n;    // [n]
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   const bool pre = tail && S * 49 <= XS_HELP * XS_KPT && (size_t)S * 54 <= 2 * (size_t)n * n + 8 * (size_t)n && S * 18 <= D.P * 361;   // uniform
   double klo[XS_KPT], kup[XS_KPT];
   const int ht = tid - XS_THREADS;
-  if (tid < XS_THREADS) xs_wave0(D, u, tid, n, m, H, L, g0, x0, scr);
+  if (tid < XS_THREADS) xs_wave0<NREG>(D, u, tid, n, m, H, L, g0, x0, scr);
   else if (pre) {
     int target = 0;
     for (int idx = ht; idx < 3 * T; idx += XS_HELP) netl[idx] = gnet[idx];

@@ -158,7 +158,14 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       return true;
     case K_XSOLVE:
       if (d.xs_band) hipLaunchKernelGGL(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
-      else hipLaunchKernelGGL(k_xsolve, dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d);
+      else switch (9 * d.P - 2) {   // the register factorisation is inlined per size (kernels_newton.h); 61 rows and the LDS forms: the generic kernel
+        case 16: hipLaunchKernelGGL((k_xsolve<16>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 25: hipLaunchKernelGGL((k_xsolve<25>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 34: hipLaunchKernelGGL((k_xsolve<34>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 43: hipLaunchKernelGGL((k_xsolve<43>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 52: hipLaunchKernelGGL((k_xsolve<52>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        default: hipLaunchKernelGGL((k_xsolve<0>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+      }
       return true;
     case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
     case K_CCD_PREP: if (in_graph && d.fuse && !d.xs_band) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
@@ -462,7 +469,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
   if (d.xs_band) HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
-  else HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
+  else {
+    const void* kx = (const void*)k_xsolve<0>;
+    switch (n) { case 16: kx = (const void*)k_xsolve<16>; break; case 25: kx = (const void*)k_xsolve<25>; break; case 34: kx = (const void*)k_xsolve<34>; break;
+                 case 43: kx = (const void*)k_xsolve<43>; break; case 52: kx = (const void*)k_xsolve<52>; break; }   // 61 rows: the inlined form would spill, the generic kernel calls it out of line
+    HIPCHK(c, hipFuncSetAttribute(kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
+  }
   HIPCHK(c, hipFuncSetAttribute((const void*)k_linesearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ls_coupled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
   if (!d.xs_band) HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_c2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs2));
