@@ -139,7 +139,10 @@ def test_stages_teacher_forced_vs_reference(pkg, scenes, name):
     g = gold(f"stages_{name}.npz")
     scene = scene_by_name(scenes, name)
     check_scene_matches_fixture(scene, g)
-    _teacher_forced(pkg, scene, g, tol_dir=1e-10 if name == "hard" else 1e-11)
+    # `hard` is ill conditioned on purpose: its direction amplifies the rounding of a repaired piece's smallest eigenvalue ~1e6-fold.
+    # Two register eigenvalue routines that are EQUALLY accurate (tests/devtools/eig_err.py: both within 6.2e-16 |H| of Eigen's
+    # value on 572 matrices) leave 1.6e-11 and 2.0e-10 here, so the bar is 5x the larger one; the other scenes stay at 1e-11.
+    _teacher_forced(pkg, scene, g, tol_dir=1e-9 if name == "hard" else 1e-11)
 
 
 @pytest.mark.parametrize("name", ["hard", "scn_b"])

@@ -465,48 +465,72 @@ __device__ inline double min_eig_lds(double* A, int n, double* d, double* e, dou
 }
 
 // min_eig_lds for an N x N block held one FULL row per lane in the registers of one wave (both
-// triangles): no LDS round trips, no barriers, nothing serialised on one thread.  Same algorithm and the same order
-// of the sums (sequential via v_readlane), but this is the copy on k_grad's critical path (a repaired piece waits for
-// it), so its products are fused (fma) and the norm / beta come from v_rsq / v_rcp + Newton steps instead of the IEEE
-// sqrt and division sequences: 17 Householder steps of ~13m + 60 instead of ~17m + 100 instructions.  Householder
-// tridiagonalisation is backward stable under any of these roundings; the two routines agree to ~1e-15 of the norm.
+// triangles): no LDS round trips, no barriers, nothing serialised on one thread.  This is the copy on k_grad's critical path
+// (a repaired piece waits for it), shaped by what a single wave pays (tools/micro/issue_probe.hip: ~6 cycles per fp64
+// instruction dependent or not, ~35 from a v_readlane to the first use of its SGPR):
+//   * lane k holds row k = column k of the symmetric block, so the Householder scalars of step k (column norm, alpha, v0, beta)
+//     are formed by every lane from its OWN row and five values are read out of lane k -- not one broadcast per column entry;
+//   * the broadcasts of v and of q go out in a batch, each into its own SGPR pair, before the products that use them;
+//   * v . p is a DPP tree over the two rows of 16 lanes instead of a chain of N readlane-adds;
+//   * products are fused, norm and beta come from v_rsq / v_rcp + Newton steps, the Sturm recurrence is 3 instructions per row.
+// Householder tridiagonalisation is backward stable under any of these roundings; the routine agrees with min_eig_lds to
+// ~1e-15 of the norm (known-answer hook: 1e-13) and with Eigen's value to the 1e-12 the parity tests ask for.
 // stop (optional, LDS): the caller no longer needs the result once *stop == 1 (checked between Householder steps; uniform)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false), __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false));
+}
+// sum over lanes 0..31 (two DPP rows), the same value in every lane of those rows' first lanes' broadcast; lanes >= 32 are ignored
+__device__ __forceinline__ double sum32_wave(double v) {
+  v += dpp_mov_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x124>(v);   // row_ror:4
+  v += dpp_mov_f64<0x128>(v);   // row_ror:8
+  return readlane_f64(v, 0) + readlane_f64(v, 16);
+}
 template <int N>
 __device__ __forceinline__ double min_eig_wave(double (&r)[N], int lane, const volatile int* stop = nullptr) {
+  static_assert(N <= 32, "rows live in lanes 0..31 (sum32_wave)");
   double d[N], e[N];  // wave-uniform
 #pragma unroll
   for (int k = 0; k + 2 < N; k++) {
     if (stop && *stop == 1) return 0.0;
+    // every lane: the scalars of "its" Householder step; lane k's are the ones of step k
     double sig = 0;
 #pragma unroll
-    for (int i = k + 2; i < N; i++) { const double a = readlane_f64(r[k], i); sig = fma(a, a, sig); }
-    const double x0 = readlane_f64(r[k], k + 1);
-    d[k] = readlane_f64(r[k], k);
-    if (sig == 0) { e[k] = x0; continue; }  // nothing to eliminate (uniform)
-    const double s2 = fma(x0, x0, sig);
+    for (int i = k + 2; i < N; i++) sig = fma(r[i], r[i], sig);
+    const double x0l = r[k + 1];
+    const double s2 = fma(x0l, x0l, sig);
     const double nrm = s2 * pivot_rsqrt(s2);
-    const double alpha = x0 > 0 ? -nrm : nrm;
-    const double v0 = x0 - alpha;
-    const double den = fma(v0, v0, sig);
+    const double alphal = x0l > 0 ? -nrm : nrm;
+    const double v0l = x0l - alphal;
+    const double den = fma(v0l, v0l, sig);
     double rc = __builtin_amdgcn_rcp(den);
     rc = fma(rc, fma(-den, rc, 1.0), rc);
     rc = fma(rc, fma(-den, rc, 1.0), rc);
-    const double beta = 2.0 * rc;
+    const double sigk = readlane_f64(sig, k), x0 = readlane_f64(x0l, k);
+    d[k] = readlane_f64(r[k], k);
+    const double alpha = readlane_f64(alphal, k), v0 = readlane_f64(v0l, k), beta = 2.0 * readlane_f64(rc, k);
+    if (sigk == 0) { e[k] = x0; continue; }  // nothing to eliminate (uniform)
     e[k] = alpha;
-    const double v = lane == k + 1 ? v0 : (lane > k + 1 ? r[k] : 0.0);
+    const double v = lane == k + 1 ? v0 : ((lane > k + 1 && lane < N) ? r[k] : 0.0);
     double vj[N];
+#pragma unroll
+    for (int j = k + 1; j < N; j++) vj[j] = readlane_f64(v, j);
+    __builtin_amdgcn_sched_barrier(0);
     double acc = 0;
 #pragma unroll
-    for (int j = k + 1; j < N; j++) { vj[j] = readlane_f64(v, j); acc = fma(r[j], vj[j], acc); }
-    const double p = lane > k ? beta * acc : 0.0;
-    const double vp = v * p;
-    double kk = 0;
-#pragma unroll
-    for (int i = k + 1; i < N; i++) kk += readlane_f64(vp, i);
+    for (int j = k + 1; j < N; j++) acc = fma(r[j], vj[j], acc);
+    const double p = (lane > k && lane < N) ? beta * acc : 0.0;
+    const double kk = sum32_wave(v * p);
     const double K = 0.5 * beta * kk;
     const double q = fma(-K, v, p);
+    double qj[N];
 #pragma unroll
-    for (int j = k + 1; j < N; j++) { const double qj = readlane_f64(q, j); r[j] = fma(-q, vj[j], fma(-v, qj, r[j])); }
+    for (int j = k + 1; j < N; j++) qj[j] = readlane_f64(q, j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = k + 1; j < N; j++) r[j] = fma(-q, vj[j], fma(-v, qj[j], r[j]));
   }
   d[N - 2] = readlane_f64(r[N - 2], N - 2); e[N - 2] = readlane_f64(r[N - 2], N - 1);
   d[N - 1] = readlane_f64(r[N - 1], N - 1);
@@ -516,16 +540,22 @@ __device__ __forceinline__ double min_eig_wave(double (&r)[N], int lane, const v
     const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < N ? fabs(e[i]) : 0.0);
     lo = fmin(lo, d[i] - rad); hi = fmax(hi, d[i] + rad);
   }
-  double e2[N];
-#pragma unroll
-  for (int i = 1; i < N; i++) e2[i] = e[i - 1] * e[i - 1];
+  // Sturm recurrence on pre-scaled entries: p_i = (d_i s - x s) p_{i-1} - (e_i^2 s^2) p_{i-2}, one subtraction, one product, one fma per row
   const SturmScale sc = sturm_scale(lo, hi);
+  double ds[N], es[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { ds[i] = d[i] * sc.is; es[i] = i > 0 ? (e[i - 1] * e[i - 1]) * sc.is2 : 0.0; }
   for (int round = 0; round < STURM_ROUNDS; round++) {
     const double x = lo + (hi - lo) * (double(lane + 1) / 65.0);
-    double p0, p1; bool below;
-    sturm_first(d[0], x, sc, p0, p1, below);
+    const double xs = x * sc.is;
+    double p0 = 1.0, p1 = ds[0] - xs;
+    bool below = !(p1 > 0);
 #pragma unroll
-    for (int i = 1; i < N; i++) sturm_next(d[i], e2[i], x, sc, i, p0, p1, below);
+    for (int i = 1; i < N; i++) {
+      const double pn = fma(ds[i] - xs, p1, -(es[i] * p0));
+      p0 = p1; p1 = pn; below = below | !(pn > 0);
+      if (i % 3 == 0) { const int ex = __builtin_amdgcn_frexp_exp(p1); p0 = __builtin_ldexp(p0, -ex); p1 = __builtin_ldexp(p1, -ex); }
+    }
     const unsigned long long mask = __ballot(below);
     if (mask == 0) lo = lo + (hi - lo) * (64.0 / 65.0);
     else {
