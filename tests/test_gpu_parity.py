@@ -117,7 +117,9 @@ def _teacher_forced(pkg, scene, g, tol_dir=1e-11):
         assert np.array_equal(s_pos, g[k + "step_pos"]), f"it{it}: obstacle CCD clamp differs"
         arm = s.stage_linesearch()
         if scene["mode"] == 1:
-            assert maxdiff(arm, g[k + "step_armijo"]) <= 1e-12   # same number of Armijo halvings
+            # same number of Armijo halvings (one more or less is a factor 0.8); where the step is the t > 0 guard -0.95 t / t_dir it carries
+            # t_direction's difference, so the bar follows the scene's direction bar (1e-12 on all scenes but `hard`)
+            assert maxdiff(arm, g[k + "step_armijo"]) <= max(1e-12, 0.1 * tol_dir)
         st = s.get_state()
         seen["mid"] = max(seen["mid"], maxdiff(st["spline"], g[k + "mid_spline"]), maxdiff(st["piece_time"], g[k + "mid_piece_time"]))
         assert maxdiff(st["spline"], g[k + "mid_spline"]) <= tol_dir
