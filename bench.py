@@ -149,29 +149,94 @@ def cpu_baseline(scene, steps, optimal_plane=False):
             "sample": f"the first {n} ADMM iterations of the same scene from the same initial trajectory (BVH build excluded)"}
 
 
-def bench_group(pkg, scene, devices, args):
-    """K iterations through tj_group (one process, one host thread per rank inside the library)"""
-    torch.cuda.set_device(devices[0])
-    grp = pkg.Group(scene, devices, stop=0.0, optimal_plane=int(args.optimal_plane))
-    K, W = args.steps, args.warmup
-    grp.iterate(300); grp.reset()          # clock ramp, like the default path
-    grp.iterate(max(W, 1)); grp.reset()
+def roofline_fracs(slv, prof, st, K, dt):
+    """(dominant kernel, its SURVEY 8(d) fraction of the HBM peak, whole-iteration fraction) from a profile_kernels() result"""
+    alg_bytes, alg_total = survey_bytes(st, slv, K)
+    per_launch_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+    dom = max((k for k, v in prof.items() if v[1] >= K), key=lambda k: prof[k][0])
+    ach = alg_bytes[dom] / (per_launch_ms[dom] * 1e-3) / 1e9
+    return dom, ach / 8000.0, alg_total / (dt / K) / 1e9 / 8000.0
+
+
+def extra_config(pkg, scene, K, W, device):
+    """One more BASELINE config on the already warm GPU: same protocol as the headline (K iterations from the initial
+    trajectory, state resident, stop test off), no CPU leg.  Returns the entry of `extra.configs`."""
+    slv = pkg.Solver(scene, device=device, stop=0.0)
+    slv.iterate(60); slv.sync(); slv.reset()          # the library looks at its counters here and picks kernel builds
+    slv.iterate_async(max(W, 1)); slv.sync(); slv.reset(); slv.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    grp.iterate(K)                         # returns after every rank's stream has drained
+    slv.iterate_async(K); slv.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"metric": "ADMM iterations/sec", "value": K / dt, "unit": "iters/s", "n_gpus": len(set(devices)), "steps": K, "warmup": W,
-           "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"{scene['name']}: {scene['U']} UAVs, {scene['P']} pieces x res 8, {'coupled' if scene['mode'] == 2 else 'decoupled'} mode",
-                      "parallelism": f"tj_group: {len(devices)} ranks on devices {devices}, robots block-sharded, exchanges by peer stores + events inside the library",
-                      "iters_timed_from": "initial trajectory"},
-           "timed_window_ms": 1e3 * dt}
+    st = slv.stats()
+    if st["error_bits"] or st["order_unresolved"]:
+        raise SystemExit(f"{scene['name']}: device error bits {st['error_bits']}, unresolved pair order {st['order_unresolved']}")
+    slv.reset()
+    prof = slv.profile_kernels(K)
+    dom, frac, whole = roofline_fracs(slv, prof, slv.stats(), K, dt)
+    n_prim = scene['tris'].shape[0] if scene.get('tris') is not None else scene['cloud'].shape[0]
+    out = {"workload": f"{scene['name']}: {scene['U']} UAVs, {n_prim} obstacle {'triangles' if scene.get('tris') is not None else 'points'}, {scene['P']} pieces x res 8, decoupled",
+           "ms_per_step": 1e3 * dt / K, "iters_per_s": K / dt, "steps": K,
+           "roofline": {"kernel": "tj::" + dom, "frac": frac}, "whole_iteration": {"frac": whole}}
+    slv.close()
+    return out
+
+
+def bench_group(pkg, scene, devices, args):
+    """K iterations through tj_group (one process, one host thread per rank inside the library).  Same top-level keys as the
+    single-GPU line; `roofline` / `cpu_baseline` are null here (they are N = 1 objects, see the default run)."""
+    torch.cuda.set_device(devices[0])
+    K, W = args.steps, args.warmup
+
+    def timed(devs):
+        grp = pkg.Group(scene, devs, stop=0.0, optimal_plane=int(args.optimal_plane))
+        grp.iterate(300); grp.reset()          # clock ramp, like the default path
+        grp.iterate(max(W, 1)); grp.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        grp.iterate(K)                         # returns after every rank's stream has drained
+        return grp, time.perf_counter() - t0
+
+    grp, dt = timed(devices)
+    transport = grp.transport
+    check = None
     if args.state_checksum:
         import hashlib
         stt = grp.get_state()
-        print("CHECK group " + hashlib.sha256(np.ascontiguousarray(stt["spline"]).tobytes() + np.ascontiguousarray(stt["piece_time"]).tobytes()).hexdigest(), flush=True)
+        check = hashlib.sha256(np.ascontiguousarray(stt["spline"]).tobytes() + np.ascontiguousarray(stt["piece_time"]).tobytes()).hexdigest()
+    ex_us = [float(x) for x in grp.profile_exchange(50)] if len(devices) > 1 else [0.0] * 5
     grp.close()
+    # the same schedule on ONE rank through the same entry point: what the phase schedule itself costs without any exchange
+    # (the default single-GPU line runs the fused 7-kernel chain instead and is faster; SCALE's N = 1 is that default line)
+    g1, dt1 = timed([devices[0]])
+    g1.close()
+    n_ex = 5 if scene["mode"] == 2 else 2
+    distinct = len(set(devices)) == len(devices)
+    out = {"metric": "ADMM iterations/sec", "value": K / dt, "unit": "iters/s", "n_gpus": len(set(devices)), "steps": K, "warmup": W,
+           "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{scene['name']}: {scene['U']} UAVs, {scene['P']} pieces x res 8, {'coupled' if scene['mode'] == 2 else 'decoupled'} mode",
+                      "parallelism": f"tj_group: {len(devices)} ranks on devices {devices}, robots block-sharded, {n_ex} exchanges/iter inside the library, transport {transport}",
+                      "iters_timed_from": "initial trajectory"},
+           "timed_window_ms": 1e3 * dt,
+           "group": {"transport": transport, "ranks": len(devices), "devices": list(devices), "distinct_devices": distinct,
+                     "exchanges_per_iter": n_ex, "exchange_us": dict(zip(["control_points", "directions", "schur_corner", "ccd_exponents", "armijo_energies"], ex_us)),
+                     "one_rank_same_schedule_ms_per_step": 1e3 * dt1 / K,
+                     "expectation": EXPECT.get(scene["name"].replace("-coupled", ""), "")},
+           "roofline": None, "cpu_baseline": None,
+           "note": "roofline and cpu_baseline belong to the single-GPU line (python bench.py); strong scaling: the fleet is fixed, each rank owns U / ranks robots"}
+    if check:
+        print("CHECK group " + check, flush=True)
     print(json.dumps(out), flush=True)
+
+
+# what sharding can and cannot buy per scene (DESIGN.md section 6), carried in the multi-GPU lines so that a scaling curve is read correctly
+EXPECT = {
+    "SCN-C": "64 UAVs: every stage is as long as its slowest single item (one wave), which does not shrink when a rank owns fewer robots; each exchange adds its latency -> N > 1 is expected to be SLOWER than N = 1 here",
+    "SCN-B": "8 UAVs: as SCN-C, nothing to gain from sharding",
+    "SCN-D": "256 UAVs: k_mid (10 000 robot-pair solves), k_grad (1 280 pieces) and k_front are throughput-bound on one GPU and partition by ownership -> these kernels shrink with N, the latency floor of the chain and the exchanges do not",
+    "SCN-D-tri": "256 UAVs x 1M triangles: as SCN-D",
+    "SCN-E": "64 UAVs through 1M points: obstacle stages shrink with N, the rest is latency",
+}
 
 
 def main():
@@ -181,6 +246,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="C", choices=["A", "B", "C", "D", "Dtri", "E", "H8"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs legs (BASELINE configs 3 and 5 timed after the headline: SCN-B, SCN-D-tri)")
     ap.add_argument("--coupled", action="store_true", help='time the coupled mode ("decouple":0, one shared piece_time) instead of the shipped decoupled mode; single GPU only')
     ap.add_argument("--optimal-plane", action="store_true", help='time the "optimal_plane":1 variant (persistent planes refined every iteration); not the headline')
     ap.add_argument("--overlap-gather", action="store_true", help="sharded schedule: start the control-point all-gather before phase 0 and join it after (async RCCL op); "
@@ -316,7 +382,7 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['tris'].shape[0] if scene.get('tris') is not None else scene['cloud'].shape[0]} obstacle {'triangles (fp64 narrow phase, fp32 outward-rounded BVH boxes)' if scene.get('tris') is not None else 'points'}, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
-                          "parallelism": f"robots sharded over {world} GPU(s), 2 all-gathers/iter" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else (6 if scene['mode'] == 0 else 7)} kernels on one queue (union kernels), enqueued ahead, no host sync",
+                          "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {5 if args.coupled else 2} RCCL all-gathers/iter on the library's exchange buffers; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else (6 if scene['mode'] == 0 else 7)} kernels on one queue (union kernels), enqueued ahead, no host sync",
                           "iters_timed_from": "initial trajectory"}}
     if world == 1:
         # per-kernel device time with hipEvents on the solver's stream, same K iterations
@@ -357,6 +423,12 @@ def main():
         out["stats_per_iter"] = {k: (v / K if k not in ("error_bits", "order_ambiguous", "iters") else v) for k, v in st2.items()}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(scene, K, args.optimal_plane)
+        # BASELINE configs 3 (8 UAVs) and 5 (256 UAVs x 1M triangles, one GPU's share of the 8-GPU config) under the driver's eyes:
+        # same K, same protocol, GPU only; the headline fields above are untouched
+        if args.scene == "C" and not (args.no_extra or args.coupled or args.optimal_plane):
+            slv.close()
+            out["extra"] = {"configs": [extra_config(pkg, sc.scn_b(), K, W, local), extra_config(pkg, sc.scn_d_tri(), K, W, local)],
+                            "note": "timed after the headline line's window on the same process / GPU; not part of `value`"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

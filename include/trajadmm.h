@@ -243,9 +243,17 @@ int tj_iterate_phase(tj_ctx* c, int phase);
  * of the per-robot loops (Optimization3D_multi.h:29-118, :120-174) are block-partitioned over n_ranks contexts, rank r on HIP
  * device devices[r] (NULL: device r; entries may repeat -- several ranks on one device, which is how the tests run it on a
  * one-GPU box).  tj_group_iterate runs the phase schedule above on every rank (one host thread per rank) and exchanges the
- * tj_exchange_buffer slices by direct peer stores + events: no collective library, no host staging.  Results are bitwise
- * those of one context.  tj_params.rank / world / device are ignored (set per rank).  Single-UAV mode has nothing to shard
- * (n_ranks must be 1). */
+ * tj_exchange_buffer slices through one of three transports (csrc/tj_group.h):
+ *   "flag"   direct peer stores + a sequence flag the consumer's next kernel polls -- device to device, nothing on the host;
+ *            the default when every rank has its own device
+ *   "event"  direct peer stores + hipEventRecord / hipStreamWaitEvent; the default when devices repeat
+ *   "rccl"   ncclCommInitAll + one in-place ncclAllGather per exchange on each rank's solver stream (the collective
+ *            Optimization3D_multi's sharding would use over xGMI); librccl.so is opened at run time, only for this transport;
+ *            needs distinct devices and uav_num divisible by n_ranks
+ * chosen by TJ_GROUP_TRANSPORT at tj_group_create or by tj_group_set_transport between batches.  Results are bitwise those of
+ * one context.  tj_params.rank / world / device are ignored (set per rank).  Single-UAV mode has nothing to shard (n_ranks
+ * must be 1).  UNVERIFIED ON HARDWARE: a group whose devices are all distinct (the configuration the feature exists for) has
+ * not run yet -- no multi-GPU box was available to rounds 1-3; same-device groups are tested bitwise against one context. */
 typedef struct tj_group tj_group;
 int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_group** out);
 void tj_group_destroy(tj_group* g);
@@ -257,6 +265,15 @@ int tj_group_set_mesh(tj_group* g, const double* vertices, int n_vertices, const
 int tj_group_init_state(tj_group* g, const double* waypoints, double piece_time0);
 int tj_group_iterate(tj_group* g, int n_iters, double* gnorm, int* iters_total, int* converged);   /* like tj_iterate */
 int tj_group_get_state(tj_group* g, int u, double* spline, double* p_slack, double* p_lambda, double* t_slack, double* t_lambda, double* piece_time);   /* from u's owner */
+const char* tj_group_transport(tj_group* g);          /* "flag", "event" or "rccl" */
+int tj_group_set_transport(tj_group* g, const char* name);   /* between batches; restarts the exchange sequence numbers */
+/* event-timed cost of one exchange of each buffer kind (microseconds, slowest rank's average over `reps`): us[5], kinds 2..4
+ * are zero outside coupled mode; all zero for one rank */
+int tj_group_profile_exchange(tj_group* g, int reps, double* us);
+/* 1 if librccl.so can be opened and exports the entry points the "rccl" transport binds (needs no GPU) */
+int tj_rccl_available(void);
+/* After a rank failed inside tj_group_iterate the ranks' exchange counts disagree: every tj_group_* call except
+ * tj_group_init_state (which drains the streams and restarts the counters) and tj_group_destroy then returns TJ_ERR_DEVICE. */
 
 #ifdef __cplusplus
 }

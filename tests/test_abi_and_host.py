@@ -166,3 +166,11 @@ def test_hot_kernels_use_no_scratch_memory(pkg, tmp_path):
     assert len(hot) >= 8, f"expected the chain's kernels in the metadata, found {sorted(seen)[:5]}..."
     bad = {k: seen[k] for k in hot if seen[k] != 0}
     assert not bad, f"scratch memory in hot kernels: {bad}"
+
+
+def test_rccl_entry_points_resolve(pkg):
+    """the "rccl" transport of tj_group binds librccl.so at run time (dlopen): the library must open here and export
+    ncclCommInitAll / ncclAllGather / ncclCommDestroy / ncclGetErrorString -- the link step of that transport, which needs no GPU"""
+    import ctypes
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    assert lib.tj_rccl_available() == 1

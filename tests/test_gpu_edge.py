@@ -67,6 +67,27 @@ def test_plane_capacity_overflow_is_reported(pkg, scenes):
     assert "-3" in str(ei.value) and "cap_" in str(ei.value)          # TJ_ERR_CAPACITY, tells which knob
 
 
+def test_refused_obstacle_set_leaves_the_previous_one_usable(pkg, scenes):
+    """tj_set_mesh that is refused (triangles + optimal_plane:1 in single-UAV mode) must not touch the cloud that was set
+    before: the next iterations run on it and give what an undisturbed solver gives; an invalid face index is refused likewise"""
+    import ctypes as C
+    scene = scenes.tiny(mode=0, U=1, n_points=500)
+    a = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    b = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    verts = np.ascontiguousarray(np.random.default_rng(1).uniform(-1, 1, (30, 3)))
+    faces = np.arange(30, dtype=np.int32).reshape(-1, 3)
+    rc = a.lib.tj_set_mesh(a._ctx, verts.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(30), faces.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(10))
+    assert rc == -5, rc                                               # TJ_ERR_UNSUPPORTED
+    bad = faces.copy(); bad[3, 1] = 99
+    rc = a.lib.tj_set_mesh(a._ctx, verts.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(30), bad.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(10))
+    assert rc == -1, rc                                               # TJ_ERR_INVALID
+    a.iterate(3); b.iterate(3)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
 def test_infeasible_start_does_not_hang(pkg, scenes):
     """robots closer than `offset` at the start: the reference spins forever in Step::self_step
     (Step.h:232-250); the device loops are capped and the call returns TJ_ERR_NO_PROGRESS"""

@@ -30,6 +30,69 @@ def test_group_equals_one_context_bitwise(pkg, scenes, mode, ranks):
     ref.close(); grp.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_flag_transport_equals_one_context_bitwise(pkg, scenes, mode):
+    """the device-to-device transport (peer stores + sequence flags polled by the consumer's next kernel, no host on the path),
+    forced on two ranks that share device 0; switching transports between batches restarts the sequence numbers"""
+    scene = dict(scenes.hard(4, 4000)); scene["mode"] = mode
+    ref = pkg.Solver(scene, stop=0.0)
+    grp = pkg.Group(scene, [0, 0], stop=0.0)
+    assert grp.transport == "event"            # the default when devices repeat
+    grp.set_transport("flag")
+    assert grp.transport == "flag"
+    done = 0
+    for batch, transport in ((2, "flag"), (3, "flag"), (2, "event"), (4, "flag")):
+        if grp.transport != transport:
+            grp.set_transport(transport)
+        g0, _, _ = ref.iterate(batch)
+        g, it, cv = grp.iterate(batch)
+        done += batch
+        assert it == done and g == g0
+        a, b = ref.get_state(), grp.get_state()
+        for n in STATE:
+            assert np.array_equal(a[n], b[n]), (n, done, transport)
+    us = grp.profile_exchange(20)
+    assert (us[:2] > 0).all() and (us[:2] < 1e5).all()
+    a, b = ref.get_state(), grp.get_state()     # re-sending the slices changed nothing
+    for n in STATE:
+        assert np.array_equal(a[n], b[n]), n
+    ref.close(); grp.close()
+
+
+def test_rccl_transport_is_refused_on_repeated_devices(pkg, scenes):
+    grp = pkg.Group(scenes.hard(4, 4000), [0, 0], stop=0.0)
+    with pytest.raises(pkg.TrajAdmmError) as ei:
+        grp.set_transport("rccl")
+    assert "-5" in str(ei.value) and "own device" in str(ei.value)      # TJ_ERR_UNSUPPORTED, says why
+    assert grp.transport == "event"
+    grp.iterate(2)                                                       # the group is still usable
+    grp.close()
+
+
+@pytest.mark.parametrize("transport", ["flag", "event", "rccl"])
+def test_group_on_two_devices(pkg, scenes, transport):
+    """the configuration the feature exists for: two ranks on two DIFFERENT GPUs (peer stores over xGMI into uncached receive
+    buffers, or RCCL all-gathers from host C++).  Skipped on a one-GPU box -- nothing else in this suite crosses a device."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    for mode in (1, 2):
+        scene = dict(scenes.hard(4, 4000)); scene["mode"] = mode
+        ref = pkg.Solver(scene, stop=0.0)
+        grp = pkg.Group(scene, [0, 1], stop=0.0)
+        assert grp.transport == "flag"
+        if transport != "flag":
+            grp.set_transport(transport)
+        for batch in (1, 4, 7):
+            g0, _, _ = ref.iterate(batch)
+            g, _, _ = grp.iterate(batch)
+            assert g == g0
+            a, b = ref.get_state(), grp.get_state()
+            for n in STATE:
+                assert np.array_equal(a[n], b[n]), (n, mode, transport)
+        ref.close(); grp.close()
+
+
 def test_group_stop_test_and_uneven_partition(pkg, scenes):
     """5 robots over 2 and 3 ranks (uneven blocks); the device stop test ends the run on every rank in the same iteration"""
     scene = scenes.crossing(5, 3000, seed=4)

@@ -28,6 +28,7 @@ EXPORTS = [
     "tj_iterate_phase", "tj_phase_count", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
     "tj_group_create", "tj_group_destroy", "tj_group_size", "tj_group_ctx", "tj_group_last_error", "tj_group_set_cloud", "tj_group_set_mesh",
+    "tj_group_transport", "tj_group_set_transport", "tj_group_profile_exchange", "tj_rccl_available",
     "tj_group_init_state", "tj_group_iterate", "tj_group_get_state",
 ]
 
@@ -450,6 +451,21 @@ class Group:
         g, it, cv = C.c_double(), C.c_int(), C.c_int()
         self._check(self.lib.tj_group_iterate(self._g, C.c_int(n), C.byref(g), C.byref(it), C.byref(cv)))
         return g.value, it.value, bool(cv.value)
+
+    @property
+    def transport(self):
+        self.lib.tj_group_transport.restype = C.c_char_p
+        return self.lib.tj_group_transport(self._g).decode()
+
+    def set_transport(self, name):
+        """"flag" | "event" | "rccl" (csrc/tj_group.h); between batches only"""
+        self._check(self.lib.tj_group_set_transport(self._g, name.encode()))
+
+    def profile_exchange(self, reps=50):
+        """event-timed microseconds of one exchange of each buffer kind (slowest rank's average)"""
+        us = np.zeros(5)
+        self._check(self.lib.tj_group_profile_exchange(self._g, C.c_int(reps), _d(us)))
+        return us
 
     def get_state(self):
         """every robot's state from the rank that owns it"""

@@ -26,6 +26,7 @@ enum : int {
                              // reference spins forever there, Step.h:83-97)
   ERR_SLACK_ARMIJO = 256,    // the slack update's Armijo loop
   ERR_PLANE_REFINE = 64,     // "optimal_plane":1 -- a plane's Newton refinement hit PLANE_NEWTON_CAP / PLANE_BACKOFF_CAP
+  ERR_PEER_TIMEOUT = 512,    // tj_group, flag transport: a peer's push did not arrive within 2 s (tj_group.h)
 };
 
 #ifdef TJ_NO_DONE_CHECK

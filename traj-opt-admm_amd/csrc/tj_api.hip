@@ -327,6 +327,7 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
   QUIESCE(c);
   if (out) *out = h;
   choose_builds(c, found64);
+  if (h.error & ERR_PEER_TIMEOUT) { c->err = "tj_group: a peer rank's slice did not arrive within 2 s (flag transport); the group must be re-initialised"; return TJ_ERR_DEVICE; }
   if (h.error & (ERR_PLANE_OVERFLOW | ERR_FRONT_OVERFLOW | ERR_PAIR_OVERFLOW)) {
     c->err = "device list overflow (error bits " + std::to_string(h.error) + "): raise cap_obs/cap_self/cap_pairs";
     return TJ_ERR_CAPACITY;
@@ -379,7 +380,8 @@ int tj_debug_phase_times(tj_ctx* c, long long* out) {
   if (!c || !out) return TJ_ERR_INVALID;
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(out, c->d.dbg, sizeof(long long) * K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemset(c->d.dbg, 0, sizeof(long long) * K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS));
+  HIPCHK(c, hipMemsetAsync(c->d.dbg, 0, sizeof(long long) * K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return K_COUNT;
 }
 #endif
@@ -540,33 +542,40 @@ int to_dev(tj_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 }  // namespace
 
 namespace {
-// verts: [n][prim][3] in the caller's order
+struct EvPair {   // the two timing events of the device build, destroyed on every exit
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EvPair() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+};
+// verts: [n][prim][3] in the caller's order.  Everything that can be refused is checked BEFORE the current obstacle set is
+// touched; from the first free on the context counts as "no obstacles" (have_cloud = false, N = 0) until a new set is
+// completely built, so a failed call can never leave tj_iterate with a half-built hierarchy.
 int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
-  QUIESCE(c);
-  drop_graph(c);
-  for (void* p : c->cloud_allocs) hipFree(p);
-  c->cloud_allocs.clear();
   Dev& d = c->d;
-  d.N = n; d.nlevels = 0; d.prim = prim; d.px = d.py = d.pz = d.tri = nullptr; d.boxes = d.leafbox = nullptr;
-  c->cloud_order.clear();
   if (prim == 3 && d.optimal_plane && d.mode == TJ_MODE_SINGLE) {
     c->err = "triangle obstacles with optimal_plane:1 in single-UAV mode are not supported (Optimal_plane::optimal_cd is defined for obstacle points only, Optimal_plane.h:160)";
     return TJ_ERR_UNSUPPORTED;
   }
+  // pyramid geometry: level 0 = boxes over 8 consecutive primitives, up to a top level of <= 64 boxes
+  std::vector<int> lvl_off, lvl_n;
+  if (n > 0) { int cnt = (n + 7) / 8, off = 0; for (;;) { lvl_off.push_back(off); lvl_n.push_back(cnt); off += cnt; if (cnt <= 64) break; cnt = (cnt + 7) / 8; } }
+  if ((int)lvl_n.size() > MAX_LEVELS) { c->err = "too many obstacle primitives for MAX_LEVELS"; return TJ_ERR_UNSUPPORTED; }
+  QUIESCE(c);
+  drop_graph(c);
+  c->have_cloud = false;
+  d.N = 0; d.nlevels = 0; d.px = d.py = d.pz = d.tri = nullptr; d.boxes = d.leafbox = nullptr;
+  for (void* p : c->cloud_allocs) hipFree(p);
+  c->cloud_allocs.clear();
+  c->cloud_order.clear();
   if (n > 0) {
     for (int k = 0; k < 3; k++) { c->cloud_lo[k] = INFINITY; c->cloud_hi[k] = -INFINITY; }
     for (size_t i = 0; i < (size_t)n * prim; i++) for (int k = 0; k < 3; k++) { c->cloud_lo[k] = std::min(c->cloud_lo[k], verts[3 * i + k]); c->cloud_hi[k] = std::max(c->cloud_hi[k], verts[3 * i + k]); }
-    // pyramid geometry: level 0 = boxes over 8 consecutive primitives, up to a top level of <= 64 boxes
-    std::vector<int> lvl_off, lvl_n;
-    { int cnt = (n + 7) / 8, off = 0; for (;;) { lvl_off.push_back(off); lvl_n.push_back(cnt); off += cnt; if (cnt <= 64) break; cnt = (cnt + 7) / 8; } }
-    if ((int)lvl_n.size() > MAX_LEVELS) { c->err = "too many obstacle primitives for MAX_LEVELS"; return TJ_ERR_UNSUPPORTED; }
     const size_t nbox = (size_t)lvl_off.back() + lvl_n.back();
     float* boxes; int r;
     if ((r = dalloc(c, &boxes, nbox * 6, &c->cloud_allocs))) return r;
     double *px = nullptr, *py = nullptr, *pz = nullptr, *tri = nullptr; float* lb = nullptr;
     if (prim == 1) { if ((r = dalloc(c, &px, n, &c->cloud_allocs)) || (r = dalloc(c, &py, n, &c->cloud_allocs)) || (r = dalloc(c, &pz, n, &c->cloud_allocs))) return r; }
     else if ((r = dalloc(c, &tri, (size_t)n * 9, &c->cloud_allocs)) || (r = dalloc(c, &lb, (size_t)n * 6, &c->cloud_allocs))) return r;
-    c->cloud_order.resize(n);
+    std::vector<int> order(n);
     c->bvh_on_device = getenv("TJ_BVH_HOST") ? 0 : 1;   // TJ_BVH_HOST=1: the host build of host_tables.h (the checker of the device build)
     if (!c->bvh_on_device) {
       HostBvh b;
@@ -574,7 +583,7 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
       if ((r = upload(c, boxes, b.boxes.data(), b.boxes.size() * 4))) return r;
       if (prim == 1) { if ((r = upload(c, px, b.px.data(), (size_t)n * 8)) || (r = upload(c, py, b.py.data(), (size_t)n * 8)) || (r = upload(c, pz, b.pz.data(), (size_t)n * 8))) return r; }
       else if ((r = upload(c, tri, b.tri.data(), (size_t)n * 72)) || (r = upload(c, lb, b.leafbox.data(), (size_t)n * 24))) return r;
-      c->cloud_order = b.order;
+      order = b.order;
       c->bvh_build_ms = 0;
     } else {
       // device build (kernels_bvh.h): bounds -> Morton keys -> stable radix sort -> gather -> box pyramid
@@ -583,10 +592,10 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
       if ((r = to_dev(c, dv, verts, (size_t)n * prim * 24)) || (r = to_dev(c, dpart, nullptr, (size_t)nb_red * 48)) || (r = to_dev(c, dlohi, nullptr, 48)) ||
           (r = to_dev(c, dkA, nullptr, (size_t)n * 8)) || (r = to_dev(c, dkB, nullptr, (size_t)n * 8)) || (r = to_dev(c, dvA, nullptr, (size_t)n * 4)) || (r = to_dev(c, dvB, nullptr, (size_t)n * 4)) ||
           (r = to_dev(c, dhist, nullptr, (size_t)256 * nblocks * 4)) || (r = to_dev(c, d64a, nullptr, (size_t)lvl_n[0] * 48)) || (r = to_dev(c, d64b, nullptr, (size_t)(lvl_n.size() > 1 ? lvl_n[1] : 1) * 48))) return r;
-      hipEvent_t e0, e1;
-      HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+      EvPair ev;
+      HIPCHK(c, hipEventCreate(&ev.e0)); HIPCHK(c, hipEventCreate(&ev.e1));
       hipStream_t s = c->stream;
-      HIPCHK(c, hipEventRecord(e0, s));
+      HIPCHK(c, hipEventRecord(ev.e0, s));
       const double* V = (const double*)dv.p;
       hipLaunchKernelGGL(k_bvh_bounds, dim3(nb_red), dim3(256), 0, s, V, n, prim, (double*)dpart.p);
       hipLaunchKernelGGL(k_bvh_bounds_final, dim3(1), dim3(64), 0, s, (const double*)dpart.p, nb_red, (double*)dlohi.p);
@@ -606,16 +615,19 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
         std::swap(cur, prev);
       }
       HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipEventRecord(e1, s));
+      HIPCHK(c, hipEventRecord(ev.e1, s));
       HIPCHK(c, hipStreamSynchronize(s));
-      float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1)); c->bvh_build_ms = ms;
-      hipEventDestroy(e0); hipEventDestroy(e1);
-      HIPCHK(c, hipMemcpy(c->cloud_order.data(), vA, (size_t)n * 4, hipMemcpyDeviceToHost));
+      float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1)); c->bvh_build_ms = ms;
+      HIPCHK(c, hipMemcpy(order.data(), vA, (size_t)n * 4, hipMemcpyDeviceToHost));
     }
+    // the build succeeded: publish it
+    c->cloud_order.swap(order);
     d.boxes = boxes; d.px = px; d.py = py; d.pz = pz; d.tri = tri; d.leafbox = lb;
     d.nlevels = (int)lvl_n.size();
     for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = lvl_off[i]; d.lvl_n[i] = lvl_n[i]; }
+    d.N = n;
   }
+  d.prim = prim;
   c->have_cloud = true;
   return TJ_OK;
 }
