@@ -194,7 +194,7 @@ def make_e2e(name, scene, max_iter=200, stop=1e-2):
                         cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), **{"final_" + k: v for k, v in st.items()})
 
 
-def make_envelope(name, scene, snap=(0, 2, 4, 6, 8), max_iter=200, stop=1e-2):
+def make_envelope(name, scene, snap=(0, 2, 4, 6, 8), max_iter=200, stop=1e-2, optimal_plane=False):
     """The headline scene's end-to-end pin.  The unmodified reference is run twice to the mains' stop test: on the scene
     and on the scene with its way points multiplied by (1 + 2.3e-16) -- a ONE-ULP input change.  Recorded: both
     iteration counts, the relative distance of the two runs' control points after every iteration (`div_hist`: how
@@ -204,6 +204,8 @@ def make_envelope(name, scene, snap=(0, 2, 4, 6, 8), max_iter=200, stop=1e-2):
     def run(pert):
         sc = dict(scene); sc["waypoints"] = scene["waypoints"] * (1.0 + pert)
         e = Engine("ref", sc)
+        if optimal_plane:
+            e.set_optimal_plane(True)
         gn, hist = [], []
         for it in range(max_iter):
             gn.append(e.iterate()); hist.append(e.get_state())
@@ -220,6 +222,13 @@ def make_envelope(name, scene, snap=(0, 2, 4, 6, 8), max_iter=200, stop=1e-2):
     for i in snap:
         rec[f"it{i}_spline"] = ha[i]["spline"]; rec[f"it{i}_piece_time"] = ha[i]["piece_time"]
     np.savez_compressed(os.path.join(HERE, f"envelope_{name}.npz"), **rec)
+
+
+def make_optplane_envelopes():
+    """the reference's own 1-ulp sensitivity with "optimal_plane":1 on the scenes tests/test_gpu_optplane.py runs end to end"""
+    make_envelope("optplane_tiny_single", pkg_scenes.tiny(0, n_points=3000), snap=(0, 2, 4, 8), max_iter=300, optimal_plane=True)
+    make_envelope("optplane_tiny_multi", pkg_scenes.tiny(1), snap=(0, 2, 4, 8), max_iter=300, optimal_plane=True)
+    make_envelope("optplane_scn_b", pkg_scenes.scn_b(), snap=(0, 2, 4, 8), max_iter=300, optimal_plane=True)
 
 
 def plane_from_witness(v, tri, dist, offset):
@@ -408,6 +417,7 @@ def make_scn_c():
     """BASELINE config 4 (the headline bench scene): per-iteration teacher-forcing data and the end-to-end envelope"""
     make_stages("scn_c", pkg_scenes.scn_c(), 14, {0, 1, 3, 6, 9, 13}, with_canon=False)
     make_envelope("scn_c", pkg_scenes.scn_c())
+    make_optplane_envelopes()
 
 
 def _flat_obs_cache(cache):

@@ -2,10 +2,13 @@
 of the unmodified reference and against the CPU oracle live.
 
 Tolerances.  The reference's refinement is a Newton iteration whose Hessian is repaired to a smallest eigenvalue of
-1e-8, with unbounded zig-zagging on some inputs: it amplifies the 1-ulp differences between glibc's and the device's
-log / sin / cos.  Known answers therefore agree to 1e-9 on the bulk of the cases and a small fraction may drift; the
-per-iteration (teacher-forced) plane lists agree to 1e-7; converged runs are compared at the sensitivity the reference
-shows against itself.  The eigenvalue kernel itself is bit-exact."""
+1e-8, with unbounded zig-zagging on some inputs: it amplifies a 1-ulp difference in log / sin / cos 1e8-fold.  Since round 3
+the device evaluates these three with csrc/dev_crmath.h (double-double pieces, rounded once), which returns glibc's bits
+wherever glibc is correctly rounded (99.8 - 99.9 % of the calls, tests/test_crmath.py): the 800 known answers and every
+refined plane of the teacher-forced fixtures are now BIT-IDENTICAL to the reference's (round 2: 93 % within 1e-9, planes
+1e-7), whole iterations agree with the oracle to 3e-11, converged runs to 5e-8 / 1e-11 with the reference's own iteration
+counts.  The bars below are ~10x these observations (TJ_PRINT_OBSERVED=1 prints them) and are tied to the reference's own
+1-ulp sensitivity in this mode through the envelope fixtures (tests/golden/envelope_optplane_*.npz)."""
 import numpy as np
 import pytest
 
@@ -15,10 +18,17 @@ pytestmark = pytest.mark.gpu
 STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
 
 
-# observed (TJ_PRINT_OBSERVED=1): tiny_multi 80 plane entries, median 0 (bit-identical), 85 % within 1e-12, 92.5 % within 1e-10, max 3.4e-9;
-# tiny_multi_coupled 64 entries, 89 % / 94 %, same max; tiny_single stores no plane on the kept iterations
-FRAC_1E12 = dict(tiny_single=1.0, tiny_multi=0.8, tiny_multi_coupled=0.85)
-FRAC_1E10 = dict(tiny_single=1.0, tiny_multi=0.9, tiny_multi_coupled=0.9)
+# observed (TJ_PRINT_OBSERVED=1): every plane entry of the three fixtures bit-identical to the reference's (tiny_multi 80 entries,
+# tiny_multi_coupled 64); a stray glibc misrounding on other data would show as ONE plane off by up to ~1e-8, so the bulk is pinned
+FRAC_1E12 = dict(tiny_single=1.0, tiny_multi=0.98, tiny_multi_coupled=0.98)
+FRAC_1E10 = dict(tiny_single=1.0, tiny_multi=0.98, tiny_multi_coupled=0.98)
+PLANE_TOL = 1e-12   # teacher-forced plane lists and tables (observed 0)
+
+
+def _obs(what, err):
+    if __import__("os").environ.get("TJ_PRINT_OBSERVED"):
+        err = np.atleast_1d(np.asarray(err, dtype=float))
+        print("OBSERVED", what, dict(n=int(err.size), max=float(err.max()), median=float(np.median(err)), exact=float(np.mean(err == 0)), le1e12=float(np.mean(err <= 1e-12))))
 
 
 def _scene(scenes, name):
@@ -49,11 +59,13 @@ def test_device_plane_refinement_known_answers(katsolver):
     fin, out = katsolver.kat_refine_planes(5, g["P_obs"], g["q_obs"], g["in_obs"])
     err = np.max(np.abs(out - g["out_obs"]), axis=1)
     assert fin.all()
-    assert np.mean(err <= 1e-9) >= 0.97 and np.median(err) <= 1e-13, (np.mean(err <= 1e-9), np.median(err), err.max())
+    _obs("kat obstacle planes", err)
+    assert np.mean(err == 0) >= 0.99 and err.max() <= 1e-9, (np.mean(err == 0), err.max())     # observed: all 400 bit-identical
     fin, out = katsolver.kat_refine_planes(6, g["P_self"], g["Q_self"], g["in_self"])
     err = np.max(np.abs(out - g["out_self"]), axis=1)
     assert fin.all()
-    assert np.mean(err <= 1e-9) >= 0.93 and np.median(err) <= 1e-13, (np.mean(err <= 1e-9), np.median(err), err.max())
+    _obs("kat pair planes", err)
+    assert np.mean(err == 0) >= 0.99 and err.max() <= 1e-9, (np.mean(err == 0), err.max())     # observed: all 400 bit-identical
     # the wave-cooperative form k_keep uses for short lists: same bits as the per-lane form
     fin_w, out_w = katsolver.kat_refine_planes(7, g["P_self"], g["Q_self"], g["in_self"])
     assert np.array_equal(fin_w, fin) and np.array_equal(out_w, out)
@@ -76,28 +88,24 @@ def test_persistent_plane_stage_teacher_forced_vs_reference(pkg, scenes, name):
             s.set_pair_cache(g[k + "pre_cache_on"], g[k + "pre_cache_cd"])
         counts, planes = s.stage_planes()
         assert np.array_equal(counts, g[k + "counts"]), f"it{it}: plane counts differ"
-        assert maxdiff(canon(counts, planes), g[k + "planes"]) <= 1e-7, it
+        assert maxdiff(canon(counts, planes), g[k + "planes"]) <= PLANE_TOL, it
         if scene["mode"] == 0:   # the same SET of remembered obstacles, the same planes
             for (ids, cd), k_n in zip(s.get_obs_cache(), g[k + "post_cache_n"]):
                 assert len(ids) == k_n
             got = {(tr, int(i)): c for tr, (ids, cd) in enumerate(s.get_obs_cache()) for i, c in zip(ids, cd)}
             want = {(tr, int(i)): c for tr, (ids, cd) in enumerate(_unflat(g[k + "post_cache_n"], g[k + "post_cache_ids"], g[k + "post_cache_cd"])) for i, c in zip(ids, cd)}
             assert got.keys() == want.keys()
-            assert max((np.max(np.abs(got[key] - want[key])) for key in got), default=0.0) <= 1e-7
+            assert max((np.max(np.abs(got[key] - want[key])) for key in got), default=0.0) <= PLANE_TOL
             diffs += [np.abs(got[key] - want[key]).ravel() for key in got]
         else:
             on, cd = s.get_pair_cache()
             assert np.array_equal(on, g[k + "post_cache_on"])
-            assert maxdiff(cd, g[k + "post_cache_cd"]) <= 1e-7
+            assert maxdiff(cd, g[k + "post_cache_cd"]) <= PLANE_TOL
             live = np.asarray(on).astype(bool)
             diffs.append(np.abs(np.asarray(cd)[live] - np.asarray(g[k + "post_cache_cd"])[live]).ravel())
     assert s.stats()["error_bits"] == 0
     s.close()
-    # Where the 1e-7 above comes from: not from an indexing or ordering difference -- the stored SETS are
-    # identical and the bulk of the refined planes is at rounding level; a few planes sit on the zig-zagging Newton
-    # iterations whose repaired eigenvalue (1e-8) amplifies the 1-ulp differences between the device's and glibc's
-    # log / sin / cos by up to 1e8.  Pin that distribution, so that a real defect (which would move the bulk) cannot hide
-    # under the loose maximum.
+    # the distribution as well: the stored SETS are identical and the refined planes bit-identical (see the module docstring)
     d = np.concatenate(diffs) if diffs else np.zeros(1)
     d = d[np.isfinite(d)]
     frac12, frac10 = float(np.mean(d <= 1e-12)), float(np.mean(d <= 1e-10))
@@ -123,18 +131,25 @@ def test_persistent_planes_every_iteration_vs_oracle_live(pkg, scenes, name):
         o.iterate(); s.iterate(1)
         a, b = s.get_state(), o.get_state()
         worst = max(worst, max(rel(a[n], b[n]) for n in STATE))
-    assert worst <= 1e-6, worst
+    _obs("iterations vs oracle " + name, worst)
+    assert worst <= dict(tiny_single=3e-10, tiny_multi=2e-11, scn_b=2e-11)[name], worst   # observed 2.8e-11 / 1.2e-12 / 1.0e-12 (round 2: bar 1e-6)
     assert s.stats()["error_bits"] == 0
     s.close()
 
 
-@pytest.mark.parametrize("name,tol", [("tiny_single", 2e-5), ("tiny_multi", 1e-6)])
+@pytest.mark.parametrize("name,tol", [("tiny_single", 5e-7), ("tiny_multi", 1e-9)])
 def test_converged_run_with_persistent_planes_vs_reference(pkg, scenes, name, tol):
+    """observed 5.2e-8 (39 = 39 iterations) and 1.0e-11 (19 = 19); round 2: 2e-5 / 1e-6, iteration count +-1.  The bars are checked
+    against the reference's OWN 1-ulp sensitivity on the same scenes (envelope fixtures): they may not exceed 20x of it"""
     g = gold(f"optplane_e2e_{name}.npz"); scene = _scene(scenes, name)
     check_scene_matches_fixture(scene, g)
+    env = gold(f"envelope_optplane_{name}.npz")
+    assert np.array_equal(env["final_spline"], g["final_spline"]) and int(env["iters"]) == int(g["iters"])   # the same reference run
+    assert tol <= 20 * float(env["div_hist"].max()), "bar looser than the reference's own 1-ulp sensitivity allows"
     s = pkg.Solver(scene, optimal_plane=1)
     gn, it, conv = s.iterate(300)
-    assert conv and abs(it - int(g["iters"])) <= 1
+    _obs(f"converged {name} (iterations {it} vs {int(g['iters'])})", rel(s.get_state()["spline"], g["final_spline"]))
+    assert conv and it == int(g["iters"])
     assert rel(s.get_state()["spline"], g["final_spline"]) <= tol
     assert s.stats()["error_bits"] == 0
     s.close()
@@ -193,6 +208,23 @@ def test_sharded_persistent_pair_planes_equal_unsharded(pkg, scenes):
         x.close()
 
 
+def test_converged_scn_b_with_persistent_planes_inside_the_reference_envelope(pkg, scenes):
+    """8 UAVs, 20k points, "optimal_plane":1 to the mains' stop test: the reference run perturbed by ONE ulp of its way points
+    ends 3.3e-3 away from itself, two iterations earlier (fixture); the HIP run must land inside 3x that envelope"""
+    env = gold("envelope_optplane_scn_b.npz")
+    scene = scenes.scn_b()
+    check_scene_matches_fixture(scene, env)
+    s = pkg.Solver(scene, optimal_plane=1)
+    gn, it, conv = s.iterate(300)
+    own = rel(env["final_spline_pert"], env["final_spline"])
+    got = rel(s.get_state()["spline"], env["final_spline"])
+    _obs(f"converged scn_b optimal_plane (iterations {it} vs {int(env['iters'])} / {int(env['iters_pert'])}; reference against itself {own:.2e})", got)
+    assert conv and min(int(env["iters"]), int(env["iters_pert"])) - 1 <= it <= max(int(env["iters"]), int(env["iters_pert"])) + 1
+    assert got <= 3 * own
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
 @pytest.mark.parametrize("multi", [False, True])
 def test_cli_optimal_plane_1(pkg, scenes, tmp_path, multi):
     """`"optimal_plane":1` in Config_File/3D.json selects the persistent-plane branch in both command-line tools"""
@@ -211,7 +243,7 @@ def test_cli_optimal_plane_1(pkg, scenes, tmp_path, multi):
     assert r.returncode == 0, r.stderr
     iters = int(open(tmp_path / "result" / (mesh + ("_result_file_multi.txt" if multi else "_result_file_admm.txt"))).read().split()[1])
     g = gold(f"optplane_e2e_{'tiny_multi' if multi else 'tiny_single'}.npz")
-    assert abs(iters - int(g["iters"])) <= 1      # the reference's own iteration count in this mode
+    assert iters == int(g["iters"])      # the reference's own iteration count in this mode
 
 
 def test_full_size_scn_c_persistent_planes_vs_oracle(pkg, scenes):
@@ -232,7 +264,8 @@ def test_full_size_scn_c_persistent_planes_vs_oracle(pkg, scenes):
         on_d, cd_d = s.get_pair_cache(); on_o, cd_o = o.get_pair_cache()
         assert np.array_equal(on_d, on_o), it          # the same pairs were switched on
     assert on_o.sum() > 500
-    assert worst <= 1e-6, worst
+    _obs("SCN-C iterations vs oracle", worst)
+    assert worst <= 5e-12, worst     # observed 3.0e-13 (round 2: bar 1e-6)
     assert s.stats()["error_bits"] == 0
     s.close()
 

@@ -95,7 +95,7 @@ def _teacher_forced(pkg, scene, g, tol_dir=1e-11):
     """tolerances = ~10x the largest difference observed against the reference's vectors (TJ_PRINT_OBSERVED=1 prints them:
     direction 1.5e-12 on tiny / SCN-C and 1.6e-11 on the ill-conditioned `hard` scene, |g| 5e-15 relative, slack/dual 7e-14)"""
     s = pkg.Solver(scene, stop=0.0)
-    seen = dict(direction=0.0, mid=0.0, gn=0.0, post=0.0)   # largest differences met (TJ_PRINT_OBSERVED=1 prints them)
+    seen = dict(planes=0.0, direction=0.0, mid=0.0, gn=0.0, post=0.0)   # largest differences met (TJ_PRINT_OBSERVED=1 prints them)
     for it in g["kept"]:
         k = f"it{it}_"
         s.set_state({n: g[k + "pre_" + n] for n in STATE})

@@ -17,6 +17,7 @@
 // stop after PLANE_NEWTON_CAP rounds / PLANE_BACKOFF_CAP back-offs and report it.
 #pragma once
 #include "dev_common.h"
+#include "dev_crmath.h"   // log / sin / cos that round like glibc's: one ulp here is 1e-8 after the reference's eigenvalue repair
 
 namespace tj {
 
@@ -124,7 +125,7 @@ __device__ inline bool opt_plane_obstacle(const double* P, double qx, double qy,
       const double dist = pc - off;
       if (dist < m) {
         const double pc0 = op_dot_row(r, c0x, c0y, c0z), pc1 = op_dot_row(r, c1x, c1y, c1z);
-        const double lg = log(dist / m);
+        const double lg = cr_log(dist / m);
         const double e1 = -(2 * (dist - m) * lg + (dist - m) * (dist - m) / dist);
         const double e2 = -(2 * lg + 4 * (dist - m) / dist - (dist - m) * (dist - m) / (dist * dist));
         g0 += e1 * pc0; g1 += 0;
@@ -159,7 +160,7 @@ __device__ inline bool opt_plane_obstacle(const double* P, double qx, double qy,
     if (fabs(dir0) > 0.5 * TJ_PI || fabs(dir1) > 0.5 * TJ_PI) { const double a = 0.5 * fabs(TJ_PI / dir0), b = 0.5 * fabs(TJ_PI / dir1); step = 0.95 * (b < a ? b : a); }
     double tx, ty, tz;
     auto cur_c = [&](double th, double ph) {
-      const double ct = cos(th), st = sin(th), cp = cos(ph), sp = sin(ph);
+      double ct, st, cp, sp; cr_sincos(th, &st, &ct); cr_sincos(ph, &sp, &cp);
       tx = ct * cx + st * (cp * c0x + sp * c1x); ty = ct * cy + st * (cp * c0y + sp * c1y); tz = ct * cz + st * (cp * c0z + sp * c1z);
     };
     auto energy = [&]() {
@@ -168,7 +169,7 @@ __device__ inline bool opt_plane_obstacle(const double* P, double qx, double qy,
       for (int j = 0; j < 6; j++) {
         const double dist = op_dot_row(P + 3 * j, tx, ty, tz) + dd;
         if (dist <= 0) return (double)INFINITY;
-        if (dist < m) e += -(dist - m) * (dist - m) * log(dist / m);
+        if (dist < m) e += -(dist - m) * (dist - m) * cr_log(dist / m);
       }
       return e;
     };
@@ -207,7 +208,7 @@ __device__ __forceinline__ OpTerm op_pair_term(const double* r, bool second, con
   const double dist = second ? -dc - d - 0.5 * off : dc + d - 0.5 * off;
   if (dist < m) {
     const double pc = sg * dc, pc0 = sg * op_dot_row(r, f.c0x, f.c0y, f.c0z), pc1 = sg * op_dot_row(r, f.c1x, f.c1y, f.c1z);
-    const double lg = log(dist / m);
+    const double lg = cr_log(dist / m);
     const double e1 = -(2 * (dist - m) * lg + (dist - m) * (dist - m) / dist);
     const double e2 = -(2 * lg + 4 * (dist - m) / dist - (dist - m) * (dist - m) / (dist * dist));
     t.g0 = e1 * pc0; t.g2 = sg * e1;
@@ -221,7 +222,7 @@ __device__ __forceinline__ bool op_pair_energy_term(const double* r, bool second
   const double dist = second ? -dc - td - 0.5 * off : dc + td - 0.5 * off;
   e = 0;
   if (dist <= 0) return false;
-  if (dist < m) e = -(dist - m) * (dist - m) * log(dist / m);
+  if (dist < m) e = -(dist - m) * (dist - m) * cr_log(dist / m);
   return true;
 }
 // LLT (always fails on this matrix: h11 == 0), eigenvalue repair, solve, clamp (:652-732): Newton direction and first step
@@ -290,16 +291,17 @@ __device__ inline bool opt_plane_pair(const double* A, const double* B, double m
       }
       return e;
     };
-    op_rotate(cos(0.0), sin(0.0), cos(0.0), sin(0.0), cx, cy, cz, f, tx, ty, tz); td = d;
+    auto rotate = [&](double th, double ph) { double ct, st, cp, sp; cr_sincos(th, &st, &ct); cr_sincos(ph, &sp, &cp); op_rotate(ct, st, cp, sp, cx, cy, cz, f, tx, ty, tz); };
+    rotate(0.0, 0.0); td = d;
     const double e0 = energy();
-    op_rotate(cos(0.0 + step * dir0), sin(0.0 + step * dir0), cos(0.0 + step * dir1), sin(0.0 + step * dir1), cx, cy, cz, f, tx, ty, tz); td = d + step * dir2;
+    rotate(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
     double e1v = energy();
     int bo = 0;
     bool stuck = false;
     while (e0 - 1e-4 * w * step < e1v) {
       if (++bo > PLANE_BACKOFF_CAP) { stuck = true; break; }
       step *= 0.8;
-      op_rotate(cos(0.0 + step * dir0), sin(0.0 + step * dir0), cos(0.0 + step * dir1), sin(0.0 + step * dir1), cx, cy, cz, f, tx, ty, tz); td = d + step * dir2;
+      rotate(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
       e1v = energy();
     }
     if (stuck) break;
@@ -336,7 +338,7 @@ __device__ inline bool opt_plane_pair_wave(const double* A, const double* B, dou
     double tx, ty, tz, td;
     auto rotate = [&](double th, double ph) {
       const double x = lane == 1 ? ph : th;
-      const double cv = cos(x), sv = sin(x);
+      double cv, sv; cr_sincos(x, &sv, &cv);
       op_rotate(gjk_rl(cv, 0), gjk_rl(sv, 0), gjk_rl(cv, 1), gjk_rl(sv, 1), cx, cy, cz, f, tx, ty, tz);
     };
     auto energy = [&]() {

@@ -18,6 +18,7 @@
 #pragma once
 #include "dev_common.h"
 #include "dev_linalg.h"
+#include "dev_crmath.h"
 
 namespace tj {
 
@@ -314,16 +315,18 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
     for (int j = 0; j < 6; j++) {
       const double ds = (A[3 * j] * e0 + A[3 * j + 1] * e1c + A[3 * j + 2] * e2c) + dpl - 0.5 * off;
       if (ds < m) {
-        const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
-        const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+        const double lg = cr_log(ds / m);   // rounds like glibc's log (dev_crmath.h): the offset is then the reference's bit for bit
+        const double g1 = -(2 * (ds - m) * lg + (ds - m) * (ds - m) / ds);
+        const double g2 = -(2 * lg + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
         grad += g1; hess += g2;
       }
     }
     for (int j = 0; j < 6; j++) {
       const double ds = -(Bq[3 * j] * e0 + Bq[3 * j + 1] * e1c + Bq[3 * j + 2] * e2c) - dpl - 0.5 * off;
       if (ds < m) {
-        const double g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
-        const double g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+        const double lg = cr_log(ds / m);
+        const double g1 = -(2 * (ds - m) * lg + (ds - m) * (ds - m) / ds);
+        const double g2 = -(2 * lg + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
         grad += -g1; hess += g2;
       }
     }
@@ -371,8 +374,9 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
     const bool act = lane < 12 && ds < m;
     double g1 = 0, g2 = 0;
     if (act) {
-      g1 = -(2 * (ds - m) * log(ds / m) + (ds - m) * (ds - m) / ds);
-      g2 = -(2 * log(ds / m) + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
+      const double lg = cr_log(ds / m);
+      g1 = -(2 * (ds - m) * lg + (ds - m) * (ds - m) / ds);
+      g2 = -(2 * lg + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
     }
     const unsigned mask = (unsigned)__ballot(act);
     double grad = 0, hess = 0;
