@@ -294,6 +294,8 @@ __device__ inline bool kdop_hulls_pass(const Dev& D, const double* A, const doub
 // A is the hull of the lower robot index.  Returns false if the hulls are farther than dist.
 // capped = true when the Newton loop hit LOOP_CAP.
 // second half of plane_pair: from the GJK witness vector to the plane (separate so that a caller can act between the halves)
+// cr_log out of line: the per-lane pair path lives in k_mid at its 256-register cap, where the inlined double-double pieces spill
+__device__ __noinline__ double cr_log_call(double x) { return cr_log(x); }
 __device__ inline bool plane_pair_finish(const V3& v, const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters = nullptr);
 __device__ inline bool plane_pair(const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr) {
   const V3 v = gjk(BodyHull{A}, BodyHull{Bq}, gjk_iters);
@@ -315,7 +317,7 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
     for (int j = 0; j < 6; j++) {
       const double ds = (A[3 * j] * e0 + A[3 * j + 1] * e1c + A[3 * j + 2] * e2c) + dpl - 0.5 * off;
       if (ds < m) {
-        const double lg = cr_log(ds / m);   // rounds like glibc's log (dev_crmath.h): the offset is then the reference's bit for bit
+        const double lg = cr_log_call(ds / m);   // rounds like glibc's log (dev_crmath.h): the offset is then the reference's bit for bit
         const double g1 = -(2 * (ds - m) * lg + (ds - m) * (ds - m) / ds);
         const double g2 = -(2 * lg + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
         grad += g1; hess += g2;
@@ -324,7 +326,7 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
     for (int j = 0; j < 6; j++) {
       const double ds = -(Bq[3 * j] * e0 + Bq[3 * j + 1] * e1c + Bq[3 * j + 2] * e2c) - dpl - 0.5 * off;
       if (ds < m) {
-        const double lg = cr_log(ds / m);
+        const double lg = cr_log_call(ds / m);
         const double g1 = -(2 * (ds - m) * lg + (ds - m) * (ds - m) / ds);
         const double g2 = -(2 * lg + 4 * (ds - m) / ds - (ds - m) * (ds - m) / (ds * ds));
         grad += -g1; hess += g2;
