@@ -141,6 +141,10 @@ int tj_set_planes(tj_ctx* c, int u, const int* counts, const double* planes);
 int tj_get_direction(tj_ctx* c, int u, double* direction, double* t_direction, double* wolfe, double* gn);
 int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361);
 int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_armijo);
+/* Energy_admm::spline_energy (HighOrderCCD/Energy_admm.h:16-44) of every OWNED robot at the current state, against the
+ * separating planes of the last iteration (the lists the last tj_iterate built): energy[uav_num], robots of other ranks 0.
+ * The value the line search calls E(x); the mains do not print it, parity tests compare it with the reference's. */
+int tj_get_energy(tj_ctx* c, double* energy);
 /* teacher forcing of the CCD / line-search stages: overwrite robot u's search direction record (direction T x 3 column-major) */
 int tj_set_direction(tj_ctx* c, int u, const double* direction, double t_direction, double wolfe, double gn);
 

@@ -71,7 +71,7 @@ def scene_by_name(scenes, name):
     if name == "hard_single":   # one UAV (admmPathPlanning3D mode, ks = 1e-8) through a cloud 0.13 from its path: obstacle planes active from iteration 0
         return dict(scenes.hard(U=1, n_points=2500, seed=12), mode=0, ks=1e-8, name="hard-single")
     return {"tiny_multi": lambda: scenes.tiny(1), "tiny_single": lambda: scenes.tiny(0, n_points=3000), "hard": scenes.hard,
-            "scn_a": scenes.scn_a, "scn_b": scenes.scn_b, "scn_c": scenes.scn_c}[name]()
+            "scn_a": scenes.scn_a, "scn_b": scenes.scn_b, "scn_c": scenes.scn_c, "scn_c3": scenes.scn_c3}[name]()
 
 
 def check_scene_matches_fixture(scene, g):

@@ -183,14 +183,26 @@ def make_stages_coupled(name, scene, iters, keep):
 
 
 def make_e2e(name, scene, max_iter=200, stop=1e-2):
-    e = Engine("ref", scene)
-    gn = []
-    for it in range(max_iter):
-        g = e.iterate(); gn.append(g)
-        if it > 1 and g < stop:
-            break
-    st = e.get_state()
-    np.savez_compressed(os.path.join(HERE, f"e2e_{name}.npz"), gnorm_hist=np.array(gn), iters=np.array(len(gn)),
+    """The unmodified reference to the mains' stop test: final state, and Energy_admm::spline_energy of every robot at the final
+    state against the separating planes OF that state (the iteration's own plane lists are locals of optimization_decouple; the
+    stage entry rebuilds them).  A second run with the way points moved by ONE ULP records how far the reference moves its own
+    final control points (`spline_env`) and energies (`energy_env`): the floor under any end-to-end tolerance."""
+    def run(pert):
+        sc = dict(scene); sc["waypoints"] = scene["waypoints"] * (1.0 + pert)
+        e = Engine("ref", sc)
+        gn = []
+        for it in range(max_iter):
+            g = e.iterate(); gn.append(g)
+            if it > 1 and g < stop:
+                break
+        st = e.get_state()
+        e.stage_planes()
+        return gn, st, np.array([e.spline_energy(u) for u in range(scene["U"])])
+    gn, st, energy = run(0.0)
+    _, st_p, energy_p = run(2.3e-16)
+    np.savez_compressed(os.path.join(HERE, f"e2e_{name}.npz"), gnorm_hist=np.array(gn), iters=np.array(len(gn)), final_energy=energy,
+                        energy_env=np.array(np.max(np.abs(energy_p - energy) / np.abs(energy))),
+                        spline_env=np.array(np.max(np.abs(st_p["spline"] - st["spline"])) / np.max(np.abs(st["spline"]))),
                         cloud_sum=np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()]), **{"final_" + k: v for k, v in st.items()})
 
 
@@ -418,6 +430,8 @@ def make_scn_c():
     make_stages("scn_c", pkg_scenes.scn_c(), 14, {0, 1, 3, 6, 9, 13}, with_canon=False)
     make_envelope("scn_c", pkg_scenes.scn_c())
     make_optplane_envelopes()
+    make_e2e("scn_c3", pkg_scenes.scn_c3())          # 64 UAVs with a 1-ulp envelope of 6e-11: the literal 1e-8 end-to-end test
+    make_envelope("scn_c3", pkg_scenes.scn_c3())
 
 
 def _flat_obs_cache(cache):

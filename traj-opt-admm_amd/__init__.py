@@ -24,7 +24,7 @@ _ip = C.POINTER(C.c_int)
 EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_set_mesh", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes", "tj_get_candidates",
-    "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_stats", "tj_get_build_info", "tj_exchange_buffer",
+    "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_energy", "tj_get_stats", "tj_get_build_info", "tj_exchange_buffer",
     "tj_iterate_phase", "tj_phase_count", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
     "tj_group_create", "tj_group_destroy", "tj_group_size", "tj_group_ctx", "tj_group_last_error", "tj_group_set_cloud", "tj_group_set_mesh",
@@ -383,6 +383,12 @@ class Solver:
         out = np.zeros((mats.shape[0], 2))
         self._check(self.lib.tj_kat_linalg(self._ctx, C.c_int(mats.shape[0]), C.c_int(mats.shape[1]), _d(mats), _d(out)))
         return out
+
+    def energy(self):
+        """Energy_admm::spline_energy of every owned robot at the current state (planes of the last iteration)"""
+        e = np.zeros(self.U)
+        self._check(self.lib.tj_get_energy(self._ctx, _d(e)))
+        return e
 
     def build_info(self):
         ms, dev = C.c_double(), C.c_int()

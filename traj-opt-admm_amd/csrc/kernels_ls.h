@@ -420,6 +420,25 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   }
 }
 
+// Energy_admm::spline_energy (Energy_admm.h:16-44) of the CURRENT state against the plane lists of the last iteration: what the
+// mains could print next to gnorm.  Same staging and the same evaluation the line search performs for E(x); all eight groups
+// evaluate it (the function's barrier is block wide), group 0 reports.
+__global__ __launch_bounds__(LS_THREADS) void k_energy(Dev D, LsLayout L, double* out) {
+  extern __shared__ double sm[];
+  __shared__ int pref[1024];
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
+  const int G = L.groups;
+  const int g = min(tid / LS_GSIZE, G - 1), gl = tid % LS_GSIZE;
+  bool in_lds;
+  const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
+  double* net = sm + L.net;
+  double* gnet = sm + L.gnet + (size_t)g * 3 * T;
+  for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = net[i];
+  __syncthreads();
+  const double e = x_energy_group(D, u, sm, L, gnet, D.piece_time[u], sm + L.ghull + (size_t)g * S * 18, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, 0, 0.0);
+  if (tid == 0) out[u] = e;
+}
+
 // ---- coupled mode ("decouple":0): Armijo search on the SUM of all robots' energies ---------------
 // Optimization3D_multi::update_spline (Optimization3D_multi.h:587-636).  One step and one piece_time for
 // every robot, accepted when e0 - 1e-4*wolfe*step >= sum_u E_u(x_u + step d_u, t + step t_dir).  The sum

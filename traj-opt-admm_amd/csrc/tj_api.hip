@@ -965,6 +965,22 @@ int tj_get_local_grad(tj_ctx* c, int u, int piece, double* g19, double* h361) {
   return TJ_OK;
 }
 
+int tj_get_energy(tj_ctx* c, double* energy) {
+  if (!c || !energy) return TJ_ERR_INVALID;
+  if (!ready(c)) return TJ_ERR_INVALID;
+  const Dev& d = c->d;
+  QUIESCE(c);
+  DevBuf out;
+  { int r = to_dev(c, out, nullptr, (size_t)d.U * 8); if (r) return r; }
+  HIPCHK(c, hipMemsetAsync(out.p, 0, (size_t)d.U * 8, c->stream));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_energy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
+  hipLaunchKernelGGL(k_energy, dim3(d.u1 - d.u0), dim3(LS_THREADS), c->lds_ls, c->stream, d, c->lsl, (double*)out.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(energy, out.p, (size_t)d.U * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TJ_OK;
+}
+
 int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_armijo) {
   if (!c) return TJ_ERR_INVALID;
   const Dev& d = c->d;
