@@ -107,3 +107,24 @@ def bvh_kat_case(prim):
     lo[:100] = np.round(lo[:100] * 8) / 8; ext[:100] = np.round(ext[:100] * 8) / 8
     boxes = np.concatenate([lo, lo + ext], axis=1)
     return np.ascontiguousarray(verts), boxes
+
+
+# Whole iterations started from the oracle's state, full-size scenes (SCN-C, SCN-D, config 5, ragged fleets).  Observed with
+# TJ_PRINT_OBSERVED=1 on MI355X (round 3): state <= 6.3e-12 relative to the buffer's largest entry (SCN-C, eighth iteration; ~1e-15
+# on most), gnorm bit-identical; the bars are ~15x the worst observation (round 2 asserted 1e-9 / 1e-10).
+TOL_STATE_FULL = 1e-10
+TOL_GNORM_FULL = 1e-12
+_OBSERVED = {"state": 0.0, "gnorm": 0.0}
+
+
+def observe_iteration(a, b, gg, go, tol_state, tol_g, it):
+    import os
+    STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
+    dg = abs(gg - go) / max(1.0, go)
+    ds = max(maxdiff(a[n], b[n]) / max(1.0, np.abs(b[n]).max()) for n in STATE)
+    _OBSERVED["state"] = max(_OBSERVED["state"], ds); _OBSERVED["gnorm"] = max(_OBSERVED["gnorm"], dg)
+    if os.environ.get("TJ_PRINT_OBSERVED"):
+        print("OBSERVED iteration vs oracle", dict(it=it, state=float("%.2g" % ds), gnorm=float("%.2g" % dg), worst_state=float("%.2g" % _OBSERVED["state"]), worst_gnorm=float("%.2g" % _OBSERVED["gnorm"])))
+    assert dg <= tol_g, (it, gg, go)
+    for n in STATE:
+        assert maxdiff(a[n], b[n]) <= tol_state * max(1.0, np.abs(b[n]).max()), (it, n, maxdiff(a[n], b[n]))
