@@ -119,6 +119,54 @@ def survey_bytes(st, slv, iters):
     return b, total
 
 
+# What ONE wavefront pays on MI355X (tools/micro/issue_probe.hip, profiles/round3_issue_probe.txt; 2.4 GHz), in ns:
+PRIM = {"fp64": 2.6,        # one fp64 VALU instruction, dependent OR independent: a wave issues one every ~6.3 cycles
+        "readlane": 16.0,   # v_readlane pair -> first VALU use of the SGPR it wrote
+        "rsq": 12.2, "sqrt": 46.6, "div": 39.0, "log": 162.0,   # v_rsq_f64 + fma; IEEE sqrt; IEEE division (11 fp64 ops + v_rcp); ocml log
+        "lds": 54.0,        # LDS write -> read round trip
+        "mem": 700.0,       # dependent global-memory round trip (L2 / Infinity Cache hit)
+        "branch": 10.0}     # branch on a fresh VALU comparison
+
+
+def critical_path(slv, st, K, per_launch_ms, n_prims):
+    """roofline.critical_path: per chain kernel the DEPENDENCY CHAIN of its longest work item -- the operations that must follow
+    one another whatever the parallel width -- priced with the measured single-wave latencies above.  It is the bound this
+    latency-dominated path can be judged against (the HBM roofline is kept beside it as SURVEY 8(d) demands): `frac` =
+    bound / measured launch time.  Unit counts come from the device (longest robot-pair GJK, Armijo evaluations) and from the
+    problem's shape; the formulas are written out in DESIGN.md section 5."""
+    p = PRIM
+    U, S, P, res = slv.U, slv.S, slv.P, slv.res
+    it = max(1, K)
+    n = 9 * P - 2
+    lv, cnt = 1, (n_prims + 7) // 8
+    while cnt > 64:
+        cnt = (cnt + 7) // 8; lv += 1
+    gjk_max = max(1.0, st["gjk_max_sum"] / it) if slv.mode >= 1 else 1.0
+    rounds = 1.0 + max(0.0, (st["energy_evals"] / it / U - 2.0) / 8.0)          # Armijo rounds of 8 candidates per robot
+    walk = (lv + 3) * p["mem"]                                                    # record, one box load per level, leaf primitives, work-item slot
+    gjk_iter = (12 * p["fp64"] + p["readlane"]) + (21 * p["fp64"] + p["sqrt"] + p["div"] + p["branch"] + p["readlane"])   # support search + triangle step
+    pair = 2 * p["mem"] + gjk_max * gjk_iter + (p["sqrt"] + 3 * p["div"] + 12 * p["fp64"]) + (p["log"] + 2 * p["div"] + 24 * p["fp64"])   # work item -> hulls, GJK, normal + offsets, one Newton round
+    m_sum = sum(range(2, 19))                                                     # Householder steps of the 19 x 19 block: trailing sizes 18 .. 2
+    eig = 17 * (p["rsq"] + 2 * p["readlane"] + 8 * p["fp64"] + 5 * (3 * p["fp64"]) + p["readlane"]) + 2 * m_sum * p["fp64"] + 9 * (18 * 3 * p["fp64"] + 30.0)
+    grad = 3 * p["mem"] + (p["log"] + p["sqrt"] + 6 * p["div"] + 30 * p["fp64"]) + 2 * p["lds"] + eig   # counts -> planes -> (vel/acc record | plane terms) -> consensus -> repair
+    xsolve = 2 * p["mem"] + p["lds"] + n * (p["rsq"] + 8 * p["fp64"] + p["readlane"] + 2 * p["fp64"]) + n * (p["readlane"] + 2 * p["fp64"]) + 3 * p["lds"] + p["mem"]
+    evalx = p["lds"] + 7 * (p["lds"] + p["sqrt"] + p["div"] + 12 * p["fp64"]) + 2 * p["log"] + 3 * (p["lds"] + 6 * p["fp64"]) + p["log"] + 6 * p["lds"] + 2 * p["lds"] + 36 * p["fp64"]
+    ls = 2 * p["mem"] + p["lds"] + rounds * evalx + (p["lds"] + 6 * p["fp64"]) + (p["mem"] + 6 * 5 * p["fp64"]) + 2 * p["mem"]   # stage, rounds, exact hulls, intervals, store + ticket
+    bound = {"k_front": walk + p["mem"], "k_mid": pair, "k_grad": grad, "k_xsolve": xsolve, "k_ccd": walk + p["mem"], "k_ccd_self_seq": 3 * p["mem"] + 200 * p["fp64"], "k_linesearch": ls}
+    out, tb, tm = {}, 0.0, 0.0
+    for k, b in bound.items():
+        ms = per_launch_ms.get(k, 0.0)
+        if ms <= 0:
+            continue
+        out["tj::" + k] = {"bound_us": b * 1e-3, "measured_us": ms * 1e3, "frac": b * 1e-3 / (ms * 1e3)}
+        tb += b * 1e-3; tm += ms * 1e3
+    return {"unit": "us", "kernels": out, "chain_bound_us": tb, "chain_measured_us": tm, "frac": tb / tm if tm else None,
+            "unit_counts": {"bvh_levels": lv, "longest_pair_gjk_iterations": gjk_max, "armijo_rounds": rounds, "newton_system_rows": n},
+            "primitives_ns": PRIM,
+            "note": "dependency chain of each kernel's longest work item x measured single-wave latencies (tools/micro/issue_probe.hip); the rest of a launch is "
+                    "instruction issue of ONE wave (one fp64 instruction per ~6.3 cycles, dependent or not) plus dispatch / drain: see DESIGN.md section 5"}
+
+
 def source_id():
     """sha256 over the product sources: keys profile files to the build they were measured on"""
     import hashlib
@@ -418,7 +466,8 @@ def main():
                                    "implementation_bytes adds the hull / swept-hull caches this implementation moves through HBM",
                            "whole_iteration": {"algorithmic_bytes": alg_total, "achieved_GBps": alg_total / (dt / K) / 1e9, "frac": alg_total / (dt / K) / 1e9 / 8000.0,
                                                "implementation_bytes": impl_total, "implementation_frac": impl_total / (dt / K) / 1e9 / 8000.0},
-                           "kernel_ms_per_launch": per_launch_ms, "source_id": source_id()}
+                           "kernel_ms_per_launch": per_launch_ms, "source_id": source_id(),
+                           "critical_path": critical_path(slv, st2, K, per_launch_ms, scene["tris"].shape[0] if scene.get("tris") is not None else scene["cloud"].shape[0])}
         out["timed_window_ms"] = 1e3 * dt
         out["stats_per_iter"] = {k: (v / K if k not in ("error_bits", "order_ambiguous", "iters") else v) for k, v in st2.items()}
         if not args.no_cpu:

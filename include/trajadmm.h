@@ -172,6 +172,8 @@ typedef struct tj_stats {
                           16 coupled Newton system not SPD */
   int order_unresolved; /* such segments for which the tree order could NOT be established (result may differ from the reference's;
                            tj_iterate returns TJ_ERR_UNSUPPORTED) -- 0 unless uav_num is in the thousands */
+  unsigned long long gjk_max_sum; /* sum over the iterations of the longest robot-pair GJK (iterations of openGJK's main loop; pairs below 6
+                                     do not report): / iters = unit count of the pair stage's critical path */
 } tj_stats;
 int tj_get_stats(tj_ctx* c, tj_stats* s);
 /* the obstacle BVH of the last tj_set_cloud / tj_set_mesh: device time of the build (Morton keys, radix sort, box pyramid;

@@ -57,6 +57,10 @@ struct Ctl {
   // coupled mode, one context: the Armijo decision, taken once by the last block of an evaluation round (kernels_ls.h)
   int lsf_epoch, lsf_r, lsf_c, ls_ticket;   // epoch it belongs to / accepted round and slot / arrival counter of the round's blocks
   double lsf_step;
+  // length of the longest robot-pair GJK of the running iteration (only pairs with >= 6 iterations report: a handful per launch)
+  // and the sum of these maxima over the iterations begun so far: the unit count of k_mid's critical path (bench.py critical_path)
+  int gjk_max, pad2;
+  unsigned long long gjk_max_sum;
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)

@@ -246,8 +246,9 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         __syncthreads();
         if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
         __syncthreads();
-        double e0, e1c, e2c, dpl; bool capped; int nit = 0;
-        const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit);
+        double e0, e1c, e2c, dpl; bool capped; int nit = 0, gkc = 0;
+        const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gkc);
+        if (lane == 0 && gkc >= 6) atomicMax(&D.ctl->gjk_max, gkc);
         if (okp && lane == 0) {
           unsigned long long* ps = D.pair_stats + 2 * ((size_t)p0 * D.S + tr);
           atomicAdd(ps, (unsigned long long)nit); atomicAdd(ps + 1, 1ull);
@@ -276,6 +277,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         if (!cut) atomicAdd((unsigned long long*)&D.dbg[((size_t)K_SEP_SELF_ROWS * TJ_TIC_BLOCKS + min(gkl, 63)) * TJ_TIC_SLOTS], 1ull);   // histogram of GJK iterations per pair (lane path)
 #endif
         TJ_ORDER(vw.x); TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
+        if (!cut && gkl >= 6) atomicMax(&D.ctl->gjk_max, gkl);
         if (cut) {   // pass the pair on NOW (the consumers start while this wave's other lanes refine their offsets): slot from a returning add, then the tagged entry
           const int slot = atomicAdd(&D.pair_ovf[0], 1);
           if (slot < D.cap_work) __hip_atomic_store(&D.pair_ovf_list[slot], ((unsigned long long)(unsigned)epoch << 32) | (unsigned long long)(tr | (p0 << 9) | (q << 19)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -323,6 +325,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
 #ifdef TJ_PHASE_TIMING
       if (lane == 0 && first && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
 #endif
+      if (lane == 0 && gk >= 6) atomicMax(&D.ctl->gjk_max, gk);   // a handful of pairs per launch
       if (okp && lane == 0) {
         // statistics per (robot, segment): ~900 waves adding to ONE word of the control block serialise there (~13 ns each) and
         // the stores below wait for it

@@ -1391,6 +1391,7 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   s->energy_evals = evals; s->llt_fail_piece = fails; s->llt_fail_robot = h.llt_fail_robot; s->newton_iters = pt[0]; s->pair_solves = pt[1];
   s->pair_tests = d.mode >= 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
   s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error; s->order_unresolved = h.order_unresolved;
+  s->gjk_max_sum = h.gjk_max_sum + (unsigned long long)h.gjk_max;
   return TJ_OK;
 }
 
