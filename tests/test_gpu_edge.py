@@ -88,6 +88,31 @@ def test_refused_obstacle_set_leaves_the_previous_one_usable(pkg, scenes):
     a.close(); b.close()
 
 
+def test_fleet_of_1500_robots_vs_oracle(pkg, scenes):
+    """beyond the 1 024 robots of rounds 1-2 (robot ids in the packed pair keys are 11 bits now): 1 500 UAVs crossing, two whole
+    iterations each started from the CPU oracle's state; plane counts equal (the pair set is exact), state at the full-size bars"""
+    from oracle.pyoracle import Engine
+    from conftest import observe_iteration, TOL_STATE_FULL, TOL_GNORM_FULL
+    scene = scenes.crossing(1500, 6000, seed=9)
+    o = Engine("port", scene); o2 = Engine("port", scene)
+    s = pkg.Solver(scene, stop=0.0)
+    for it in range(2):
+        st0 = o.get_state()
+        s.set_state(st0); o2.set_state(st0)
+        co, _ = o2.stage_planes()
+        go = o.iterate()
+        gg, _, _ = s.iterate(1)
+        cg, _ = s.get_planes()
+        assert np.array_equal(co, cg), f"it{it}: plane counts differ"
+        observe_iteration(s.get_state(), o.get_state(), gg, go, TOL_STATE_FULL, TOL_GNORM_FULL, it)
+    st = s.stats()
+    assert st["error_bits"] == 0 and st["order_unresolved"] == 0 and st["planes_self"] > 0
+    s.close()
+    with pytest.raises(pkg.TrajAdmmError) as ei:
+        pkg.Solver(scenes.crossing(2049, 100, seed=1), stop=0.0)
+    assert "-5" in str(ei.value) and "2048" in str(ei.value)
+
+
 def test_infeasible_start_does_not_hang(pkg, scenes):
     """robots closer than `offset` at the start: the reference spins forever in Step::self_step
     (Step.h:232-250); the device loops are capped and the call returns TJ_ERR_NO_PROGRESS"""

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """Kernel statistics and one-iteration timeline from a rocprofv3 rocpd database (rocprofv3 --kernel-trace -d DIR -o NAME).
-Usage: python tools/rocpd_timeline.py DB [--iter K] [--csv OUT]   -- stats for all tj:: kernels; timeline of the K-th k_begin..k_begin span"""
+Usage: python tools/rocpd_timeline.py DB [--iter K] [--csv OUT] [--regime START:COUNT]
+  stats for all tj:: kernels; timeline of the K-th iteration.  --regime restricts the STATISTICS to the iterations
+  [START, START + COUNT) of the run (an iteration begins with k_front): bench.py runs 300 untimed clock-ramp iterations with the
+  stop test off, most of them at the fixed point, then W warm-up iterations, then the K timed ones -- `--regime 303:20` is the
+  timed window of the default command (K = 20, W = 3), the regime the headline number describes."""
 import argparse, csv, sqlite3, sys
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("db"); ap.add_argument("--iter", type=int, default=315); ap.add_argument("--csv")
+    ap = argparse.ArgumentParser(); ap.add_argument("db"); ap.add_argument("--iter", type=int, default=315); ap.add_argument("--csv"); ap.add_argument("--regime")
     a = ap.parse_args()
     db = sqlite3.connect(a.db); cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -18,8 +22,18 @@ def main():
             return n.replace(".kd", "")
         k = int(m.group(1)); st = m.end()
         return n[st:st + k]
+    stat_rows = rows
+    if a.regime:
+        r0, rc = (int(x) for x in a.regime.split(":"))
+        b_all = [i for i, r in enumerate(rows) if short(r[0]) in ("k_front", "k_obs_query")]
+        if len(b_all) >= r0 + rc:
+            lo = b_all[r0]; hi = b_all[r0 + rc] if len(b_all) > r0 + rc else len(rows)
+            stat_rows = rows[lo:hi]
+            print(f"# statistics over iterations [{r0}, {r0 + rc}) of the run: {len(stat_rows)} launches, span {1e-3 * (stat_rows[-1][2] - stat_rows[0][1]):.1f} us = {1e-3 * (stat_rows[-1][2] - stat_rows[0][1]) / rc:.2f} us per iteration under the profiler")
+        else:
+            print(f"# --regime {a.regime}: the run has only {len(b_all)} iterations; statistics over all launches")
     st = {}
-    for n, s, e, _, _ in rows:
+    for n, s, e, _, _ in stat_rows:
         st.setdefault(short(n), []).append(e - s)
     tot = sum(sum(v) for v in st.values())
     out = [("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")]

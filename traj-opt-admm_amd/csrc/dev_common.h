@@ -144,7 +144,7 @@ struct Dev {
                                    // address is hot; the host sums them when it reads the control block and picks k_ccd's build from the rate
   int pair_rows;                   // rows per tile of the robot-pair broad phase (kernels_pairs.h)
   int pair_pass_on;   // 1 (default): large fleets pass long pair solves on to idle waves; TJ_PAIR_PASS_ON=0 keeps every pair on its lane (test hook: same bits either way)
-  int* pair_ovf; unsigned long long* pair_ovf_list;   // large fleets: [0] pairs passed on by the lane solve, [1] producer waves done, [2] consumer cursor; entries (epoch << 32 | q << 19 | p0 << 9 | segment), cap_work of them
+  int* pair_ovf; unsigned long long* pair_ovf_list;   // large fleets: [0] pairs passed on by the lane solve, [1] producer waves done, [2] consumer cursor; entries (epoch << 32 | q << 20 | p0 << 9 | segment), cap_work of them
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
   // "optimal_plane":1 -- planes that persist across iterations (the reference's is_seperate / seperate_c / seperate_d and
   // is_self_seperate / self_seperate_c / self_seperate_d tables, CCDUtils.cpp:30-36).  Obstacle planes (mode 0): a list per

@@ -242,7 +242,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         }
         if (!have || (e & PAIR_OVF_STOP)) { TJ_TIC(D, K_SEP_SELF_SOLVE, 2); return; }
         if (i == bid - np) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
-        const int tr = (int)(e & 0x1ff), p0 = (int)((e >> 9) & 0x3ff), q = (int)((e >> 19) & 0x3ff);
+        const int tr = (int)(e & 0x1ff), p0 = (int)((e >> 9) & 0x7ff), q = (int)((e >> 20) & 0x7ff);   // 9 + 11 + 11 bits, bit 31 = PAIR_OVF_STOP
         __syncthreads();
         if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
         __syncthreads();
@@ -280,7 +280,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         if (!cut && gkl >= 6) atomicMax(&D.ctl->gjk_max, gkl);
         if (cut) {   // pass the pair on NOW (the consumers start while this wave's other lanes refine their offsets): slot from a returning add, then the tagged entry
           const int slot = atomicAdd(&D.pair_ovf[0], 1);
-          if (slot < D.cap_work) __hip_atomic_store(&D.pair_ovf_list[slot], ((unsigned long long)(unsigned)epoch << 32) | (unsigned long long)(tr | (p0 << 9) | (q << 19)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (slot < D.cap_work) __hip_atomic_store(&D.pair_ovf_list[slot], ((unsigned long long)(unsigned)epoch << 32) | (unsigned long long)(tr | (p0 << 9) | (q << 20)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);   // cannot happen (the list holds cap_work entries and there are at most that many pairs); never drop a pair silently
         }
         if (!cut && plane_pair_finish(vw, Ag, Bg, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {

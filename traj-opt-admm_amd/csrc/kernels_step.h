@@ -130,7 +130,8 @@ __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
 // Phase A: one wave per (segment, lower robot p0, chunk of 64 partners p1 > p0); lanes over the partners.  Acting pairs go to
 // ONE global list as sortable keys; the replay kernel sorts it, so (segment, p0, p1) is a lexicographic, deterministic order.
 constexpr int ACT_CAP = 4096;                                    // acting pairs of one iteration (all segments)
-__device__ __forceinline__ int act_key(int tr, int p0, int p1) { return (tr << 20) | (p0 << 10) | p1; }   // S < 512, U <= 1024
+constexpr int ROBOT_BITS = 11;                                   // robot ids in packed pair keys: U <= 2048 (with S < 512 a key is 31 bits)
+__device__ __forceinline__ int act_key(int tr, int p0, int p1) { return (tr << (2 * ROBOT_BITS)) | (p0 << ROBOT_BITS) | p1; }
 __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid, double* lds) {
   int tr, rb, cb;
   pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
@@ -235,10 +236,10 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     int ambiguous = 0, unresolved = 0;
     for (int pos = 0; pos < n_act;) {
       // 1. this segment's acting pairs, lexicographic (p0, p1); does any robot appear twice?
-      const int tr = keys[pos] >> 20;
+      const int tr = keys[pos] >> (2 * ROBOT_BITS);
       int m = 0; bool share = false;
-      while (pos < n_act && (keys[pos] >> 20) == tr) {
-        const int p0 = (keys[pos] >> 10) & 1023, p1 = keys[pos] & 1023;
+      while (pos < n_act && (keys[pos] >> (2 * ROBOT_BITS)) == tr) {
+        const int p0 = (keys[pos] >> ROBOT_BITS) & ((1 << ROBOT_BITS) - 1), p1 = keys[pos] & ((1 << ROBOT_BITS) - 1);
         if (seen[p0] == tr || seen[p1] == tr) share = true;
         blk_sync<true>();
         if (lane == 0) { seen[p0] = tr; seen[p1] = tr; if (m < SEQ_ACT_CAP) { act0[m] = p0; act1[m] = p1; } }

@@ -449,7 +449,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
 #ifdef TJ_PHASE_TIMING
   { int r_ = dalloc(c, &d.dbg, (size_t)K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS); if (r_) return r_; }
 #endif
-  if (d.U > 1024) { c->err = "more than 1024 robots are not supported (pair keys pack robot ids into 10 bits)"; return TJ_ERR_UNSUPPORTED; }
+  if (d.U > 2048) { c->err = "more than 2048 robots are not supported (pair keys pack robot ids into 11 bits; the dense [S][U][U] plane tables are 5.4 GB + 0.7 GB there)"; return TJ_ERR_UNSUPPORTED; }
   if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
   if (d.res > GRAD_MAXRES) { c->err = "res > 16 segments per piece is not supported by the gradient kernel"; return TJ_ERR_UNSUPPORTED; }
   d.seq_tree = (d.mode == TJ_MODE_MULTI_DECOUPLE && seq_lds_bytes(d.U, d.S, true) <= lds_max) ? 1 : 0;
