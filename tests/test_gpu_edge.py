@@ -219,7 +219,7 @@ def test_cli_coupled_mode_and_log_data(pkg, scenes, tmp_path):
         assert mine.shape == out.shape and np.max(np.abs(mine - out)) <= 1e-12
 
 
-@pytest.mark.parametrize("P,res,mode", [(3, 8, 1), (4, 4, 1), (7, 8, 1), (8, 8, 1), (9, 8, 2), (3, 8, 2), (6, 8, 0), (10, 8, 1), (12, 8, 1), (20, 8, 1), (14, 8, 0), (31, 8, 1)])
+@pytest.mark.parametrize("P,res,mode", [(3, 8, 1), (4, 4, 1), (7, 8, 1), (8, 8, 1), (9, 8, 2), (3, 8, 2), (6, 8, 0), (10, 8, 1), (12, 8, 1), (20, 8, 1), (14, 8, 0), (31, 8, 1), (12, 8, 2), (16, 8, 2)])
 def test_piece_counts_and_resolutions_vs_oracle(pkg, scenes, P, res, mode):
     """every size class of the per-robot Newton system: n = 9P-2 in {25,...,61} takes the register-resident
     factorisation, P = 8..10 the dense LDS one, P > 10 (the reference sizes everything from the init file,

@@ -247,7 +247,9 @@ __device__ __forceinline__ bool chol_arrow_wave(double (&r)[N], double& y, int l
 // the FAST chol_arrow_lds / chol_arrow_backsolve_lds (fma(-l_ik, l_jk, a_ij), k ascending; reciprocal root on the diagonal), executed by
 // ONE wave; y rides along (y <- L^-1 y).  Returns false on a pivot <= 0.
 constexpr int BAND_BS = 18;   // half-bandwidth 17 + diagonal
-__device__ inline bool chol_band_lds(double* Bd, double* Ar, int n, int tid, double* y) {
+// last_pivot = false (coupled mode): the arrow row's diagonal is left as the Schur complement a_nn - sum l_nk^2 and y[n-1] as the
+// matching reduced right-hand side, like chol_arrow_lds with npiv = n - 1 (the shared-time corner is completed across robots)
+__device__ inline bool chol_band_lds(double* Bd, double* Ar, int n, int tid, double* y, bool last_pivot = true) {
   __shared__ double s_colb[CHOL_MB + 2];
   const int m = n - 1, BS = BAND_BS;
   int er[3], ec[3];
@@ -286,6 +288,7 @@ __device__ inline bool chol_band_lds(double* Bd, double* Ar, int n, int tid, dou
     if (tid == 63) { Ar[m] = fma(-la, la, add); y[m] = fma(-yk, la, ylast); }
   }
   blk_sync<true>();
+  if (!last_pivot) return true;
   const double x = Ar[m];
   if (x <= 0) return false;
   blk_sync<true>();

@@ -503,7 +503,12 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   __shared__ int s_acc[2];
   __shared__ double s_step0, s_accstep;
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
-  const int g = tid / LS_GSIZE, gl = tid % LS_GSIZE;
+  // G = L.groups candidates side by side (8 up to piece_num = 10; 4 or 2 for long trajectories, whose hull buffers are larger): a
+  // round's LS_GROUPS candidates then take LS_GROUPS / G passes.  Waves beyond G shadow the last group (same values into the same
+  // buffers), which keeps every barrier uniform.
+  const int G = L.groups;
+  const int g = min(tid / LS_GSIZE, G - 1), gl = tid % LS_GSIZE;
+  const bool shadow = tid / LS_GSIZE >= G;
   // the early exit needs every robot's energies of the earlier rounds: a sharded context (u1 - u0 < U) only has its own until
   // the all-gather after the last round, so it evaluates every round (same decision, taken by k_ls_commit on the gathered table)
   // One context: the LAST block of a round to finish takes the decision over the rounds evaluated so far and leaves it in the
@@ -518,16 +523,23 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   double* net = sm + L.net; double* dir = sm + L.dir;
   double* gnet = sm + L.gnet + (size_t)g * 3 * T;
   double* ghull = sm + L.ghull + (size_t)g * S * 18;
-  const int k = lsc_cand_k(round, g);
-  double step = step0;
-  for (int i = 0; i < k; i++) step *= 0.8;
-  const double pt = k < 0 ? t0 : t0 + step * t_dir;
-  for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
-  __syncthreads();
-  const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
-  if (!one_ctx) { if (gl == 0) D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + g] = e; return; }
-  // write-through store, performed before this wave arrives at the barrier; then the block's ticket
-  if (gl == 0) __hip_atomic_store(&D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + g], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int pass = 0; pass < LS_GROUPS / G; pass++) {
+    const int slot = pass * G + g;                      // this group's candidate of the round
+    const int k = lsc_cand_k(round, slot);
+    double step = step0;
+    for (int i = 0; i < k; i++) step *= 0.8;
+    const double pt = k < 0 ? t0 : t0 + step * t_dir;
+    __syncthreads();                                    // the previous pass is through with the group buffers
+    for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
+    __syncthreads();
+    const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
+    if (gl == 0 && !shadow) {
+      double* dst = &D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + slot];
+      if (one_ctx) __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = e;   // one context: write-through, read by the deciding block of THIS launch
+    }
+  }
+  if (!one_ctx) return;
+  // the stores were performed before this wave arrives at the barrier; then the block's ticket
   __builtin_amdgcn_s_waitcnt(0);
   __shared__ int s_last;
   __syncthreads();

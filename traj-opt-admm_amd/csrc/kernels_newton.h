@@ -800,6 +800,20 @@ __global__ __launch_bounds__(XB_THREADS) void k_xsolve_band(Dev D) {
   assemble();
   __syncthreads();
   __shared__ int s_ok;
+  if (D.coupled()) {
+    // Optimization3D_multi::update_spline (Optimization3D_multi.h:519-557) on band storage: eliminate the m control-point unknowns;
+    // the band factor, the arrow row with the robot's Schur-complement contribution left on its diagonal, the forward-substituted
+    // right-hand side and the raw gradient go to HBM for k_xsolve_c2_band (what k_xsolve leaves as a dense block up to piece_num 10)
+    if (tid < 64) { const bool ok = chol_band_lds(Bd, Ar, n, tid, y, false); if (tid == 0) s_ok = ok; }
+    __syncthreads();
+    if (!s_ok && tid == 0) { atomicAdd(&D.ctl->llt_fail_robot, 1ull); atomicOr(&D.ctl->error, ERR_NOT_SPD); }
+    const size_t per = (size_t)m * BS + n;
+    double* oL = D.xL + (size_t)u * per; double* oy = D.xy + (size_t)u * n; double* og = D.xg + (size_t)u * n;
+    for (size_t idx = tid; idx < per; idx += XB_THREADS) oL[idx] = Bd[idx];   // Bd and Ar are contiguous in LDS
+    for (int i = tid; i < n; i += XB_THREADS) { oy[i] = y[i]; og[i] = g0[i]; }
+    if (tid == 0) { double* oc = D.xcorner + (size_t)u * 4; oc[0] = Ar[m]; oc[1] = y[m]; oc[2] = g0[m]; oc[3] = 0; }
+    return;
+  }
   if (tid < 64) { const bool ok = chol_band_lds(Bd, Ar, n, tid, y); if (tid == 0) s_ok = ok; }
   __syncthreads();
   if (!s_ok) {
@@ -895,6 +909,55 @@ __global__ __launch_bounds__(XS_THREADS) void k_xsolve_c2(Dev D) {
     D.gn(u) = esum(scr + n, m);         // sum_j g_j^2
     D.tdir(u) = y[m];                   // shared t_direction (same bits on every robot)
     D.xdir[(size_t)u * D.xs + 3 * T + 3] = g0[m];  // this robot's share of G_t
+  }
+}
+
+// k_xsolve_c2 for long trajectories (piece_num > 10): the same corner sum, corner pivot and back substitution on the band
+// factor k_xsolve_band left (Bd[m][18] | Ar[n]), by one wave per robot
+__global__ __launch_bounds__(XS_THREADS) void k_xsolve_c2_band(Dev D) {
+  if (TJ_DONE(D)) return;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, u = D.u0 + blockIdx.x;
+  const int T = D.T, m = 3 * (T - 4), n = m + 1, BS = BAND_BS;
+  const size_t per = (size_t)m * BS + n;
+  double* Bd = sm; double* Ar = Bd + (size_t)m * BS; double* y = Ar + n; double* g0 = y + n; double* scr = g0 + n;  // scr [2n]
+  __shared__ double s_red[3];
+  const double* gL = D.xL + (size_t)u * per;
+  for (size_t idx = tid; idx < per; idx += XS_THREADS) Bd[idx] = gL[idx];
+  for (int i = tid; i < n; i += XS_THREADS) { y[i] = D.xy[(size_t)u * n + i]; g0[i] = D.xg[(size_t)u * n + i]; }
+  {
+    __shared__ double s_cstage[256];
+    double acc = 0;
+    for (int r0 = 0; r0 < D.U; r0 += 64) {
+      const int nr = min(64, D.U - r0);
+      blk_sync<true>();
+      for (int i = tid; i < 4 * nr; i += XS_THREADS) s_cstage[i] = D.xcorner[(size_t)r0 * 4 + i];
+      blk_sync<true>();
+      if (tid < 3) for (int r = 0; r < nr; r++) acc += s_cstage[4 * r + tid];
+    }
+    if (tid < 3) s_red[tid] = acc;
+  }
+  blk_sync<true>();
+  const double corner = s_red[0], rhs = s_red[1];
+  if (!(corner > 0) && tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_NOT_SPD);
+  const double lc = pivot_rsqrt(corner);
+  if (tid == 0) { Ar[m] = lc; y[m] = rhs * lc; }
+  blk_sync<true>();
+  chol_band_backsolve_lds(Bd, Ar, n, y, tid);
+  for (int i = tid; i < n; i += XS_THREADS) y[i] = -y[i];
+  blk_sync<true>();
+  for (int i = tid; i < m; i += XS_THREADS) { scr[i] = y[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
+  blk_sync<true>();
+  double* dir = D.dirp(u);
+  for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
+    const int row = idx % T, a = idx / T;
+    dir[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0;
+  }
+  if (tid == 0) {
+    D.wolfe(u) = esum(scr, m);
+    D.gn(u) = esum(scr + n, m);
+    D.tdir(u) = y[m];
+    D.xdir[(size_t)u * D.xs + 3 * T + 3] = g0[m];
   }
 }
 

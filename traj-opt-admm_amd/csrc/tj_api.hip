@@ -167,7 +167,9 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
         default: hipLaunchKernelGGL((k_xsolve<0>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
       }
       return true;
-    case K_XSOLVE_C2: if (coupled) hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); return coupled;
+    case K_XSOLVE_C2:
+      if (coupled) { if (d.xs_band) hipLaunchKernelGGL(k_xsolve_c2_band, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); else hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); }
+      return coupled;
     case K_CCD_PREP: if (in_graph && d.fuse && !d.xs_band) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
       hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
     case K_CCD: if (!in_graph && !in_phase) return false;
@@ -437,9 +439,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   const size_t lds_max = 160 * 1024 - 1024;
   // long trajectories: the dense per-robot system no longer fits LDS -> band storage (decoupled / single-UAV modes)
   d.xs_band = (xsolve_lds_doubles(n) * sizeof(double) > lds_max || getenv("TJ_XS_BAND")) ? 1 : 0;
-  if (d.xs_band && p->mode == TJ_MODE_MULTI_COUPLED) { c->err = "coupled mode (decouple:0) supports piece_num <= 10 (the arrowhead system's per-robot factor is exchanged as a dense block)"; return TJ_ERR_UNSUPPORTED; }
   c->lds_xs = (d.xs_band ? xsolve_band_lds_doubles(n) : xsolve_lds_doubles(n)) * sizeof(double);
-  c->lds_xs2 = ((size_t)n * n + 4 * (size_t)n) * sizeof(double);
+  c->lds_xs2 = (d.xs_band ? (size_t)(n - 1) * BAND_BS + 5 * (size_t)n : (size_t)n * n + 4 * (size_t)n) * sizeof(double);   // k_xsolve_c2 / k_xsolve_c2_band
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
   if (const char* e = getenv("TJ_LS_EXACT_HULLS")) if (atoi(e)) {   // A/B hook: every trial hull as basis * (x + step d)
     c->lsl = ls_layout_g(d.S, d.T, d.P, 120 * 1024, LS_GROUPS);
@@ -480,6 +481,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   HIPCHK(c, hipFuncSetAttribute((const void*)k_linesearch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ls_coupled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_ls));
   if (!d.xs_band) HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_c2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs2));
+  else HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_c2_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs2));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ccd_self_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_seq));
 
   HostTables t;
@@ -515,7 +517,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
         (r = dalloc(c, &d.kpair_cd, m0 ? 1 : S * U * U * 4))) return r;
   }
   if (d.mode == TJ_MODE_MULTI_COUPLED &&
-      ((r = dalloc(c, &d.xL, U * (size_t)n * n)) || (r = dalloc(c, &d.xy, U * (size_t)n)) || (r = dalloc(c, &d.xg, U * (size_t)n)) ||
+      ((r = dalloc(c, &d.xL, U * (d.xs_band ? (size_t)(n - 1) * BAND_BS + n : (size_t)n * n))) || (r = dalloc(c, &d.xy, U * (size_t)n)) || (r = dalloc(c, &d.xg, U * (size_t)n)) ||
        (r = dalloc(c, &d.xcorner, U * 4)) || (r = dalloc(c, &d.k_obs_f, U)) || (r = dalloc(c, &d.ls_e, (size_t)LSC_ROUNDS * U * LS_GROUPS)))) return r;
   return TJ_OK;
 }
