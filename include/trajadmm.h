@@ -168,8 +168,8 @@ typedef struct tj_stats {
   int order_ambiguous; /* segments whose inter-robot clamp depended on pair order (two acting pairs sharing a robot): replayed in the
                           order of the reference's per-segment dynamic AABB tree (Step.h:213-251, AABB.cc:669-734) */
   int error_bits;      /* 1 plane list overflow, 2 BVH frontier overflow, 4 a loop hit its cap (detail: 32 coupled Armijo range, 64 plane
-                          refinement, 128 CCD contact at every step = state in collision, 256 slack Armijo), 8 pair list overflow,
-                          16 coupled Newton system not SPD */
+                          refinement, 128 CCD contact at every step = state in collision, 256 slack Armijo, 1024 a wait for passed-on pairs timed out), 8 pair list overflow,
+                          16 coupled Newton system not SPD, 512 tj_group: a peer's slice did not arrive */
   int order_unresolved; /* such segments for which the tree order could NOT be established (result may differ from the reference's;
                            tj_iterate returns TJ_ERR_UNSUPPORTED) -- 0 unless uav_num is in the thousands */
   unsigned long long gjk_max_sum; /* sum over the iterations of the longest robot-pair GJK (iterations of openGJK's main loop; pairs below 6
@@ -180,32 +180,8 @@ int tj_get_stats(tj_ctx* c, tj_stats* s);
  * upload excluded) -- the counterpart of the reference's tree construction (BVH.cpp:53-93: 95 ms for 20k points) */
 int tj_get_build_info(tj_ctx* c, double* bvh_build_ms, int* built_on_device);
 
-/* ---- known-answer hooks: the device primitives of the hot path on caller-supplied batches -------
- * (host pointers; one case per GPU lane; used by the parity tests against tests/golden/) */
-/* GJK witness vector (replaces gjk(), lib/opengjk/src/openGJK.c:754): n1 in {6,12}, n2 in {1,3,6,12} (3 = obstacle triangle);
- * a[n][n1][3], b[n][n2][3], v[n][3] */
-int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
-/* the same query solved cooperatively by a whole wavefront (the form the inter-robot kernels use): must give the same bits */
-int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
-/* what: 0 Separate::opengjk (Separate.h:18) P[n][6][3], Q = points [n][3] -> out[n][5] = ok,cx,cy,cz,d
- *       1 Separate::selfgjk + Optimal_plane::optimal_d (Separate.h:165, Optimal_plane.h:13), Q[n][6][3] -> ok,c,d
- *       2 CCD::KDOPDCD (CCD.h:354), 3 CCD::SelfKDOPDCD (CCD.h:535) -> out[n][5], out[.][0] = pass
- *       4 = 1 computed by one wavefront per pair (plane_pair_wave, the form k_sep_self_solve uses)
- *       5 Optimal_plane::optimal_cd (Optimal_plane.h:160), Q = points; 6 Optimal_plane::self_optimal_cd (:620), Q = hulls:
- *         7 = 6 computed by one wavefront per plane (opt_plane_pair_wave, the form k_keep uses for short lists);
- *         out[n][5] is IN/OUT, out[.][1..4] = the plane (c, d) to refine, out[.][0] = finished within the iteration caps */
-int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out);
-/* CCD::GJKCCD / SelfGJKCCD (CCD.h:116,227) on swept hulls, tu[n][2] = (tMax, _tMax): out[n][2] booleans */
-int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double* Q, const double* E, const double* q, const double* tu, double d, double* out);
-/* broad phase alone (replaces aabb::Tree::query(AABB, margin), AABB.cc:829-839 / :608-667, on the tree of BVH::InitPointcloud or
- * BVH::InitObstacle): boxes[nq][6] = lo.xyz, hi.xyz; counts[nq]; ids[nq][cap] = indices into the caller's cloud / face list */
-int tj_kat_query(tj_ctx* c, int nq, const double* boxes, double margin, int cap, int* counts, int* ids);
-/* triangle obstacle bodies (tj_set_mesh): P, D [n][6][3] hull and direction hull, tri[n][3][3], t[n] step; out[n][8] =
- * plane ok, cx, cy, cz, d of Separate::opengjk with a 3-vertex body at distance dist | CCD::KDOPDCD(P, tri, dist) |
- * CCD::KDOPDCD({P, P + t D}, tri, off) | CCD::GJKDCD({P, P + t D}, tri, off)  -- the predicates Step::mix_step uses (Step.h:390-404) */
-int tj_kat_tri(tj_ctx* c, int n, const double* P, const double* D, const double* tri, const double* t, double dist, double off, double* out);
-/* dense LLT failure test + smallest eigenvalue (Eigen LLT / SelfAdjointEigenSolver as used at Gradient_admm.h:38-53): out[nmat][2] */
-int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out);
+/* (The known-answer hooks of the parity tests -- tj_kat_* -- are declared in trajadmm_kat.h and exist only in the TEST build
+ * libtrajadmm_kat.so (-DTJ_KAT): the product library carries no test surface.) */
 
 /* ---- initial-trajectory planner (replaces ompl_init + simplify_path + edge_collision, Main/multiPathPlanning3D.cpp:123-340
  * and HighOrderCCD/OMPL/OMPL.cpp; OMPL itself is not needed) -------------------------------------------------------------- */

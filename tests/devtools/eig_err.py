@@ -2,7 +2,7 @@ import importlib, sys, numpy as np
 sys.path.insert(0, '/root/repo')
 pkg = importlib.import_module("traj-opt-admm_amd")
 g = np.load('/root/repo/tests/golden/prims_kat.npz')
-s = pkg.Solver(pkg.scenes.tiny(mode=1, U=2, n_points=200), stop=0.0)
+s = pkg.Solver(pkg.scenes.tiny(mode=1, U=2, n_points=200), stop=0.0, kat=True)
 out = s.kat_linalg(g["llt_mats"])
 scale = np.abs(g["llt_mats"]).max(axis=(1, 2))
 err = np.abs(out[:, 1] - g["min_eig"]) / np.maximum(1.0, scale)

@@ -12,7 +12,7 @@ from oracle.pyoracle import Engine, Prims  # noqa: E402
 
 sc = pkg.scenes.hard(4, 4000)
 o = Engine("port", sc); o.set_optimal_plane(True)
-s = pkg.Solver(sc, stop=0.0, optimal_plane=1)
+s = pkg.Solver(sc, stop=0.0, optimal_plane=1, kat=True)
 st = o.get_state()
 s.stage_planes(); o.stage_planes()
 on_d, c_d = s.get_pair_cache(); on_o, c_o = o.get_pair_cache()

@@ -12,8 +12,8 @@ import pytest
 from conftest import ROOT
 
 
-def _header_functions():
-    txt = open(os.path.join(ROOT, "include", "trajadmm.h")).read()
+def _header_functions(name="trajadmm.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(tj_[a-z_0-9]+)\s*\(", txt)))
 
@@ -26,6 +26,14 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/trajadmm.h but not exported"
     assert set(pkg.EXPORTS) <= set(declared)
+    # the product library carries no test surface; the known-answer hooks (include/trajadmm_kat.h) are exported by the TEST build only
+    kat_declared = [n for n in _header_functions("trajadmm_kat.h") if n.startswith("tj_kat_")]
+    assert sorted(kat_declared) == sorted(pkg.KAT_EXPORTS)
+    assert not [n for n in kat_declared if hasattr(lib, n)]
+    assert os.path.exists(pkg.KAT_LIB_PATH), "libtrajadmm_kat.so missing: run __graft_entry__.build()"
+    kat = C.CDLL(pkg.KAT_LIB_PATH)
+    for name in declared + kat_declared:
+        assert hasattr(kat, name), f"{name} not exported by the test build"
 
 
 def test_params_struct_layout_matches_header(pkg):

@@ -49,7 +49,7 @@ def _unflat(n, ids, cd):
 
 @pytest.fixture(scope="module")
 def katsolver(pkg, scenes):
-    s = pkg.Solver(scenes.tiny(1), stop=0.0)
+    s = pkg.Solver(scenes.tiny(1), stop=0.0, kat=True)      # the TEST build libtrajadmm_kat.so: the product library has no tj_kat_* hooks
     yield s
     s.close()
 

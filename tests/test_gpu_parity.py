@@ -17,14 +17,17 @@ STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
 
 @pytest.fixture(scope="module")
 def katsolver(pkg, scenes):
-    s = pkg.Solver(scenes.tiny(1), stop=0.0)
+    s = pkg.Solver(scenes.tiny(1), stop=0.0, kat=True)      # the TEST build libtrajadmm_kat.so: the product library has no tj_kat_* hooks
     yield s
     s.close()
 
 
-def test_native_library_is_loaded(pkg, katsolver):
+def test_native_library_is_loaded(pkg, katsolver, scenes):
     """the parity tests below must exercise the in-tree HIP library, never a fallback"""
+    s0 = pkg.Solver(scenes.tiny(1), stop=0.0); s0.iterate(1); s0.close()       # the PRODUCT library (the known-answer fixture loads the test build)
     paths = {ln.split()[-1] for ln in open("/proc/self/maps") if "/" in ln}
+    kat = [p for p in paths if p.endswith("libtrajadmm_kat.so")]
+    assert len(kat) == 1 and os.path.dirname(os.path.realpath(kat[0])) == os.path.dirname(os.path.realpath(pkg.__file__))
     mine = [p for p in paths if p.endswith("libtrajadmm.so")]
     assert len(mine) == 1 and os.path.samefile(mine[0], pkg.LIB_PATH), mine      # the in-tree build, exactly once
     assert os.path.dirname(os.path.realpath(mine[0])) == os.path.dirname(os.path.realpath(pkg.__file__))
@@ -33,6 +36,22 @@ def test_native_library_is_loaded(pkg, katsolver):
     import subprocess
     needed = subprocess.run(["readelf", "-d", pkg.LIB_PATH], capture_output=True, text=True).stdout
     assert "liboracle" not in needed and "libref" not in needed
+
+
+def test_kat_build_equals_product_build(pkg, scenes):
+    """libtrajadmm_kat.so is libtrajadmm.so + the known-answer hooks (-DTJ_KAT): the hot path of the two builds must agree bit for
+    bit, or the known answers would pin something the product does not run; and the product must carry no test surface"""
+    import ctypes
+    prod = ctypes.CDLL(pkg.LIB_PATH)
+    assert not [n for n in pkg.KAT_EXPORTS if hasattr(prod, n)], "the product library exports known-answer hooks"
+    for sc in (scenes.hard(4, 4000), scenes.tiny(0, n_points=3000)):
+        a = pkg.Solver(sc, stop=0.0); b = pkg.Solver(sc, stop=0.0, kat=True)
+        assert a.lib is not b.lib
+        a.iterate(6); b.iterate(6)
+        sa, sb = a.get_state(), b.get_state()
+        for n in STATE:
+            assert np.array_equal(sa[n], sb[n]), n
+        a.close(); b.close()
 
 
 @pytest.mark.parametrize("shape", ["6v1", "6v6", "12v1", "12v12"])

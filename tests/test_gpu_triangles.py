@@ -18,7 +18,7 @@ STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
 
 @pytest.fixture(scope="module")
 def katsolver(pkg, scenes):
-    s = pkg.Solver(scenes.tiny(1), stop=0.0)
+    s = pkg.Solver(scenes.tiny(1), stop=0.0, kat=True)      # the TEST build libtrajadmm_kat.so: the product library has no tj_kat_* hooks
     yield s
     s.close()
 
@@ -56,7 +56,7 @@ def test_broad_phase_candidate_sets_vs_reference_trees(pkg, scenes, prim):
         sc["cloud"] = verts
     else:
         sc["tris"] = verts
-    s = pkg.Solver(sc, stop=0.0)
+    s = pkg.Solver(sc, stop=0.0, kat=True)
     for d in (0.125, 0.2, 0.1):
         got = s.kat_query(boxes, d)
         n = g[f"p{prim}_d{d}_n"]; ids = g[f"p{prim}_d{d}_ids"]
@@ -74,10 +74,10 @@ def test_device_bvh_build_equals_host_build(pkg, scenes, prim, monkeypatch):
     sc["cloud"] = np.concatenate([sc["cloud"], sc["cloud"][:37]])          # exact duplicates -> equal Morton keys
     if prim == 3:
         sc = scenes.triangulate(sc, size=0.025)
-    a = pkg.Solver(sc, stop=0.0)
+    a = pkg.Solver(sc, stop=0.0, kat=True)
     assert a.build_info()["on_device"]
     monkeypatch.setenv("TJ_BVH_HOST", "1")
-    b = pkg.Solver(sc, stop=0.0)
+    b = pkg.Solver(sc, stop=0.0, kat=True)
     assert not b.build_info()["on_device"]
     rng = np.random.default_rng(3)
     lo = rng.uniform(-4, 4, (300, 3)); boxes = np.concatenate([lo, lo + rng.uniform(0, 1.5, (300, 3))], axis=1)

@@ -5,7 +5,7 @@ import numpy as np
 pkg = importlib.import_module("traj-opt-admm_amd")
 g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "gjk_kat.npz"))
 p = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "prims_kat.npz"))
-s = pkg.Solver(pkg.scenes.tiny(1), stop=0.0)
+s = pkg.Solver(pkg.scenes.tiny(1), stop=0.0, kat=True)
 def t(f, reps=200):
     f(); t0 = time.perf_counter()
     for _ in range(reps): f()

@@ -25,7 +25,7 @@ EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_set_mesh", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes", "tj_get_candidates",
     "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_energy", "tj_get_stats", "tj_get_build_info", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_phase_count", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name", "tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg",
+    "tj_iterate_phase", "tj_phase_count", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
     "tj_group_create", "tj_group_destroy", "tj_group_size", "tj_group_ctx", "tj_group_last_error", "tj_group_set_cloud", "tj_group_set_mesh",
     "tj_group_transport", "tj_group_set_transport", "tj_group_profile_exchange", "tj_rccl_available",
@@ -53,21 +53,35 @@ class TrajAdmmError(RuntimeError):
     pass
 
 
+# the known-answer hooks (include/trajadmm_kat.h) live in a TEST build of the same translation unit, never in the product library
+KAT_EXPORTS = ["tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg"]
+KAT_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtrajadmm_kat.so")
 _lib = None
+_kat_lib = None
 
 
-def load_library():
-    """dlopen libtrajadmm.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
-    global _lib
+def _open(path):
+    if not os.path.exists(path):
+        raise TrajAdmmError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.tj_last_error.restype = C.c_char_p
+    lib.tj_stream.restype = C.c_void_p
+    lib.tj_group_last_error.restype = C.c_char_p
+    lib.tj_group_ctx.restype = C.c_void_p
+    return lib
+
+
+def load_library(kat=False):
+    """dlopen libtrajadmm.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if absent.  kat=True: the test build
+    libtrajadmm_kat.so (same sources + the tj_kat_* hooks), unless TRAJADMM_LIB points somewhere else."""
+    global _lib, _kat_lib
+    if kat and "TRAJADMM_LIB" not in os.environ:
+        if _kat_lib is None:
+            _kat_lib = _open(KAT_LIB_PATH)
+        return _kat_lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise TrajAdmmError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-        _lib = C.CDLL(LIB_PATH)
-        _lib.tj_last_error.restype = C.c_char_p
-        _lib.tj_stream.restype = C.c_void_p
-        _lib.tj_group_last_error.restype = C.c_char_p
-        _lib.tj_group_ctx.restype = C.c_void_p
+        _lib = _open(LIB_PATH)
     return _lib
 
 
@@ -93,8 +107,8 @@ def _i(a):
 class Solver:
     """One ADMM problem resident on one GPU (one `tj_ctx`)."""
 
-    def __init__(self, scene, params=None, device=0, rank=0, world=1, stop=None, **caps):
-        self.lib = load_library()
+    def __init__(self, scene, params=None, device=0, rank=0, world=1, stop=None, kat=False, **caps):
+        self.lib = load_library(kat)          # kat=True: the test build with the known-answer hooks (kat_* methods)
         p = dict(scenes.DEFAULT_PARAMS)
         if params:
             p.update(params)

@@ -27,6 +27,8 @@ enum : int {
   ERR_SLACK_ARMIJO = 256,    // the slack update's Armijo loop
   ERR_PLANE_REFINE = 64,     // "optimal_plane":1 -- a plane's Newton refinement hit PLANE_NEWTON_CAP / PLANE_BACKOFF_CAP
   ERR_PEER_TIMEOUT = 512,    // tj_group, flag transport: a peer's push did not arrive within 2 s (tj_group.h)
+  ERR_PASS_TIMEOUT = 1024,   // large fleets: a wave waiting for passed-on robot pairs gave up after 5 ms (the queue was descheduled, e.g. several
+                             // processes on one GPU); the pairs it would have taken are unsolved -- set together with ERR_LOOP_CAP
 };
 
 #ifdef TJ_NO_DONE_CHECK

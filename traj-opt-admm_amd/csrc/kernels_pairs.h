@@ -237,7 +237,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         for (;;) {
           e = __hip_atomic_load(&D.pair_ovf_list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((int)(e >> 32) == epoch) { have = true; break; }
-          if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP); break; }
+          if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); break; }
           __builtin_amdgcn_s_sleep(16);
         }
         if (!have || (e & PAIR_OVF_STOP)) { TJ_TIC(D, K_SEP_SELF_SOLVE, 2); return; }

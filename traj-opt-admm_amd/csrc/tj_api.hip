@@ -23,7 +23,10 @@
 #include "kernels_keep.h"
 #include "kernels_newton.h"
 #include "kernels_step.h"
-#include "kernels_debug.h"
+#ifdef TJ_KAT
+#include "../../include/trajadmm_kat.h"
+#include "kernels_debug.h"   // known-answer kernels: test build only (libtrajadmm_kat.so)
+#endif
 #include "kernels_plan.h"
 #include "kernels_bvh.h"
 
@@ -340,6 +343,7 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
     if (h.error & ERR_CCD_STUCK) c->err += ": a CCD clamp found contact at every step (the state itself is in collision; the reference loops forever here)";
     if (h.error & ERR_SLACK_ARMIJO) c->err += ": the slack update's Armijo search";
     if (h.error & ERR_PLANE_REFINE) c->err += ": optimal_plane, a plane refinement did not terminate within its caps";
+    if (h.error & ERR_PASS_TIMEOUT) c->err += ": NOT an infeasible state -- a wave waiting for passed-on robot pairs timed out after 5 ms (GPU queue descheduled / shared with other processes); re-run the iteration or set TJ_PAIR_PASS_ON=0";
     return TJ_ERR_NO_PROGRESS;
   }
   if (h.order_unresolved) { c->err = "inter-robot CCD clamp: two acting pairs of a segment share a robot and the reference's pair order could not be replayed (fleet too large for the LDS-resident tree)"; return TJ_ERR_UNSUPPORTED; }
@@ -996,6 +1000,7 @@ int tj_get_steps(tj_ctx* c, double* step_self, double* step_obs, double* step_ar
   return TJ_OK;
 }
 
+#ifdef TJ_KAT
 // ---- known-answer hooks ------------------------------------------------------------------------
 
 int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v) {
@@ -1051,6 +1056,8 @@ int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, 
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)n * 40, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
+
+#endif  // TJ_KAT
 
 // ---- "optimal_plane":1 : host access to the persistent plane tables (teacher-forced parity tests, checkpointing) ----
 int tj_get_obs_cache(tj_ctx* c, int u, int seg, int cap, int* ids, double* cd) {
@@ -1302,6 +1309,7 @@ int tj_plan_init(tj_ctx* c, int n_robots, const double* starts, const double* go
   return TJ_OK;
 }
 
+#ifdef TJ_KAT
 int tj_kat_ccd(tj_ctx* c, int n, const double* P, const double* D, const double* Q, const double* E, const double* q, const double* tu, double d, double* out) {
   if (!c || n < 0 || !P || !D || !Q || !E || !q || !tu || !out) return TJ_ERR_INVALID;
   DevBuf b[6], dout; int r;
@@ -1361,6 +1369,8 @@ int tj_kat_linalg(tj_ctx* c, int nmat, int n, const double* mats, double* out) {
   HIPCHK(c, hipMemcpy(out, dout.p, (size_t)nmat * 16, hipMemcpyDeviceToHost));
   return TJ_OK;
 }
+
+#endif  // TJ_KAT
 
 int tj_get_build_info(tj_ctx* c, double* bvh_build_ms, int* built_on_device) {
   if (!c) return TJ_ERR_INVALID;
