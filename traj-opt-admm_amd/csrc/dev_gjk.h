@@ -331,27 +331,20 @@ __device__ __forceinline__ V3 gjk(const B1& b1, const B2& b2, int* iters_out = n
 }
 
 // ---- wave-cooperative variant -----------------------------------------------------------------
-// One query per WAVEFRONT (the inter-robot kernels: a robot pair per wave).  A single lane walking the whole
-// algorithm issues ~1500 instructions per iteration of the main loop; with 64 lanes available the independent
-// pieces run side by side and the results are broadcast back with v_readlane, so every decision is taken on
-// wave-uniform values:
-//   * both support searches at once: lanes 0..15 hold the vertices of body 1, lanes 16..31 those of body 2;
-//     a 4-step DPP butterfly gives each row its maximum, a ballot picks the FIRST lane that attains it
-//     (openGJK's "first maximum wins"), and the previous support is kept unless the maximum is strictly larger;
-//   * the faces a tetrahedron step has to visit (up to three) are solved by lanes 0..2 in parallel.
+// One query per WAVEFRONT (the inter-robot kernels: a robot pair per wave; the per-candidate obstacle solve).  With 64 lanes
+// available the independent pieces run side by side and the results are broadcast back with v_readlane, so every decision is
+// taken on wave-uniform values:
+//   * both support searches at once: lanes 0..15 hold the vertices of body 1, lanes 16..31 those of body 2 (loaded once per
+//     query); a 4-step DPP butterfly gives each row its maximum, a ballot picks the FIRST lane that attains it (openGJK's
+//     "first maximum wins"), and the previous support -- tracked as a lane index -- is kept unless it is not among them;
+//   * the three edges a triangle step may fall back to are solved speculatively on three lanes (seg_core, gjk_tri_uni);
+//   * the faces a tetrahedron step has to visit (up to three) are solved by lanes 0..2 in parallel (gjk_tet_wave).
 // Every floating-point expression is the one the per-lane version evaluates, on the same operands, so the
 // witness vector is bit-identical (pinned by the same golden vectors, tests/test_gpu_parity.py).
 __device__ __forceinline__ double gjk_rl(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 __device__ __forceinline__ V3 gjk_rl3(const V3& v, int lane) { return V3{gjk_rl(v.x, lane), gjk_rl(v.y, lane), gjk_rl(v.z, lane)}; }
-template <int CTRL>
-__device__ __forceinline__ double gjk_dpp(double v) {
-  // old = the lane's own value: a lane whose DPP source is disabled sees itself, which is neutral for max
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
 // maximum over each row of 16 lanes, left in every lane of the row (NaNs are ignored like the `>` test does)
 // Every lane of a row is a valid DPP source for these controls, so the moves need no `old` operand (no copy in front of them),
 // and the maximum is the bare instruction: fmax() would first quiet a signalling NaN of the shuffled operand -- one more
@@ -367,35 +360,6 @@ __device__ __forceinline__ double gjk_row_max(double v) {
   v = gjk_vmax(v, gjk_dpp_mov<0x124>(v));  // row_ror:4
   v = gjk_vmax(v, gjk_dpp_mov<0x128>(v));  // row_ror:8
   return v;
-}
-
-template <class B1, class B2>
-__device__ __forceinline__ void support_wave(const B1& b1, const B2& b2, const V3& dir1, const V3& dir2, V3& s1, V3& s2, int lane) {
-  static_assert(B1::N <= 16 && B2::N <= 16, "one body per row of 16 lanes");
-  const bool row1 = lane < 16, row2 = lane >= 16 && lane < 32;
-  const int idx = lane & 15;
-  const bool valid = (row1 && idx < B1::N) || (row2 && idx < B2::N);
-  V3 p{0, 0, 0};
-  if (row1 && idx < B1::N) p = b1.get(idx);
-  if (row2 && idx < B2::N) p = b2.get(idx);
-  const V3 dir = row1 ? dir1 : dir2;
-  const double sd = valid ? dot(p, dir) : -INFINITY;
-  const double m = gjk_row_max(sd);
-  const unsigned long long hit = __ballot(valid && sd == m);
-  const double base1 = dot(s1, dir1), base2 = dot(s2, dir2);
-  const unsigned h1 = (unsigned)(hit & 0xFFFFull), h2 = (unsigned)((hit >> 16) & 0xFFFFull);
-  if (h1) {  // uniform
-    const int l = __ffs(h1) - 1;
-    const double best = gjk_rl(m, l);
-    const V3 q = gjk_rl3(p, l);
-    if (best > base1) s1 = q;
-  }
-  if (h2) {
-    const int l = 16 + __ffs(h2) - 1;
-    const double best = gjk_rl(m, l);
-    const V3 q = gjk_rl3(p, l);
-    if (best > base2) s2 = q;
-  }
 }
 
 // gjk_tet with the visited faces solved by lanes 0..2 side by side (see gjk_tet for the case analysis)
