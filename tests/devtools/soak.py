@@ -36,3 +36,13 @@ for k in range(20):
     y = pkg.Solver(sc.scn_a(), stop=0.0, optimal_plane=1); y.iterate(3); y.get_obs_cache(); y.close()
 free1 = free_mem()
 print("create/destroy x40 with optimal_plane + planner: free memory before %.1f MB after %.1f MB" % (free0 / 2**20, free1 / 2**20))
+# tj_group: uncached receive buffers / flag words / events are per group -- create, run both transports, destroy
+# (the first cycles grow a pool of the HIP runtime once -- ~336 MB with three queues active on one device -- which later
+#  cycles reuse: tests/devtools/group_leak.py separates the two; the loss is measured after a warm cycle)
+for k in range(20):
+    gr = pkg.Group(sc.scn_b(), [0, 0, 0], stop=0.0); gr.iterate(3); gr.close()
+free0 = free_mem()
+for k in range(30):
+    gr = pkg.Group(sc.scn_b(), [0, 0, 0], stop=0.0); gr.iterate(3); gr.set_transport("flag"); gr.iterate(3); gr.profile_exchange(3); gr.close()
+free1 = free_mem()
+print("tj_group create/destroy x30 (3 ranks on device 0, both transports): free memory before %.1f MB after %.1f MB" % (free0 / 2**20, free1 / 2**20))
