@@ -119,7 +119,7 @@ def survey_bytes(st, slv, iters):
     return b, total
 
 
-# What ONE wavefront pays on MI355X (tools/micro/issue_probe.hip, profiles/round3_issue_probe.txt; 2.4 GHz), in ns:
+# What ONE wavefront pays on MI355X (tools/micro/issue_probe.hip, profiles/round3_v2_issue_probe.txt; 2.4 GHz), in ns:
 PRIM = {"fp64": 2.6,        # one fp64 VALU instruction, dependent OR independent: a wave issues one every ~6.3 cycles
         "readlane": 16.0,   # v_readlane pair -> first VALU use of the SGPR it wrote
         "rsq": 12.2, "sqrt": 46.6, "div": 39.0, "log": 162.0,   # v_rsq_f64 + fma; IEEE sqrt; IEEE division (11 fp64 ops + v_rcp); ocml log
