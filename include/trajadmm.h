@@ -172,6 +172,8 @@ typedef struct tj_stats {
                           16 coupled Newton system not SPD, 512 tj_group: a peer's slice did not arrive */
   int order_unresolved; /* such segments for which the tree order could NOT be established (result may differ from the reference's;
                            tj_iterate returns TJ_ERR_UNSUPPORTED) -- 0 unless uav_num is in the thousands */
+  int head_starts;      /* robot-pair GJK queries whose first iterations ran inside the broad-phase kernel and were continued by the solve
+                           kernel (pairs that were slow in the previous iteration; same bits either way) */
   unsigned long long gjk_max_sum; /* sum over the iterations of the longest robot-pair GJK (iterations of openGJK's main loop; pairs below 6
                                      do not report): / iters = unit count of the pair stage's critical path */
 } tj_stats;

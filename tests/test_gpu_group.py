@@ -164,8 +164,32 @@ def test_passing_long_pair_solves_on_changes_no_bit(pkg, scenes, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["scn_c", "hard8", "scn_b_coupled"])
+def test_gjk_head_start_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
+    """k_front runs the first GJK iterations of the robot pairs that were slow in the previous iteration and k_mid continues the
+    saved loop (kernels_pairs.h: spec_pair_body).  Where a query's iterations run must not matter: the state after many
+    iterations is bitwise the one with TJ_PAIR_HEAD_START=0, the pair-solve statistics agree, and head starts were actually
+    taken (the longest query of a launch is unchanged: the iteration count continues across the two kernels)."""
+    scene = {"scn_c": scenes.scn_c, "hard8": lambda: scenes.hard(8, 20000), "scn_b_coupled": lambda: dict(scenes.scn_b(), mode=2)}[scene_name]()
+    monkeypatch.setenv("TJ_PAIR_HEAD_START", "0")
+    a = pkg.Solver(scene, stop=0.0)
+    monkeypatch.setenv("TJ_PAIR_HEAD_START", "1")
+    b = pkg.Solver(scene, stop=0.0)
+    for n_it in (1, 2, 9, 28):   # several batches: the list of slow pairs crosses batch boundaries
+        a.iterate(n_it); b.iterate(n_it)
+        sa, sb = a.get_state(), b.get_state()
+        for n in sa:
+            assert np.array_equal(sa[n], sb[n]), f"{n} differs with the GJK head start after a batch of {n_it}"
+    ta, tb = a.stats(), b.stats()
+    assert ta["pair_solves"] == tb["pair_solves"] and ta["newton_iters"] == tb["newton_iters"] and ta["gjk_max_sum"] == tb["gjk_max_sum"]
+    assert ta["error_bits"] == 0 and tb["error_bits"] == 0
+    assert ta["head_starts"] == 0 and tb["head_starts"] > 0, "no head start was ever continued: the test compares nothing"
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
-                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}],
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state

@@ -55,7 +55,8 @@ def main():
     t = out[kf]; live = t[:, 0] != 0
     if live.any():
         t0 = t[live, 0].min(); n_obs = scene["U"] * scene["P"] * 8
-        for lab, lo, hi in (("obstacle query", 0, n_obs), ("pair rows", n_obs, 65536)):
+        n_hs = 128 if (scene["mode"] >= 1 and os.environ.get("TJ_PAIR_HEAD_START", "1") != "0") else 0   # GJK head-start blocks lead the grid
+        for lab, lo, hi in (("gjk head start", 0, n_hs), ("obstacle query", n_hs, n_hs + n_obs), ("pair rows", n_hs + n_obs, 65536)):
             sel = live.copy(); sel[:lo] = False; sel[hi:] = False
             if sel.any():
                 st = (t[sel, 0] - t0) * 0.01; en = (t[sel, 1] - t0) * 0.01; du = en - st
@@ -83,12 +84,13 @@ def main():
         print("   mean us      " + " ".join(f"{x:12.2f}" for x in d.mean(0)))
         print("   max us       " + " ".join(f"{x:12.2f}" for x in d.max(0)))
         if name == "k_sep_self_solve":
-            gk, nit = t[:, 6], t[:, 7]
+            hs = t[:, 6] >= 1000; gk, nit = t[:, 6] % 1000, t[:, 7]   # + 1000: the query was continued from a head start (k_front)
+            print(f"   head starts continued: {int(hs.sum())}; queries of >= 5 iterations: {int((gk >= 5).sum())}, of them with a head start: {int((hs & (gk >= 5)).sum())}")
             print("   GJK iterations: hist", np.bincount(gk.astype(int), minlength=51)[[1,2,3,4,5,6,8,10,15,20,30,40,50]], "(at 1,2,3,4,5,6,8,10,15,20,30,40,50); mean", gk.mean(), "max", gk.max())
             print("   Newton iterations (accepted pairs): mean", nit[nit >= 0].mean() if (nit >= 0).any() else 0, "max", nit.max(), "rejected", int((nit < 0).sum()))
             print("   corr(total us, gjk iters) =", np.corrcoef(tot, gk)[0, 1], " corr(total us, newton) =", np.corrcoef(tot, np.maximum(nit, 0))[0, 1])
             o = np.argsort(-tot)[:8]
-            print("   slowest:", [(round(float(tot[i]), 1), int(gk[i]), int(nit[i])) for i in o])
+            print("   slowest (us, gjk iterations, newton, head start):", [(round(float(tot[i]), 1), int(gk[i]), int(nit[i]), bool(hs[i])) for i in o])
         if name == "k_sep_self_solve":
             acc = (t[:, 3] >= t[:, 1]) & (t[:, 4] >= t[:, 3]) & (t[:, 5] >= t[:, 4]) & (t[:, 2] >= t[:, 5])   # stamps of THIS iteration (rejected pairs leave older ones)
             if acc.any():

@@ -48,7 +48,7 @@ struct Ctl {
   int any_pair;        // robot pairs within `offset` at full step this iteration (entries of Dev::pair_list): work of the sequential CCD replay
   int order_unresolved; // segments whose pair order mattered but could not be replayed in the reference's tree order
   int ticket;          // k_linesearch blocks that have finished (the last one does the next iteration's k_begin work)
-  int pad1;
+  int gjk_prev;        // gjk_max of the iteration before the running one (k_begin): the GJK head start's threshold follows it
 
   double gnorm;        // reference global `gnorm`
   // statistics for the algorithmic-byte model; accumulated over iterations
@@ -61,7 +61,7 @@ struct Ctl {
   double lsf_step;
   // length of the longest robot-pair GJK of the running iteration (only pairs with >= 6 iterations report: a handful per launch)
   // and the sum of these maxima over the iterations begun so far: the unit count of k_mid's critical path (bench.py critical_path)
-  int gjk_max, pad2;
+  int gjk_max, spec_taken;   // spec_taken: GJK head starts k_mid continued from (kernels_pairs.h), summed over the iterations
   unsigned long long gjk_max_sum;
 };
 
@@ -82,7 +82,11 @@ constexpr int TJ_TIC_BLOCKS = 65536, TJ_TIC_SLOTS = 8;   // blocks per kernel th
 #ifdef TJ_PHASE_TIMING
 #define TJ_TICB(D, kid, slot) do { if (threadIdx.x == 192 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)   /* first thread of k_grad's second wave group */
 #define TJ_ORDER(v) asm volatile("" :: "v"(v))   /* the value is computed before the next stamp is taken */
+#ifdef TJ_PHASE_LIGHT   /* a stamp costs the wave ~0.3 us (s_memrealtime + wait): the light build keeps only the block start / end stamps of the union kernels */
+#define TJ_TIC(D, kid, slot) do { if (((kid) == K_MID || (kid) == K_FRONT) && threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
+#else
 #define TJ_TIC(D, kid, slot) do { if (threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
+#endif
 #else
 #define TJ_TIC(D, kid, slot) do {} while (0)
 #define TJ_TICB(D, kid, slot) do {} while (0)
@@ -148,6 +152,9 @@ struct Dev {
   int pair_pass_on;   // 1 (default): large fleets pass long pair solves on to idle waves; TJ_PAIR_PASS_ON=0 keeps every pair on its lane (test hook: same bits either way)
   int* pair_ovf; unsigned long long* pair_ovf_list;   // large fleets: [0] pairs passed on by the lane solve, [1] producer waves done, [2] consumer cursor; entries (epoch << 32 | q << 20 | p0 << 9 | segment), cap_work of them
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
+  // GJK head start (kernels_pairs.h: spec_pair_body): pairs whose GJK was long in one iteration get the first iterations of the
+  // next one's query inside k_front, next to the broad phase; k_mid continues from the saved state.  0 = off (TJ_PAIR_HEAD_START=0: same bits).
+  int spec, spec_budget, spec_min; int* spec_n; int* spec_list; unsigned long long* spec_tag; double* spec_state; int* spec_sti;
   // "optimal_plane":1 -- planes that persist across iterations (the reference's is_seperate / seperate_c / seperate_d and
   // is_self_seperate / self_seperate_c / self_seperate_d tables, CCDUtils.cpp:30-36).  Obstacle planes (mode 0): a list per
   // (robot, segment) in insertion order, keyed by the sorted point index.  Pair planes (modes 1, 2): dense [S][U][U] table,

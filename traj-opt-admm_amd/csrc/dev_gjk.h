@@ -562,9 +562,14 @@ __device__ __forceinline__ void gjk_tri_uni(Simplex& s, int lane) {
 }
 
 // witness vector of conv(b1) - conv(b2), computed by the whole wave; all lanes must call it with the same bodies
-// and all lanes return the same vector
+// and all lanes return the same vector.
+// The loop is RESUMABLE: its whole state between two iterations is GjkState (the bodies' vertices are reloaded), all of it
+// wave-uniform.  gjk_wave_run leaves the loop after iteration k_stop if the query has not ended by then (finished = false)
+// and continues from a saved state (fresh = false) with the same instruction sequence -- the iterations of a query may be
+// spread over two kernels (kernels_pairs.h: spec_pair_body) and arrive at the same bits.
+struct GjkState { Simplex s; V3 v; double wmax2; int c1, c2, k; };
 template <class B1, class B2>
-__device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int* iters_out = nullptr, long long* prof = nullptr) {   // prof (timing builds): [0] support, [1..3] segment / triangle / tetrahedron steps (100 MHz ticks), [4..6] their counts
+__device__ __forceinline__ V3 gjk_wave_run(const B1& b1, const B2& b2, int lane, GjkState& st, bool fresh, int k_stop, bool& finished, long long* prof = nullptr) {   // prof (timing builds): [0] support, [1..3] segment / triangle / tetrahedron steps (100 MHz ticks), [4..6] their counts
   static_assert(B1::N <= 16 && B2::N <= 16, "one body per row of 16 lanes");
   const double eps_rel2 = 1e-5 * 1e-5, eps_tot = 1e-15;
   // lanes 0..15 hold the vertices of body 1, lanes 16..31 those of body 2, once for the whole query
@@ -586,7 +591,15 @@ __device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int
   s.w0 = s.w1 = s.w2 = s.w3 = 0; s.l0 = s.l1 = s.l2 = s.l3 = 0;
   double wmax2 = 0;
   int k = 0;
-  do {
+  if (!fresh) {   // member by member: a struct copy under a run-time condition leaves a stack object behind (k_mid then reserves scratch)
+    s.n = st.s.n; s.w0 = st.s.w0; s.w1 = st.s.w1; s.w2 = st.s.w2; s.w3 = st.s.w3;
+    s.v0.x = st.s.v0.x; s.v0.y = st.s.v0.y; s.v0.z = st.s.v0.z; s.v1.x = st.s.v1.x; s.v1.y = st.s.v1.y; s.v1.z = st.s.v1.z;
+    s.v2.x = st.s.v2.x; s.v2.y = st.s.v2.y; s.v2.z = st.s.v2.z; s.v3.x = st.s.v3.x; s.v3.y = st.s.v3.y; s.v3.z = st.s.v3.z;
+    s.l0 = st.s.l0; s.l1 = st.s.l1; s.l2 = st.s.l2; s.l3 = st.s.l3;
+    v.x = st.v.x; v.y = st.v.y; v.z = st.v.z; wmax2 = st.wmax2; c1 = st.c1; c2 = st.c2; k = st.k;
+  }
+  finished = true;
+  for (;;) {
     k++;
 #ifdef TJ_PHASE_TIMING
     const long long tp0 = prof ? wall_clock64() : 0;
@@ -630,8 +643,17 @@ __device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int
     if (s.n > 2) { double t = sq(s.v2); if (uni(t > wmax2)) wmax2 = t; }
     if (s.n > 3) { double t = sq(s.v3); if (uni(t > wmax2)) wmax2 = t; }
     if (uni(sq(v) <= (eps_tot * eps_tot * wmax2))) break;
-  } while ((s.n != 4) && (k != 50));
-  if (iters_out) *iters_out = k;
+    if (!((s.n != 4) && (k != 50))) break;
+    if (k == k_stop) { finished = false; break; }   // to be continued: the state below is that of "about to start iteration k + 1"
+  }
+  st.s = s; st.v = v; st.wmax2 = wmax2; st.c1 = c1; st.c2 = c2; st.k = k;
+  return v;
+}
+template <class B1, class B2>
+__device__ __forceinline__ V3 gjk_wave(const B1& b1, const B2& b2, int lane, int* iters_out = nullptr, long long* prof = nullptr) {
+  GjkState st; bool fin;
+  const V3 v = gjk_wave_run(b1, b2, lane, st, true, 50, fin, prof);
+  if (iters_out) *iters_out = st.k;
   return v;
 }
 

@@ -305,7 +305,7 @@ __device__ __forceinline__ void begin_body(const Dev& D) {
     if (!done) { h.pending = 1; h.epoch++; h.slack_next = 1; }
     D.ctl->iter = h.iter; D.ctl->pending = h.pending; D.ctl->slack_now = h.slack_now; D.ctl->slack_next = h.slack_next;
     D.ctl->done = h.done; D.ctl->epoch = h.epoch; D.ctl->any_pair = 0;   // error bits and counters are only ever touched by atomics elsewhere
-    D.ctl->gjk_max_sum = h.gjk_max_sum + (unsigned long long)h.gjk_max; D.ctl->gjk_max = 0;
+    D.ctl->gjk_max_sum = h.gjk_max_sum + (unsigned long long)h.gjk_max; D.ctl->gjk_prev = h.gjk_max; D.ctl->gjk_max = 0;
   }
   __syncthreads();
   if (done) return;

@@ -193,6 +193,67 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
   }
 }
 
+// ---- GJK head start ------------------------------------------------------------------------------------------------------
+// Once the work list is spread evenly (sep_self_solve_body), k_mid is as long as its slowest robot pair: a pair of stacked hulls
+// whose GJK takes 10 - 16 iterations of ~1.3 us while the machine idles; k_front in front of it lasts ~10 us whatever the pairs
+// do.  In the steady phase of a run the slow pairs are the same from one iteration to the next (tests/devtools/
+// gjk_persistence.py: 17 of 18 on SCN-C; in the first twenty iterations one to two thirds), and a GJK query is a pure function
+// of the two hulls, which are final when k_front starts (hull cache).  So: k_mid lists the pairs whose query took at least
+// max(SPEC_GJK_MIN, longest of the previous launch - SPEC_GJK_WINDOW) iterations; the next k_front carries SPEC_CAP extra
+// one-wave blocks at the head of its grid, block b runs the first SPEC_GJK_BUDGET iterations of entry b's query (three: the
+// blocks then end with the obstacle queries) and stores the loop state (GjkState, 20 doubles + 9 ints) under a tag (epoch, pair);
+// wave b of k_mid is dedicated to entry b and continues the same loop at t = 0 of that kernel.  Same instructions on the same
+// operands in the same order: the witness vector and the iteration count are those of an uninterrupted query (test: head start
+// on / off, bitwise).  A listed pair that left the broad phase costs two waves that publish nothing; the list's order is free.
+constexpr int SPEC_CAP = 128, SPEC_GJK_MIN = 5, SPEC_GJK_WINDOW = 10, SPEC_GJK_BUDGET = 3;
+constexpr int SPEC_STATE_DOUBLES = 20, SPEC_STATE_INTS = 16;
+__device__ __forceinline__ unsigned pair_key(int tr, int p0, int q) { return (unsigned)(tr | (p0 << 9) | (q << 20)); }   // 9 + 11 + 11 bits
+__device__ __forceinline__ void spec_pair_body(const Dev& D, int b) {
+  const int lane = lane_id();
+  const int epoch = D.ctl->epoch, par = epoch & 1;
+  if (b == 0 && lane == 0) D.spec_n[par] = 0;   // the list this iteration's k_mid fills
+  const int n = min(D.spec_n[par ^ 1], SPEC_CAP);
+  // every block leaves a tag, valid or not: the tags k_mid sees are always those of the k_front in front of it
+  if (b >= n) { if (lane == 0) D.spec_tag[b] = 0ull; return; }
+  const unsigned key = (unsigned)D.spec_list[(par ^ 1) * SPEC_CAP + b];
+  const int tr = (int)(key & 0x1ff), p0 = (int)((key >> 9) & 0x7ff), q = (int)((key >> 20) & 0x7ff);
+  if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) D.spec_tag[b] = 0ull; return; }   // (cannot happen: the list is this context's own)
+  const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_INFO_STRIDE;
+  const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_INFO_STRIDE;
+  GjkState st; bool fin;
+  gjk_wave_run(BodyHull{A}, BodyHull{B}, lane, st, true, D.spec_budget, fin);
+  if (lane == 0) {
+    double* o = D.spec_state + (size_t)b * SPEC_STATE_DOUBLES;
+    o[0] = st.v.x; o[1] = st.v.y; o[2] = st.v.z;
+    o[3] = st.s.v0.x; o[4] = st.s.v0.y; o[5] = st.s.v0.z; o[6] = st.s.v1.x; o[7] = st.s.v1.y; o[8] = st.s.v1.z;
+    o[9] = st.s.v2.x; o[10] = st.s.v2.y; o[11] = st.s.v2.z; o[12] = st.s.v3.x; o[13] = st.s.v3.y; o[14] = st.s.v3.z;
+    o[15] = st.s.l0; o[16] = st.s.l1; o[17] = st.s.l2; o[18] = st.s.l3; o[19] = st.wmax2;
+    int* oi = D.spec_sti + (size_t)b * SPEC_STATE_INTS;
+    oi[0] = st.s.n; oi[1] = st.s.w0; oi[2] = st.s.w1; oi[3] = st.s.w2; oi[4] = st.s.w3; oi[5] = st.c1; oi[6] = st.c2; oi[7] = st.k; oi[8] = fin ? 1 : 0;
+    D.spec_tag[b] = ((unsigned long long)(unsigned)epoch << 32) | key;
+  }
+}
+// the state entry b holds, fetched by the whole wave (one load per lane, then broadcasts).  The values go straight back into
+// vector registers: left in scalar ones (50 of them, live across the merge with the fresh query's start) they cost k_mid a stack frame.
+__device__ __forceinline__ double spec_bcast(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  int vlo, vhi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vlo), "=v"(vhi) : "s"(lo), "s"(hi));
+  return __hiloint2double(vhi, vlo);
+}
+__device__ __forceinline__ void spec_state_load(const Dev& D, int b, int lane, GjkState& st, bool& fin) {
+  const double x = D.spec_state[(size_t)b * SPEC_STATE_DOUBLES + min(lane, SPEC_STATE_DOUBLES - 1)];
+  const int y = D.spec_sti[(size_t)b * SPEC_STATE_INTS + (lane & (SPEC_STATE_INTS - 1))];
+  st.v = V3{spec_bcast(x, 0), spec_bcast(x, 1), spec_bcast(x, 2)};
+  st.s.v0 = V3{spec_bcast(x, 3), spec_bcast(x, 4), spec_bcast(x, 5)}; st.s.v1 = V3{spec_bcast(x, 6), spec_bcast(x, 7), spec_bcast(x, 8)};
+  st.s.v2 = V3{spec_bcast(x, 9), spec_bcast(x, 10), spec_bcast(x, 11)}; st.s.v3 = V3{spec_bcast(x, 12), spec_bcast(x, 13), spec_bcast(x, 14)};
+  st.s.l0 = spec_bcast(x, 15); st.s.l1 = spec_bcast(x, 16); st.s.l2 = spec_bcast(x, 17); st.s.l3 = spec_bcast(x, 18); st.wmax2 = spec_bcast(x, 19);
+  st.s.n = __builtin_amdgcn_readlane(y, 0); st.s.w0 = __builtin_amdgcn_readlane(y, 1); st.s.w1 = __builtin_amdgcn_readlane(y, 2);
+  st.s.w2 = __builtin_amdgcn_readlane(y, 3); st.s.w3 = __builtin_amdgcn_readlane(y, 4);
+  st.c1 = __builtin_amdgcn_readlane(y, 5); st.c2 = __builtin_amdgcn_readlane(y, 6); st.k = __builtin_amdgcn_readlane(y, 7);
+  fin = __builtin_amdgcn_readlane(y, 8) != 0;
+}
+
 __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
   if (TJ_DONE(D)) return;
   __shared__ double lds[PAIR_LDS_DOUBLES];
@@ -200,10 +261,14 @@ __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
 }
 
 // one wavefront per robot pair (stride over the work list: wave bid of nwaves), solved cooperatively by its lanes (plane_pair_wave)
-__device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int nwaves) {
+__device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int nwaves, bool head_start = false) {   // head_start: k_mid only -- the k_front of the same iteration ran in front of it
   const int lane = lane_id();
   __shared__ double A[18], B[18];
   __shared__ int wpre[513];
+  // (SPEC_CAP = 128: two tags per lane) issued first, used after the work item has arrived; the list takes the pairs within
+  // SPEC_GJK_WINDOW iterations of the previous launch's longest query, so that it holds the tail and not the first to report
+  const unsigned long long spec_tag0 = head_start ? D.spec_tag[lane] : 0ull, spec_tag1 = head_start ? D.spec_tag[64 + lane] : 0ull;
+  const int spec_thr = head_start ? max(D.spec_min, D.ctl->gjk_prev - SPEC_GJK_WINDOW) : 0;
   const int n = pair_work_prefix(D, wpre, lane), U = D.U;
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
@@ -307,43 +372,121 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     if (any_capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
     return;
   }
-  // The first `nwaves` items are taken statically (no atomic on the common path: SCN-C has fewer pairs than waves); a
-  // wave that finishes early then draws further items from a shared cursor, so a long list (hundreds of robots) is
-  // balanced dynamically instead of striding -- solve times vary 1 : 30.
-  for (int w = bid; w < n;) {
-    const bool first = w == bid;   // phase stamps (timing build only) describe a wave's first work item
-    if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
-    const size_t sl = (size_t)pair_work_slot(D, wpre, w);
-    const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
-    __syncthreads();
-    if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
-    __syncthreads();
-    if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
-    {
-      double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
-      const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk, first ? &D : nullptr);  // whole wave, uniform result
-#ifdef TJ_PHASE_TIMING
-      if (lane == 0 && first && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
-#endif
-      if (lane == 0 && gk >= 6) atomicMax(&D.ctl->gjk_max, gk);   // a handful of pairs per launch
-      if (okp && lane == 0) {
-        // statistics per (robot, segment): ~900 waves adding to ONE word of the control block serialise there (~13 ns each) and
-        // the stores below wait for it
-        unsigned long long* ps = D.pair_stats + 2 * ((size_t)p0 * D.S + tr);
-        atomicAdd(ps, (unsigned long long)nit); atomicAdd(ps + 1, 1ull);
-        if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
-        const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
-        double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
-        q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
-        q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
-        D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
-      }
+  // ---- one wave per pair -------------------------------------------------------------------------------------------------
+  // SCN-C lists ~3 000 pairs per iteration for 1 024 - 1 728 waves: a wave solves two or three, and what it pays per pair besides
+  // the arithmetic (2 - 6 us) were three dependent memory round trips (cursor -> work item -> hulls, ~0.9 us each: the lines were
+  // written by another XCD a kernel earlier).  So the assignment is STATIC (wave r of the Wg generic waves takes the items r,
+  // r + Wg, ...; at most five, n <= 4 nwaves here): lane j fetches the work item of the wave's j-th pair, all of them in one
+  // round trip, and the hulls of the next pair travel while the current one is solved.
+  // The pairs that were slow in the previous iteration do not wait in that queue: wave b of the first SPEC_CAP waves is
+  // DEDICATED to head-start entry b (kernels_pairs.h: spec_pair_body) -- it needs the tag only to know its pair, starts at t = 0
+  // from the saved GJK state, and publishes the plane if the broad phase listed the pair again (its segment's part of the work
+  // list is scanned while the GJK runs); the generic wave that meets the pair in the list skips it.
+  const bool tv0 = head_start && (int)(spec_tag0 >> 32) == epoch && lane < nwaves, tv1 = head_start && (int)(spec_tag1 >> 32) == epoch && 64 + lane < nwaves;
+  const unsigned long long vm0 = ballot(tv0), vm1 = ballot(tv1);
+  const int nd = __popcll(vm0) + __popcll(vm1);
+  const bool dedicated = bid < SPEC_CAP && (((bid < 64 ? vm0 >> bid : vm1 >> (bid - 64)) & 1ull) != 0);
+  auto publish = [&](bool okp, int tr, int p0, int q, double e0, double e1c, double e2c, double dpl, bool capped, int nit, int gk) {
+    if (lane == 0 && head_start && gk >= spec_thr) {   // a few dozen pairs per launch: candidates for the next iteration's head start
+      const int slot = atomicAdd(&D.spec_n[epoch & 1], 1);
+      if (slot < SPEC_CAP) D.spec_list[(epoch & 1) * SPEC_CAP + slot] = (int)pair_key(tr, p0, q);
     }
+#ifdef TJ_PHASE_TIMING
+    if (lane == 0 && gk >= 4) {   // (key, iterations) of the slower queries of this launch: tests/devtools/gjk_persistence.py
+      long long* base = D.dbg + (size_t)K_SEP_SELF_ROWS * TJ_TIC_BLOCKS * TJ_TIC_SLOTS;
+      const unsigned long long i = atomicAdd((unsigned long long*)base, 1ull);
+      if (i < 4000) { base[8 + 2 * i] = (long long)pair_key(tr, p0, q); base[9 + 2 * i] = gk; }
+    }
+#endif
+    if (lane == 0 && gk >= 6) atomicMax(&D.ctl->gjk_max, gk);   // a handful of pairs per launch
+    if (okp && lane == 0) {
+      // statistics per (robot, segment): ~900 waves adding to ONE word of the control block serialise there (~13 ns each) and
+      // the stores below wait for it
+      unsigned long long* ps = D.pair_stats + 2 * ((size_t)p0 * D.S + tr);
+      atomicAdd(ps, (unsigned long long)nit); atomicAdd(ps + 1, 1ull);
+      if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+      const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
+      double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
+      q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
+      q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
+      D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+    }
+  };
+  if (dedicated) {
+    TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
+    const unsigned long long tg = bid < 64 ? __shfl(spec_tag0, bid) : __shfl(spec_tag1, bid - 64);
+    const unsigned key = (unsigned)tg;
+    const int tr = (int)(key & 0x1ff), p0 = (int)((key >> 9) & 0x7ff), q = (int)((key >> 20) & 0x7ff);
+    if (tr >= D.S || p0 >= U || q >= U) return;   // (cannot happen)
+    // in flight together: both hulls, the saved state, this segment's part of the work list
+    if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
+    GjkState hs; bool hs_fin = false;
+    spec_state_load(D, bid, lane, hs, hs_fin);
+    const int cnt = wpre[tr + 1] - wpre[tr];
+    const int* wl = D.pair_work + 3 * (size_t)tr * pair_work_cap_seg(D);
+    bool member = false;
+    for (int i = lane; i < cnt; i += 64) member = member || (wl[3 * i + 1] == p0 && wl[3 * i + 2] == q);
+    __syncthreads();
+    TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
+    double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
+    const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk, nullptr, hs, true, hs_fin);
+#ifdef TJ_PHASE_TIMING
+    if (lane == 0 && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk + 1000; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
+#endif
+    if (ballot(member)) {   // the broad phase listed the pair in this iteration too: the plane counts
+      if (lane == 0) atomicAdd(&D.ctl->spec_taken, 1);
+      publish(okp, tr, p0, q, e0, e1c, e2c, dpl, capped, nit, gk);
+    }
+    TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
+    return;
+  }
+  const int below = bid < 64 ? __popcll(vm0 & ((1ull << bid) - 1ull)) : (bid < 128 ? __popcll(vm0) + __popcll(vm1 & ((1ull << (bid - 64)) - 1ull)) : nd);
+  const int r = bid - below, Wg = nwaves - nd;
+  if (r >= n) return;
+  TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
+  // lane j: the wave's j-th work item (all of them in one round trip)
+  int it_tr = 0, it_p0 = 0, it_q = 0;
+  const int n_mine = (n - r + Wg - 1) / Wg;   // <= 5 (n <= 4 nwaves, Wg >= nwaves - SPEC_CAP)
+  if (lane < n_mine) {
+    const size_t sl = (size_t)pair_work_slot(D, wpre, r + lane * Wg);
+    it_tr = D.pair_work[3 * sl]; it_p0 = D.pair_work[3 * sl + 1]; it_q = D.pair_work[3 * sl + 2];
+  }
+  int tr = __builtin_amdgcn_readlane(it_tr, 0), p0 = __builtin_amdgcn_readlane(it_p0, 0), q = __builtin_amdgcn_readlane(it_q, 0);
+  // this lane's entry of the pair's two hulls: lanes 0..17 A, 18..35 B
+  auto hull_entry_of = [&](int tr_, int p0_, int q_) -> double {
+    const int robot = lane < 18 ? p0_ : q_, e = lane < 18 ? lane : lane - 18;
+    return lane < 36 ? D.hullinfo[((size_t)robot * D.S + tr_) * HULL_STRIDE + e] : 0.0;
+  };
+  double hv = hull_entry_of(tr, p0, q);
+  for (int j = 0; j < n_mine; j++) {
+    const bool first = j == 0;   // phase stamps (timing build only) describe a wave's first work item
+    __syncthreads();
+    if (lane < 18) A[lane] = hv; else if (lane < 36) B[lane - 18] = hv;
+    __syncthreads();
+    const int ctr = tr, cp0 = p0, cq = q;
+    if (j + 1 < n_mine) {   // the next pair's hulls travel while this one is solved
+      tr = __builtin_amdgcn_readlane(it_tr, j + 1); p0 = __builtin_amdgcn_readlane(it_p0, j + 1); q = __builtin_amdgcn_readlane(it_q, j + 1);
+      hv = hull_entry_of(tr, p0, q);
+    }
+    if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
+    if (head_start) {   // a dedicated wave has this pair
+      const unsigned long long want = ((unsigned long long)(unsigned)epoch << 32) | pair_key(ctr, cp0, cq);
+      if (ballot((tv0 && spec_tag0 == want) || (tv1 && spec_tag1 == want))) continue;
+    }
+    double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
+    GjkState gs;
+    const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk,
+#ifdef TJ_PHASE_LIGHT
+                                     nullptr,
+#else
+                                     first ? &D : nullptr,
+#endif
+                                     gs, false, false);  // whole wave, uniform result
+#ifdef TJ_PHASE_TIMING
+    if (lane == 0 && first && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
+#endif
+    publish(okp, ctr, cp0, cq, e0, e1c, e2c, dpl, capped, nit, gk);
     if (first) TJ_TIC(D, K_SEP_SELF_SOLVE, 2);
-    if (n <= nwaves) break;   // every item had its own wave (SCN-C): no cursor to ask -- its return value was a memory round trip at the end of every wave
-    int nxt = 0;
-    if (lane == 0) nxt = nwaves + atomicAdd(D.pair_work_n + D.S, 1);
-    w = __shfl(nxt, 0);
   }
 }
 __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {

@@ -345,16 +345,20 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
 // LDS): wave-cooperative GJK, then the Newton refinement of the offset with its 12 barrier terms (the only
 // transcendental work) evaluated by 12 lanes and summed in the reference's order.  Same expressions, same
 // summation order as plane_pair => identical results.
-__device__ inline bool plane_pair_wave(const double* A, const double* Bq, double dist, double m, double off, int lane, double& e0, double& e1c, double& e2c, double& dpl,
-                                       bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr, const Dev* tic = nullptr) {
+__device__ __forceinline__ bool plane_pair_wave(const double* A, const double* Bq, double dist, double m, double off, int lane, double& e0, double& e1c, double& e2c, double& dpl,
+                                       bool& capped, int* newton_iters, int* gjk_iters, const Dev* tic,
+                                       GjkState& gst, bool resume, bool resume_finished) {   // resume: the query's first iterations were run elsewhere (spec_pair_body) and gst holds their state
   capped = false;
+  bool gfin;
+  V3 v;
 #ifdef TJ_PHASE_TIMING
   long long prof[7] = {0, 0, 0, 0, 0, 0, 0};
-  const V3 v = gjk_wave(BodyHull{A}, BodyHull{Bq}, lane, gjk_iters, tic ? prof : nullptr);
+  if (resume && resume_finished) v = gst.v; else v = gjk_wave_run(BodyHull{A}, BodyHull{Bq}, lane, gst, !resume, 50, gfin, tic ? prof : nullptr);
   if (tic && threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) for (int i = 0; i < 7; i++) tic->dbg[((size_t)K_OBS_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + i] = prof[i];
 #else
-  const V3 v = gjk_wave(BodyHull{A}, BodyHull{Bq}, lane, gjk_iters);
+  if (resume && resume_finished) v = gst.v; else v = gjk_wave_run(BodyHull{A}, BodyHull{Bq}, lane, gst, !resume, 50, gfin);
 #endif
+  if (gjk_iters) *gjk_iters = gst.k;
   TJ_ORDER(v.x);
   if (tic) TJ_TIC(*tic, K_SEP_SELF_SOLVE, 3);
   const double cn = norm3(v.x, v.y, v.z);
@@ -398,6 +402,12 @@ __device__ inline bool plane_pair_wave(const double* A, const double* Bq, double
   TJ_ORDER(dpl);
   if (tic) TJ_TIC(*tic, K_SEP_SELF_SOLVE, 5);
   return true;
+}
+
+__device__ inline bool plane_pair_wave(const double* A, const double* Bq, double dist, double m, double off, int lane, double& e0, double& e1c, double& e2c, double& dpl,
+                                       bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr, const Dev* tic = nullptr) {
+  GjkState gst;
+  return plane_pair_wave(A, Bq, dist, m, off, lane, e0, e1c, e2c, dpl, capped, newton_iters, gjk_iters, tic, gst, false, false);
 }
 
 // ---- obstacle planes in three steps --------------------------------------------------------------------------------

@@ -569,8 +569,11 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
   __shared__ double lds[OBS_LDS_DOUBLES > PAIR_LDS_DOUBLES ? OBS_LDS_DOUBLES : PAIR_LDS_DOUBLES];   // one buffer for whichever body this block runs
-  if ((int)blockIdx.x < n_obs) obs_query_body<PRIM>(D, blockIdx.x, lds, true);
-  else sep_self_rows_body(D, blockIdx.x - n_obs, lds);
+  const int n_spec = D.spec ? SPEC_CAP : 0;   // GJK head starts of last iteration's slow pairs lead the grid: they are the longest blocks
+  const int b = (int)blockIdx.x - n_spec;
+  if (b < 0) spec_pair_body(D, blockIdx.x);
+  else if (b < n_obs) obs_query_body<PRIM>(D, b, lds, true);
+  else sep_self_rows_body(D, b - n_obs, lds);
   TJ_TIC(D, K_FRONT, 1);
 }
 // two waves per SIMD (<= 256 VGPRs; 244 used, no spills since the slack body was rewritten): 2 048 one-wave blocks are resident
@@ -582,9 +585,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int n_slack = (D.u1 - D.u0) * D.P;
   const int b = blockIdx.x;
   TJ_TIC(D, K_MID, 0);
+#ifdef TJ_PHASE_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) {   // where the block runs: HW_ID (wave, SIMD, CU, SE) and XCC_ID
+    D.dbg[((size_t)K_MID * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    D.dbg[((size_t)K_MID * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
   if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
   else if (TJ_DONE(D)) return;
-  else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves);
+  else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves, D.spec != 0);
   else obs_solve_body<PRIM>(D, b - n_slack - n_pair_waves, n_obs_waves);
   TJ_TIC(D, K_MID, 1);
 }

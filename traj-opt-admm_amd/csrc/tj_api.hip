@@ -53,6 +53,7 @@ struct tj_ctx {
   bool ccd_lean = true;        // which build of k_ccd the chain launches (kernels_step.h); re-decided whenever the control block is read
   unsigned ccd_found_seen = 0; long long iters_enqueued = 0, iters_seen = 0;
   bool grad_fold = true;       // k_grad compacts its own segments (one launch less); TJ_GRAD_FOLD=0 keeps k_sep_self_compact + the 192-thread k_grad
+  int n_solve_env = 0;         // TJ_N_SOLVE: pair-solve waves of k_mid (launch-shape switch)
   bool split_unions = false;   // k_front / k_ccd as two launches each (hundreds of robots), see launch_kernel
   LsLayout lsl;
   // cloud-dependent allocations (rebuilt by tj_set_cloud)
@@ -122,10 +123,13 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   // 4096 + 1024 blocks the last ones started 50 us into a 60 us kernel).
   // Large fleets (one pair per lane, long solves passed on to idle waves -- sep_self_solve_body): half as many waves again, they
   // are the consumers of the passed-on pairs (SCN-D: k_mid 62 us with 1024, 58 with 1536, 62 with 2048).
-  const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, d.U >= 192 ? 1536 : 1024) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
+  // Small fleets (a wave per pair, two or three pairs per wave): 1 728 = what is left of k_mid's 2 048 resident waves beside SCN-C's
+  // 320 slack blocks (1 024: k_mid 31.5 us, 1 536: 28.2, 1 728: 27.6, 2 048: 27.6 before the static assignment; alike after it).
+  const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, c->n_solve_env > 0 ? c->n_solve_env : (d.U >= 192 ? 1536 : 1728)) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 1024 : 0;   // (512: SCN-E's k_mid 43.7 us, 1024: 38.3, 2048: 37.8; SCN-C indifferent)
   const int n_rows = multi ? d.S * pair_units(d.U, d.pair_rows) : 0;   // one wave per (segment, tile of pair_rows lower robots x 64 partners)
-  const int n_front = owned * d.S + n_rows, n_ccd = n_front;
+  const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + (d.spec ? SPEC_CAP : 0);
+  const int n_mid_slack = owned * d.P;
   switch (kid) {
     case K_BEGIN: if (chain_pos & 1) return false; hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
     case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
@@ -147,7 +151,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       return true;
     case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d); return true;
     case K_MID: if (!in_graph && !in_phase) return false;
-      if (tri) hipLaunchKernelGGL((k_mid<3>), dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else hipLaunchKernelGGL((k_mid<1>), dim3(owned * d.P + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
+      if (tri) hipLaunchKernelGGL((k_mid<3>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else hipLaunchKernelGGL((k_mid<1>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
       return true;
     case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
@@ -469,6 +473,14 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.pair_pass_on = 1;
   if (const char* e = getenv("TJ_PAIR_PASS_ON")) d.pair_pass_on = atoi(e) != 0;
   if (const char* e = getenv("TJ_SPLIT_UNIONS")) c->split_unions = atoi(e) != 0;
+  // GJK head start for last iteration's slow robot pairs (kernels_pairs.h: spec_pair_body); TJ_PAIR_HEAD_START=0 switches it off (test hook: same bits)
+  d.spec = (d.mode >= 1 && !d.optimal_plane && !c->split_unions) ? 1 : 0;
+  if (const char* e = getenv("TJ_PAIR_HEAD_START")) d.spec = d.spec && atoi(e) != 0;
+  c->n_solve_env = 0;
+  if (const char* e = getenv("TJ_N_SOLVE")) c->n_solve_env = std::max(1, atoi(e));
+  d.spec_budget = SPEC_GJK_BUDGET; d.spec_min = SPEC_GJK_MIN;
+  if (const char* e = getenv("TJ_HS_BUDGET")) d.spec_budget = std::max(1, atoi(e));   // development hooks (same bits for any value)
+  if (const char* e = getenv("TJ_HS_MIN")) d.spec_min = std::max(1, atoi(e));
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
     return TJ_ERR_UNSUPPORTED;
@@ -508,7 +520,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) || (r = dalloc(c, &d.blk_stats, U * P + U)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
-      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.pair_ovf, 4)) || (r = dalloc(c, &d.pair_ovf_list, (size_t)d.cap_work + PAIR_CONSUMERS_MAX)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.pair_ovf, 4)) || (r = dalloc(c, &d.spec_n, 2)) || (r = dalloc(c, &d.spec_list, 2 * SPEC_CAP)) || (r = dalloc(c, &d.spec_tag, SPEC_CAP)) || (r = dalloc(c, &d.spec_state, SPEC_CAP * SPEC_STATE_DOUBLES)) || (r = dalloc(c, &d.spec_sti, SPEC_CAP * SPEC_STATE_INTS)) || (r = dalloc(c, &d.pair_ovf_list, (size_t)d.cap_work + PAIR_CONSUMERS_MAX)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
@@ -718,6 +730,8 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   if (d.mode >= 1) HIPCHK(c, hipMemsetAsync(d.pairstamp, 0, (size_t)d.S * U * U * 4, c->stream));  // epochs restart at 1
   HIPCHK(c, hipMemsetAsync(d.pair_ovf_list, 0, ((size_t)d.cap_work + PAIR_CONSUMERS_MAX) * 8, c->stream));                  // (entries are tagged with the epoch)
   HIPCHK(c, hipMemsetAsync(d.pair_ovf, 0, 16, c->stream));
+  HIPCHK(c, hipMemsetAsync(d.spec_n, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(d.spec_tag, 0, SPEC_CAP * 8, c->stream));                                                          // (tags carry the epoch)
   c->have_state = true;
   return TJ_OK;
 }
@@ -1404,6 +1418,7 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   s->pair_tests = d.mode >= 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
   s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error; s->order_unresolved = h.order_unresolved;
   s->gjk_max_sum = h.gjk_max_sum + (unsigned long long)h.gjk_max;
+  s->head_starts = h.spec_taken;
   return TJ_OK;
 }
 
