@@ -4,6 +4,7 @@
 Tolerances: bit-exact for GJK witness vectors / planes / CCD exponents / candidate counts;
 1e-12-class absolute for per-stage floating point (SURVEY 8c: teacher-forced 1e-12);
 1e-8 relative end-to-end on the control points (BASELINE.json north_star)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -254,6 +255,32 @@ def test_inter_robot_clamp_replays_the_references_tree_order(pkg, monkeypatch):
     with pytest.raises(pkg.TrajAdmmError, match="pair order"):
         s.stage_steps()
     s.close()
+
+
+def test_folded_replay_replays_the_references_tree_order_too(pkg):
+    """In the iteration chain the sequential pair replay is the tail of k_ccd (its last block, tree storage in global memory:
+    kernels_step.h ccd_union_body) -- the same order-dependent cases through THAT path: phase 2 of the sharded schedule
+    (swept-hull cache, k_ccd, line search) on one rank, steps read back afterwards.  Same bits as the reference, and the
+    order-dependent branch is taken."""
+    from conftest import ccd_order_case
+    g = gold("ccd_order_kat.npz")
+    hit = 0
+    for seed in g["seeds"]:
+        scene, dirs = ccd_order_case(int(seed))
+        s = pkg.Solver(scene, stop=0.0)
+        s.run_stage("begin")
+        for u in range(scene["U"]):
+            s.set_direction(u, dirs[u], 0.0, 1.0, 1.0)
+        s.iterate_phase(2)
+        a = np.zeros(s.U); b = np.zeros(s.U)
+        s._check(s.lib.tj_get_steps(s._ctx, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), None))
+        st = s.stats()
+        assert np.array_equal(a, g[f"s{seed}_step_self"]), (int(seed), a, g[f"s{seed}_step_self"])
+        assert np.array_equal(b, g[f"s{seed}_step_pos"])
+        assert st["order_unresolved"] == 0 and (st["error_bits"] & ~4) == 0   # (the line search behind it runs on a made-up direction: its back-off cap may fire)
+        hit += st["order_ambiguous"]
+        s.close()
+    assert hit > 0, "fixture no longer exercises the order-dependent case"
 
 
 def test_headline_scene_free_running_within_reference_envelope(pkg, scenes):

@@ -63,6 +63,10 @@ struct Ctl {
   // and the sum of these maxima over the iterations begun so far: the unit count of k_mid's critical path (bench.py critical_path)
   int gjk_max, spec_taken;   // spec_taken: GJK head starts k_mid continued from (kernels_pairs.h), summed over the iterations
   unsigned long long gjk_max_sum;
+  // k_ccd's pair-selection blocks that have finished, counted in two levels (sixteen sub-counters, then this one: hundreds of returning
+  // atomics on ONE address serialise at ~13 ns each); the last one runs the sequential pair replay + gnorm (Dev::seq_fold)
+  int ccd_ticket, pad3;
+  int ccd_sub[16];
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
@@ -154,6 +158,7 @@ struct Dev {
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration
   // GJK head start (kernels_pairs.h: spec_pair_body): pairs whose GJK was long in one iteration get the first iterations of the
   // next one's query inside k_front, next to the broad phase; k_mid continues from the saved state.  0 = off (TJ_PAIR_HEAD_START=0: same bits).
+  int seq_fold; double* seq_gmem_d; int* seq_gmem_i;   // > 0: k_ccd's last block finishes with k_ccd_self_seq's work (kernels_step.h); the value = acting pairs its sort holds
   int spec, spec_budget, spec_min; int* spec_n; int* spec_list; unsigned long long* spec_tag; double* spec_state; int* spec_sti;
   // "optimal_plane":1 -- planes that persist across iterations (the reference's is_seperate / seperate_c / seperate_d and
   // is_self_seperate / self_seperate_c / self_seperate_d tables, CCDUtils.cpp:30-36).  Obstacle planes (mode 0): a list per

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
 constexpr int ACT_CAP = 4096;                                    // acting pairs of one iteration (all segments)
 constexpr int ROBOT_BITS = 11;                                   // robot ids in packed pair keys: U <= 2048 (with S < 512 a key is 31 bits)
 __device__ __forceinline__ int act_key(int tr, int p0, int p1) { return (tr << (2 * ROBOT_BITS)) | (p0 << ROBOT_BITS) | p1; }
-__device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid, double* lds) {
+__device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double* lds) {   // returns the acting pairs this tile listed
   int tr, rb, cb;
   pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
   const int lane = lane_id();
@@ -142,7 +142,8 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid, doubl
   // swept boxes (lanes over partners), then swept 49-axis intervals (lanes over axes): BVH::SelfCCDCollision + CCD::SelfKDOPCCD
   const int m = pair_tile_filter(D.cbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, 0, U,
                                  [&](int q) { return D.ccdinfo + ((size_t)q * D.S + tr) * CCD_STRIDE; }, 48, 97, off, rowbox, list, lane);
-  if (m == 0) return;
+  if (m == 0) return 0;
+  int found = 0;
   // A pair can only ever ACT in the sequential replay if its swept hulls are within `offset` at FULL step: hulls are
   // nested in the step (conv{P, P+tD} shrinks with t), and the replay evaluates them at steps <= 1.  Deciding that
   // here, in parallel over all tiles (one surviving pair per lane), leaves the one-wave replay kernel with the (rare)
@@ -158,17 +159,19 @@ __device__ __forceinline__ void ccd_self_pairs_body(const Dev& D, int bid, doubl
       ok = v.x * v.x + v.y * v.y + v.z * v.z <= off * off;
     }
     const unsigned long long mask = ballot(ok);
+    found += __popcll(mask);
     if (mask) {   // rare
       int base = 0;
       if (lane == 0) base = atomicAdd(&D.ctl->any_pair, __popcll(mask));   // any_pair = number of acting pairs this iteration
       base = __shfl(base, 0);
       const int w = base + prefix_count(mask);
       if (ok) {
-        if (w < ACT_CAP) D.pair_list[w] = act_key(tr, p0, p1);
+        if (w < ACT_CAP) __hip_atomic_store(&D.pair_list[w], act_key(tr, p0, p1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through: the folded replay reads it inside the same launch)
         else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
       }
     }
   }
+  return found;
 }
 
 __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
@@ -193,27 +196,42 @@ __host__ __device__ inline size_t seq_lds_bytes(int U, int S, bool with_tree) {
   (void)S;
   return b;
 }
-__global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
-  if (TJ_DONE(D)) return;
+// where the replay keeps its arrays: the stand-alone kernel carves everything from its dynamic LDS; folded into the tail of
+// k_ccd (below) the small arrays live in that kernel's static buffer and the tree -- touched by lane 0 only, and only when two
+// acting pairs of a segment share a robot -- in global memory
+struct SeqMem {
+  double *tbox, *tarea, *bx, *gns;   // tree nodes [12U], [2U]; swept boxes of the segment [6U]; gnorm staging [U]
+  int *ti, *ks, *seen, *keys, *act0, *act1, *ord, *stk;
+  int key_cap;        // acting pairs the sort can hold (a power of two)
+  bool lane0_stages;  // bx is global memory: lane 0 copies the boxes itself (no cross-lane traffic through global memory)
+};
+// doubles of k_ccd's static buffer the folded replay needs, and what the tree needs in global memory
+__host__ __device__ inline size_t seq_fold_lds_bytes(int U, int key_cap) { return (size_t)U * sizeof(double) + (2 * (size_t)U + key_cap + 3 * SEQ_ACT_CAP) * sizeof(int); }
+__host__ __device__ inline size_t seq_fold_gmem_doubles(int U) { return 20 * (size_t)U; }
+__host__ __device__ inline size_t seq_fold_gmem_ints(int U) { return 10 * (size_t)U + 2 * SEQ_STK_CAP; }
+
+// FOLD: called by the last block of k_ccd to finish (decoupled mode only); what other blocks of the SAME launch produced --
+// the acting-pair keys and their count -- is read with agent-scope atomic loads (the producers store them that way and wait
+// for the stores before they take their ticket).
+template <bool FOLD>
+__device__ __forceinline__ void ccd_self_seq_body(const Dev& D, const SeqMem& M, bool with_gnorm = true) {
   const int lane = lane_id();
-  extern __shared__ double seq_sm[];
-  // doubles first (alignment): tree nodes + the segment's swept boxes + gnorm staging, then the int arrays
-  double* tbox = seq_sm; double* tarea = tbox + (D.seq_tree ? 12 * (size_t)D.U : 0); double* bx = tarea + (D.seq_tree ? 2 * (size_t)D.U : 0);
-  double* gns = bx + (D.seq_tree ? 6 * (size_t)D.U : 0);        // [U]
-  int* ti = (int*)(gns + D.U);                                   // [5][2U] parent, left, right, height, particle
-  int* ks = ti + (D.seq_tree ? 10 * (size_t)D.U : 0);           // [U] exponents
-  int* seen = ks + D.U;                                          // [U] last segment in which the robot appeared
-  int* keys = seen + D.U;                                        // [ACT_CAP] acting pairs, sorted
-  int* act0 = keys + ACT_CAP; int* act1 = act0 + SEQ_ACT_CAP; int* ord = act1 + SEQ_ACT_CAP;
-  int* stk = ord + SEQ_ACT_CAP;
+  double* tbox = M.tbox; double* tarea = M.tarea; double* bx = M.bx; double* gns = M.gns;
+  int* ti = M.ti; int* ks = M.ks; int* seen = M.seen; int* keys = M.keys;
+  int* act0 = M.act0; int* act1 = M.act1; int* ord = M.ord; int* stk = M.stk;
   TJ_TIC(D, K_CCD_SELF_SEQ, 0);
   for (int i = lane; i < D.U; i += 64) { ks[i] = 0; seen[i] = -1; }
   // usually no pair is within `offset` at full step (any_pair counts the acting pairs the selection kernel listed)
-  const int n_act = D.multi() ? min(D.ctl->any_pair, ACT_CAP) : 0;
+  int n_act = 0;
+  if (D.multi()) {
+    const int listed = FOLD ? __hip_atomic_load(&D.ctl->any_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : D.ctl->any_pair;
+    n_act = min(listed, min(ACT_CAP, M.key_cap));
+    if (listed > n_act && listed <= ACT_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);   // more acting pairs than the folded replay can sort (beyond ACT_CAP the selection has reported it)
+  }
   if (n_act > 0) {
     // stage the keys and sort them ascending = (segment, p0, p1) lexicographic: bitonic network over the next power of two
     int npow = 1; while (npow < n_act) npow <<= 1;
-    for (int i = lane; i < npow; i += 64) keys[i] = i < n_act ? D.pair_list[i] : 0x7fffffff;
+    for (int i = lane; i < npow; i += 64) keys[i] = i < n_act ? (FOLD ? __hip_atomic_load(&D.pair_list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : D.pair_list[i]) : 0x7fffffff;
     blk_sync<true>();
     for (int k = 2; k <= npow; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
@@ -251,15 +269,17 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
       bool tree_order = false;
       if (share && !shared && m >= 2) {
         if (D.seq_tree) {
-          for (int i = lane; i < 6 * D.U; i += 64) { const int k = i / D.U, u = i % D.U; bx[6 * u + k] = D.cbox[((size_t)tr * 6 + k) * D.U + u]; }  // swept boxes of ALL robots (BVH.cpp:301-325)
+          if (M.lane0_stages) { if (lane == 0) for (int i = 0; i < 6 * D.U; i++) { const int k = i / D.U, u = i % D.U; bx[6 * u + k] = D.cbox[((size_t)tr * 6 + k) * D.U + u]; } }
+          else for (int i = lane; i < 6 * D.U; i += 64) { const int k = i / D.U, u = i % D.U; bx[6 * u + k] = D.cbox[((size_t)tr * 6 + k) * D.U + u]; }  // swept boxes of ALL robots (BVH.cpp:301-325)
           blk_sync<true>();
+          int found = 0;
           if (lane == 0) {
             DynTree t{tbox, tarea, ti, ti + 2 * D.U, ti + 4 * D.U, ti + 6 * D.U, ti + 8 * D.U, DT_NIL, 0};
             for (int u = 0; u < D.U; u++) dt_insert(t, u, bx + 6 * u);
-            stk[2 * SEQ_STK_CAP - 1] = dt_pair_order(t, D.offset, act0, act1, m, ord, stk, SEQ_STK_CAP - 1);
+            found = dt_pair_order(t, D.offset, act0, act1, m, ord, stk, SEQ_STK_CAP - 1);
           }
           blk_sync<true>();
-          tree_order = stk[2 * SEQ_STK_CAP - 1] == m;
+          tree_order = __shfl(found, 0) == m;
         }
         if (tree_order) ambiguous++; else unresolved++;
       }
@@ -291,8 +311,9 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     const int kshared = ks[0];
     __syncthreads();
     for (int i = lane; i < D.U; i += 64) { D.k_self[i] = D.coupled() ? kshared : ks[i]; seen[i] = 0; }
-    if (D.coupled()) for (int i = D.u0 + lane; i < D.u1; i += 64) D.k_obs_f[i] = (double)D.k_obs[i];   // exchange buffer 3 (sharded contexts)
+    if constexpr (!FOLD) if (D.coupled()) for (int i = D.u0 + lane; i < D.u1; i += 64) D.k_obs_f[i] = (double)D.k_obs[i];   // exchange buffer 3 (sharded contexts)
   }
+  if (!with_gnorm) return;
   // gnorm exactly as the drivers form it (Optimization3D_multi.h:57,72,750; _admm.h:499): a
   // sequential sum in robot order; the values are first pulled into LDS by all lanes
   __syncthreads();
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   __syncthreads();
   TJ_TIC(D, K_CCD_SELF_SEQ, 3);
   double gt = 0, xg = 0;
-  if (D.coupled()) {   // per-robot terms of G_t and x0.G: fetched by the lanes (one round trip per 64 robots), added by lane 0 in robot order
+  if constexpr (!FOLD) if (D.coupled()) {   // per-robot terms of G_t and x0.G: fetched by the lanes (one round trip per 64 robots), added by lane 0 in robot order
     __shared__ double s_cp[2][64];
     for (int u0 = 0; u0 < D.U; u0 += 64) {
       const int nu = min(64, D.U - u0);
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
   if (lane == 0) {
     double gsum = 0;
     for (int u = 0; u < D.U; u++) gsum += gns[u];
-    if (D.coupled()) {
+    if (!FOLD && D.coupled()) {
       // gnorm = |G| / uav_num and wolfe = -x0.G over the whole arrowhead system (Optimization3D_multi.h:558,580);
       // k_xsolve_c2 left per-robot partial sums, the shared-time entries are added here
       D.ctl->gnorm = sqrt(gsum + gt * gt) / double(D.U);
@@ -321,6 +342,22 @@ __global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
     } else D.ctl->gnorm = (D.mode == 1) ? gsum / double(D.U) : gns[0];
   }
   TJ_TIC(D, K_CCD_SELF_SEQ, 4);
+}
+__global__ __launch_bounds__(64) void k_ccd_self_seq(Dev D) {
+  if (TJ_DONE(D)) return;
+  extern __shared__ double seq_sm[];
+  // doubles first (alignment): tree nodes + the segment's swept boxes + gnorm staging, then the int arrays
+  SeqMem M;
+  M.tbox = seq_sm; M.tarea = M.tbox + (D.seq_tree ? 12 * (size_t)D.U : 0); M.bx = M.tarea + (D.seq_tree ? 2 * (size_t)D.U : 0);
+  M.gns = M.bx + (D.seq_tree ? 6 * (size_t)D.U : 0);               // [U]
+  M.ti = (int*)(M.gns + D.U);                                        // [5][2U] parent, left, right, height, particle
+  M.ks = M.ti + (D.seq_tree ? 10 * (size_t)D.U : 0);                // [U] exponents
+  M.seen = M.ks + D.U;                                               // [U] last segment in which the robot appeared
+  M.keys = M.seen + D.U;                                             // [ACT_CAP] acting pairs, sorted
+  M.act0 = M.keys + ACT_CAP; M.act1 = M.act0 + SEQ_ACT_CAP; M.ord = M.act1 + SEQ_ACT_CAP;
+  M.stk = M.ord + SEQ_ACT_CAP;
+  M.key_cap = ACT_CAP; M.lane0_stages = false;
+  ccd_self_seq_body<false>(D, M);
 }
 
 // ---- slack (z) and dual update -------------------------------------------------------------------
@@ -601,8 +638,54 @@ template <int PRIM>
 __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   __shared__ double lds[CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES];
+  int found = 0;
   if ((int)blockIdx.x < n_obs) ccd_obs_body<PRIM>(D, blockIdx.x, lds);
-  else ccd_self_pairs_body(D, blockIdx.x - n_obs, lds);
+  else found = ccd_self_pairs_body(D, blockIdx.x - n_obs, lds);
+  // The sequential replay of the acting pairs + gnorm (k_ccd_self_seq: one wave with ~1 us of work in the usual case of no acting
+  // pair, 4.6 us as a launch of its own) is finished inside this launch.  A first version -- every block takes a ticket, the
+  // last one finishes -- cost 35 us (2 720 returning atomics on one address, ~13 ns each), and with two-level tickets of the
+  // pair-selection blocks only the finisher's two atomic round trips + the replay's own loads still hung 3.5 us behind the
+  // kernel's natural end.  Now nobody waits for a ticket: a selection block adds 1 (+ 65 536 if it listed an acting pair) to one of sixteen
+  // counters, fire and forget, after its list entries have been performed (write-through stores); block 0 forms gnorm (which
+  // needs nothing of this launch) and then polls the sixteen counters -- one load per lane -- until every selection block is
+  // in.  Their sum also tells it whether any pair acts: none, almost always, and then it is done (k_begin has zeroed k_self).
+  if (!D.seq_fold) return;
+  const int lane = lane_id();
+  const int n_t = (int)gridDim.x - n_obs;   // selection blocks
+  if ((int)blockIdx.x >= n_obs) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) atomicAdd(&D.ctl->ccd_sub[((int)blockIdx.x - n_obs) & 15], 1 + (found ? 0x10000 : 0));
+  }
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  SeqMem M;
+  M.gns = lds;                                   // [U]
+  M.ks = (int*)(lds + D.U); M.seen = M.ks + D.U;  // [U], [U]
+  M.act0 = M.seen + D.U; M.act1 = M.act0 + SEQ_ACT_CAP; M.ord = M.act1 + SEQ_ACT_CAP;
+  M.keys = M.ord + SEQ_ACT_CAP; M.key_cap = D.seq_fold;   // Dev::seq_fold = the key capacity that fits the buffer (a power of two)
+  M.tbox = D.seq_gmem_d; M.tarea = M.tbox + 12 * (size_t)D.U; M.bx = M.tarea + 2 * (size_t)D.U;
+  M.ti = D.seq_gmem_i; M.stk = M.ti + 10 * (size_t)D.U;
+  M.lane0_stages = true;
+  {   // gnorm: the sequential sum in robot order (Optimization3D_multi.h:57,72,750)
+    for (int i = lane; i < D.U; i += 64) M.gns[i] = D.gn(i);
+    __syncthreads();
+    if (lane == 0) { double gsum = 0; for (int u = 0; u < D.U; u++) gsum += M.gns[u]; D.ctl->gnorm = gsum / double(D.U); }
+    __syncthreads();
+  }
+  int any_act = 0;
+  {
+    const long long t_end = wall_clock64() + 500000;   // 5 ms: a logic error must not hang the device
+    for (;;) {
+      int v = lane < 16 ? __hip_atomic_load(&D.ctl->ccd_sub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      v = __shfl(v, 0);
+      if ((v & 0xffff) == n_t) { any_act = v >> 16; break; }
+      if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (lane < 16) D.ctl->ccd_sub[lane] = 0;
+  }
+  if (any_act > 0) ccd_self_seq_body<true>(D, M, false);   // (reads the pairs' count and keys with agent-scope loads)
 }
 // Two builds of the same code.  The per-lane swept-hull GJK needs ~240 VGPRs, which leaves 2 waves per SIMD -- fewer slots
 // (2 048) than SCN-C has units (2 720), although almost none of them ever reaches the GJK there.  k_ccd_lean is compiled

@@ -193,6 +193,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       return true;
     case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_SEQ:
+      if ((in_graph || in_phase) && d.seq_fold && !(c->split_unions && multi)) return false;   // the last block of k_ccd has done it
       if (!multi && in_graph) return false;   // single UAV: no pairs to replay, and k_xsolve has left gnorm = |g| itself -- one launch less in the chain
       hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
     case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
@@ -476,6 +477,16 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   // GJK head start for last iteration's slow robot pairs (kernels_pairs.h: spec_pair_body); TJ_PAIR_HEAD_START=0 switches it off (test hook: same bits)
   d.spec = (d.mode >= 1 && !d.optimal_plane && !c->split_unions) ? 1 : 0;
   if (const char* e = getenv("TJ_PAIR_HEAD_START")) d.spec = d.spec && atoi(e) != 0;
+  // k_ccd's last block finishes with the sequential pair replay + gnorm (kernels_step.h): decoupled mode, when the replay's small
+  // arrays fit k_ccd's static LDS buffer with room for at least 256 acting-pair keys (the value is that capacity)
+  d.seq_fold = 0;
+  if (d.mode == TJ_MODE_MULTI_DECOUPLE && !c->split_unions) {
+    const size_t buf = sizeof(double) * (size_t)(CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES);
+    int cap = 4096;
+    while (cap >= 256 && seq_fold_lds_bytes(d.U, cap) > buf) cap >>= 1;
+    if (cap >= 256 && (size_t)d.S * pair_units(d.U, d.pair_rows) < 65536) d.seq_fold = cap;   // (the finisher counts the selection blocks in 16 bits)
+  }
+  if (const char* e = getenv("TJ_SEQ_FOLD")) if (atoi(e) == 0) d.seq_fold = 0;   // launch-shape switch (same bits)
   c->n_solve_env = 0;
   if (const char* e = getenv("TJ_N_SOLVE")) c->n_solve_env = std::max(1, atoi(e));
   d.spec_budget = SPEC_GJK_BUDGET; d.spec_min = SPEC_GJK_MIN;
@@ -520,7 +531,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) || (r = dalloc(c, &d.blk_stats, U * P + U)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
       (r = dalloc(c, &d.pairstamp, d.mode >= 1 ? S * U * U : 1)) ||
-      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.pair_ovf, 4)) || (r = dalloc(c, &d.spec_n, 2)) || (r = dalloc(c, &d.spec_list, 2 * SPEC_CAP)) || (r = dalloc(c, &d.spec_tag, SPEC_CAP)) || (r = dalloc(c, &d.spec_state, SPEC_CAP * SPEC_STATE_DOUBLES)) || (r = dalloc(c, &d.spec_sti, SPEC_CAP * SPEC_STATE_INTS)) || (r = dalloc(c, &d.pair_ovf_list, (size_t)d.cap_work + PAIR_CONSUMERS_MAX)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
+      (r = dalloc(c, &d.pair_work, 3 * (size_t)d.cap_work)) || (r = dalloc(c, &d.pair_work_n, (size_t)d.S + 1)) || (r = dalloc(c, &d.pair_ovf, 4)) || (r = dalloc(c, &d.seq_gmem_d, seq_fold_gmem_doubles(d.U))) || (r = dalloc(c, &d.seq_gmem_i, seq_fold_gmem_ints(d.U))) || (r = dalloc(c, &d.spec_n, 2)) || (r = dalloc(c, &d.spec_list, 2 * SPEC_CAP)) || (r = dalloc(c, &d.spec_tag, SPEC_CAP)) || (r = dalloc(c, &d.spec_state, SPEC_CAP * SPEC_STATE_DOUBLES)) || (r = dalloc(c, &d.spec_sti, SPEC_CAP * SPEC_STATE_INTS)) || (r = dalloc(c, &d.pair_ovf_list, (size_t)d.cap_work + PAIR_CONSUMERS_MAX)) || (r = dalloc(c, &d.ccd_found, 64)) || (r = dalloc(c, &d.ctl, 1)) ||
       (r = dalloc(c, &d.ocand, U * S * d.cap_obs)) || (r = dalloc(c, &d.ocand_n, U * S)) || (r = dalloc(c, &d.ohull, U * S * 18)) ||
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
