@@ -639,22 +639,26 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   __shared__ double lds[CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES];
   int found = 0;
-  if ((int)blockIdx.x < n_obs) ccd_obs_body<PRIM>(D, blockIdx.x, lds);
-  else found = ccd_self_pairs_body(D, blockIdx.x - n_obs, lds);
+  // with the replay folded in (below) the grid has one block more: block 0 is the finisher and has no other work
+  const int fin = D.seq_fold ? 1 : 0;
+  const int b = (int)blockIdx.x - fin;
+  if (b >= 0 && b < n_obs) ccd_obs_body<PRIM>(D, b, lds);
+  else if (b >= 0) found = ccd_self_pairs_body(D, b - n_obs, lds);
   // The sequential replay of the acting pairs + gnorm (k_ccd_self_seq: one wave with ~1 us of work in the usual case of no acting
   // pair, 4.6 us as a launch of its own) is finished inside this launch.  A first version -- every block takes a ticket, the
   // last one finishes -- cost 35 us (2 720 returning atomics on one address, ~13 ns each), and with two-level tickets of the
   // pair-selection blocks only the finisher's two atomic round trips + the replay's own loads still hung 3.5 us behind the
   // kernel's natural end.  Now nobody waits for a ticket: a selection block adds 1 (+ 65 536 if it listed an acting pair) to one of sixteen
-  // counters, fire and forget, after its list entries have been performed (write-through stores); block 0 forms gnorm (which
+  // counters, fire and forget, after its list entries have been performed (write-through stores); block 0 -- an extra block
+  // with no other work -- forms gnorm (which
   // needs nothing of this launch) and then polls the sixteen counters -- one load per lane -- until every selection block is
   // in.  Their sum also tells it whether any pair acts: none, almost always, and then it is done (k_begin has zeroed k_self).
   if (!D.seq_fold) return;
   const int lane = lane_id();
-  const int n_t = (int)gridDim.x - n_obs;   // selection blocks
-  if ((int)blockIdx.x >= n_obs) {
+  const int n_t = (int)gridDim.x - 1 - n_obs;   // selection blocks
+  if (b >= n_obs) {
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) atomicAdd(&D.ctl->ccd_sub[((int)blockIdx.x - n_obs) & 15], 1 + (found ? 0x10000 : 0));
+    if (lane == 0) atomicAdd(&D.ctl->ccd_sub[(b - n_obs) & 15], 1 + (found ? 0x10000 : 0));
   }
   if (blockIdx.x != 0) return;
   __syncthreads();

@@ -185,8 +185,11 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
         hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
-      if (c->ccd_lean) { if (tri) hipLaunchKernelGGL((k_ccd_lean<3>), dim3(n_ccd), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_lean<1>), dim3(n_ccd), dim3(64), 0, s, d); }
-      else { if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(n_ccd), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(n_ccd), dim3(64), 0, s, d); }
+      {
+        const int g = n_ccd + (d.seq_fold ? 1 : 0);   // + the finisher of the folded pair replay (kernels_step.h)
+        if (c->ccd_lean) { if (tri) hipLaunchKernelGGL((k_ccd_lean<3>), dim3(g), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_lean<1>), dim3(g), dim3(64), 0, s, d); }
+        else { if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(g), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(g), dim3(64), 0, s, d); }
+      }
       return true;
     case K_CCD_OBS: if (in_graph) return false;
       if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d);
