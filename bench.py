@@ -119,7 +119,7 @@ def survey_bytes(st, slv, iters):
     return b, total
 
 
-# What ONE wavefront pays on MI355X (tools/micro/issue_probe.hip, profiles/round3_v2_issue_probe.txt; 2.4 GHz), in ns:
+# What ONE wavefront pays on MI355X (tools/micro/issue_probe.hip, profiles/round3_v3_issue_probe.txt; 2.4 GHz), in ns:
 PRIM = {"fp64": 2.6,        # one fp64 VALU instruction, dependent OR independent: a wave issues one every ~6.3 cycles
         "readlane": 16.0,   # v_readlane pair -> first VALU use of the SGPR it wrote
         "rsq": 12.2, "sqrt": 46.6, "div": 39.0, "log": 162.0,   # v_rsq_f64 + fma; IEEE sqrt; IEEE division (11 fp64 ops + v_rcp); ocml log
@@ -152,7 +152,9 @@ def critical_path(slv, st, K, per_launch_ms, n_prims):
     xsolve = 2 * p["mem"] + p["lds"] + n * (p["rsq"] + 8 * p["fp64"] + p["readlane"] + 2 * p["fp64"]) + n * (p["readlane"] + 2 * p["fp64"]) + 3 * p["lds"] + p["mem"]
     evalx = p["lds"] + 7 * (p["lds"] + p["sqrt"] + p["div"] + 12 * p["fp64"]) + 2 * p["log"] + 3 * (p["lds"] + 6 * p["fp64"]) + p["log"] + 6 * p["lds"] + 2 * p["lds"] + 36 * p["fp64"]
     ls = 2 * p["mem"] + p["lds"] + rounds * evalx + (p["lds"] + 6 * p["fp64"]) + (p["mem"] + 6 * 5 * p["fp64"]) + 2 * p["mem"]   # stage, rounds, exact hulls, intervals, store + ticket
-    bound = {"k_front": walk + p["mem"], "k_mid": pair, "k_grad": grad, "k_xsolve": xsolve, "k_ccd": walk + p["mem"], "k_ccd_self_seq": 3 * p["mem"] + 200 * p["fp64"], "k_linesearch": ls}
+    folded = slv.mode >= 1 and per_launch_ms.get("k_ccd_self_seq", 0.0) <= 0   # the sequential pair replay + gnorm is the tail of k_ccd: + the counter's landing and one poll
+    bound = {"k_front": walk + p["mem"], "k_mid": pair, "k_grad": grad, "k_xsolve": xsolve, "k_ccd": walk + p["mem"] + (2 * p["mem"] if folded else 0.0),
+             "k_ccd_self_seq": 3 * p["mem"] + 200 * p["fp64"], "k_linesearch": ls}
     out, tb, tm = {}, 0.0, 0.0
     for k, b in bound.items():
         ms = per_launch_ms.get(k, 0.0)
