@@ -84,15 +84,24 @@ constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates 
 // a block stores the constant-rate wall clock at a phase boundary.  The product build has none.
 constexpr int TJ_TIC_BLOCKS = 65536, TJ_TIC_SLOTS = 8;   // blocks per kernel that leave stamps (timing builds only)
 #ifdef TJ_PHASE_TIMING
-#define TJ_TICB(D, kid, slot) do { if (threadIdx.x == 192 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)   /* first thread of k_grad's second wave group */
+#define TJ_STAMP_(D, kid, slot, thr) do { if (threadIdx.x == (thr) && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
 #define TJ_ORDER(v) asm volatile("" :: "v"(v))   /* the value is computed before the next stamp is taken */
-#ifdef TJ_PHASE_LIGHT   /* a stamp costs the wave ~0.3 us (s_memrealtime + wait): the light build keeps only the block start / end stamps of the union kernels */
-#define TJ_TIC(D, kid, slot) do { if (((kid) == K_MID || (kid) == K_FRONT) && threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
+#ifdef TJ_PHASE_LIGHT
+/* A stamp costs its wave ~0.3 us (s_memrealtime + wait): three per GJK iteration made a slow pair look 60 % slower than it is.
+   The light build (`make timing_light`) keeps what cannot distort a chain: the union kernels' block start / end, and for the block
+   kernels the entry (TJ_TIC_ENTRY: first instruction, slot 7), the first phase stamp and the last one. */
+#define TJ_LIGHT_KEEP(kid, slot) ((kid) == K_MID || (kid) == K_FRONT || (kid) == K_CCD || ((kid) == K_GRAD && ((slot) == 0 || (slot) == 6)) || ((kid) == K_XSOLVE && ((slot) == 0 || (slot) == 6)) || ((kid) == K_LINESEARCH && ((slot) == 0 || (slot) == 5 || (slot) == 6)))
+#define TJ_TIC(D, kid, slot) do { if (TJ_LIGHT_KEEP(kid, slot)) TJ_STAMP_(D, kid, slot, 0); } while (0)
+#define TJ_TIC_ENTRY(D, kid) TJ_STAMP_(D, kid, 7, 0)
+#define TJ_TICB(D, kid, slot) do {} while (0)
 #else
-#define TJ_TIC(D, kid, slot) do { if (threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) (D).dbg[((size_t)(kid) * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (slot)] = wall_clock64(); } while (0)
+#define TJ_TIC(D, kid, slot) TJ_STAMP_(D, kid, slot, 0)
+#define TJ_TIC_ENTRY(D, kid) do {} while (0)
+#define TJ_TICB(D, kid, slot) TJ_STAMP_(D, kid, slot, 192)   /* first thread of k_grad's second wave group */
 #endif
 #else
 #define TJ_TIC(D, kid, slot) do {} while (0)
+#define TJ_TIC_ENTRY(D, kid) do {} while (0)
 #define TJ_TICB(D, kid, slot) do {} while (0)
 #define TJ_ORDER(v) do {} while (0)
 #endif

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     if (begin_next && blockIdx.x == 0 && threadIdx.x == 0) { D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0; }
     return;
   }
+  TJ_TIC_ENTRY(D, K_LINESEARCH);
   extern __shared__ double sm[];
   __shared__ int pref[1024];   // plane prefix per segment (S <= 511 checked on the host); [512 + tr]: obstacle planes of segment tr
   __shared__ int s_accept;
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
       begin_body(D);
     }
   }
+  TJ_TIC(D, K_LINESEARCH, 6);
 }
 
 // Energy_admm::spline_energy (Energy_admm.h:16-44) of the CURRENT state against the plane lists of the last iteration: what the

@@ -226,6 +226,7 @@ __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, do
 template <bool FOLD>
 __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
   if (TJ_DONE(D)) return;
+  TJ_TIC_ENTRY(D, K_GRAD);
   if constexpr (FOLD) {
     const int u_ = D.u0 + blockIdx.x / D.P, sp_ = blockIdx.x % D.P;
     for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64) compact_segment(D, u_, sp_ * D.res + i, threadIdx.x & 63);
@@ -580,6 +581,7 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
 template <int NREG>
 __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   if (TJ_DONE(D)) return;
+  TJ_TIC_ENTRY(D, K_XSOLVE);
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
   const int u = D.u0 + blockIdx.x;
@@ -753,6 +755,9 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
       o[48 + k] = lo; o[97 + k] = up;
     }
   }
+#ifdef TJ_PHASE_LIGHT
+  __builtin_amdgcn_s_waitcnt(0);   // the stamp after the block's stores have been acknowledged
+#endif
   TJ_TIC(D, K_XSOLVE, 6);
 }
 

@@ -639,11 +639,13 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   __shared__ double lds[CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES];
   int found = 0;
+  TJ_TIC(D, K_CCD, 0);
   // with the replay folded in (below) the grid has one block more: block 0 is the finisher and has no other work
   const int fin = D.seq_fold ? 1 : 0;
   const int b = (int)blockIdx.x - fin;
   if (b >= 0 && b < n_obs) ccd_obs_body<PRIM>(D, b, lds);
   else if (b >= 0) found = ccd_self_pairs_body(D, b - n_obs, lds);
+  TJ_TIC(D, K_CCD, 1);
   // The sequential replay of the acting pairs + gnorm (k_ccd_self_seq: one wave with ~1 us of work in the usual case of no acting
   // pair, 4.6 us as a launch of its own) is finished inside this launch.  A first version -- every block takes a ticket, the
   // last one finishes -- cost 35 us (2 720 returning atomics on one address, ~13 ns each), and with two-level tickets of the
@@ -690,6 +692,7 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
     if (lane < 16) D.ctl->ccd_sub[lane] = 0;
   }
   if (any_act > 0) ccd_self_seq_body<true>(D, M, false);   // (reads the pairs' count and keys with agent-scope loads)
+  TJ_TIC(D, K_CCD, 2);
 }
 // Two builds of the same code.  The per-lane swept-hull GJK needs ~240 VGPRs, which leaves 2 waves per SIMD -- fewer slots
 // (2 048) than SCN-C has units (2 720), although almost none of them ever reaches the GJK there.  k_ccd_lean is compiled
