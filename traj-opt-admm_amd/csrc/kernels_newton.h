@@ -380,6 +380,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     }
   }
   if (tid < 128) {
+    __builtin_amdgcn_s_setprio(3);   // the check and the eigenvalue set the block's length: ahead of the other block's waves on the CU
     double r[19];
     const int row = min(tid & 63, 18);
 #pragma unroll
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   const bool pre = tail && S * 49 <= XS_HELP * XS_KPT && (size_t)S * 54 <= 2 * (size_t)n * n + 8 * (size_t)n && S * 18 <= D.P * 361;   // uniform
   double klo[XS_KPT], kup[XS_KPT];
   const int ht = tid - XS_THREADS;
-  if (tid < XS_THREADS) xs_wave0<NREG>(D, u, tid, n, m, H, L, g0, x0, scr);
+  if (tid < XS_THREADS) { __builtin_amdgcn_s_setprio(3); xs_wave0<NREG>(D, u, tid, n, m, H, L, g0, x0, scr); __builtin_amdgcn_s_setprio(0); }   // the factorisation: ahead of the helper wave on its SIMD
   else if (pre) {
     int target = 0;
     for (int idx = ht; idx < 3 * T; idx += XS_HELP) netl[idx] = gnet[idx];

@@ -209,6 +209,7 @@ constexpr int SPEC_CAP = 128, SPEC_GJK_MIN = 5, SPEC_GJK_WINDOW = 10, SPEC_GJK_B
 constexpr int SPEC_STATE_DOUBLES = 20, SPEC_STATE_INTS = 16;
 __device__ __forceinline__ unsigned pair_key(int tr, int p0, int q) { return (unsigned)(tr | (p0 << 9) | (q << 20)); }   // 9 + 11 + 11 bits
 __device__ __forceinline__ void spec_pair_body(const Dev& D, int b) {
+  __builtin_amdgcn_s_setprio(3);   // the longest blocks of the launch, on SIMDs they share with four or five query waves
   const int lane = lane_id();
   const int epoch = D.ctl->epoch, par = epoch & 1;
   if (b == 0 && lane == 0) D.spec_n[par] = 0;   // the list this iteration's k_mid fills
@@ -413,6 +414,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     }
   };
   if (dedicated) {
+    __builtin_amdgcn_s_setprio(3);   // k_mid's tail: ahead of whatever shares the SIMD
     TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
     const unsigned long long tg = bid < 64 ? __shfl(spec_tag0, bid) : __shfl(spec_tag1, bid - 64);
     const unsigned key = (unsigned)tg;
