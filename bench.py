@@ -432,7 +432,7 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['tris'].shape[0] if scene.get('tris') is not None else scene['cloud'].shape[0]} obstacle {'triangles (fp64 narrow phase, fp32 outward-rounded BVH boxes)' if scene.get('tris') is not None else 'points'}, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
-                          "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {5 if args.coupled else 2} RCCL all-gathers/iter on the library's exchange buffers; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else (6 if scene['mode'] == 0 else 7)} kernels on one queue (union kernels), enqueued ahead, no host sync",
+                          "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {5 if args.coupled else 2} RCCL all-gathers/iter on the library's exchange buffers; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else 6} kernels on one queue (union kernels), enqueued ahead, no host sync",
                           "iters_timed_from": "initial trajectory"}}
     if world == 1:
         # per-kernel device time with hipEvents on the solver's stream, same K iterations
