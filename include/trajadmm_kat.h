@@ -16,6 +16,9 @@ extern "C" {
 int tj_kat_gjk(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
 /* the same query solved cooperatively by a whole wavefront (the form the inter-robot kernels use): must give the same bits */
 int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, double* v);
+/* the same query interrupted after k_stop iterations, its loop state taken through memory and the loop continued (what the GJK head start of the
+ * robot-pair stage does across two kernels): v_iters[4 n] = witness vector, iterations of the whole query */
+int tj_kat_gjk_wave_split(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, int k_stop, double* v_iters);
 /* what: 0 Separate::opengjk (Separate.h:18) P[n][6][3], Q = points [n][3] -> out[n][5] = ok,cx,cy,cz,d
  *       1 Separate::selfgjk + Optimal_plane::optimal_d (Separate.h:165, Optimal_plane.h:13), Q[n][6][3] -> ok,c,d
  *       2 CCD::KDOPDCD (CCD.h:354), 3 CCD::SelfKDOPDCD (CCD.h:535) -> out[n][5], out[.][0] = pass

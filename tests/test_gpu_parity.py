@@ -75,6 +75,22 @@ def test_device_gjk_wave_cooperative_bit_exact(katsolver, shape):
     assert same.all(), f"{(~same).any(axis=1).sum()} of {len(v)} witness vectors differ"
 
 
+@pytest.mark.parametrize("shape", ["6v6", "12v12"])
+@pytest.mark.parametrize("k_stop", [1, 2, 3, 5, 9])
+def test_device_gjk_wave_resumed_from_a_saved_state_bit_exact(katsolver, shape, k_stop):
+    """The GJK head start of the robot-pair stage runs the first iterations of a query in one kernel and the rest in the next
+    (kernels_pairs.h: spec_pair_body, gjk_wave_run): the query interrupted after k_stop iterations, its loop state taken through
+    memory, and continued must give the reference's witness vector bit for bit -- wherever it is cut -- and some queries of
+    the fixture must really be cut there."""
+    g = gold("gjk_kat.npz")
+    v, its = katsolver.kat_gjk_wave_split(g[f"gjk_{shape}_a"], g[f"gjk_{shape}_b"], k_stop)
+    want = g[f"gjk_{shape}_v"]
+    same = (v == want) | (np.isnan(v) & np.isnan(want))
+    assert same.all(), f"{(~same).any(axis=1).sum()} of {len(v)} witness vectors differ when the query is cut after {k_stop} iterations"
+    if k_stop <= 3:
+        assert (its > k_stop).sum() > 20, f"only {(its > k_stop).sum()} queries of the fixture run past {k_stop} iterations"
+
+
 def test_device_pair_plane_wave_equals_lane_version(katsolver):
     g = gold("prims_kat.npz")
     a = katsolver.kat_planes(1, g["P"], g["Q"], 0.3)

@@ -54,7 +54,7 @@ class TrajAdmmError(RuntimeError):
 
 
 # the known-answer hooks (include/trajadmm_kat.h) live in a TEST build of the same translation unit, never in the product library
-KAT_EXPORTS = ["tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg"]
+KAT_EXPORTS = ["tj_kat_gjk", "tj_kat_gjk_wave", "tj_kat_gjk_wave_split", "tj_kat_planes", "tj_kat_ccd", "tj_kat_tri", "tj_kat_query", "tj_kat_linalg"]
 KAT_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtrajadmm_kat.so")
 _lib = None
 _kat_lib = None
@@ -314,6 +314,13 @@ class Solver:
         n = a.shape[0]; v = np.zeros((n, 3))
         self._check(self.lib.tj_kat_gjk_wave(self._ctx, C.c_int(n), C.c_int(a.shape[1]), _d(a), C.c_int(b.shape[1]), _d(b), _d(v)))
         return v
+
+    def kat_gjk_wave_split(self, a, b, k_stop):
+        """gjk_wave interrupted after k_stop iterations and continued from the state it left in memory: (witness vectors, iterations)"""
+        a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        n = a.shape[0]; out = np.zeros((n, 4))
+        self._check(self.lib.tj_kat_gjk_wave_split(self._ctx, C.c_int(n), C.c_int(a.shape[1]), _d(a), C.c_int(b.shape[1]), _d(b), C.c_int(k_stop), _d(out)))
+        return out[:, :3], out[:, 3].astype(int)
 
     def kat_planes(self, what, P, Q, dist):
         P = np.ascontiguousarray(P, dtype=np.float64); Q = np.ascontiguousarray(Q, dtype=np.float64)

@@ -34,6 +34,40 @@ __global__ __launch_bounds__(64) void k_dbg_gjk_wave(int n, const double* a, con
   const V3 v = gjk_wave(BodyPts<K1>{a + (size_t)i * 3 * K1}, BodyPts<K2>{b + (size_t)i * 3 * K2}, lane_id());
   if (threadIdx.x == 0) { out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z; }
 }
+// gjk_wave interrupted after k_stop iterations, its state taken through memory (20 doubles + 8 ints per case in `scratch`, the
+// layout of the head start: kernels_pairs.h spec_pair_body) and the loop continued from there: out = witness vector, iterations
+template <int K1, int K2>
+__global__ __launch_bounds__(64) void k_dbg_gjk_wave_split(int n, const double* a, const double* b, int k_stop, double* scratch, double* out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const int lane = lane_id();
+  const BodyPts<K1> ba{a + (size_t)i * 3 * K1}; const BodyPts<K2> bb{b + (size_t)i * 3 * K2};
+  GjkState st; bool fin;
+  V3 v = gjk_wave_run(ba, bb, lane, st, true, k_stop, fin);
+  double* o = scratch + (size_t)i * 32;
+  if (lane == 0) {
+    o[0] = st.v.x; o[1] = st.v.y; o[2] = st.v.z;
+    o[3] = st.s.v0.x; o[4] = st.s.v0.y; o[5] = st.s.v0.z; o[6] = st.s.v1.x; o[7] = st.s.v1.y; o[8] = st.s.v1.z;
+    o[9] = st.s.v2.x; o[10] = st.s.v2.y; o[11] = st.s.v2.z; o[12] = st.s.v3.x; o[13] = st.s.v3.y; o[14] = st.s.v3.z;
+    o[15] = st.s.l0; o[16] = st.s.l1; o[17] = st.s.l2; o[18] = st.s.l3; o[19] = st.wmax2;
+    int* oi = (int*)(o + 20);
+    oi[0] = st.s.n; oi[1] = st.s.w0; oi[2] = st.s.w1; oi[3] = st.s.w2; oi[4] = st.s.w3; oi[5] = st.c1; oi[6] = st.c2; oi[7] = st.k;
+  }
+  __threadfence();
+  __syncthreads();
+  if (!fin) {
+    GjkState r;
+    const int* oi = (const int*)(o + 20);
+    r.v = V3{o[0], o[1], o[2]};
+    r.s.v0 = V3{o[3], o[4], o[5]}; r.s.v1 = V3{o[6], o[7], o[8]}; r.s.v2 = V3{o[9], o[10], o[11]}; r.s.v3 = V3{o[12], o[13], o[14]};
+    r.s.l0 = o[15]; r.s.l1 = o[16]; r.s.l2 = o[17]; r.s.l3 = o[18]; r.wmax2 = o[19];
+    r.s.n = oi[0]; r.s.w0 = oi[1]; r.s.w1 = oi[2]; r.s.w2 = oi[3]; r.s.w3 = oi[4]; r.c1 = oi[5]; r.c2 = oi[6]; r.k = oi[7];
+    bool fin2;
+    v = gjk_wave_run(ba, bb, lane, r, false, 50, fin2);
+    st.k = r.k;
+  }
+  if (threadIdx.x == 0) { out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = (double)st.k; }
+}
 // plane_pair_wave: one robot pair per wavefront (the form k_sep_self_solve uses)
 __global__ __launch_bounds__(64) void k_dbg_pair_wave(Dev D, int n, const double* P, const double* Q, double dist, double* out) {
   const int i = blockIdx.x;

@@ -1069,6 +1069,21 @@ int tj_kat_gjk_wave(tj_ctx* c, int n, int n1, const double* a, int n2, const dou
   return TJ_OK;
 }
 
+int tj_kat_gjk_wave_split(tj_ctx* c, int n, int n1, const double* a, int n2, const double* b, int k_stop, double* v_iters) {
+  if (!c || n < 0 || !a || !b || !v_iters || k_stop < 1) return TJ_ERR_INVALID;
+  DevBuf da, db, ds, dv; int r;
+  if ((r = to_dev(c, da, a, (size_t)n * n1 * 24)) || (r = to_dev(c, db, b, (size_t)n * n2 * 24)) || (r = to_dev(c, ds, nullptr, (size_t)n * 256)) || (r = to_dev(c, dv, nullptr, (size_t)n * 32))) return r;
+  dim3 g(std::max(n, 1)), t(64);
+  const double *A = (const double*)da.p, *B = (const double*)db.p; double* S = (double*)ds.p; double* V = (double*)dv.p;
+  if (n1 == 6 && n2 == 6) hipLaunchKernelGGL((k_dbg_gjk_wave_split<6, 6>), g, t, 0, c->stream, n, A, B, k_stop, S, V);
+  else if (n1 == 12 && n2 == 12) hipLaunchKernelGGL((k_dbg_gjk_wave_split<12, 12>), g, t, 0, c->stream, n, A, B, k_stop, S, V);
+  else { c->err = "tj_kat_gjk_wave_split: body sizes must be 6v6 or 12v12"; return TJ_ERR_INVALID; }
+  HIPCHK(c, hipGetLastError());
+  QUIESCE(c);
+  HIPCHK(c, hipMemcpy(v_iters, dv.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  return TJ_OK;
+}
+
 int tj_kat_planes(tj_ctx* c, int what, int n, const double* P, const double* Q, double dist, double* out) {
   if (!c || n < 0 || what < 0 || what > 7 || !P || !Q || !out) return TJ_ERR_INVALID;
   const size_t qbytes = (what == 0 || what == 2 || what == 5) ? (size_t)n * 24 : (size_t)n * 144;  // what 1, 3, 4, 6: hull vs hull
