@@ -513,6 +513,10 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
     const int q = 64 * c + lane;
     pst[c] = (pair_part && q < U) ? D.pairstamp[((size_t)tr * U + u) * U + q] : 0;
   }
+  // The planes of the first 64 partner slots travel WITH the stamps (stamped or not: 2 KB per segment), and a candidate's plane
+  // with its stamp: two dependent round trips instead of three at the head of every k_grad block.
+  double pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0;
+  if (pair_part && lane < U) { const double* p = D.pairplane + 4 * (((size_t)tr * U + u) * U + lane); pp0 = p[0]; pp1 = p[1]; pp2 = p[2]; pp3 = p[3]; }
   double* outp = D.splanes + seg * D.cap_self * 4;
   int pbase = 0;
   if (pair_part) {
@@ -524,7 +528,10 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
       const unsigned long long mask = ballot(ok);
       const int idx = pbase + prefix_count(mask);
       if (ok) {
-        if (idx < D.cap_self) { const double* p = D.pairplane + 4 * slot; outp[4 * idx] = p[0]; outp[4 * idx + 1] = p[1]; outp[4 * idx + 2] = p[2]; outp[4 * idx + 3] = p[3]; }
+        if (idx < D.cap_self) {
+          if (q0 == 0) { outp[4 * idx] = pp0; outp[4 * idx + 1] = pp1; outp[4 * idx + 2] = pp2; outp[4 * idx + 3] = pp3; }
+          else { const double* p = D.pairplane + 4 * slot; outp[4 * idx] = p[0]; outp[4 * idx + 1] = p[1]; outp[4 * idx + 2] = p[2]; outp[4 * idx + 3] = p[3]; }
+        }
         else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
       }
       pbase += __popcll(mask);
@@ -534,11 +541,14 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
     double* out = D.oplanes + seg * D.cap_obs * 4;
     int base = 0;
     for (int s0 = 0; s0 < n; s0 += 64) {
-      const int sl = s0 + lane;
-      const bool ok = sl < n && D.ostamp[seg * D.cap_obs + min(sl, n - 1)] == epoch;
+      const int sl = s0 + lane, slc = min(sl, n - 1);
+      const int stamp = D.ostamp[seg * D.cap_obs + slc];
+      const double* p = D.oraw + (seg * D.cap_obs + slc) * 4;
+      const double o0 = p[0], o1 = p[1], o2 = p[2], o3 = p[3];   // (issued with the stamp; the 64 candidate slots fetched with the first trip, whatever the count, measured slower)
+      const bool ok = sl < n && stamp == epoch;
       const unsigned long long mask = ballot(ok);
       const int idx = base + prefix_count(mask);
-      if (ok) { const double* p = D.oraw + (seg * D.cap_obs + sl) * 4; out[4 * idx] = p[0]; out[4 * idx + 1] = p[1]; out[4 * idx + 2] = p[2]; out[4 * idx + 3] = p[3]; }
+      if (ok) { out[4 * idx] = o0; out[4 * idx + 1] = o1; out[4 * idx + 2] = o2; out[4 * idx + 3] = o3; }
       base += __popcll(mask);
     }
     if (lane == 0) { D.ocount[seg] = base; atomicAdd(&D.seg_stats[seg * 6 + 4], (unsigned long long)base); }   // fire-and-forget
