@@ -51,8 +51,20 @@ template <> struct PrimOf<3> {
 // (or -1) and may use wave collectives.  Returns candidates found; adds visited boxes to *visits.
 // BQ_UNROLL: chunks of 8 frontier nodes whose box loads are in flight together (4 in the plane query, whose kernel has
 // registers to spare; 1 in the CCD query, where the per-lane GJK already fills the register file)
+// The top level's boxes do not depend on the query: a caller can fetch its lane's box (bvh_top_box) TOGETHER with the record that
+// holds the query box and hand it in -- one dependent round trip less at the head of the walk.
+struct TopBox { float b[6]; };
+__device__ __forceinline__ TopBox bvh_top_box(const Dev& D) {
+  TopBox t{{0, 0, 0, 0, 0, 0}};
+  if (D.N == 0) return t;
+  const int top = D.nlevels - 1, lane = lane_id();
+  const float* p = D.boxes + (size_t)(D.lvl_off[top] + min(lane, D.lvl_n[top] - 1)) * 6;
+#pragma unroll
+  for (int k = 0; k < 6; k++) t.b[k] = p[k];
+  return t;
+}
 template <int BQ_UNROLL, int PRIM, class F>
-__device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb, int* cand, unsigned long long* visits, F&& process) {
+__device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb, int* cand, unsigned long long* visits, F&& process, const TopBox* pre = nullptr) {
   const int lane = lane_id();
   if (D.N == 0) return 0;
   int top = D.nlevels - 1;
@@ -61,7 +73,7 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
   {
     const int n = D.lvl_n[top];
     bool hit = false;
-    if (lane < n) hit = box_hit(D.boxes + (size_t)(D.lvl_off[top] + lane) * 6, q, m);
+    if (lane < n) hit = pre ? box_hit(pre->b, q, m) : box_hit(D.boxes + (size_t)(D.lvl_off[top] + lane) * 6, q, m);
     const unsigned long long mask = ballot(hit);
     if (hit) fa[prefix_count(mask)] = lane;
     count = __popcll(mask);
@@ -437,6 +449,7 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
   const double* net = D.spline + (size_t)u * 3 * D.T;
   TJ_TIC(D, K_SEP_OBS, 0);
   QBox q;
+  const TopBox topb = bvh_top_box(D);   // travels with the segment's record
   if (use_cache && D.multi()) {
     const double* h = D.hullinfo + ((size_t)u * D.S + tr) * HULL_INFO_STRIDE;
     if (lane < 18) P[lane] = h[lane];
@@ -476,7 +489,7 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
       else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
     }
     base += __popcll(mask);
-  });
+  }, &topb);
   TJ_TIC(D, K_SEP_OBS, 4);
   const int cnt = min(base, D.cap_obs);
   if (cnt > 0 && lane < 18) D.ohull[seg * 18 + lane] = P[lane];   // read by the solve waves of this segment's candidates only

@@ -84,6 +84,7 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
   bool kax_ready = false;
   V3 axv{0, 0, 0}; double lo_ax = 0, hi_ax = 0;
   const double* src = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
+  const TopBox topb = bvh_top_box(D);   // travels with the segment's record
   for (int i = lane; i < CCD_STRIDE; i += 64) info[i] = src[i];
   __syncthreads();
   QBox q;
@@ -112,7 +113,7 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
         if (k > kmax) { kmax = k; atomicMax(&D.k_obs[u], k); }
       }
     }
-  });
+  }, &topb);
   if (lane == 0) {   // fire-and-forget atomics: a read-modify-write would keep the wave alive for another memory round trip
     unsigned long long* st = D.seg_stats + ((size_t)u * D.S + tr) * 6;
     atomicAdd(&st[2], visits); atomicAdd(&st[3], (unsigned long long)found);
