@@ -70,8 +70,22 @@ def scene_by_name(scenes, name):
         return sc
     if name == "hard_single":   # one UAV (admmPathPlanning3D mode, ks = 1e-8) through a cloud 0.13 from its path: obstacle planes active from iteration 0
         return dict(scenes.hard(U=1, n_points=2500, seed=12), mode=0, ks=1e-8, name="hard-single")
+    if name == "stack030":      # SCN-C's fleet stacked at EXACTLY the barrier's range over a small cloud (tests/golden/make_golden.py:stack030)
+        return dict(scenes.crossing(64, 4000, seed=777, dz=0.30), name="stack030")
     return {"tiny_multi": lambda: scenes.tiny(1), "tiny_single": lambda: scenes.tiny(0, n_points=3000), "hard": scenes.hard,
             "scn_a": scenes.scn_a, "scn_b": scenes.scn_b, "scn_c": scenes.scn_c, "scn_c3": scenes.scn_c3}[name]()
+
+
+def backoff_exponent(step):
+    """number of factors of 0.8 in a step the reference formed by repeated `step *= 0.8` from 1.0 (exact inverse of that loop)"""
+    out = np.zeros(np.shape(step), dtype=np.int64)
+    for i, s in enumerate(np.ravel(step)):
+        x, k = 1.0, 0
+        while x != s and k < 4000:
+            x *= 0.8; k += 1
+        assert x == s, f"{s!r} is not 0.8^k by repeated multiplication"
+        out.flat[i] = k
+    return out
 
 
 def check_scene_matches_fixture(scene, g):

@@ -152,6 +152,39 @@ def make_stages(name, scene, iters, keep, with_canon=True):
     np.savez_compressed(os.path.join(HERE, f"stages_{name}.npz"), **rec)
 
 
+def stack030():
+    """SCN-C's fleet stacked at EXACTLY the barrier's range (0.30 = offset + 2 margin) over a small cloud: in iteration 0 most robots carry
+    an x-energy of ~1e-45 (barrier terms a rounding error inside their range) or exactly 0 and a direction of ~1e-29 or 0, while the global
+    `wolfe` is the last robot's 1.1e-3 -- the reference's Armijo loop (Optimization3D_multi.h:792) then only ends by rounding, after 519 ... 559
+    back-offs, or when 1e-4*wolfe*step underflows to zero: 3 268 back-offs, step 2e-317."""
+    sc = pkg_scenes.crossing(64, 4000, seed=777, dz=0.30)
+    sc["name"] = "stack030"
+    return sc
+
+
+def make_backoff():
+    """The reference's long loops followed to their own end: (1) stack030, four whole iterations with every stage's outputs;
+    (2) CCD back-off counts beyond 200 (Step.h:89, :229): the directions of a hard scene's iteration scaled by 1e6 ... 1e21, so that the
+    clamps need hundreds of factors of 0.8 -- steps of Step::position_step / self_step as the reference returns them."""
+    make_stages("stack030", stack030(), 4, {0, 1, 2, 3}, with_canon=False)
+    scene = pkg_scenes.hard()
+    e = Engine("ref", scene)
+    for _ in range(3): e.iterate()
+    rec = {}
+    for n_, v in e.get_state().items(): rec["pre_" + n_] = v
+    e.stage_planes()
+    d = e.stage_direction()
+    rec["direction"] = d["direction"]; rec["t_direction"] = d["t_direction"]; rec["wolfe"] = d["wolfe"]; rec["gn"] = d["gn"]
+    scales = np.array([1.0, 1e6, 1e12, 1e18, 1e21])
+    ss, sp = [], []
+    for sc in scales:
+        for u in range(scene["U"]): e.set_direction(u, d["direction"][u] * sc, float(d["t_direction"][u]), float(d["wolfe"][u]), float(d["gn"][u]))
+        a, b = e.stage_steps()
+        ss.append(a.copy()); sp.append(b.copy())
+    rec["scales"] = scales; rec["step_self"] = np.array(ss); rec["step_pos"] = np.array(sp)
+    np.savez_compressed(os.path.join(HERE, "backoff_kat.npz"), **rec)
+
+
 def coupled(scene):
     """the same scene run with "decouple":0 (Optimization3D_multi::optimization, one shared piece_time)"""
     sc = dict(scene); sc["mode"] = 2; sc["name"] = scene["name"] + "-coupled"
@@ -557,6 +590,9 @@ if __name__ == "__main__":
     if "--optplane-only" in sys.argv:
         make_optplane()
         sys.exit(0)
+    if "--backoff-only" in sys.argv:
+        make_backoff()
+        sys.exit(0)
     make_tables()
     make_prims()
     make_stages("tiny_multi", pkg_scenes.tiny(1), 8, {0, 1, 4, 7})
@@ -573,4 +609,5 @@ if __name__ == "__main__":
     make_tri_prims()
     make_bvh_kat()
     make_single_solve()
+    make_backoff()
     print("golden vectors written to", HERE)

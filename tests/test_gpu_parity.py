@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import observe_iteration, TOL_STATE_FULL, TOL_GNORM_FULL, canon, check_scene_matches_fixture, gold, maxdiff, rel, scene_by_name
+from conftest import backoff_exponent, observe_iteration, TOL_STATE_FULL, TOL_GNORM_FULL, canon, check_scene_matches_fixture, gold, maxdiff, rel, scene_by_name
 
 pytestmark = pytest.mark.gpu
 STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
@@ -181,6 +181,65 @@ def test_stages_teacher_forced_vs_reference(pkg, scenes, name):
     # Two register eigenvalue routines that are EQUALLY accurate (tests/devtools/eig_err.py: both within 6.2e-16 |H| of Eigen's
     # value on 572 matrices) leave 1.6e-11 and 2.0e-10 here, so the bar is 5x the larger one; the other scenes stay at 1e-11.
     _teacher_forced(pkg, scene, g, tol_dir=1e-9 if name == "hard" else 1e-11)
+
+
+def test_long_armijo_loops_end_where_the_references_do(pkg, scenes):
+    """A fleet stacked at exactly the barrier's range (tests/golden/make_golden.py:stack030): in iteration 0 the reference's Armijo loop
+    (Optimization3D_multi.h:792) ends by rounding only -- 519 ... 559 back-offs where a robot's energy is ~1e-45, 3 268 (step 2e-317, where
+    1e-4*wolfe*step underflows) where it is exactly 0.  The device follows it to the same step, bit for bit (round 3 stopped at 0.8^200
+    with TJ_ERR_NO_PROGRESS): teacher-forced from the reference's planes and direction, and free-running through the six-kernel chain."""
+    g = gold("stages_stack030.npz")
+    scene = scene_by_name(scenes, "stack030")
+    check_scene_matches_fixture(scene, g)
+    s = pkg.Solver(scene, stop=0.0)
+    for it in g["kept"]:
+        k = f"it{it}_"
+        s.set_state({n: g[k + "pre_" + n] for n in STATE})
+        counts, planes = s.stage_planes()
+        assert np.array_equal(counts, g[k + "counts"])
+        assert np.array_equal(canon(counts, planes), canon(g[k + "counts"], g[k + "planes_raw"]))
+        s.set_planes(g[k + "counts"], g[k + "planes_raw"])
+        d = s.stage_direction()
+        assert maxdiff(d["direction"], g[k + "direction"]) <= 1e-11
+        for u in range(scene["U"]):
+            s.set_direction(u, g[k + "direction"][u], float(g[k + "t_direction"][u]), float(g[k + "wolfe"][u]), float(g[k + "gn"][u]))
+        s_self, s_pos = s.stage_steps()
+        assert np.array_equal(s_self, g[k + "step_self"]) and np.array_equal(s_pos, g[k + "step_pos"])
+        arm = s.stage_linesearch()
+        assert np.array_equal(arm, g[k + "step_armijo"]), (it, backoff_exponent(arm), backoff_exponent(g[k + "step_armijo"]))
+    assert s.stats()["error_bits"] == 0
+    s.close()
+    # free-running, production path: four iterations of the chain from the initial trajectory
+    s = pkg.Solver(scene, stop=0.0)
+    for it in range(4):
+        s.iterate(1)
+        arm = s.last_armijo_steps()
+        if it == 0:   # the initial state is the fixture's: same loop lengths (519 ... 3 268 factors), same steps, bit for bit
+            assert np.array_equal(arm, g["it0_step_armijo"]), (backoff_exponent(arm), backoff_exponent(g["it0_step_armijo"]))
+        else:         # later iterations start from the t > 0 guard -0.95 t / t_dir: same number of factors (one more or less is 20 %)
+            assert np.allclose(arm, g[f"it{it}_step_armijo"], rtol=1e-10, atol=0), it
+        st = s.get_state()
+        for n in STATE:
+            assert maxdiff(st[n], g[f"it{it}_post_" + n]) <= 1e-9 * max(1.0, np.abs(g[f"it{it}_post_" + n]).max()), (it, n)
+    assert s.stats()["error_bits"] == 0
+    s.close()
+
+
+def test_ccd_backoffs_follow_the_reference(pkg, scenes):
+    """Step::position_step / self_step (Step.h:89, :229) on directions scaled by up to 1e21: up to 177 factors of 0.8 per robot, and --
+    beyond the scale at which GJK on the swept hull loses the 0.1 offset -- clamps that stop acting, exactly like the reference's"""
+    g = gold("backoff_kat.npz")
+    scene = scenes.hard()
+    s = pkg.Solver(scene, stop=0.0)
+    s.set_state({n: g["pre_" + n] for n in STATE})
+    s.stage_planes(); s.stage_direction()
+    for i, sc in enumerate(g["scales"]):
+        for u in range(scene["U"]):
+            s.set_direction(u, g["direction"][u] * sc, float(g["t_direction"][u]), float(g["wolfe"][u]), float(g["gn"][u]))
+        a, b = s.stage_steps()
+        assert np.array_equal(a, g["step_self"][i]) and np.array_equal(b, g["step_pos"][i]), (sc, backoff_exponent(a), backoff_exponent(b))
+    assert s.stats()["error_bits"] == 0
+    s.close()
 
 
 @pytest.mark.parametrize("name", ["hard", "scn_b"])

@@ -4,7 +4,7 @@ unmodified reference (tests/golden/make_golden.py).  This is what pins the oracl
 import numpy as np
 import pytest
 
-from conftest import canon, check_scene_matches_fixture, gold, maxdiff, rel, scene_by_name
+from conftest import backoff_exponent, canon, check_scene_matches_fixture, gold, maxdiff, rel, scene_by_name
 from oracle.pyoracle import Engine, Prims
 
 
@@ -106,6 +106,45 @@ def test_stages_teacher_forced(scenes, name):
         st = e.get_state()
         for n in st:
             assert maxdiff(st[n], g[k + "post_" + n]) <= 1e-12 * max(1.0, np.abs(g[k + "post_" + n]).max()), (it, n)
+
+
+def test_long_armijo_loops_end_where_the_references_do(scenes):
+    """A fleet stacked at exactly the barrier's range: in iteration 0 the reference's Armijo loop (Optimization3D_multi.h:792) ends by
+    rounding only -- 519 ... 559 back-offs for robots whose energy is ~1e-45, 3 268 (step 2e-317, where 1e-4*wolfe*step underflows) for
+    robots whose energy is exactly 0.  The oracle has to take the same number of factors (its loop bound lies beyond the fixed point of
+    step *= 0.8)."""
+    g = gold("stages_stack030.npz")
+    scene = scene_by_name(scenes, "stack030")
+    check_scene_matches_fixture(scene, g)
+    want0 = backoff_exponent(g["it0_step_armijo"])
+    assert want0.max() == 3268 and np.sum(want0 > 500) >= 60     # the fixture is what its name says
+    e = Engine("port", scene)
+    for it in g["kept"]:
+        k = f"it{it}_"
+        e.set_state({n: g[k + "pre_" + n] for n in ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")})
+        counts, planes = e.stage_planes()
+        assert np.array_equal(counts, g[k + "counts"]) and np.array_equal(planes, g[k + "planes_raw"])
+        e.stage_direction()
+        s_self, s_pos = e.stage_steps()
+        assert np.array_equal(s_self, g[k + "step_self"]) and np.array_equal(s_pos, g[k + "step_pos"])
+        arm = e.stage_linesearch()
+        assert np.array_equal(arm, g[k + "step_armijo"]), (it, backoff_exponent(arm), backoff_exponent(g[k + "step_armijo"]))
+
+
+def test_ccd_backoffs_follow_the_reference(scenes):
+    """Step::position_step / self_step (Step.h:89, :229) on directions scaled by up to 1e18: up to 177 factors of 0.8 per robot, and --
+    beyond the scale at which GJK on the swept hull loses the 0.1 offset -- the reference's clamp stops acting; same steps bit for bit"""
+    g = gold("backoff_kat.npz")
+    scene = scenes.hard()
+    e = Engine("port", scene)
+    e.set_state({n: g["pre_" + n] for n in ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")})
+    e.stage_planes(); e.stage_direction()
+    assert backoff_exponent(g["step_pos"]).max() >= 170
+    for i, sc in enumerate(g["scales"]):
+        for u in range(scene["U"]):
+            e.set_direction(u, g["direction"][u] * sc, float(g["t_direction"][u]), float(g["wolfe"][u]), float(g["gn"][u]))
+        a, b = e.stage_steps()
+        assert np.array_equal(a, g["step_self"][i]) and np.array_equal(b, g["step_pos"][i]), (sc, a, b)
 
 
 @pytest.mark.parametrize("name", ["scn_b", "scn_a", "scn_c3"])

@@ -289,6 +289,12 @@ class Solver:
         self._check(self.lib.tj_get_steps(self._ctx, None, None, _d(s)))
         return s
 
+    def last_armijo_steps(self):
+        """accepted Armijo step of every robot in the last iteration (diagnostic; tj_get_steps)"""
+        s = np.zeros(self.U)
+        self._check(self.lib.tj_get_steps(self._ctx, None, None, _d(s)))
+        return s
+
     def stage_slack(self):
         self.run_stage("slack")
         self.run_stage("end")

@@ -8,7 +8,16 @@
 namespace tj {
 
 constexpr int WAVE = 64;
-constexpr int LOOP_CAP = 200;      // bound on every data-dependent device loop (the reference has none)
+// Bounds of the data-dependent device loops.  The reference has none; each bound below is placed where the reference's own loop
+// can no longer end, so reaching it is true non-termination (reported, never silently different):
+//  * back-off loops (`step *= 0.8`: Armijo Optimization3D_multi.h:792 / :486, CCD Step.h:89,229): 0.8^k by repeated
+//    multiplication reaches its fixed point -- two denormal units, 1e-323 -- at k = 3332; an Armijo test that has not passed by
+//    then (e - 1e-4*wolfe*step < E with step, hence E, no longer changing) never passes, a CCD contact still found there is a
+//    contact of the state itself.  Dev::pow08 holds all 3333 values, so pow08[min(k, STEP_CAP)] IS the reference's step for any k.
+//  * Newton on a pair plane's offset (Optimal_plane.h:23, exit |grad| < 1e-2 only): quadratically convergent on feasible
+//    input; beyond NEWTON_CAP rounds the iterate is NaN or cycling (the reference spins).
+constexpr int STEP_CAP = 3332;
+constexpr int NEWTON_CAP = 4000;
 constexpr int MAX_LEVELS = 12;     // 8-ary levels of the static BVH: 8^12 leaves
 constexpr int FRONT_CAP = 1024;    // BFS frontier capacity per wave (LDS)
 
@@ -16,13 +25,13 @@ constexpr int FRONT_CAP = 1024;    // BFS frontier capacity per wave (LDS)
 enum : int {
   ERR_PLANE_OVERFLOW = 1,    // more separating planes for one segment than the configured capacity
   ERR_FRONT_OVERFLOW = 2,    // BVH frontier overflow (query box far larger than expected)
-  ERR_LOOP_CAP = 4,          // a back-off / Newton / Armijo loop hit LOOP_CAP (infeasible state)
+  ERR_LOOP_CAP = 4,          // a back-off / Newton / Armijo loop reached STEP_CAP / NEWTON_CAP: the reference's loop would not end (infeasible state)
   ERR_PAIR_OVERFLOW = 8,     // inter-robot CCD survivor list overflow
   ERR_NOT_SPD = 16,          // coupled mode: the arrowhead Newton system is not positive definite (the reference's
                              // SimplicialLLT has no fallback there either, Optimization3D_multi.h:553-557)
   // detail bits, set together with ERR_LOOP_CAP
   ERR_LS_RANGE = 32,         // coupled mode: no step among the 8 * LSC_ROUNDS evaluated Armijo candidates (0.8^0 .. 0.8^30) was accepted
-  ERR_CCD_STUCK = 128,       // a CCD clamp found a contact at every step down to 0.8^LOOP_CAP: the state itself is in collision (the
+  ERR_CCD_STUCK = 128,       // a CCD clamp found a contact at every step down to 0.8^STEP_CAP (the fixed point of step *= 0.8): the state itself is in collision (the
                              // reference spins forever there, Step.h:83-97)
   ERR_SLACK_ARMIJO = 256,    // the slack update's Armijo loop
   ERR_PLANE_REFINE = 64,     // "optimal_plane":1 -- a plane's Newton refinement hit PLANE_NEWTON_CAP / PLANE_BACKOFF_CAP
@@ -124,7 +133,7 @@ struct Dev {
   const double* convert;  // [P][36]
   const double* mdyn;     // [36]
   const double* kdop;     // [49][3]
-  const double* pow08;    // [LOOP_CAP+1]  0.8^k by repeated multiplication
+  const double* pow08;    // [STEP_CAP+1]  0.8^k by repeated multiplication, up to its fixed point
   // ---- obstacles: Morton-sorted primitives + implicit 8-ary box hierarchy ----
   // prim = 1: a point cloud (the reference's live path, BVH::InitPointcloud BVH.cpp:53-93); prim = 3: triangles (the
   // reference's dormant BVH::InitObstacle / Step::mix_step path, BVH.cpp:15-51, Step.h:313-411: BASELINE config 5)

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   // scalars of the search first: two dependent global round trips that now overlap the staging below
   const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
-  double step0 = D.pow08[min(LOOP_CAP, max(D.k_obs[u], D.k_self[u]))];
+  double step0 = D.pow08[min(STEP_CAP, max(D.k_obs[u], D.k_self[u]))];
   bool in_lds;
   const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
   TJ_TIC(D, K_LINESEARCH, 2);
@@ -350,11 +350,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
 
   double e_base = 0, step_acc = step0, pt_acc = t0;
   int k_acc = -1, evals = 0, wg = 0;
+  double step = step0; int k_done = 0;                 // step = step0 * 0.8^k_done, kept across the rounds (a round adds G factors)
   for (int round = 0; k_acc < 0; round++) {
     // candidate of this group: -1 = E(x) (round 0, group 0), otherwise trial index k >= 0
     const int k = round == 0 ? g - 1 : (G - 1) + (round - 1) * G + g;
-    double step = step0;
-    for (int i = 0; i < k; i++) step *= 0.8;           // same rounding as the reference's repeated step *= 0.8
+    for (; k_done < k; k_done++) step *= 0.8;          // same rounding as the reference's repeated step *= 0.8
     const double pt = k < 0 ? t0 : t0 + step * t_dir;
     for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
     __syncthreads();
@@ -382,8 +382,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
       wg = acc;
       const double* win = sm + L.gnet + (size_t)acc * 3 * T;
       for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
-    } else if ((G - 1) + round * G >= LOOP_CAP) {
-      // no acceptable step: behave like the capped sequential loop (take the last candidate)
+    } else if ((G - 1) + round * G >= STEP_CAP) {
+      // no acceptable step although step *= 0.8 has reached its fixed point (every further candidate is this one again): the
+      // reference's loop would never end (Optimization3D_multi.h:792).  Take the last candidate and report.
       if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
       k_acc = (G - 1) + (round - 1) * G + G - 1;
       step_acc = res[LS_GROUPS + G - 1];
@@ -459,7 +460,7 @@ __device__ __forceinline__ double lsc_step0(const Dev& D, int tid, double t0, do
     for (int r = tid; r < D.U; r += 64) kmax = max(kmax, sharded ? (int)D.k_obs_f[r] : D.k_obs[r]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
-    double step0 = D.pow08[min(LOOP_CAP, kmax)];
+    double step0 = D.pow08[min(STEP_CAP, kmax)];
     if (t0 + step0 * t_dir <= 0) step0 = -0.95 * t0 / t_dir;
     if (tid == 0) *s_val = step0;
   }

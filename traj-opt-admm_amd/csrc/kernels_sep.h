@@ -304,7 +304,7 @@ __device__ inline bool kdop_hulls_pass(const Dev& D, const double* A, const doub
 
 // Separate::selfgjk (Separate.h:165-304) + Optimal_plane::optimal_d (Optimal_plane.h:13-71).
 // A is the hull of the lower robot index.  Returns false if the hulls are farther than dist.
-// capped = true when the Newton loop hit LOOP_CAP.
+// capped = true when the Newton loop hit NEWTON_CAP.
 // second half of plane_pair: from the GJK witness vector to the plane (separate so that a caller can act between the halves)
 // cr_log out of line: the per-lane pair path lives in k_mid at its 256-register cap, where the inlined double-double pieces spill
 __device__ __noinline__ double cr_log_call(double x) { return cr_log(x); }
@@ -324,7 +324,7 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
   dpl = 0.5 * (d0 + d1);
   if (!refine) return true;
   int it = 0;
-  for (; it < LOOP_CAP; it++) {  // Newton on the offset until |grad| < 1e-2
+  for (; it < NEWTON_CAP; it++) {  // Newton on the offset until |grad| < 1e-2
     double grad = 0, hess = 0;
     for (int j = 0; j < 6; j++) {
       const double ds = (A[3 * j] * e0 + A[3 * j + 1] * e1c + A[3 * j + 2] * e2c) + dpl - 0.5 * off;
@@ -348,7 +348,7 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
     dpl = dpl + 1.0 * dir;
     if (fabs(grad) < 1e-2) break;
   }
-  capped = it == LOOP_CAP;
+  capped = it == NEWTON_CAP;
   if (newton_iters) *newton_iters = it + 1;
   return true;
 }
@@ -386,7 +386,7 @@ __device__ __forceinline__ bool plane_pair_wave(const double* A, const double* B
   const double* pt = lane < 6 ? A + 3 * j : Bq + 3 * j;
   const double px = pt[0], py = pt[1], pz = pt[2];
   int it = 0;
-  for (; it < LOOP_CAP; it++) {  // Newton on the offset until |grad| < 1e-2 (Optimal_plane.h:13-71)
+  for (; it < NEWTON_CAP; it++) {  // Newton on the offset until |grad| < 1e-2 (Optimal_plane.h:13-71)
     const double dp = px * e0 + py * e1c + pz * e2c;
     const double ds = lane < 6 ? dp + dpl - 0.5 * off : -dp - dpl - 0.5 * off;
     const bool act = lane < 12 && ds < m;
@@ -409,7 +409,7 @@ __device__ __forceinline__ bool plane_pair_wave(const double* A, const double* B
     dpl = dpl + 1.0 * dir;
     if (fabs(grad) < 1e-2) break;
   }
-  capped = it == LOOP_CAP;
+  capped = it == NEWTON_CAP;
   if (newton_iters) *newton_iters = it + 1;
   TJ_ORDER(dpl);
   if (tic) TJ_TIC(*tic, K_SEP_SELF_SOLVE, 5);

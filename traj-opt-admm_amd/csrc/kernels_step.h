@@ -104,12 +104,12 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
     if (pt >= 0) {
       if (pass) {
         int k = max(kmax, atomicAdd(&D.k_obs[u], 0));  // any earlier value is a valid lower bound
-        while (k < LOOP_CAP) {
+        while (k < STEP_CAP) {
           const V3 v = gjk(BodySwept{info, info + 18, D.pow08[k]}, qb);
           if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off * off)) break;
           k++;
         }
-        if (k >= LOOP_CAP) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
+        if (k >= STEP_CAP) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
         if (k > kmax) { kmax = k; atomicMax(&D.k_obs[u], k); }
       }
     }
@@ -292,12 +292,12 @@ __device__ __forceinline__ void ccd_self_seq_body(const Dev& D, const SeqMem& M,
         const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
         int k0 = ks[shared ? 0 : p0], k1 = ks[shared ? 0 : p1];
         int guard = 0;
-        while (guard++ < LOOP_CAP) {
-          const V3 v = gjk_wave(BodySwept{a, a + 18, D.pow08[min(k0, LOOP_CAP)]}, BodySwept{b, b + 18, D.pow08[min(k1, LOOP_CAP)]}, lane);  // the wave is uniform here: solve the pair cooperatively
+        while (guard++ < STEP_CAP) {
+          const V3 v = gjk_wave(BodySwept{a, a + 18, D.pow08[min(k0, STEP_CAP)]}, BodySwept{b, b + 18, D.pow08[min(k1, STEP_CAP)]}, lane);  // the wave is uniform here: solve the pair cooperatively
           if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off2)) break;
           k0++; k1++;
         }
-        if (guard > LOOP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
+        if (guard > STEP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
         blk_sync<true>();
         if (lane == 0) { if (shared) ks[0] = k0; else { ks[p0] = k0; ks[p1] = k1; } }
         blk_sync<true>();
@@ -568,7 +568,7 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
     blk_sync<true>();
     const double en = z_energy_wave(D, md, cx, pt, zt, tt, lam, tl, pwc, w18, tid);
     if (!(e - 1e-4 * wolfe * step < en)) break;
-    if (++guard >= LOOP_CAP) { if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_SLACK_ARMIJO); break; }
+    if (++guard >= STEP_CAP) { if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_SLACK_ARMIJO); break; }
     step *= 0.8;
     tt = t_init + step * t_dir;
     pwc = pow(tt, 1.1);

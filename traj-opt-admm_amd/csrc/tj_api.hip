@@ -515,7 +515,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   HIPCHK(c, hipFuncSetAttribute((const void*)k_ccd_self_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_seq));
 
   HostTables t;
-  build_tables(d.P, d.res, LOOP_CAP, t);
+  build_tables(d.P, d.res, STEP_CAP, t);
   double *basis, *convert, *mdyn, *kdop, *pow08;
   int r;
   if ((r = dalloc(c, &basis, t.basis.size())) || (r = dalloc(c, &convert, t.convert.size())) || (r = dalloc(c, &mdyn, 36)) ||
