@@ -232,14 +232,69 @@ def extra_config(pkg, scene, K, W, device):
     return out
 
 
+STATE_KEYS = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
+
+
+def one_rank_state(pkg, scene, device, n_it, optimal_plane):
+    """state after n_it iterations of the DEFAULT single-context path (the fused chain the N = 1 line times) on one device: what every
+    sharded run has to reproduce bit for bit"""
+    slv = pkg.Solver(scene, device=device, stop=0.0, optimal_plane=int(optimal_plane))
+    slv.iterate(n_it)
+    st = slv.get_state()
+    bits = slv.stats()["error_bits"]
+    slv.close()
+    if bits:
+        raise SystemExit(f"one-rank reference run: device error bits {bits}")
+    return st
+
+
+def states_equal(a, b, u0=0, u1=None):
+    return all(np.array_equal(a[k][u0:u1], b[k][u0:u1]) for k in STATE_KEYS)
+
+
 def bench_group(pkg, scene, devices, args):
     """K iterations through tj_group (one process, one host thread per rank inside the library).  Same top-level keys as the
-    single-GPU line; `roofline` / `cpu_baseline` are null here (they are N = 1 objects, see the default run)."""
+    single-GPU line; `roofline` / `cpu_baseline` are null here (they are N = 1 objects, see the default run).
+    SELF-VALIDATING: before anything is timed, every transport (flag -> event -> rccl, or the one TJ_GROUP_TRANSPORT names) runs V
+    iterations and its state is compared BITWISE with V iterations of one rank; the first transport that reproduces it is the one
+    timed, and `group.transports` says what happened to each (error string included) -- a wrong exchange cannot yield a number."""
     torch.cuda.set_device(devices[0])
-    K, W = args.steps, args.warmup
+    K, W, V = args.steps, args.warmup, args.validate_iters
+    multi = len(devices) > 1
+    ref = one_rank_state(pkg, scene, devices[0], V, args.optimal_plane)
+    order = [os.environ["TJ_GROUP_TRANSPORT"]] if os.environ.get("TJ_GROUP_TRANSPORT") else (["flag", "event", "rccl"] if multi else ["event"])
+    tried, chosen = {}, None
+    for t in order:
+        grp = None
+        try:
+            grp = pkg.Group(scene, devices, stop=0.0, optimal_plane=int(args.optimal_plane))
+            if multi:
+                grp.set_transport(t)
+            grp.iterate(1)                 # a transport that cannot deliver fails here, after two exchanges
+            grp.iterate(V - 1)
+            ok = states_equal(grp.get_state(), ref)
+            tried[t] = {"ran": True, "bitwise_equal_to_one_rank": bool(ok), "rccl_ranks": (grp.rccl_ranks if t == "rccl" else None)}
+            if ok and chosen is None:
+                chosen = t
+        except pkg.TrajAdmmError as e:
+            tried[t] = {"ran": False, "bitwise_equal_to_one_rank": False, "error": str(e)}
+        finally:
+            if grp is not None:
+                try:
+                    grp.close()
+                except Exception:
+                    pass
+    validation = {"iterations": V, "reference": "one rank, default fused chain, same device 0", "transports": tried, "timed_transport": chosen,
+                  "bitwise_equal_to_one_rank": chosen is not None}
+    if chosen is None:
+        print(json.dumps({"metric": "ADMM iterations/sec", "value": None, "unit": "iters/s", "n_gpus": len(set(devices)), "steps": K, "warmup": W,
+                          "error": "no transport reproduced the one-rank state bit for bit; nothing was timed", "group": {"validation": validation}}), flush=True)
+        raise SystemExit(3)
 
-    def timed(devs):
+    def timed(devs, transport):
         grp = pkg.Group(scene, devs, stop=0.0, optimal_plane=int(args.optimal_plane))
+        if len(devs) > 1:
+            grp.set_transport(transport)
         grp.iterate(300); grp.reset()          # clock ramp, like the default path
         grp.iterate(max(W, 1)); grp.reset()
         torch.cuda.synchronize()
@@ -247,18 +302,19 @@ def bench_group(pkg, scene, devices, args):
         grp.iterate(K)                         # returns after every rank's stream has drained
         return grp, time.perf_counter() - t0
 
-    grp, dt = timed(devices)
+    grp, dt = timed(devices, chosen)
     transport = grp.transport
+    rccl_ranks = grp.rccl_ranks
     check = None
     if args.state_checksum:
         import hashlib
         stt = grp.get_state()
         check = hashlib.sha256(np.ascontiguousarray(stt["spline"]).tobytes() + np.ascontiguousarray(stt["piece_time"]).tobytes()).hexdigest()
-    ex_us = [float(x) for x in grp.profile_exchange(50)] if len(devices) > 1 else [0.0] * 5
+    ex_us = [float(x) for x in grp.profile_exchange(50)] if multi else [0.0] * 5
     grp.close()
     # the same schedule on ONE rank through the same entry point: what the phase schedule itself costs without any exchange
-    # (the default single-GPU line runs the fused 7-kernel chain instead and is faster; SCALE's N = 1 is that default line)
-    g1, dt1 = timed([devices[0]])
+    # (the default single-GPU line runs the fused chain instead and is faster; SCALE's N = 1 is that default line)
+    g1, dt1 = timed([devices[0]], "event")
     g1.close()
     n_ex = 5 if scene["mode"] == 2 else 2
     distinct = len(set(devices)) == len(devices)
@@ -268,7 +324,8 @@ def bench_group(pkg, scene, devices, args):
                       "parallelism": f"tj_group: {len(devices)} ranks on devices {devices}, robots block-sharded, {n_ex} exchanges/iter inside the library, transport {transport}",
                       "iters_timed_from": "initial trajectory"},
            "timed_window_ms": 1e3 * dt,
-           "group": {"transport": transport, "ranks": len(devices), "devices": list(devices), "distinct_devices": distinct,
+           "group": {"launcher": "tj_group (one process, one host thread per rank)", "transport": transport, "ranks": len(devices), "devices": list(devices), "distinct_devices": distinct,
+                     "rccl_ranks": rccl_ranks, "bitwise_equal_to_one_rank": True, "validation": validation,
                      "exchanges_per_iter": n_ex, "exchange_us": dict(zip(["control_points", "directions", "schur_corner", "ccd_exponents", "armijo_energies"], ex_us)),
                      "one_rank_same_schedule_ms_per_step": 1e3 * dt1 / K,
                      "expectation": EXPECT.get(scene["name"].replace("-coupled", ""), "")},
@@ -306,6 +363,7 @@ def main():
                                                             "(RCCL refuses two ranks on one device); exercises the multi-process schedule on a 1-GPU box")
     ap.add_argument("--group-devices", default=None, help="ONE process drives several ranks through the library's own sharding (tj_group: peer stores + events, no torch "
                                                           "collectives), e.g. 0,1,2,3 -- entries may repeat (0,0 = two ranks on one GPU).  `--gpus N` without torchrun selects devices 0..N-1")
+    ap.add_argument("--validate-iters", type=int, default=8, help="multi-GPU runs: iterations of the untimed self-validation (sharded state == one-rank state, bitwise) that precedes the timing")
     ap.add_argument("--state-checksum", action="store_true", help="each rank also prints 'CHECK <rank> <sha256 of its owned robots\' final control points and piece times>'")
     args = ap.parse_args()
 
@@ -392,6 +450,32 @@ def main():
         slv.sync()
         torch.cuda.synchronize()
 
+    # SELF-VALIDATION of the sharded path (world > 1, or --force-dist): V iterations through the very schedule that is timed below, then
+    # V iterations of ONE rank (the default fused chain, a second context on this rank's own GPU); the robots this rank owns must
+    # agree bit for bit.  Every rank checks its slice, the verdict is the minimum over the ranks.
+    validation = None
+    if sharded:
+        V = args.validate_iters
+        run(V)
+        barrier()
+        st_sh = slv.get_state()
+        u0, u1 = rank * scene["U"] // world, (rank + 1) * scene["U"] // world
+        bits = slv.stats()["error_bits"]
+        ref = one_rank_state(pkg, scene, local, V, args.optimal_plane)
+        mine_ok = bits == 0 and states_equal(st_sh, ref, u0, u1)
+        flag = torch.tensor([1.0 if mine_ok else 0.0], dtype=torch.float64, device=f"cuda:{local}")
+        nok = flag.clone()
+        if not args.same_gpu:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN); dist.all_reduce(nok, op=dist.ReduceOp.SUM)
+        else:   # gloo stages through the host
+            fh, nh = flag.cpu(), nok.cpu()
+            dist.all_reduce(fh, op=dist.ReduceOp.MIN); dist.all_reduce(nh, op=dist.ReduceOp.SUM)
+            flag, nok = fh, nh
+        validation = {"iterations": V, "reference": "one rank, default fused chain, a second context on each rank's own GPU", "checked": "every state array of the robots each rank owns",
+                      "bitwise_equal_to_one_rank": bool(flag.item() == 1.0), "ranks_equal": int(nok.item()), "ranks": world}
+        slv.reset()
+        barrier()
+
     # clock ramp: a freshly started process finds the GPU at its idle clock (543 MHz sclk on the bench box); ~60 ms of the same
     # work, untimed and before the W warm-up steps, lets the power management settle so that K short steps are not timed on the ramp
     if sharded:
@@ -434,6 +518,11 @@ def main():
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
                           "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {5 if args.coupled else 2} RCCL all-gathers/iter on the library's exchange buffers; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else 6} kernels on one queue (union kernels), enqueued ahead, no host sync",
                           "iters_timed_from": "initial trajectory"}}
+        if sharded:
+            out["group"] = {"launcher": "torch.distributed.run, one process per GPU", "backend": dist.get_backend(), "transport": "gloo through host memory (TEST ONLY)" if args.same_gpu else "RCCL all_gather_into_tensor on the library's exchange buffers (zero copy)",
+                            "ranks": world, "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0),
+                            "bitwise_equal_to_one_rank": validation["bitwise_equal_to_one_rank"], "validation": validation,
+                            "expectation": EXPECT.get(scene["name"].split("-coupled")[0], "")}
     if world == 1:
         # per-kernel device time with hipEvents on the solver's stream, same K iterations
         slv.reset()

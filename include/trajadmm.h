@@ -228,9 +228,10 @@ int tj_iterate_phase(tj_ctx* c, int phase);
  * device devices[r] (NULL: device r; entries may repeat -- several ranks on one device, which is how the tests run it on a
  * one-GPU box).  tj_group_iterate runs the phase schedule above on every rank (one host thread per rank) and exchanges the
  * tj_exchange_buffer slices through one of three transports (csrc/tj_group.h):
- *   "flag"   direct peer stores + a sequence flag the consumer's next kernel polls -- device to device, nothing on the host;
- *            the default when every rank has its own device
- *   "event"  direct peer stores + hipEventRecord / hipStreamWaitEvent; the default when devices repeat
+ *   "event"  direct peer stores + hipEventRecord / hipStreamWaitEvent: plain HIP stream semantics; THE DEFAULT
+ *   "flag"   direct peer stores + a sequence flag the consumer's next kernel polls -- device to device, nothing on the host; the
+ *            fastest with the ranks on one device, opt-in until it has run across xGMI (a peer whose push does not arrive
+ *            within 2 s fails the batch with TJ_ERR_DEVICE / error bit 512; the foreign slices are then NOT unpacked)
  *   "rccl"   ncclCommInitAll + one in-place ncclAllGather per exchange on each rank's solver stream (the collective
  *            Optimization3D_multi's sharding would use over xGMI); librccl.so is opened at run time, only for this transport;
  *            needs distinct devices and uav_num divisible by n_ranks
@@ -256,6 +257,8 @@ int tj_group_set_transport(tj_group* g, const char* name);   /* between batches;
 int tj_group_profile_exchange(tj_group* g, int reps, double* us);
 /* 1 if librccl.so can be opened and exports the entry points the "rccl" transport binds (needs no GPU) */
 int tj_rccl_available(void);
+/* ranks the group's RCCL communicator reports (ncclCommCount); 0 unless the "rccl" transport is selected */
+int tj_group_rccl_ranks(tj_group* g);
 /* After a rank failed inside tj_group_iterate the ranks' exchange counts disagree: every tj_group_* call except
  * tj_group_init_state (which drains the streams and restarts the counters) and tj_group_destroy then returns TJ_ERR_DEVICE. */
 

@@ -175,7 +175,7 @@ def make_backoff():
     e.stage_planes()
     d = e.stage_direction()
     rec["direction"] = d["direction"]; rec["t_direction"] = d["t_direction"]; rec["wolfe"] = d["wolfe"]; rec["gn"] = d["gn"]
-    scales = np.array([1.0, 1e6, 1e12, 1e18, 1e21])
+    scales = np.array([1.0, 10.0, 1e2, 1e3, 1e4, 1e5, 1e6, 1e12, 1e18, 1e21])
     ss, sp = [], []
     for sc in scales:
         for u in range(scene["U"]): e.set_direction(u, d["direction"][u] * sc, float(d["t_direction"][u]), float(d["wolfe"][u]), float(d["gn"][u]))

@@ -332,6 +332,8 @@ def test_bench_two_processes_sharded_equals_single_process(tmp_path, coupled):
     assert two.returncode == 0, two.stderr[-3000:]
     j = json.loads(two.stdout[two.stdout.index('{"metric"'):].split("\n")[0])
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["value"] > 0
+    # the line validates itself: before timing, both ranks compared their robots with a one-rank run, bit for bit
+    assert j["group"]["bitwise_equal_to_one_rank"] is True and j["group"]["validation"]["ranks_equal"] == 2 and j["group"]["validation"]["iterations"] == 8
     # single-process checksum covers all 8 robots; recompute the halves from a library run to compare per rank
     import hashlib
     import importlib
@@ -347,3 +349,22 @@ def test_bench_two_processes_sharded_equals_single_process(tmp_path, coupled):
     got = {int(r): h for r, h in re.findall(r"CHECK (\d+) ([0-9a-f]{64})", two.stdout)}   # the ranks' lines may interleave
     assert got == want, (got, want)
     s.close()
+
+
+def test_bench_group_line_validates_itself(tmp_path):
+    """bench.py --group-devices 0,0 (tj_group, two ranks on the one GPU): every transport is tried in the order flag -> event -> rccl, each is
+    compared bitwise with a one-rank run BEFORE anything is timed, and the line says what happened to each -- rccl is refused on repeated
+    devices and the line carries the library's reason instead of the run dying on it"""
+    import json
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TJ_GROUP_TRANSPORT", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group-devices", "0,0", "--steps", "4", "--warmup", "1", "--scene", "B", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout[r.stdout.index('{"metric"'):].split("\n")[0])
+    g = j["group"]
+    assert j["value"] > 0 and g["bitwise_equal_to_one_rank"] is True and g["transport"] == "flag" and g["validation"]["timed_transport"] == "flag"
+    tr = g["validation"]["transports"]
+    assert tr["flag"]["bitwise_equal_to_one_rank"] and tr["event"]["bitwise_equal_to_one_rank"]
+    assert tr["rccl"]["ran"] is False and "own device" in tr["rccl"]["error"]

@@ -80,9 +80,11 @@ def test_group_on_two_devices(pkg, scenes, transport):
         scene = dict(scenes.hard(4, 4000)); scene["mode"] = mode
         ref = pkg.Solver(scene, stop=0.0)
         grp = pkg.Group(scene, [0, 1], stop=0.0)
-        assert grp.transport == "flag"
-        if transport != "flag":
+        assert grp.transport == "event"     # the default everywhere; flag is opt-in until it has passed HERE
+        if transport != "event":
             grp.set_transport(transport)
+        if transport == "rccl":
+            assert grp.rccl_ranks == 2
         for batch in (1, 4, 7):
             g0, _, _ = ref.iterate(batch)
             g, _, _ = grp.iterate(batch)
@@ -189,7 +191,7 @@ def test_gjk_head_start_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
-                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state

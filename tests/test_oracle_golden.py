@@ -132,8 +132,9 @@ def test_long_armijo_loops_end_where_the_references_do(scenes):
 
 
 def test_ccd_backoffs_follow_the_reference(scenes):
-    """Step::position_step / self_step (Step.h:89, :229) on directions scaled by up to 1e18: up to 177 factors of 0.8 per robot, and --
-    beyond the scale at which GJK on the swept hull loses the 0.1 offset -- the reference's clamp stops acting; same steps bit for bit"""
+    """Step::position_step / self_step (Step.h:89, :229) on directions scaled by 1 ... 1e21: up to 177 factors of 0.8 per robot, and --
+    beyond the scale at which GJK on the swept hull loses the 0.1 offset -- the reference's clamp stops acting; same steps bit for bit
+    (the port walks the candidates in the reference's own tree order, so it follows even where that order matters: scales > 1e5)"""
     g = gold("backoff_kat.npz")
     scene = scenes.hard()
     e = Engine("port", scene)

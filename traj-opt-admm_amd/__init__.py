@@ -28,7 +28,7 @@ EXPORTS = [
     "tj_iterate_phase", "tj_phase_count", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
     "tj_group_create", "tj_group_destroy", "tj_group_size", "tj_group_ctx", "tj_group_last_error", "tj_group_set_cloud", "tj_group_set_mesh",
-    "tj_group_transport", "tj_group_set_transport", "tj_group_profile_exchange", "tj_rccl_available",
+    "tj_group_transport", "tj_group_set_transport", "tj_group_profile_exchange", "tj_rccl_available", "tj_group_rccl_ranks",
     "tj_group_init_state", "tj_group_iterate", "tj_group_get_state",
 ]
 
@@ -493,6 +493,11 @@ class Group:
     def set_transport(self, name):
         """"flag" | "event" | "rccl" (csrc/tj_group.h); between batches only"""
         self._check(self.lib.tj_group_set_transport(self._g, name.encode()))
+
+    @property
+    def rccl_ranks(self):
+        """ranks RCCL's communicator reports for this group (0 unless the rccl transport is selected)"""
+        return max(0, int(self.lib.tj_group_rccl_ranks(self._g)))
 
     def profile_exchange(self, reps=50):
         """event-timed microseconds of one exchange of each buffer kind (slowest rank's average)"""

@@ -313,6 +313,7 @@ __device__ __forceinline__ void begin_body(const Dev& D) {
   if (D.multi()) for (int i = threadIdx.x; i <= D.S; i += blockDim.x) D.pair_work_n[i] = 0;   // per-segment counts, [S] = cursor of the pair-solve waves
   if (threadIdx.x == 0) *D.obs_work_n = 0;
   if (threadIdx.x < 3 && D.multi()) D.pair_ovf[threadIdx.x] = 0;
+  if (threadIdx.x < 16) D.ctl->ccd_sub[threadIdx.x] = 0;   // arrival counters of k_ccd's selection blocks (folded pair replay)
   if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
 }
 

@@ -295,7 +295,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     if (pass_on && bid >= np) {   // ---- consumer: the long solves, one per wave ----
       if (bid - np >= nc) return;
       TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
-      const long long t_end = wall_clock64() + 500000;   // 5 ms: a logic error must not hang the device
+      const long long t_end = wall_clock64() + 500000 + 100ll * nwaves;   // 5 ms + 1 us per launched wave (a profiler or a shared GPU stretches a large launch): a logic error must not hang the device
       for (int i = bid - np;; i += nc) {
         unsigned long long e = 0;
         bool have = false;
@@ -383,7 +383,10 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   // DEDICATED to head-start entry b (kernels_pairs.h: spec_pair_body) -- it needs the tag only to know its pair, starts at t = 0
   // from the saved GJK state, and publishes the plane if the broad phase listed the pair again (its segment's part of the work
   // list is scanned while the GJK runs); the generic wave that meets the pair in the list skips it.
-  const bool tv0 = head_start && (int)(spec_tag0 >> 32) == epoch && lane < nwaves, tv1 = head_start && (int)(spec_tag1 >> 32) == epoch && 64 + lane < nwaves;
+  // At most half of the launched waves are dedicated (an entry beyond that stays with the generic wave that meets it in the list), so
+  // the generic waves are never fewer than nwaves / 2 and a wave's share of the list stays <= 8 items whatever TJ_N_SOLVE / TJ_HS_MIN say.
+  const int n_ded = min(nwaves / 2, SPEC_CAP);
+  const bool tv0 = head_start && (int)(spec_tag0 >> 32) == epoch && lane < n_ded, tv1 = head_start && (int)(spec_tag1 >> 32) == epoch && 64 + lane < n_ded;
   const unsigned long long vm0 = ballot(tv0), vm1 = ballot(tv1);
   const int nd = __popcll(vm0) + __popcll(vm1);
   const bool dedicated = bid < SPEC_CAP && (((bid < 64 ? vm0 >> bid : vm1 >> (bid - 64)) & 1ull) != 0);
@@ -448,7 +451,8 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
   // lane j: the wave's j-th work item (all of them in one round trip)
   int it_tr = 0, it_p0 = 0, it_q = 0;
-  const int n_mine = (n - r + Wg - 1) / Wg;   // <= 5 (n <= 4 nwaves, Wg >= nwaves - SPEC_CAP)
+  const int n_mine = (n - r + Wg - 1) / Wg;   // <= 8 (n <= 4 nwaves, Wg >= nwaves / 2)
+  if (n_mine > 64) { if (lane == 0) atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW); return; }   // (cannot happen: a lane holds one item)
   if (lane < n_mine) {
     const size_t sl = (size_t)pair_work_slot(D, wpre, r + lane * Wg);
     it_tr = D.pair_work[3 * sl]; it_p0 = D.pair_work[3 * sl + 1]; it_q = D.pair_work[3 * sl + 2];

@@ -681,7 +681,7 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   }
   int any_act = 0;
   {
-    const long long t_end = wall_clock64() + 500000;   // 5 ms: a logic error must not hang the device
+    const long long t_end = wall_clock64() + 500000 + 100ll * gridDim.x;   // 5 ms + 1 us per block of the launch: a logic error must not hang the device
     for (;;) {
       int v = lane < 16 ? __hip_atomic_load(&D.ctl->ccd_sub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -690,7 +690,7 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
       if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); break; }
       __builtin_amdgcn_s_sleep(8);
     }
-    if (lane < 16) D.ctl->ccd_sub[lane] = 0;
+    // (the counters are zeroed by the next iteration's begin_body, not here: after a timeout late blocks may still be adding)
   }
   if (any_act > 0) ccd_self_seq_body<true>(D, M, false);   // (reads the pairs' count and keys with agent-scope loads)
   TJ_TIC(D, K_CCD, 2);

@@ -8,14 +8,14 @@
 // Armijo energies) the slices are exchanged by one of three TRANSPORTS (TJ_GROUP_TRANSPORT=flag|event|rccl, or
 // tj_group_set_transport):
 //
-//   flag   (default when the ranks sit on DISTINCT devices) device-to-device, no host on the path, no event, no collective
+//   flag   (opt-in until it has run across xGMI; the fastest with ranks on one device) device-to-device, no host on the path, no event, no collective
 //          library.  k_group_push: the owner stores its slice straight into a receive buffer on EVERY peer (peer-mapped memory:
 //          N-1 point-to-point xGMI transfers leave in parallel, there is no ring), fences at system scope and then stores the
 //          exchange's sequence number into its flag word on every peer.  k_group_wait_unpack, next on the consumer's own stream:
 //          one lane per peer polls that peer's flag word (system-scope acquire; wall-clock timeout -> ERR_PEER_TIMEOUT, never a
 //          hang), then the block moves the foreign slices into the buffer the kernels read.  Two small launches per exchange.
-//   event  (default when devices repeat: ranks sharing a GPU may share a hardware queue, where a polling kernel could sit in
-//          front of the very push it waits for) k_group_push, hipEventRecord; the peers' host threads wait for the record to
+//   event  (the default: plain HIP stream / event semantics; ranks sharing a GPU may share a hardware queue, where the flag
+//          transport's polling kernel could sit in front of the very push it waits for) k_group_push, hipEventRecord; the peers' host threads wait for the record to
 //          exist and make their streams wait on the event (hipStreamWaitEvent), then k_group_unpack.
 //   rccl   the collective north_star names, driven from host C++: ncclCommInitAll over the group's devices, one in-place
 //          ncclAllGather per exchange on each rank's solver stream (called by that rank's host thread).  librccl.so is opened
@@ -67,14 +67,18 @@ __global__ __launch_bounds__(GROUP_FLAG_THREADS) void k_group_push_flag(const do
 constexpr long long GROUP_FLAG_TIMEOUT_TICKS = 200000000ll;   // 2 s of the 100 MHz wall clock: a lost peer must not hang the device
 // flags: this rank's words, one per peer (already offset to the exchange's kind and parity)
 __global__ __launch_bounds__(GROUP_FLAG_THREADS) void k_group_wait_unpack(double* dst, const double* rx, GroupPeers mine, int n_peers, unsigned long long seq, size_t own_off, size_t own_count, size_t total, Ctl* ctl) {
+  __shared__ int s_lost;
+  if (threadIdx.x == 0) s_lost = 0;
+  __syncthreads();
   if ((int)threadIdx.x < n_peers) {
     const long long t_end = wall_clock64() + GROUP_FLAG_TIMEOUT_TICKS;
     while (__hip_atomic_load(mine.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (wall_clock64() > t_end) { atomicOr(&ctl->error, ERR_PEER_TIMEOUT); break; }
+      if (wall_clock64() > t_end) { atomicOr(&ctl->error, ERR_PEER_TIMEOUT); s_lost = 1; break; }
       __builtin_amdgcn_s_sleep(8);
     }
   }
   __syncthreads();
+  if (s_lost) return;   // a peer's slice never arrived: leave the buffer as it is (the error bit fails the batch) rather than unpack stale data
   for (size_t i = threadIdx.x; i < total; i += GROUP_FLAG_THREADS)
     if (i < own_off || i >= own_off + own_count) dst[i] = __builtin_nontemporal_load(rx + i);
 }
@@ -89,6 +93,8 @@ struct RcclApi {
   int (*CommDestroy)(void* comm) = nullptr;                                                                          // ncclCommDestroy
   int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;  // ncclAllGather
   const char* (*GetErrorString)(int) = nullptr;                                                                      // ncclGetErrorString
+  int (*CommCount)(void* comm, int* count) = nullptr;                                                                // ncclCommCount (optional: reporting only)
+  std::string err;                                                                                                   // why the library could not be bound (taken once, where dlopen failed)
   bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GetErrorString; }
 };
 constexpr int kNcclFloat64 = 8;   // ncclDouble / ncclFloat64 (rccl.h ncclDataType_t)
@@ -97,12 +103,21 @@ RcclApi& rccl_api() {
   static std::once_flag once;
   std::call_once(once, [] {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
+    for (const char* n : names) {
+      api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+      const char* e = dlerror();   // one call: dlerror() clears the pending message
+      if (!api.err.empty()) api.err += "; ";
+      api.err += e ? e : (std::string(n) + ": dlopen failed");
+    }
     if (!api.lib) return;
+    api.err.clear();
     api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
     api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+    if (!api.ok()) api.err = "librccl.so lacks ncclCommInitAll / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
   });
   return api;
 }
@@ -212,7 +227,7 @@ int group_select_transport(tj_group* g, int t) {
     if (!g->distinct) return group_fail(g, TJ_ERR_UNSUPPORTED, "transport rccl needs every rank on its own device (RCCL refuses two ranks on one GPU)");
     if (g->ctx[0]->d.U % g->n != 0) return group_fail(g, TJ_ERR_UNSUPPORTED, "transport rccl needs the robot count to be divisible by the number of ranks (ncclAllGather gathers equal slices)");
     RcclApi& api = rccl_api();
-    if (!api.ok()) return group_fail(g, TJ_ERR_DEVICE, std::string("transport rccl: librccl.so could not be opened: ") + (dlerror() ? dlerror() : "symbols missing"));
+    if (!api.ok()) return group_fail(g, TJ_ERR_DEVICE, std::string("transport rccl: librccl.so could not be bound: ") + (api.err.empty() ? std::string("symbols missing") : api.err));
     if (g->comms.empty()) {
       g->comms.assign(g->n, nullptr);
       const int rc = api.CommInitAll(g->comms.data(), g->n, g->dev.data());
@@ -275,7 +290,10 @@ int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_grou
     if (!ualloc(g->dev[r], sizeof(unsigned long long) * 5 * 2 * tj::GROUP_MAX, (void**)&g->flags[r])) return bail(TJ_ERR_DEVICE, "flag allocation failed (hipExtMallocWithFlags, uncached)");
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(TJ_ERR_DEVICE, "stream synchronisation failed");
   }
-  int t = g->distinct ? TJ_TRANSPORT_FLAG : TJ_TRANSPORT_EVENT;
+  // Default: event, on distinct devices too.  The flag transport (no host, no event on the path) is the fastest one measured with the ranks
+  // on one device, but it has not crossed xGMI yet: it is opt-in (TJ_GROUP_TRANSPORT=flag / tj_group_set_transport) until
+  // test_group_on_two_devices[flag] has passed on a multi-GPU box; bench.py tries flag -> event -> rccl and validates each bitwise.
+  int t = TJ_TRANSPORT_EVENT;
   if (const char* e = getenv("TJ_GROUP_TRANSPORT")) {
     if (!strcmp(e, "flag")) t = TJ_TRANSPORT_FLAG; else if (!strcmp(e, "event")) t = TJ_TRANSPORT_EVENT; else if (!strcmp(e, "rccl")) t = TJ_TRANSPORT_RCCL;
     else return bail(TJ_ERR_INVALID, std::string("TJ_GROUP_TRANSPORT=") + e + ": expected flag, event or rccl");
@@ -306,6 +324,13 @@ int tj_group_size(tj_group* g) { return g ? g->n : TJ_ERR_INVALID; }
 tj_ctx* tj_group_ctx(tj_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[rank] : nullptr; }
 const char* tj_group_last_error(tj_group* g) { return g ? g->err.c_str() : g_group_create_err.c_str(); }
 const char* tj_group_transport(tj_group* g) { return g ? transport_name(g->transport) : ""; }
+// ranks the group's RCCL communicator reports (ncclCommCount of rank 0's comm); 0 unless the rccl transport is selected and initialised
+int tj_group_rccl_ranks(tj_group* g) {
+  if (!g) return TJ_ERR_INVALID;
+  if (g->transport != TJ_TRANSPORT_RCCL || g->comms.empty() || !g->comms[0] || !rccl_api().CommCount) return 0;
+  int n = 0;
+  return rccl_api().CommCount(g->comms[0], &n) == 0 ? n : 0;
+}
 int tj_group_set_transport(tj_group* g, const char* name) {
   if (!g || !name) return TJ_ERR_INVALID;
   if (g->poisoned) return group_fail(g, TJ_ERR_DEVICE, "group is poisoned by an earlier failure: " + g->err);
