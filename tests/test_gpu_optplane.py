@@ -18,11 +18,20 @@ pytestmark = pytest.mark.gpu
 STATE = ("spline", "p_slack", "p_lambda", "t_slack", "t_lambda", "piece_time")
 
 
-# observed (TJ_PRINT_OBSERVED=1): every plane entry of the three fixtures bit-identical to the reference's (tiny_multi 80 entries,
-# tiny_multi_coupled 64); a stray glibc misrounding on other data would show as ONE plane off by up to ~1e-8, so the bulk is pinned
-FRAC_1E12 = dict(tiny_single=1.0, tiny_multi=0.98, tiny_multi_coupled=0.98)
-FRAC_1E10 = dict(tiny_single=1.0, tiny_multi=0.98, tiny_multi_coupled=0.98)
-PLANE_TOL = 1e-12   # teacher-forced plane lists and tables (observed 0)
+# Round 3 made the plane refinements BIT-IDENTICAL to the reference (dev_crmath.h: log / sin / cos rounded like glibc's); the tests assert
+# exactly that.  glibc's functions are not correctly rounded (99.8 - 99.9 % of the calls on this path's arguments are), so on OTHER data
+# a stray misrounding could move ONE plane by up to ~1e-8 relative to the repaired eigenvalue; if a fixture ever meets one, it is named
+# here with the argument that shows it (tests/devtools/libm_agreement.py prints the offending argument) -- none is known.
+KNOWN_LIBM_ESCAPES = {}   # {(fixture, what): [indices]}
+
+
+def assert_bits(got, want, what, fixture=None):
+    got = np.asarray(got, dtype=np.float64); want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
+    for i in KNOWN_LIBM_ESCAPES.get((fixture, what), []):
+        bad.reshape(-1)[i] = False
+    assert not bad.any(), (what, fixture, int(bad.sum()), float(np.nanmax(np.abs(got - want)[bad])))
 
 
 def _obs(what, err):
@@ -60,12 +69,12 @@ def test_device_plane_refinement_known_answers(katsolver):
     err = np.max(np.abs(out - g["out_obs"]), axis=1)
     assert fin.all()
     _obs("kat obstacle planes", err)
-    assert np.mean(err == 0) >= 0.99 and err.max() <= 1e-9, (np.mean(err == 0), err.max())     # observed: all 400 bit-identical
+    assert_bits(out, g["out_obs"], "kat obstacle planes", "optplane_kat")              # all 400 bit-identical (round 2: 93 % within 1e-9)
     fin, out = katsolver.kat_refine_planes(6, g["P_self"], g["Q_self"], g["in_self"])
     err = np.max(np.abs(out - g["out_self"]), axis=1)
     assert fin.all()
     _obs("kat pair planes", err)
-    assert np.mean(err == 0) >= 0.99 and err.max() <= 1e-9, (np.mean(err == 0), err.max())     # observed: all 400 bit-identical
+    assert_bits(out, g["out_self"], "kat pair planes", "optplane_kat")
     # the wave-cooperative form k_keep uses for short lists: same bits as the per-lane form
     fin_w, out_w = katsolver.kat_refine_planes(7, g["P_self"], g["Q_self"], g["in_self"])
     assert np.array_equal(fin_w, fin) and np.array_equal(out_w, out)
@@ -88,19 +97,20 @@ def test_persistent_plane_stage_teacher_forced_vs_reference(pkg, scenes, name):
             s.set_pair_cache(g[k + "pre_cache_on"], g[k + "pre_cache_cd"])
         counts, planes = s.stage_planes()
         assert np.array_equal(counts, g[k + "counts"]), f"it{it}: plane counts differ"
-        assert maxdiff(canon(counts, planes), g[k + "planes"]) <= PLANE_TOL, it
+        assert_bits(canon(counts, planes), g[k + "planes"], f"it{it} planes", name)
         if scene["mode"] == 0:   # the same SET of remembered obstacles, the same planes
             for (ids, cd), k_n in zip(s.get_obs_cache(), g[k + "post_cache_n"]):
                 assert len(ids) == k_n
             got = {(tr, int(i)): c for tr, (ids, cd) in enumerate(s.get_obs_cache()) for i, c in zip(ids, cd)}
             want = {(tr, int(i)): c for tr, (ids, cd) in enumerate(_unflat(g[k + "post_cache_n"], g[k + "post_cache_ids"], g[k + "post_cache_cd"])) for i, c in zip(ids, cd)}
             assert got.keys() == want.keys()
-            assert max((np.max(np.abs(got[key] - want[key])) for key in got), default=0.0) <= PLANE_TOL
+            for key in got:
+                assert_bits(got[key], want[key], f"it{it} stored plane {key}", name)
             diffs += [np.abs(got[key] - want[key]).ravel() for key in got]
         else:
             on, cd = s.get_pair_cache()
             assert np.array_equal(on, g[k + "post_cache_on"])
-            assert maxdiff(cd, g[k + "post_cache_cd"]) <= PLANE_TOL
+            assert_bits(cd, g[k + "post_cache_cd"], f"it{it} pair table", name)
             live = np.asarray(on).astype(bool)
             diffs.append(np.abs(np.asarray(cd)[live] - np.asarray(g[k + "post_cache_cd"])[live]).ravel())
     assert s.stats()["error_bits"] == 0
@@ -111,7 +121,7 @@ def test_persistent_plane_stage_teacher_forced_vs_reference(pkg, scenes, name):
     frac12, frac10 = float(np.mean(d <= 1e-12)), float(np.mean(d <= 1e-10))
     if __import__("os").environ.get("TJ_PRINT_OBSERVED"):
         print("OBSERVED", name, dict(n=int(d.size), max=float(d.max()), median=float(np.median(d)), frac_1e12=frac12, frac_1e10=frac10))
-    assert np.median(d) <= 1e-14 and frac12 >= FRAC_1E12[name] and frac10 >= FRAC_1E10[name], (float(np.median(d)), frac12, frac10)
+    assert d.max() == 0.0, (float(d.max()), frac12, frac10)
 
 
 @pytest.mark.parametrize("name", ["tiny_single", "tiny_multi", "scn_b"])

@@ -111,7 +111,7 @@ def test_device_planes_kdop_ccd_vs_reference(katsolver):
     d_gpu, d_ref = out[ok, 4], g["plane_self"][ok, 4]
     fin = ~np.isnan(d_ref)
     assert np.array_equal(np.isnan(d_gpu), np.isnan(d_ref))                          # 0/0 quirk of optimal_d reproduced
-    assert np.max(np.abs(d_gpu[fin] - d_ref[fin])) <= 1e-13                           # Newton offset: device log vs glibc log
+    assert np.array_equal(d_gpu[fin], d_ref[fin])                                    # Newton offset: bit-exact since the offset Newton takes cr_log (dev_crmath.h); round 2: <= 1e-13
     assert np.array_equal(katsolver.kat_planes(2, g["P"], g["q"], 0.2)[:, 0], g["kdop_dcd"].astype(float))
     assert np.array_equal(katsolver.kat_planes(3, g["P"], g["Q"], 0.3)[:, 0], g["kdop_self_dcd"].astype(float))
     out = katsolver.kat_ccd(g["ccd_P"], g["ccd_D"], g["ccd_Q"], g["ccd_E"], g["ccd_q"], g["ccd_t"], 0.1)
@@ -138,9 +138,9 @@ def _teacher_forced(pkg, scene, g, tol_dir=1e-11):
         counts, planes = s.stage_planes()
         assert np.array_equal(counts, g[k + "counts"]), f"it{it}: plane counts differ"
         # list ORDER is implementation defined (static BVH vs the reference's dynamic tree); the
-        # planes themselves are bit-exact for obstacles, 1e-13 for pair offsets (device log)
+        # planes themselves are bit-exact: obstacle planes always were, pair offsets since round 3 (cr_log)
         want = g[k + "planes"] if k + "planes" in g else canon(g[k + "counts"], g[k + "planes_raw"])
-        assert maxdiff(canon(counts, planes), want) <= 1e-13
+        assert np.array_equal(canon(counts, planes), want), (it, maxdiff(canon(counts, planes), want))
         s.set_planes(g[k + "counts"], g[k + "planes_raw"])       # then continue from the reference's exact lists
         d = s.stage_direction()
         assert maxdiff(d["gn"], g[k + "gn"]) <= 1e-13 * max(1.0, np.abs(g[k + "gn"]).max())
@@ -261,14 +261,17 @@ def test_stages_teacher_forced_vs_oracle_live(pkg, scenes, name):
     scene = scene_by_name(scenes, name)
     o = Engine("port", scene)
     s = pkg.Solver(scene, stop=0.0)
+    seen = dict(planes=0.0, direction=0.0)
     for it in range(14):
         s.set_state(o.get_state())
         co, po = o.stage_planes(); cg, pg = s.stage_planes()
         assert np.array_equal(co, cg)
-        assert maxdiff(canon(co, po), canon(cg, pg)) <= 1e-13
+        seen["planes"] = max(seen["planes"], maxdiff(canon(co, po), canon(cg, pg)))
+        assert np.array_equal(canon(co, po), canon(cg, pg))    # observed 0 on all 28 iterations (the oracle's glibc log and the device's cr_log agree on every offset here)
         s.set_planes(co, po)
         do = o.stage_direction(); dg = s.stage_direction()
-        assert maxdiff(do["direction"], dg["direction"]) <= 1e-9
+        seen["direction"] = max(seen["direction"], maxdiff(do["direction"], dg["direction"]))
+        assert maxdiff(do["direction"], dg["direction"]) <= (5e-10 if name == "hard" else 5e-11)   # ~10x the observed 4.1e-11 / 3.8e-12 (TJ_PRINT_OBSERVED=1); round 3 asserted 1e-9
         assert maxdiff(do["gn"], dg["gn"]) <= 1e-11 * max(1.0, do["gn"].max())
         so = o.stage_steps(); sg = s.stage_steps()
         assert np.array_equal(so[0], sg[0]) and np.array_equal(so[1], sg[1])
@@ -280,6 +283,8 @@ def test_stages_teacher_forced_vs_oracle_live(pkg, scenes, name):
         for n in STATE:
             assert maxdiff(a[n], b[n]) <= 1e-12 * max(1.0, np.abs(b[n]).max())
     s.close()
+    if os.environ.get("TJ_PRINT_OBSERVED"):
+        print("OBSERVED live", name, {k: float("%.2g" % v) for k, v in seen.items()})
 
 
 @pytest.mark.parametrize("name", ["scn_b", "scn_a", "scn_c3"])
