@@ -119,13 +119,19 @@ def survey_bytes(st, slv, iters):
     return b, total
 
 
-# What ONE wavefront pays on MI355X (tools/micro/issue_probe.hip, profiles/round3_v3_issue_probe.txt; 2.4 GHz), in ns:
-PRIM = {"fp64": 2.6,        # one fp64 VALU instruction, dependent OR independent: a wave issues one every ~6.3 cycles
-        "readlane": 16.0,   # v_readlane pair -> first VALU use of the SGPR it wrote
-        "rsq": 12.2, "sqrt": 46.6, "div": 39.0, "log": 162.0,   # v_rsq_f64 + fma; IEEE sqrt; IEEE division (11 fp64 ops + v_rcp); ocml log
-        "lds": 54.0,        # LDS write -> read round trip
-        "mem": 700.0,       # dependent global-memory round trip (L2 / Infinity Cache hit)
-        "branch": 10.0}     # branch on a fresh VALU comparison
+# What ONE wavefront pays on MI355X, in ns; every entry cites the line of the committed probe output it was read from
+# (tools/micro/issue_probe.hip -> profiles/round4_issue_probe.txt, tools/micro/mem_probe.hip -> profiles/round4_mem_probe.txt; 2.39 GHz):
+PRIM = {"fp64": 2.6,        # issue_probe:2-3   one fp64 VALU instruction, dependent (2.52) OR one of four independent chains (2.64): a wave issues one every ~6.3 cycles
+        "readlane": 16.1,   # issue_probe:5     v_readlane pair -> first VALU use of the SGPR it wrote
+        "rsq": 10.6,        # issue_probe:6     v_rsq_f64 + fma
+        "sqrt": 46.7,       # issue_probe:7     IEEE sqrt (mem_probe:9 measures 67 with the loop's add and counter)
+        "div": 32.8,        # issue_probe:8     IEEE division (round 3's row was folded away by the compiler: 0.94 ns; mem_probe:8: 45 with the loop's add and counter)
+        "log": 158.4,       # issue_probe:11    ocml log
+        "lds": 50.6,        # issue_probe:10    LDS write -> read round trip
+        "mem": 240.0,       # mem_probe:4       dependent global load of a line the PREVIOUS kernel wrote on another XCD (= an Infinity-Cache hit, mem_probe:2: 238;
+                            #                   own-L2 hit 101, mem_probe:1; miss to HBM 390, mem_probe:3).  Rounds 1-3 priced this at 700 ns without a measurement.
+        "branch": 38.0}     # mem_probe:6-7     scalar branch on a fresh VALU comparison (v_cmp, v_readfirstlane, s_cbranch): 64.6 ns per iteration against 26.8 for the
+                            #                   same recurrence with a select (which also pays a second fma): 64.6 - 26.8 = 37.8; round 3 priced it at 10
 
 
 def critical_path(slv, st, K, per_launch_ms, n_prims):
@@ -165,7 +171,7 @@ def critical_path(slv, st, K, per_launch_ms, n_prims):
     return {"unit": "us", "kernels": out, "chain_bound_us": tb, "chain_measured_us": tm, "frac": tb / tm if tm else None,
             "unit_counts": {"bvh_levels": lv, "longest_pair_gjk_iterations": gjk_max, "armijo_rounds": rounds, "newton_system_rows": n},
             "primitives_ns": PRIM,
-            "note": "dependency chain of each kernel's longest work item x measured single-wave latencies (tools/micro/issue_probe.hip); the rest of a launch is "
+            "note": "dependency chain of each kernel's longest work item x measured single-wave latencies (profiles/round4_issue_probe.txt, profiles/round4_mem_probe.txt; a dependent global round trip is 240 ns measured, not the 700 ns rounds 1-3 assumed: frac fell from 0.28 to what is printed here); the rest of a launch is "
                     "instruction issue of ONE wave (one fp64 instruction per ~6.3 cycles, dependent or not) plus dispatch / drain: see DESIGN.md section 5"}
 
 

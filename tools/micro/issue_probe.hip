@@ -46,11 +46,12 @@ __global__ __launch_bounds__(256) void k_probe(double* out, long long* stamps, i
   for (int i = 0; i < N / 8; i++) a = sqrt(a + 2.0);                  // IEEE sqrt sequence
   STAMP(6);
 #pragma unroll 16
-  for (int i = 0; i < N / 8; i++) a = 1.0 / (a + 2.0);                // IEEE division sequence
+  for (int i = 0; i < N / 8; i++) { a = 1.0 / (a + 2.0); asm volatile("" : "+v"(a)); }   // IEEE division sequence (the opaque asm keeps every division: without it the
+                                                                                         // compiler proved the recurrence's fixed point and round 3's row read 0.94 ns)
   STAMP(7);
   int sel = lane;
 #pragma unroll 16
-  for (int i = 0; i < N; i++) { a = (sel & 1) ? a : b; sel = sel * 3 + 1; }   // v_cndmask pair + integer ops
+  for (int i = 0; i < N; i++) { a = (sel & 1) ? a : b + a; sel = sel * 3 + 1; asm volatile("" : "+v"(a)); }   // v_add_f64 + v_cndmask pair + integer ops
   STAMP(8);
 #pragma unroll 16
   for (int i = 0; i < N / 4; i++) { lds[lane] = a; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); a = lds[(lane + 1) & 63] + c; }   // LDS write -> read round trip
@@ -66,7 +67,7 @@ int main() {
   double* out; long long* st;
   hipMalloc(&out, 4096); hipMalloc(&st, 64 * 8);
   const char* names[] = {"dependent v_fma_f64", "4 independent v_fma_f64 chains", "dependent v_mul_f64 + v_add_f64 (or fma)", "2 v_readlane + v_fma via SGPR (dependent)", "v_rsq_f64 + fma (dependent)",
-                         "IEEE sqrt (dependent)", "IEEE division (dependent)", "cndmask pair + 2 int ops", "LDS write->read round trip", "log()"};
+                         "IEEE sqrt (dependent)", "IEEE division (dependent)", "v_add_f64 + cndmask pair + 2 int ops", "LDS write->read round trip", "log()"};
   const int ops[] = {N, N, N, N, N / 8, N / 8, N / 8, N, N / 4, N / 4};
   for (int busy : {0, 4, 7}) {
     for (int rep = 0; rep < 3; rep++) {
