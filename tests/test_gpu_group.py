@@ -191,7 +191,7 @@ def test_gjk_head_start_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
-                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state
@@ -204,7 +204,8 @@ def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     b = pkg.Solver(scene, stop=0.0)
-    a.iterate(6); b.iterate(6)
+    n_it = 30 if "TJ_LS_FAST" in env else 6    # the team shape of the line search's round 0 only starts once robots accept the full step
+    a.iterate(n_it); b.iterate(n_it)
     sa, sb = a.get_state(), b.get_state()
     for n in sa:
         assert np.array_equal(sa[n], sb[n]), f"{n} differs with {env}"

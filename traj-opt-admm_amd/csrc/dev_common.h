@@ -203,6 +203,8 @@ struct Dev {
   double *xs_scr;                 // k_xsolve_band: per-robot dense scratch [owned][n*n + 4n] for the eigenvalue fallback
   int *k_obs, *k_self;            // [U] exponents: step = 0.8^k
   double *step_out;               // [U] accepted Armijo step (diagnostics)
+  int *ls_hist; int ls_fast;      // [U] Armijo exponent each robot accepted in the previous iteration (-1: none yet) -- k_linesearch evaluates round 0 in the
+                                  // team shape for a robot that took the full step last time (kernels_ls.h: x_energy_team); ls_fast = 0 (TJ_LS_FAST=0): never (same bits)
   double *ccdinfo;                // [U][S][CCD_STRIDE] swept-hull cache of the current direction
   int *pair_list;                 // [ACT_CAP] inter-robot CCD: keys (segment, p0, p1) of the pairs within `offset` at full step; Ctl::any_pair counts them
   // per-(robot, segment) statistics slots {nodes_dcd, cand_dcd, nodes_ccd, cand_ccd, planes_obs, planes_self}:

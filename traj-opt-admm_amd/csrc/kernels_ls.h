@@ -212,6 +212,117 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
   return e;
 }
 
+// ---- the same E(net, pt), evaluated by a TEAM of four waves (round 0 of a robot that accepted the full step last time) ----------
+// In the steady phase of a run nearly every robot accepts candidate 0, so all a launch has to decide is E(x) against E(x + s0 d) --
+// and x_energy_group walks each of them through 7 serial velocity / acceleration passes and ~3 plane passes on ONE wave while six
+// other waves evaluate candidates nobody looks at.  Here a pass is a UNIT: unit u (velocity passes, then acceleration passes, then
+// plane passes, the order x_energy_group meets them in) is taken by wave u & 3 of the team, which leaves its lane's TERM
+// (0.0 where the record is inactive: x + 0.0 == x bit for bit, the sums start at +0) in terms[u][lane]; wave 3 also forms the
+// consensus / dual terms.  After one block barrier wave 0 of the team adds every lane's terms in unit order -- the very sequence of
+// additions x_energy_group performs in that lane -- and finishes with the same butterfly and the same statement order.  Same
+// operands, same operations, same order: the value is BITWISE x_energy_group's (test: TJ_LS_FAST=0 changes no bit), so it does not
+// matter which shape evaluated E(x) when a later round compares candidates against it -- which the loops that end by rounding
+// (stages_stack030) rely on.  Both teams run this in lock step (uniform trip counts; a violated limit does not leave early here).
+struct LsTeamUnits { int nv, na, np; __device__ int total() const { return nv + na + np; } };
+__device__ __forceinline__ LsTeamUnits ls_team_units(int S, int M) { return LsTeamUnits{(5 * S + 63) / 64, (4 * S + 63) / 64, (6 * M + 63) / 64}; }
+__device__ __forceinline__ double x_energy_team(const Dev& D, const double* sm, const LsLayout& L, const double* net, double pt, const double* hulls, double* terms,
+                                                double* cons, int* bad_flag, double* out, int M, int tw, int gl) {
+  const int S = D.S, T = D.T;
+  const double* wsg = sm + L.wseg;
+  const double m = D.margin;
+  const LsTeamUnits U4 = ls_team_units(S, M);
+  const double* pl_lds = sm + L.planes;
+  const int* pltr = (const int*)(sm + L.pltr);
+  int bad = 0;
+  for (int unit = tw; unit < U4.total(); unit += 4) {
+    double term = 0.0;
+    if (unit < U4.nv) {
+      const int it = gl + 64 * unit;
+      if (it < S * 5) {
+        const int tr = it / 5, b = it % 5;
+        const double w = wsg[tr];
+        const double* Pp = hulls + tr * 18;
+        const double vx = 5 * (Pp[3 * (b + 1)] - Pp[3 * b]), vy = 5 * (Pp[3 * (b + 1) + 1] - Pp[3 * b + 1]), vz = 5 * (Pp[3 * (b + 1) + 2] - Pp[3 * b + 2]);
+        const double d = D.vel_limit - norm3(vx, vy, vz) / (w * pt);
+        if (d <= 0) bad = 1;
+        else if (d < m) term = barrier(w, d, m);
+      }
+    } else if (unit < U4.nv + U4.na) {
+      const int it = gl + 64 * (unit - U4.nv);
+      if (it < S * 4) {
+        const int tr = it / 4, j = it % 4;
+        const double w = wsg[tr];
+        const double* Pp = hulls + tr * 18;
+        const double ax = 20 * (Pp[3 * (j + 2)] - 2 * Pp[3 * (j + 1)] + Pp[3 * j]), ay = 20 * (Pp[3 * (j + 2) + 1] - 2 * Pp[3 * (j + 1) + 1] + Pp[3 * j + 1]),
+                     az = 20 * (Pp[3 * (j + 2) + 2] - 2 * Pp[3 * (j + 1) + 2] + Pp[3 * j + 2]);
+        const double d = D.acc_limit - norm3(ax, ay, az) / (w * w * pt * pt);
+        if (d <= 0) bad = 1;
+        else if (d < m) term = barrier(w, d, m);
+      }
+    } else {
+      const int it = gl + 64 * (unit - U4.nv - U4.na);
+      if (it < 6 * M) {
+        const int ip = it / 6, j = it - 6 * ip, tr = pltr[ip];
+        const double* Pp = hulls + tr * 18 + 3 * j; const double* pl = pl_lds + 4 * ip;
+        const double d = Pp[0] * pl[0] + Pp[1] * pl[1] + Pp[2] * pl[2] + pl[3];
+        if (d <= 0) bad = 1;
+        else if (d < m) term = barrier(wsg[tr], d, m);
+      }
+    }
+    terms[unit * 64 + gl] = term;
+  }
+  if (__ballot(bad != 0) != 0ull && gl == 0) *bad_flag = 1;
+  const int P6 = 6 * D.P;
+  double* delta = cons; double* cterms = cons + 18 * D.P;
+  if (tw == 3) {   // augmented-Lagrangian terms, statement for statement as in x_energy_group
+    const double* cv = sm + L.convert; const double* sl = sm + L.slack; const double* la = sm + L.lambda;
+    for (int it = gl; it < 18 * D.P; it += LS_GSIZE) {
+      const int sp = it / 18, r = it % 18, a = r / 6, j = r % 6;
+      const double* C = cv + (size_t)sp * 36 + j * 6;
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += C[k] * net[sp * 3 + k + T * a];
+      delta[it] = acc - sl[sp * 6 + j + P6 * a];
+    }
+    blk_sync<true>();
+    for (int sp = gl; sp < D.P; sp += LS_GSIZE) {
+      const double* dl = delta + 18 * sp;
+      double prod[18];
+#pragma unroll
+      for (int i = 0; i < 18; i++) prod[i] = dl[i] * dl[i];
+      double* t = cterms + 6 * sp;
+      t[0] = D.mu / 2.0 * esum(prod, 18);
+      const double dt = pt - sm[L.tsl + sp];
+      t[1] = D.mu / 2.0 * (dt * dt);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        double pr[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) pr[j] = la[sp * 6 + j + P6 * a] * dl[j + 6 * a];
+        t[2 + a] = esum(pr, 6);
+      }
+      t[5] = sm[L.tla + sp] * (pt - sm[L.tsl + sp]);
+    }
+  }
+  __syncthreads();
+  double e = 0;
+  if (tw == 0) {
+    double part = 0, partb = 0;
+    for (int u = 0; u < U4.nv + U4.na; u++) partb += terms[u * 64 + gl];
+    for (int u = U4.nv + U4.na; u < U4.total(); u++) part += terms[u * 64 + gl];
+#pragma unroll
+    for (int off = LS_GSIZE / 2; off > 0; off >>= 1) {
+      part += __shfl_xor(part, off, LS_GSIZE);
+      partb += __shfl_xor(partb, off, LS_GSIZE);
+    }
+    e = D.lambda * part + D.lambda * partb;
+    for (int i = 0; i < 6 * D.P; i++) e += cterms[i];
+    if (*bad_flag) e = INFINITY;
+    if (gl == 0) *out = e;
+  }
+  return e;
+}
+
 // Stage everything an evaluation reuses into LDS: tables, this robot's slack/dual blocks, control net,
 // search direction and (if they fit) its planes with their segment ids.  Returns the plane count M and
 // whether the planes are LDS resident.  Called by the whole block (contains barriers).
@@ -226,6 +337,11 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
   for (int i = tid; i < P; i += nth) { sm[L.tsl + i] = D.t_slack[u * P + i]; sm[L.tla + i] = D.t_lambda[u * P + i]; }
   for (int i = tid; i < 3 * T; i += nth) { net[i] = gspline[i]; dir[i] = D.dirp(u)[i]; }
   for (int i = tid; i < S; i += nth) sm[L.wseg + i] = seg_weight(D, i);
+  if (L.affine) {   // hull(x) and hull(d) straight from global memory, in the same round trip as everything above (they used to wait for the LDS copies of
+                    // basis / net / dir behind the barrier below); same expression, same bits.  Consumed after the second barrier.
+    const double* gdir = D.dirp(u);
+    for (int idx = tid; idx < S * 18; idx += nth) { sm[L.hn + idx] = ls_hull_entry(D, D.basis, gspline, idx); sm[L.hd + idx] = ls_hull_entry(D, D.basis, gdir, idx); }
+  }
   if (tid < 64) {  // plane-count prefix over the segments: lanes load, wave scan (a one-thread loop was 2S dependent loads, ~4 us)
     int run = 0;
     for (int base = 0; base < S; base += 64) {
@@ -243,9 +359,6 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
   }
   __syncthreads();
   TJ_TIC(D, K_LINESEARCH, 1);
-  if (L.affine) {   // consumed after the barrier below
-    for (int idx = tid; idx < S * 18; idx += nth) { sm[L.hn + idx] = ls_hull_entry(D, sm + L.basis, net, idx); sm[L.hd + idx] = ls_hull_entry(D, sm + L.basis, dir, idx); }
-  }
   const int M = pref[S];
   const bool in_lds = M <= L.plane_cap;
   if (in_lds) {
@@ -329,6 +442,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   extern __shared__ double sm[];
   __shared__ int pref[1024];   // plane prefix per segment (S <= 511 checked on the host); [512 + tr]: obstacle planes of segment tr
   __shared__ int s_accept;
+  __shared__ int s_bad[2];
   const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
   // G = L.groups candidates per round.  With G < 8 (long trajectories) the waves beyond G shadow the last group: they compute
   // the same candidate into the same buffers (identical values), which keeps every barrier uniform.
@@ -344,6 +458,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   const double wolfe = D.wolfe(D.U - 1);  // reference quirk: the global left by the LAST robot (Optimization3D_multi.h:730,792)
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   double step0 = D.pow08[min(STEP_CAP, max(D.k_obs[u], D.k_self[u]))];
+  const int hist = D.ls_hist[u];   // exponent this robot accepted in the previous iteration (-1: none yet): the round-0 shape follows it
   bool in_lds;
   const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
   TJ_TIC(D, K_LINESEARCH, 2);
@@ -351,10 +466,41 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
 
   double e_base = 0, step_acc = step0, pt_acc = t0;
   int k_acc = -1, evals = 0, wg = 0;
+  int k_first = -1;   // candidate of group 0 in the next generic round: -1 = E(x) is still to be evaluated (it is group 0's job in that round)
+  // Round 0 in the TEAM shape (x_energy_team): waves 0-3 evaluate E(x), waves 4-7 candidate 0 -- for a robot that accepted the full step
+  // in the previous iteration (hist == 0; in the steady phase of a run that is nearly every robot, every iteration).  If candidate 0 fails
+  // the search goes on with candidates 1, 2, ... in the one-wave-per-candidate rounds below; the accepted step is the reference's either way.
+  const LsTeamUnits tu = ls_team_units(S, M);
+  if (D.ls_fast && hist == 0 && G == LS_GROUPS && in_lds && tu.total() * 64 <= 2 * S * 18) {
+    const int team = tid >> 8, tw = (tid >> 6) & 3, tl = tid & 255;
+    double* tnet = sm + L.gnet + (size_t)(4 * team) * 3 * T;
+    double* thull = sm + L.ghull + (size_t)(4 * team) * S * 18;
+    double* tterms = sm + L.ghull + (size_t)(4 * team + 1) * S * 18;   // the buffers of the team's groups 1 and 2: 2 * S * 18 doubles
+    double* tcons = sm + L.gcons + (size_t)(4 * team) * 24 * P;
+    const double pt = team ? t0 + step0 * t_dir : t0;
+    for (int i = tl; i < 3 * T; i += 256) tnet[i] = team ? net[i] + step0 * dir[i] : net[i];
+    if (tid < 2) s_bad[tid] = 0;
+    __syncthreads();
+    if (L.affine) { const double* hn = sm + L.hn; const double* hd = sm + L.hd; for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = team ? hn[idx] + step0 * hd[idx] : hn[idx]; }
+    else for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = ls_hull_entry(D, sm + L.basis, tnet, idx);
+    __syncthreads();
+    TJ_TIC(D, K_LINESEARCH, 3);
+    x_energy_team(D, sm, L, tnet, pt, thull, tterms, tcons, &s_bad[team], &res[team], M, tw, gl);
+    __syncthreads();
+    TJ_TIC(D, K_LINESEARCH, 4);
+    e_base = res[0];
+    k_first = 1;   // E(x) is known, candidate 0 has been looked at
+    if (!(e_base - 1e-4 * wolfe * step0 < res[1])) {
+      k_acc = 0; step_acc = step0; pt_acc = t0 + step0 * t_dir; evals = 2; wg = 4;
+      const double* win = sm + L.gnet + (size_t)4 * 3 * T;   // team 1's trial net = group 4's buffer
+      for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+    }
+    __syncthreads();
+  }
   double step = step0; int k_done = 0;                 // step = step0 * 0.8^k_done, kept across the rounds (a round adds G factors)
-  for (int round = 0; k_acc < 0; round++) {
-    // candidate of this group: -1 = E(x) (round 0, group 0), otherwise trial index k >= 0
-    const int k = round == 0 ? g - 1 : (G - 1) + (round - 1) * G + g;
+  for (int round = 0; k_acc < 0; round++, k_first += G) {
+    // candidate of this group: -1 = E(x), otherwise trial index k >= 0
+    const int k = k_first + g;
     for (; k_done < k; k_done++) step *= 0.8;          // same rounding as the reference's repeated step *= 0.8
     const double pt = k < 0 ? t0 : t0 + step * t_dir;
     for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
@@ -365,9 +511,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     if (gl == 0 && !shadow) { res[g] = e; res[LS_GROUPS + g] = step; }
     if (tid == 0) s_accept = -1;
     __syncthreads();
-    if (round == 0) e_base = res[0];
+    if (k_first < 0) e_base = res[0];
     if (tid == 0) {
-      for (int c = (round == 0 ? 1 : 0); c < G; c++) {
+      for (int c = (k_first < 0 ? 1 : 0); c < G; c++) {
         const double st = res[LS_GROUPS + c];
         if (!(e_base - 1e-4 * wolfe * st < res[c])) { s_accept = c; break; }
       }
@@ -375,7 +521,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     __syncthreads();
     const int acc = s_accept;
     if (acc >= 0) {
-      k_acc = round == 0 ? acc - 1 : (G - 1) + (round - 1) * G + acc;
+      k_acc = k_first + acc;
       step_acc = res[LS_GROUPS + acc];
       pt_acc = t0 + step_acc * t_dir;
       evals = 2 + k_acc;
@@ -383,11 +529,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
       wg = acc;
       const double* win = sm + L.gnet + (size_t)acc * 3 * T;
       for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
-    } else if ((G - 1) + round * G >= STEP_CAP) {
+    } else if (k_first + G - 1 >= STEP_CAP) {
       // no acceptable step although step *= 0.8 has reached its fixed point (every further candidate is this one again): the
       // reference's loop would never end (Optimization3D_multi.h:792).  Take the last candidate and report.
       if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
-      k_acc = (G - 1) + (round - 1) * G + G - 1;
+      k_acc = k_first + G - 1;
       step_acc = res[LS_GROUPS + G - 1];
       pt_acc = t0 + step_acc * t_dir;
       evals = 2 + k_acc;
@@ -407,7 +553,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     ls_publish_hullinfo(D, u, wh, tid, LS_THREADS);
   }
   TJ_TIC(D, K_LINESEARCH, 5);
-  if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)evals; }   // per robot: one writer, no atomic in front of the ticket
+  if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; D.ls_hist[u] = k_acc; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)evals; }   // per robot: one writer, no atomic in front of the ticket
   if (begin_next) {
     // No fence: nothing another block of THIS kernel writes is read here (gnorm and the counters come from earlier kernels;
     // what begin_body resets was consumed by every block before its ticket), and what is written here is read by later

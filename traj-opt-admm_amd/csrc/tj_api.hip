@@ -495,6 +495,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.spec_budget = SPEC_GJK_BUDGET; d.spec_min = SPEC_GJK_MIN;
   if (const char* e = getenv("TJ_HS_BUDGET")) d.spec_budget = std::max(1, atoi(e));   // development hooks (same bits for any value)
   if (const char* e = getenv("TJ_HS_MIN")) d.spec_min = std::max(1, atoi(e));
+  d.ls_fast = 1;
+  if (const char* e = getenv("TJ_LS_FAST")) d.ls_fast = atoi(e) != 0;   // launch-shape switch (same bits): round 0 of k_linesearch in the team shape
   if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
     return TJ_ERR_UNSUPPORTED;
@@ -529,7 +531,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.oplanes, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ocount, U * S)) ||
       (r = dalloc(c, &d.splanes, U * S * d.cap_self * 4)) || (r = dalloc(c, &d.scount, U * S)) ||
       (r = dalloc(c, &d.lg, U * P * 19)) || (r = dalloc(c, &d.lh, U * P * 361)) || (r = dalloc(c, &d.xdir, U * d.xs)) ||
-      (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) ||
+      (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) || (r = dalloc(c, &d.ls_hist, U)) ||
       (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, ACT_CAP)) ||
       (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) || (r = dalloc(c, &d.blk_stats, U * P + U)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
@@ -741,6 +743,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemsetAsync(d.seg_stats, 0, (size_t)U * d.S * 6 * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(d.pair_stats, 0, (size_t)U * d.S * 2 * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(d.blk_stats, 0, ((size_t)U * d.P + U) * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(d.ls_hist, 0xff, (size_t)U * 4, c->stream));   // -1: no line search yet
   if (d.mode >= 1) HIPCHK(c, hipMemsetAsync(d.pairstamp, 0, (size_t)d.S * U * U * 4, c->stream));  // epochs restart at 1
   HIPCHK(c, hipMemsetAsync(d.pair_ovf_list, 0, ((size_t)d.cap_work + PAIR_CONSUMERS_MAX) * 8, c->stream));                  // (entries are tagged with the epoch)
   HIPCHK(c, hipMemsetAsync(d.pair_ovf, 0, 16, c->stream));
