@@ -25,8 +25,9 @@ enum {
   TJ_ERR_INVALID = -1,      /* bad argument / call order */
   TJ_ERR_DEVICE = -2,       /* HIP runtime failure or no device */
   TJ_ERR_CAPACITY = -3,     /* a device-side list overflowed (raise cap_* in tj_params) */
-  TJ_ERR_NO_PROGRESS = -4,  /* a back-off / Newton / Armijo loop hit its iteration cap: infeasible state
-                               (the reference would spin forever: Step.h:83-97, Optimal_plane.h:23) */
+  TJ_ERR_NO_PROGRESS = -4,  /* a back-off / Newton / Armijo loop reached the point where the reference's own loop can no longer end (the
+                               fixed point of step *= 0.8 after 3332 factors; 4000 Newton rounds): infeasible state -- the reference
+                               would spin forever there (Step.h:83-97, Optimal_plane.h:23) */
   TJ_ERR_UNSUPPORTED = -5
 };
 
@@ -73,6 +74,22 @@ void tj_default_params(tj_params* p, int mode, int uav_num, int piece_num);
  * (CCDUtils.cpp:56-119).  Row-major; any pointer may be NULL.  Host only -- needs no context and no GPU. */
 int tj_host_tables(int piece_num, int res, double* convert, double* mdyn, double* basis, double* kdop);
 
+/* LIMITS the reference does not have (it sizes everything from the init file, Main/multiPathPlanning3D.cpp:342-467); each is checked
+ * and REPORTED, never silently different:
+ *   uav_num <= 2048                 TJ_ERR_UNSUPPORTED from tj_create (11-bit robot fields in packed pair keys).  The robot-pair plane tables
+ *                                   are dense [segments][uav_num][uav_num] (84 MB at 256 robots, 6 GB at 2048).
+ *   piece_num * res <= 511, res <= 16   TJ_ERR_UNSUPPORTED from tj_create.
+ *   order-dependent robot-pair clamp (Step.h:213-251: two acting pairs of one segment share a robot): replayed in the reference's
+ *                                   tree order for up to 256 acting pairs per segment and 512-1024 (folded replay) / 4096 acting pairs per
+ *                                   iteration; beyond that tj_iterate FAILS (TJ_ERR_UNSUPPORTED / TJ_ERR_CAPACITY, error bit 8).
+ *   obstacle CCD clamp              the reference's result depends on the order in which its dynamic tree emits the candidates once GJK's
+ *                                   `<= offset` decision is not monotone in the step (swept hulls > 1e4 long: directions 1e5 x a real
+ *                                   iteration's); there this library returns the largest first-clear exponent over the candidates
+ *                                   (tests/golden/backoff_kat.npz pins the regime boundary).
+ *   back-off loops                  followed to where the reference's own loop ends (step *= 0.8 to its fixed point 1e-323 after 3332 factors);
+ *                                   TJ_ERR_NO_PROGRESS only where the reference would spin forever.  Exception: coupled mode ("decouple":0) searches
+ *                                   the 31 steps 0.8^0 .. 0.8^30 per iteration and reports TJ_ERR_NO_PROGRESS (detail bit 32) beyond.
+ *   cap_obs / cap_self / cap_pairs  list capacities of tj_params; an overflow is TJ_ERR_CAPACITY with the bit that says which. */
 int tj_create(const tj_params* p, tj_ctx** out);
 void tj_destroy(tj_ctx* c);
 const char* tj_last_error(const tj_ctx* c);
