@@ -32,6 +32,10 @@ constexpr int GRAD_MAXRES = 16;  // segments per piece staged at once ("res" of 
 __host__ __device__ inline size_t grad_lds_doubles(int npl, int res) {  // sized by the actual res: 2 blocks must fit one CU
   return (size_t)res * (18 + 36) + 16 * (size_t)npl + (size_t)res * 9 * 20 + (size_t)res * 54 + 361 + 19 + 4 * 19 + 2 * GRAD_MAXRES + 16;
 }
+// folded launch only: behind that layout, the planes the block's own compaction hands to the gradient through LDS -- per segment the
+// first GRAD_PST obstacle planes and the first GRAD_PST robot-pair planes (a longer list is read back from the global list, as before)
+constexpr int GRAD_PST = 16;
+__host__ __device__ inline size_t grad_fold_extra_doubles(int res) { return (size_t)res * GRAD_PST * 4 * 2; }
 
 // Velocity / acceleration barrier terms of a piece (Gradient_admm.h:107-129, :409-572).  grad_velacc_records: one thread per
 // (segment, record) -- 5 velocity and 4 acceleration records per segment -- writes the GRAD_REC values the accumulation needs and
@@ -146,7 +150,8 @@ template <bool GSYNC>
 __device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, GRAD_THREADS / 64); else __syncthreads(); }
 template <bool GSYNC>
 __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
-                                                 const double* Pall, const double* Ball, const double* wseg, const int* segn, const int* segno, int* sego, double* Mv, const GradRole R, GradSync& gs, double run) {   // run: this thread's running sum (Hessian or gradient entry) in, updated sum out
+                                                 const double* Pall, const double* Ball, const double* wseg, const int* segn, const int* segno, int* sego, double* Mv, const GradRole R, GradSync& gs, double run,
+                                                 const double* pst = nullptr) {   // run: this thread's running sum (Hessian or gradient entry) in, updated sum out; pst: the planes are in LDS already (folded launch)
   const int tid = R.tid, hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv;
     // offsets of the batch's segments: every wave writes the same values itself (lanes over segments), so only wave-local
     // ordering is needed -- no barrier, no serial loop on one thread
@@ -158,8 +163,9 @@ __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, do
       const int w = it >> 2, c = it & 3;
       int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
       const int tr = sp * res + i, k = w - sego[i], no = segno[i];
-      pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
-                      : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
+      if (pst) pcb[it] = k < no ? pst[((size_t)(2 * i) * GRAD_PST + k) * 4 + c] : pst[((size_t)(2 * i + 1) * GRAD_PST + (k - no)) * 4 + c];
+      else pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
+                           : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
     }
     grad_sync<GSYNC>(gs);
     TJ_TIC(D, K_SEP_SELF_COMPACT, 4);
@@ -227,15 +233,22 @@ template <bool FOLD>
 __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
   if (TJ_DONE(D)) return;
   TJ_TIC_ENTRY(D, K_GRAD);
+  extern __shared__ double sm[];
+  __shared__ int s_cnt[GRAD_MAXRES][2];   // folded launch: {obstacle planes, robot-pair planes} of the block's segments, left by its own compaction
+  __shared__ int s_fits;                  // ... and whether every list fits the LDS hand-over (else the gradient reads the global lists, as the one-group launch does)
+  const int npl = D.grad_npl;
+  double* pst = sm + grad_lds_doubles(npl, D.res);   // [res][2][GRAD_PST][4] (folded launch only: its dynamic LDS is that much longer)
+  double pall_v = 0, ball_v = 0;
   if constexpr (FOLD) {
     const int u_ = D.u0 + blockIdx.x / D.P, sp_ = blockIdx.x % D.P;
-    for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64) compact_segment(D, u_, sp_ * D.res + i, threadIdx.x & 63);
-    __threadfence_block();
+    // hulls and bases of the piece's segments: issued first, so that their round trip runs under the compaction's
+    if ((int)threadIdx.x < D.res * 18) pall_v = hull_entry(D, D.spline + (size_t)u_ * 3 * D.T, sp_ * D.res + threadIdx.x / 18, (threadIdx.x % 18) / 3, threadIdx.x % 3);
+    if ((int)threadIdx.x < D.res * 36) ball_v = D.basis[(size_t)sp_ * D.res * 36 + threadIdx.x];
+    if (threadIdx.x == 0) s_fits = 1;
     __syncthreads();
-    if (threadIdx.x >= 2 * GRAD_THREADS) return;   // the remaining barriers count surviving waves only
+    for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64)
+      compact_segment(D, u_, sp_ * D.res + i, threadIdx.x & 63, pst + (size_t)(2 * i) * GRAD_PST * 4, pst + (size_t)(2 * i + 1) * GRAD_PST * 4, s_cnt[i], GRAD_PST, &s_fits);
   }
-  extern __shared__ double sm[];
-  const int npl = D.grad_npl;
   double* Pall = sm;                          // [res][18] hulls of the piece's segments, row-major [6][3]
   double* Ball = Pall + D.res * 18;           // [res][36] their bases
   double* pc = Ball + D.res * 36;             // [npl][4] planes of the current batch of segments
@@ -272,16 +285,36 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   if (threadIdx.x < 2) s_gsync[threadIdx.x] = 0;
   __shared__ double s_wseg[GRAD_MAXRES];   // seg_weight of the piece's segments (two divisions and a modulo per use otherwise)
   if (threadIdx.x >= 64 && threadIdx.x < 64 + res) s_wseg[threadIdx.x - 64] = seg_weight(D, sp * res + threadIdx.x - 64);
-  // ---- stage every segment of the piece once: hull, basis, plane counts ----
-  for (int idx = threadIdx.x; idx < res * 18; idx += NTH) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
-  for (int idx = threadIdx.x; idx < res * 36; idx += NTH) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
   __shared__ int s_no[GRAD_MAXRES];   // obstacle planes per segment (the plane lists are read without a second trip for the count)
-  if (threadIdx.x < res) {
-    const int no = D.ocount[u * D.S + sp * res + threadIdx.x];
-    s_no[threadIdx.x] = no;
-    segn[threadIdx.x] = no + (D.multi() ? D.scount[u * D.S + sp * res + threadIdx.x] : 0);
+  bool staged = false;
+  if constexpr (FOLD) {
+    // ---- folded launch: hulls and bases arrived under the compaction; counts and planes come from it through LDS ----
+    if ((int)threadIdx.x < res * 18) Pall[threadIdx.x] = pall_v;
+    if ((int)threadIdx.x < res * 36) Ball[threadIdx.x] = ball_v;
+    __threadfence_block();
+    __syncthreads();
+    staged = s_fits != 0;
+    if (threadIdx.x >= 2 * GRAD_THREADS) return;   // waves 6, 7: the remaining barriers count surviving waves only
+    if ((int)threadIdx.x < res) {
+      if (staged) { s_no[threadIdx.x] = s_cnt[threadIdx.x][0]; segn[threadIdx.x] = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1]; }
+      else {
+        const int no = D.ocount[u * D.S + sp * res + threadIdx.x];
+        s_no[threadIdx.x] = no;
+        segn[threadIdx.x] = no + (D.multi() ? D.scount[u * D.S + sp * res + threadIdx.x] : 0);
+      }
+    }
+    __syncthreads();
+  } else {
+    // ---- stage every segment of the piece once: hull, basis, plane counts ----
+    for (int idx = threadIdx.x; idx < res * 18; idx += NTH) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
+    for (int idx = threadIdx.x; idx < res * 36; idx += NTH) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
+    if (threadIdx.x < res) {
+      const int no = D.ocount[u * D.S + sp * res + threadIdx.x];
+      s_no[threadIdx.x] = no;
+      segn[threadIdx.x] = no + (D.multi() ? D.scount[u * D.S + sp * res + threadIdx.x] : 0);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   TJ_TIC(D, K_GRAD, 1);
   const int qhi = max(qi, qk), qlo = min(qi, qk);
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       int se = sb, tot = 0;
       while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
       if (tot > 0) {
-        if (tot <= npl) pacc_ = grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_);
+        if (tot <= npl) pacc_ = grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_, staged ? pst : nullptr);
         else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); pacc_ = grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_); }
       }
       sb = se;

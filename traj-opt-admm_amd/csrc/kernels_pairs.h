@@ -504,7 +504,10 @@ __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
 // the robot-pair planes from the stamped partner slots (ascending partner): deterministic lists, no atomics
 // The loads are ordered so that the chain is three memory latencies long, not six: epoch, candidate count and the first 256
 // partner stamps go out together; then the candidate stamps and the stamped partners' planes; then the candidates' planes.
-__device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int lane) {   // one wave
+// hand-over (k_grad's folded launch): besides the global lists the wave leaves its segment's planes -- the first `pst_cap` of each
+// list -- and the two counts in LDS (pst_o / pst_s: [pst_cap][4], cnt: {obstacle planes, all planes}), so that the gradient that
+// follows in the same block reads neither the counts nor the lists back from global memory; *fits is cleared if a list is longer.
+__device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int lane, double* pst_o = nullptr, double* pst_s = nullptr, int* cnt = nullptr, int pst_cap = 0, int* fits = nullptr) {   // one wave
   const int U = D.U, epoch = D.ctl->epoch;
   const size_t seg = (size_t)u * D.S + tr;
   const bool obs_part = !(D.optimal_plane && !D.multi());  // single-UAV "optimal_plane":1 -- k_keep wrote the obstacle plane list itself
@@ -533,8 +536,11 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
       const int idx = pbase + prefix_count(mask);
       if (ok) {
         if (idx < D.cap_self) {
-          if (q0 == 0) { outp[4 * idx] = pp0; outp[4 * idx + 1] = pp1; outp[4 * idx + 2] = pp2; outp[4 * idx + 3] = pp3; }
-          else { const double* p = D.pairplane + 4 * slot; outp[4 * idx] = p[0]; outp[4 * idx + 1] = p[1]; outp[4 * idx + 2] = p[2]; outp[4 * idx + 3] = p[3]; }
+          double v0, v1, v2, v3;
+          if (q0 == 0) { v0 = pp0; v1 = pp1; v2 = pp2; v3 = pp3; }
+          else { const double* p = D.pairplane + 4 * slot; v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; }
+          outp[4 * idx] = v0; outp[4 * idx + 1] = v1; outp[4 * idx + 2] = v2; outp[4 * idx + 3] = v3;
+          if (pst_s && idx < pst_cap) { pst_s[4 * idx] = v0; pst_s[4 * idx + 1] = v1; pst_s[4 * idx + 2] = v2; pst_s[4 * idx + 3] = v3; }
         }
         else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
       }
@@ -552,15 +558,20 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
       const bool ok = sl < n && stamp == epoch;
       const unsigned long long mask = ballot(ok);
       const int idx = base + prefix_count(mask);
-      if (ok) { out[4 * idx] = o0; out[4 * idx + 1] = o1; out[4 * idx + 2] = o2; out[4 * idx + 3] = o3; }
+      if (ok) {
+        out[4 * idx] = o0; out[4 * idx + 1] = o1; out[4 * idx + 2] = o2; out[4 * idx + 3] = o3;
+        if (pst_o && idx < pst_cap) { pst_o[4 * idx] = o0; pst_o[4 * idx + 1] = o1; pst_o[4 * idx + 2] = o2; pst_o[4 * idx + 3] = o3; }
+      }
       base += __popcll(mask);
     }
     if (lane == 0) { D.ocount[seg] = base; atomicAdd(&D.seg_stats[seg * 6 + 4], (unsigned long long)base); }   // fire-and-forget
-  }
+    if (cnt && lane == 0) { cnt[0] = base; if (base > pst_cap) *fits = 0; }
+  } else if (cnt && lane == 0) *fits = 0;   // ("optimal_plane":1, single UAV: k_keep wrote the obstacle list itself -- the gradient reads it from global memory)
   if (pair_part && lane == 0) {
     D.scount[seg] = min(pbase, D.cap_self);
     atomicAdd(&D.seg_stats[seg * 6 + 5], (unsigned long long)pbase);
   }
+  if (cnt && lane == 0) { const int ns = pair_part ? min(pbase, D.cap_self) : 0; cnt[1] = ns; if (ns > pst_cap) *fits = 0; }
 }
 __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
   if (TJ_DONE(D)) return;

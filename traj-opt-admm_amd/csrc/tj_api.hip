@@ -160,7 +160,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_SEP_SELF_COMPACT: if ((in_graph || in_phase) && c->grad_fold) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
       hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD:
-      if ((in_graph || in_phase) && c->grad_fold) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad, s, d);
+      if ((in_graph || in_phase) && c->grad_fold) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double), s, d);
       else hipLaunchKernelGGL((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
       return true;
     case K_XSOLVE:
@@ -497,11 +497,11 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if (const char* e = getenv("TJ_HS_MIN")) d.spec_min = std::max(1, atoi(e));
   d.ls_fast = 1;
   if (const char* e = getenv("TJ_LS_FAST")) d.ls_fast = atoi(e) != 0;   // launch-shape switch (same bits): round 0 of k_linesearch in the team shape
-  if (c->lds_grad > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
+  if (c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double) > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
     return TJ_ERR_UNSUPPORTED;
   }
-  HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double))));
   HIPCHK(c, hipFuncSetAttribute((const void*)k_grad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_grad));
   if (d.xs_band) HIPCHK(c, hipFuncSetAttribute((const void*)k_xsolve_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_xs));
   else {
