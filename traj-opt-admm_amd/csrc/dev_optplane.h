@@ -313,59 +313,109 @@ __device__ inline bool opt_plane_pair(const double* A, const double* B, double m
 
 // The same refinement computed by a whole wave for ONE plane (all 64 lanes call it with the same arguments): the 12 barrier
 // terms -- the logarithms and divisions, i.e. nearly all of the work -- sit on lanes 0..11 and are summed in the reference's
-// order (an inactive term adds +0.0, which is exact); the 3x3 algebra is uniform; sin and cos of the two angles are taken by
-// lanes 0 and 1 in one call each.  Same expressions as opt_plane_pair => identical results, ~1/4 of the dependent-instruction
-// chain per Newton round.
-__device__ inline bool opt_plane_pair_wave(const double* A, const double* B, double m, double off, int lane, double& cx, double& cy, double& cz, double& d, int* rounds = nullptr) {
+// order (an inactive term adds +0.0, which is exact); the 3x3 algebra is uniform.  Same expressions as opt_plane_pair =>
+// identical results.
+// The Armijo search of a round is the long part: a step clamped to a quarter turn, or an offset component of 1e8 behind the repaired 1e-8
+// eigenvalue, is backed off tens to hundreds of times, each time a rotation (two sin / cos pairs) and an energy (12 logarithms) -- measured
+// on SCN-C: 20 - 40 rounds of ~7 us each for the slowest plane of a launch, which is what k_keep lasts.  Here FIVE evaluations run side by
+// side: lanes 12 s .. 12 s + 11 hold the 12 barrier terms of slot s (the first pass: e0 and candidates 0..3; later passes: five more
+// candidates), lanes 2 s and 2 s + 1 take the slot's two sin / cos pairs, the slots' sums are formed by five lanes in the reference's
+// order out of LDS, and the candidates are then looked at IN ORDER -- the first that passes the Armijo test is the one the sequential
+// loop would have stopped at, its energy the same expression on the same operands.  te64: 64 doubles of wave-private LDS.
+__device__ inline bool opt_plane_pair_wave(const double* A, const double* B, double m, double off, int lane, double& cx, double& cy, double& cz, double& d, double* te64, int* rounds = nullptr, long long* dbgout = nullptr) {
   const int j = lane < 12 ? lane : 0;
   const bool second = j >= 6;
   const double* rp = second ? B + 3 * (j - 6) : A + 3 * j;
   const double r[3] = {rp[0], rp[1], rp[2]};
+  // the same point again for the slot layout of the Armijo passes: lane 12 s + q holds point q of slot s
+  const int slot = min(lane / 12, 4), q5 = lane - 12 * slot;
+  const bool live = lane < 60;
+  const bool second5 = q5 >= 6 && live;
+  const double* rp5 = live ? (second5 ? B + 3 * (q5 - 6) : A + 3 * q5) : A;
+  const double r5[3] = {rp5[0], rp5[1], rp5[2]};
   int guard = 0;
   bool ok = false;
+#ifdef TJ_PHASE_TIMING
+  long long tt[4] = {0, 0, 0, 0}; int npass = 0; long long tq;
+#define OPT_T0 tq = wall_clock64()
+#define OPT_T(i) do { const long long n_ = wall_clock64(); tt[i] += n_ - tq; tq = n_; } while (0)
+#else
+#define OPT_T0 do {} while (0)
+#define OPT_T(i) do {} while (0)
+#endif
   for (; guard < PLANE_NEWTON_CAP; guard++) {
+    OPT_T0;
     const OpFrame f = op_frame(cx, cy, cz);
     OpTerm t = op_pair_term(r, second, f, cx, cy, cz, d, m, off);
     if (lane >= 12) t = OpTerm{0, 0, 0, 0, 0, 0};
+    TJ_ORDER(t.h22); OPT_T(0);
     double g0 = 0, g1 = 0, g2 = 0, h00 = 0, h10 = 0, h20 = 0, h11 = 0, h21 = 0, h22 = 0;
 #pragma unroll
     for (int q = 0; q < 12; q++) {
       g0 += gjk_rl(t.g0, q); g1 += 0; g2 += gjk_rl(t.g2, q); h00 += gjk_rl(t.h00, q); h10 += gjk_rl(t.h10, q); h20 += gjk_rl(t.h20, q); h11 += 0; h21 += 0; h22 += gjk_rl(t.h22, q);
     }
+    TJ_ORDER(h22); OPT_T(1);
     if (sqrt(op_sum3v(g0 * g0, g1 * g1, g2 * g2)) < 1e-2) { ok = true; break; }
     double dir0, dir1, dir2, w, step;
     op_pair_direction(g0, g1, g2, h00, h10, h20, h11, h21, h22, dir0, dir1, dir2, w, step);
-    double tx, ty, tz, td;
-    auto rotate = [&](double th, double ph) {
-      const double x = lane == 1 ? ph : th;
-      double cv, sv; cr_sincos(x, &sv, &cv);
-      op_rotate(gjk_rl(cv, 0), gjk_rl(sv, 0), gjk_rl(cv, 1), gjk_rl(sv, 1), cx, cy, cz, f, tx, ty, tz);
-    };
-    auto energy = [&]() {
+    TJ_ORDER(step); OPT_T(2);
+    // one pass: slot s evaluates the energy at step `sv[s]` (NaN marks "angles exactly 0, offset d": e0)
+    double e0 = 0, tx = cx, ty = cy, tz = cz, td = d;
+    bool have_e0 = false, stuck = false, accepted = false;
+    int gi = 0;   // index of the next candidate in the sequential loop's order (0 = the first trial step, then the back-offs)
+    while (!accepted && !stuck) {
+#ifdef TJ_PHASE_TIMING
+      npass++;
+#endif
+      double sv[5];
+      int first = 0;
+      if (!have_e0) { sv[0] = 0.0; first = 1; }
+      for (int s_ = first; s_ < 5; s_++) { sv[s_] = step; step *= 0.8; }   // the sequential loop's step *= 0.8, five at a time (uniform)
+      const bool is_e0 = !have_e0 && slot == 0;
+      const double my_step = slot == 0 ? sv[0] : (slot == 1 ? sv[1] : (slot == 2 ? sv[2] : (slot == 3 ? sv[3] : sv[4])));
+      // sin / cos: lane 2 s takes theta of slot s, lane 2 s + 1 its phi
+      const int as = min(lane >> 1, 4);
+      const double a_step = as == 0 ? sv[0] : (as == 1 ? sv[1] : (as == 2 ? sv[2] : (as == 3 ? sv[3] : sv[4])));
+      const bool a_e0 = !have_e0 && as == 0;
+      const double ang = a_e0 ? 0.0 : ((lane & 1) ? 0.0 + a_step * dir1 : 0.0 + a_step * dir0);
+      double cvv, svv; cr_sincos(ang, &svv, &cvv);
+      const double ct = __shfl(cvv, 2 * slot), st = __shfl(svv, 2 * slot), cp = __shfl(cvv, 2 * slot + 1), sp = __shfl(svv, 2 * slot + 1);
+      double ux, uy, uz;
+      op_rotate(ct, st, cp, sp, cx, cy, cz, f, ux, uy, uz);
+      const double ud = is_e0 ? d : d + my_step * dir2;
       double te;
-      const bool fine = op_pair_energy_term(r, second, tx, ty, tz, td, m, off, te) || lane >= 12;
-      if (__ballot(!fine) != 0ull) return (double)INFINITY;
-      if (lane >= 12) te = 0;
-      double e = 0;
+      const bool fine = op_pair_energy_term(r5, second5, ux, uy, uz, ud, m, off, te) || !live;
+      if (!live) te = 0;
+      const unsigned long long notfine = __ballot(!fine);
+      te64[lane] = te;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+      double es = 0;
+      if (lane < 5) {
 #pragma unroll
-      for (int q = 0; q < 12; q++) e += gjk_rl(te, q);
-      return e;
-    };
-    rotate(0.0, 0.0); td = d;
-    const double e0 = energy();
-    rotate(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
-    double e1v = energy();
-    int bo = 0;
-    bool stuck = false;
-    while (e0 - 1e-4 * w * step < e1v) {
-      if (++bo > PLANE_BACKOFF_CAP) { stuck = true; break; }
-      step *= 0.8;
-      rotate(0.0 + step * dir0, 0.0 + step * dir1); td = d + step * dir2;
-      e1v = energy();
+        for (int q = 0; q < 12; q++) es += te64[12 * lane + q];
+        if ((notfine >> (12 * lane)) & 0xfffull) es = INFINITY;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+      if (!have_e0) { e0 = gjk_rl(es, 0); have_e0 = true; }
+      for (int s_ = first; s_ < 5; s_++) {   // uniform: in the sequential loop's order
+        if (gi > PLANE_BACKOFF_CAP) { stuck = true; break; }
+        const double e1v = s_ == 1 ? gjk_rl(es, 1) : (s_ == 2 ? gjk_rl(es, 2) : (s_ == 3 ? gjk_rl(es, 3) : (s_ == 4 ? gjk_rl(es, 4) : gjk_rl(es, 0))));
+        if (!(e0 - 1e-4 * w * sv[s_] < e1v)) {
+          const int src = 12 * s_;
+          tx = gjk_rl(ux, src); ty = gjk_rl(uy, src); tz = gjk_rl(uz, src); td = gjk_rl(ud, src);
+          accepted = true;
+          break;
+        }
+        gi++;
+      }
     }
+    TJ_ORDER(td); OPT_T(3);
     if (stuck) break;
     cx = tx; cy = ty; cz = tz; d = td;
   }
+#ifdef TJ_PHASE_TIMING
+  if (dbgout && lane == 0 && guard >= 8) { dbgout[0] = guard; dbgout[1] = npass; dbgout[2] = tt[0]; dbgout[3] = tt[1]; dbgout[4] = tt[2]; dbgout[5] = tt[3]; }
+#endif
   if (rounds) *rounds = guard;
   return ok;
 }

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(64) void k_dbg_optpair_wave(Dev D, int n, const dou
   if (i >= n) return;
   double* o = out + (size_t)i * 5;
   double cx = o[1], cy = o[2], cz = o[3], d = o[4];
-  const bool ok = opt_plane_pair_wave(P + (size_t)i * 18, Q + (size_t)i * 18, D.margin, D.offset, lane_id(), cx, cy, cz, d);
+  __shared__ double te64[64];
+  const bool ok = opt_plane_pair_wave(P + (size_t)i * 18, Q + (size_t)i * 18, D.margin, D.offset, lane_id(), cx, cy, cz, d, te64);
   if (lane_id() == 0) { o[0] = ok; o[1] = cx; o[2] = cy; o[3] = cz; o[4] = d; }
 }
 

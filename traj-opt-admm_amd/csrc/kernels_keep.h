@@ -90,7 +90,15 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     }
     D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
   };
+  // statistics of this mode (tj_stats): newton_iters / pair_solves = Newton rounds / planes refined (Optimal_plane::self_optimal_cd's outer loop),
+  // gjk_max_sum = sum over the iterations of the longest refinement of a launch, in rounds -- the unit count of k_keep's critical path
+  auto note_rounds = [&](int tr, int p0, int rounds) {
+    unsigned long long* ps = D.pair_stats + 2 * ((size_t)p0 * D.S + tr);
+    atomicAdd(ps, (unsigned long long)rounds); atomicAdd(ps + 1, 1ull);
+    if (rounds >= 6) atomicMax(&D.ctl->gjk_max, rounds);
+  };
   __shared__ int wpre[513];
+  __shared__ double s_te[64];   // opt_plane_pair_wave: the energy terms of five Armijo candidates
   const int nwork = pair_work_prefix(D, wpre, lane), nold = D.kpair_n[1];
   // Few planes (up to a handful per wave of the grid): one WAVE per plane -- the 12 barrier terms of a Newton round on 12
   // lanes (opt_plane_pair_wave), a quarter of the dependent chain; the kernel is as long as its slowest plane.  Many planes
@@ -106,8 +114,9 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
       double cx, cy, cz, d; bool cp;
       if (!plane_pair(A, B, dist, m, off, false, cx, cy, cz, d, cp)) continue;   // every lane, same arguments: uniform
       if (lane == 0) { D.kpair_on[s0] = 1; D.kpair_list[atomicAdd(D.kpair_n, 1)] = (int)s0; }
-      capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d);
-      if (lane == 0) publish(s0, tr, p0, q, cx, cy, cz, d);
+      int rounds = 0;
+      capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d, s_te, &rounds, D.dbg ? D.dbg + ((size_t)K_KEEP * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS : nullptr);
+      if (lane == 0) { publish(s0, tr, p0, q, cx, cy, cz, d); note_rounds(tr, p0, rounds); }
     }
     for (int w = blockIdx.x; w < nold; w += gridDim.x) {     // part 2 (:310-338)
       const size_t s0 = (size_t)D.kpair_list[w];
@@ -116,8 +125,9 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
       const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
       const double* k = D.kpair_cd + 4 * s0;
       double cx = k[0], cy = k[1], cz = k[2], d = k[3];
-      capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d);
-      if (lane == 0) publish(s0, tr, p0, q, cx, cy, cz, d);
+      int rounds = 0;
+      capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d, s_te, &rounds, D.dbg ? D.dbg + ((size_t)K_KEEP * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS : nullptr);
+      if (lane == 0) { publish(s0, tr, p0, q, cx, cy, cz, d); note_rounds(tr, p0, rounds); }
     }
     if (capped && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PLANE_REFINE);
     return;
