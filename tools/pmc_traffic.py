@@ -29,25 +29,40 @@ def short_name(n):
     return n[st:st + k]
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, regime=None):
+    """{kernel: (launches, summed counter)}; regime = (start, count): only the launches of the ADMM iterations [start, start + count) of the run
+    (an iteration begins with k_front / k_obs_query), i.e. the TIMED window of the default bench command for 303:20 -- the same window the
+    kernel statistics of tools/rocpd_timeline.py --regime describe"""
     db = sqlite3.connect(path); cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     t = lambda k: [x for x in tabs if x.startswith(k)][0]
     pm, ip, kd, ks = t("rocpd_pmc_event"), t("rocpd_info_pmc"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
-    q = (f"select s.kernel_name, count(*), sum(e.value) from {pm} e join {ip} i on e.pmc_id=i.id "
-         f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id where i.name=? group by s.kernel_name")
+    q = (f"select s.kernel_name, d.start, sum(e.value) from {pm} e join {ip} i on e.pmc_id=i.id "
+         f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id where i.name=? group by d.event_id order by d.start")
+    rows = [(short_name(n), st, v) for n, st, v in cur.execute(q, (counter,))]
+    if regime:
+        r0, rc = regime
+        begins = [i for i, r in enumerate(rows) if r[0] in ("k_front", "k_obs_query")]
+        if len(begins) >= r0 + rc:
+            lo = begins[r0]; hi = begins[r0 + rc] if len(begins) > r0 + rc else len(rows)
+            rows = rows[lo:hi]
+        else:
+            print(f"# --regime: the run has only {len(begins)} iterations; all launches are used")
     out = {}
-    for name, n, v in cur.execute(q, (counter,)):
-        out[short_name(name)] = (n, v)
+    for name, _, v in rows:
+        n0, v0 = out.get(name, (0, 0.0))
+        out[name] = (n0 + 1, v0 + v)
     return out
 
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("fetch_db"); ap.add_argument("write_db"); ap.add_argument("--scene", default="SCN-C")
     ap.add_argument("--command", default="python3 bench.py --steps 20 --warmup 3 --no-cpu"); ap.add_argument("--out")
+    ap.add_argument("--regime", default=None, help="START:COUNT -- only the launches of these ADMM iterations (303:20 = the timed window of the default bench command)")
     a = ap.parse_args()
-    f, w = per_kernel(a.fetch_db, "FETCH_SIZE"), per_kernel(a.write_db, "WRITE_SIZE")
-    res = {"scene": a.scene, "command": a.command, "source_id": source_id(),
+    regime = tuple(int(x) for x in a.regime.split(":")) if a.regime else None
+    f, w = per_kernel(a.fetch_db, "FETCH_SIZE", regime), per_kernel(a.write_db, "WRITE_SIZE", regime)
+    res = {"scene": a.scene, "command": a.command, "source_id": source_id(), "regime": (f"iterations [{regime[0]}, {regime[0] + regime[1]}) of the run: the timed window" if regime else "all launches of the run (clock ramp and warm-up included)"),
            "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; KB per launch x 1024; FETCH raw (x2 = wide-streaming-read correction of the guide, shown beside it)",
            "kernels": {}}
     for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (1, 0))[1] + w.get(k, (1, 0))[1])):

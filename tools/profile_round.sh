@@ -18,17 +18,19 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python3 $REPO/bench.py $
 DB=$(find $OUT/kt -name '*_results.db' | head -1)
 python3 $REPO/tools/rocpd_timeline.py "$DB" --csv $OUT/kernel_stats.csv --regime 303:20 > $OUT/timeline.txt 2>&1      # statistics over the TIMED window only (300 ramp + 3 warm-up iterations come first)
 python3 $REPO/tools/rocpd_timeline.py "$DB" --csv $OUT/kernel_stats_all_launches.csv > /dev/null 2>&1
+python3 $REPO/tools/rocpd_periter.py "$DB" --regime 303:20 > $OUT/per_iteration.txt 2>&1                               # one row per timed iteration, one column per kernel
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o x -- python3 $REPO/bench.py $ARGS > $OUT/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o x -- python3 $REPO/bench.py $ARGS > $OUT/pw.log 2>&1
 F=$(find $OUT/pf -name '*_results.db' | head -1); W=$(find $OUT/pw -name '*_results.db' | head -1)
 SCENE=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['workload'].split(':')[0])")
-python3 $REPO/tools/pmc_traffic.py "$F" "$W" --scene "$SCENE" --command "python3 bench.py $ARGS" --out $OUT/pmc.json > $OUT/pmc.txt 2>&1
+python3 $REPO/tools/pmc_traffic.py "$F" "$W" --scene "$SCENE" --command "python3 bench.py $ARGS" --regime 303:20 --out $OUT/pmc.json > $OUT/pmc.txt 2>&1      # the TIMED window only, like the kernel statistics
 # 3. SQ counters in their own pass: waves, busy cycles, VALU instructions, cycles some wave waited -- "latency bound" in counters
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY -d $OUT/ps -o x -- python3 $REPO/bench.py $ARGS > $OUT/ps.log 2>&1
 S=$(find $OUT/ps -name '*_results.db' | head -1)
 python3 $REPO/tools/pmc_sq.py "$S" --out $OUT/sq.json > $OUT/sq.txt 2>&1
 # 4. what one wave pays per instruction (the unit of bench.py's critical_path)
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o $OUT/issue_probe $REPO/tools/micro/issue_probe.hip 2>/dev/null && $OUT/issue_probe > $OUT/issue_probe.txt 2>&1; rm -f $OUT/issue_probe
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result -o $OUT/issue_probe $REPO/tools/micro/issue_probe.hip 2>/dev/null && $OUT/issue_probe > $OUT/issue_probe.txt 2>&1; rm -f $OUT/issue_probe
+hipcc -O3 --offload-arch=gfx950 -Wno-unused-result -o $OUT/mem_probe $REPO/tools/micro/mem_probe.hip 2>/dev/null && $OUT/mem_probe > $OUT/mem_probe.txt 2>&1; rm -f $OUT/mem_probe
 rm -rf $OUT/kt $OUT/pf $OUT/pw $OUT/ps      # the databases are large; the summaries are what is kept
 tail -n 3 $OUT/bench.json | cut -c1-600
 head -20 $OUT/timeline.txt
