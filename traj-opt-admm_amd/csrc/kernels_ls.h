@@ -77,7 +77,8 @@ __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_bu
 __device__ __forceinline__ double ls_hull_entry(const Dev& D, const double* basis, const double* net, int idx) {
   const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
   const double* B = basis + (size_t)tr * 36 + j * 6;
-  const double* col = net + (tr / D.res) * 3 + D.T * a;
+  const int piece = (int)(((float)tr + 0.5f) * (1.0f / (float)D.res));   // tr / res for tr < 512 (exact; the integer division by a run-time value is ~40 instructions, and every hull entry pays it)
+  const double* col = net + piece * 3 + D.T * a;
   double acc = 0;
 #pragma unroll
   for (int k = 0; k < 6; k++) acc += B[k] * col[k];
@@ -331,7 +332,10 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
   double* net = sm + L.net; double* dir = sm + L.dir;
   const double* gspline = D.spline + (size_t)u * 3 * T;
   TJ_TIC(D, K_LINESEARCH, 0);
-  for (int i = tid; i < S * 36; i += nth) sm[L.basis + i] = D.basis[i];
+  // plane counts of the first 64 segments: issued FIRST by wave 0 (its scan below is the only dependent step of this phase)
+  int c_no = 0, c_all = 0;
+  if (tid < 64 && tid < S) { c_no = D.ocount[u * S + tid]; c_all = c_no + (D.multi() ? D.scount[u * S + tid] : 0); }
+  if (!L.affine) for (int i = tid; i < S * 36; i += nth) sm[L.basis + i] = D.basis[i];   // (affine layout: the only users of the basis -- hull(x), hull(d) and the published hulls -- read it from global memory)
   for (int i = tid; i < P * 36; i += nth) sm[L.convert + i] = D.convert[i];
   for (int i = tid; i < 18 * P; i += nth) { sm[L.slack + i] = D.p_slack[(size_t)u * 3 * P6 + i]; sm[L.lambda + i] = D.p_lambda[(size_t)u * 3 * P6 + i]; }
   for (int i = tid; i < P; i += nth) { sm[L.tsl + i] = D.t_slack[u * P + i]; sm[L.tla + i] = D.t_lambda[u * P + i]; }
@@ -346,8 +350,8 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
     int run = 0;
     for (int base = 0; base < S; base += 64) {
       const int tr = base + tid;
-      const int no_ = tr < S ? D.ocount[u * S + tr] : 0;
-      const int c = tr < S ? no_ + (D.multi() ? D.scount[u * S + tr] : 0) : 0;
+      const int no_ = base == 0 ? c_no : (tr < S ? D.ocount[u * S + tr] : 0);
+      const int c = base == 0 ? c_all : (tr < S ? no_ + (D.multi() ? D.scount[u * S + tr] : 0) : 0);
       if (tr < S) pref[512 + tr] = no_;   // obstacle planes of the segment: the plane gather below needs no second trip for it
       int x = c;
 #pragma unroll
@@ -480,9 +484,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     const double pt = team ? t0 + step0 * t_dir : t0;
     for (int i = tl; i < 3 * T; i += 256) tnet[i] = team ? net[i] + step0 * dir[i] : net[i];
     if (tid < 2) s_bad[tid] = 0;
-    __syncthreads();
-    if (L.affine) { const double* hn = sm + L.hn; const double* hd = sm + L.hd; for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = team ? hn[idx] + step0 * hd[idx] : hn[idx]; }
-    else for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = ls_hull_entry(D, sm + L.basis, tnet, idx);
+    if (L.affine) { const double* hn = sm + L.hn; const double* hd = sm + L.hd; for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = team ? hn[idx] + step0 * hd[idx] : hn[idx]; }   // (needs nothing of tnet: one barrier for both)
+    else { __syncthreads(); for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = ls_hull_entry(D, sm + L.basis, tnet, idx); }
     __syncthreads();
     TJ_TIC(D, K_LINESEARCH, 3);
     x_energy_team(D, sm, L, tnet, pt, thull, tterms, tcons, &s_bad[team], &res[team], M, tw, gl);
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     double* wh = sm + L.ghull + (size_t)wg * S * 18;
     if (L.affine) {   // the published hulls are exactly basis * (accepted control net), like k_hullinfo's
       const double* win = sm + L.gnet + (size_t)wg * 3 * T;
-      for (int idx = tid; idx < S * 18; idx += LS_THREADS) wh[idx] = ls_hull_entry(D, sm + L.basis, win, idx);
+      for (int idx = tid; idx < S * 18; idx += LS_THREADS) wh[idx] = ls_hull_entry(D, D.basis, win, idx);
       __syncthreads();
     }
     ls_publish_hullinfo(D, u, wh, tid, LS_THREADS);
