@@ -222,18 +222,22 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int prefix_count(unsigned long long m) { return __popcll(m & ((1ull << lane_id()) - 1ull)); }
 
+// a / b for 0 <= a < 2^20, b >= 1, exact: (a + 0.5) / b is at least 0.5 / b away from an integer and the float product is off by less than
+// 0.13 / b.  The integer division by a run-time value is ~40 VALU instructions, and several per-lane index computations (segment ->
+// piece, segment -> sub-segment) sit in front of the first load of a block.
+__device__ __forceinline__ int div_small(int a, int b) { return (int)(((float)a + 0.5f) * (1.0f / (float)b)); }
 // hull of segment tr of a T x 3 column-major control net: out[j*3+a] = sum_k basis[j][k] * net[3*piece+k][a]
 // accumulated in k order from zero, as every variant in the reference does (e.g. Energy_admm.h:116-129)
 __device__ __forceinline__ double hull_entry(const Dev& D, const double* net, int tr, int j, int a) {
   const double* B = D.basis + (size_t)tr * 36 + j * 6;
-  const double* col = net + (tr / D.res) * 3 + D.T * a;
+  const double* col = net + div_small(tr, D.res) * 3 + D.T * a;
   double acc = 0;
 #pragma unroll
   for (int k = 0; k < 6; k++) acc += B[k] * col[k];
   return acc;
 }
 __device__ __forceinline__ double seg_weight(const Dev& D, int tr) {
-  int k = tr % D.res;
+  int k = tr - D.res * div_small(tr, D.res);
   return (k + 1) / double(D.res) - k / double(D.res);
 }
 __device__ __forceinline__ double norm3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }

@@ -77,8 +77,7 @@ __host__ __device__ inline LsLayout ls_layout(int S, int T, int P, size_t lds_bu
 __device__ __forceinline__ double ls_hull_entry(const Dev& D, const double* basis, const double* net, int idx) {
   const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
   const double* B = basis + (size_t)tr * 36 + j * 6;
-  const int piece = (int)(((float)tr + 0.5f) * (1.0f / (float)D.res));   // tr / res for tr < 512 (exact; the integer division by a run-time value is ~40 instructions, and every hull entry pays it)
-  const double* col = net + piece * 3 + D.T * a;
+  const double* col = net + div_small(tr, D.res) * 3 + D.T * a;
   double acc = 0;
 #pragma unroll
   for (int k = 0; k < 6; k++) acc += B[k] * col[k];

@@ -698,7 +698,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     for (int idx = ht; idx < S * 18; idx += XS_HELP) {
       const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
       const double* B = D.basis + (size_t)tr * 36 + j * 6;
-      const int r0 = (tr / D.res) * 3 + T * a;
+      const int r0 = div_small(tr, D.res) * 3 + T * a;
       double p = 0;
 #pragma unroll
       for (int k = 0; k < 6; k++) p += B[k] * netl[r0 + k];
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     for (int idx = tid; idx < S * 18; idx += XS_LOAD_THREADS) {
       const int tr = idx / 18, e = idx % 18, j = e / 3, a = e % 3;
       const double* B = D.basis + (size_t)tr * 36 + j * 6;
-      const int r0 = (tr / D.res) * 3 + T * a;
+      const int r0 = div_small(tr, D.res) * 3 + T * a;
       double p = 0, dh = 0, pd = 0;
 #pragma unroll
       for (int k = 0; k < 6; k++) { p += B[k] * netl[r0 + k]; dh += B[k] * dl[r0 + k]; pd += B[k] * (netl[r0 + k] + dl[r0 + k]); }

@@ -37,7 +37,7 @@ __device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net
   else if (lane < 54) {  // basis * (bz + bz_d), the box the reference uses for the cloud query
     const int j = (lane - 36) / 3, a = (lane - 36) % 3;
     const double* B = D.basis + (size_t)tr * 36 + j * 6;
-    const int r0 = (tr / D.res) * 3 + D.T * a;
+    const int r0 = div_small(tr, D.res) * 3 + D.T * a;
     double acc = 0;
     for (int k = 0; k < 6; k++) acc += B[k] * (net[r0 + k] + dir[r0 + k]);
     PD[lane - 36] = acc;
