@@ -191,12 +191,13 @@ def test_gjk_head_start_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
-                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state
     after several iterations is bitwise the default's.  (TJ_GRAD_NPL=8 forces k_grad's plane batches through several rounds and
-    its HBM staging path, TJ_GRAD_FOLD=0 the one-group k_grad behind a separate compaction.)"""
+    its HBM staging path, TJ_GRAD_FOLD=0 the one-group k_grad behind a separate compaction; TJ_LS_HELP: blocks per robot in the line
+    search, 1 = none -- the default on this fleet is 8; TJ_LS_HELP_MUTE=1: helpers that never post, every primary times out and goes on alone.)"""
     scene = scenes.crossing(24, 6000, seed=17, name="crossing-U24-switches")
     for k in env:
         monkeypatch.delenv(k, raising=False)
@@ -204,7 +205,7 @@ def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     b = pkg.Solver(scene, stop=0.0)
-    n_it = 30 if "TJ_LS_FAST" in env else 6    # the team shape of the line search's round 0 only starts once robots accept the full step
+    n_it = 30 if any(k.startswith("TJ_LS_") for k in env) else 6    # the line search: through the back-off iterations of the start and into the steady phase (the default here is 8 blocks per robot)
     a.iterate(n_it); b.iterate(n_it)
     sa, sb = a.get_state(), b.get_state()
     for n in sa:

@@ -87,6 +87,10 @@ enum { K_BEGIN = 0, K_HULLINFO, K_FRONT, K_SEP_OBS /* k_obs_query */, K_SEP_SELF
        K_CCD_PREP, K_CCD, K_CCD_OBS, K_CCD_SELF_PAIRS, K_CCD_SELF_SEQ, K_LINESEARCH,
        K_LS_COUPLED, K_LS_COMMIT,   // coupled mode only
        K_SLACK, K_COUNT };
+constexpr int LS_HELP_MAX = 8;                 // k_linesearch: at most this many blocks per robot (16 candidates per super-round)
+constexpr int LS_TAB_STRIDE = 3 * LS_HELP_MAX * 2;   // Dev::ls_tab per robot: three rotating sets (super-round % 3) of LS_HELP_MAX blocks x 2 candidates
+constexpr unsigned LS_WORD_DONE = 0x7fffffffu;
+constexpr unsigned long long LS_TAB_EMPTY = ~0ull;   // a NaN no evaluation produces (and a false "empty" only sends the primary to its own evaluation)
 constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates evaluated per launch (steps 0.8^0 .. 0.8^30)
 
 // Phase stamps for kernel tuning: compiled in only by `make timing` (-DTJ_PHASE_TIMING); thread 0 of
@@ -205,6 +209,11 @@ struct Dev {
   double *step_out;               // [U] accepted Armijo step (diagnostics)
   int *ls_hist; int ls_fast;      // [U] Armijo exponent each robot accepted in the previous iteration (-1: none yet) -- k_linesearch evaluates round 0 in the
                                   // team shape for a robot that took the full step last time (kernels_ls.h: x_energy_team); ls_fast = 0 (TJ_LS_FAST=0): never (same bits)
+  // helper workgroups of k_linesearch (kernels_ls.h, "super-rounds"): with fewer robots than compute units the launch carries ls_help blocks per
+  // robot; block h of a robot evaluates candidates 2h-1 and 2h of a super-round in the team shape on a CU of its own and posts the two energies.
+  int ls_help, ls_help_mute;      // blocks per robot (1 = none); host: compute units / owned robots, at most LS_HELP_MAX.  ls_help_mute (TJ_LS_HELP_MUTE=1, test hook): helpers leave at once
+  double *ls_tab;                 // [U][3][LS_HELP_MAX][2] posted energies (set = super-round % 3) (all-ones = not there yet; reset by begin_body and, between super-rounds, by the robot's primary block)
+  unsigned long long *ls_word;    // [U] (epoch << 32) | super-round the primary asks for (LS_WORD_DONE: the search is over, helpers leave)
   double *ccdinfo;                // [U][S][CCD_STRIDE] swept-hull cache of the current direction
   int *pair_list;                 // [ACT_CAP] inter-robot CCD: keys (segment, p0, p1) of the pairs within `offset` at full step; Ctl::any_pair counts them
   // per-(robot, segment) statistics slots {nodes_dcd, cand_dcd, nodes_ccd, cand_ccd, planes_obs, planes_self}:

@@ -225,8 +225,11 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
 // (stages_stack030) rely on.  Both teams run this in lock step (uniform trip counts; a violated limit does not leave early here).
 struct LsTeamUnits { int nv, na, np; __device__ int total() const { return nv + na + np; } };
 __device__ __forceinline__ LsTeamUnits ls_team_units(int S, int M) { return LsTeamUnits{(5 * S + 63) / 64, (4 * S + 63) / 64, (6 * M + 63) / 64}; }
+// abort_word (helper blocks running a super-round ahead of the primary's word, k_linesearch): thread 0 of the block reads the robot's word once,
+// mid-evaluation, and if the search is over by then (LS_WORD_DONE of this epoch) every wave leaves at the barrier -- *s_abort says so, the value is not used.
 __device__ __forceinline__ double x_energy_team(const Dev& D, const double* sm, const LsLayout& L, const double* net, double pt, const double* hulls, double* terms,
-                                                double* cons, int* bad_flag, double* out, int M, int tw, int gl) {
+                                                double* cons, int* bad_flag, double* out, int M, int tw, int gl,
+                                                const unsigned long long* abort_word = nullptr, unsigned epoch = 0, int* s_abort = nullptr) {
   const int S = D.S, T = D.T;
   const double* wsg = sm + L.wseg;
   const double m = D.margin;
@@ -234,7 +237,9 @@ __device__ __forceinline__ double x_energy_team(const Dev& D, const double* sm, 
   const double* pl_lds = sm + L.planes;
   const int* pltr = (const int*)(sm + L.pltr);
   int bad = 0;
+  unsigned long long w_abort = 0;
   for (int unit = tw; unit < U4.total(); unit += 4) {
+    if (abort_word && threadIdx.x == 0 && unit + 4 >= U4.total()) w_abort = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // before this wave's last unit; used at the barrier
     double term = 0.0;
     if (unit < U4.nv) {
       const int it = gl + 64 * unit;
@@ -304,8 +309,10 @@ __device__ __forceinline__ double x_energy_team(const Dev& D, const double* sm, 
       t[5] = sm[L.tla + sp] * (pt - sm[L.tsl + sp]);
     }
   }
+  if (abort_word && threadIdx.x == 0) *s_abort = (unsigned)(w_abort >> 32) == epoch && (unsigned)w_abort == LS_WORD_DONE;
   __syncthreads();
   double e = 0;
+  if (abort_word && *s_abort) return e;   // (uniform)
   if (tw == 0) {
     double part = 0, partb = 0;
     for (int u = 0; u < U4.nv + U4.na; u++) partb += terms[u * 64 + gl];
@@ -430,6 +437,7 @@ __device__ __forceinline__ void begin_body(const Dev& D) {
   if (threadIdx.x == 0) *D.obs_work_n = 0;
   if (threadIdx.x < 3 && D.multi()) D.pair_ovf[threadIdx.x] = 0;
   if (threadIdx.x < 16) D.ctl->ccd_sub[threadIdx.x] = 0;   // arrival counters of k_ccd's selection blocks (folded pair replay)
+  if (D.ls_help > 1) for (int i = threadIdx.x; i < (D.u1 - D.u0) * LS_TAB_STRIDE; i += blockDim.x) ((unsigned long long*)D.ls_tab)[(size_t)D.u0 * LS_TAB_STRIDE + i] = LS_TAB_EMPTY;   // k_linesearch's helper posts
   if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
 }
 
@@ -446,7 +454,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   __shared__ int pref[1024];   // plane prefix per segment (S <= 511 checked on the host); [512 + tr]: obstacle planes of segment tr
   __shared__ int s_accept;
   __shared__ int s_bad[2];
-  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
+  __shared__ int s_flag;        // super-rounds: 0 = go on, 1 = leave the team loop
+  __shared__ int s_abort;       // super-rounds, helper ahead of the word: the search ended during this evaluation
+  __shared__ double s_accst;    // super-rounds: step of the accepted candidate
+  // ls_help blocks per robot (super-rounds, below): block h of robot ui is blockIdx = ui + h * owned -- the primaries (h = 0) lead the grid
+  const int nown = D.u1 - D.u0, H = D.ls_help;
+  const int h = H > 1 ? (int)blockIdx.x / nown : 0;
+  const int tid = threadIdx.x, u = D.u0 + (int)blockIdx.x - h * nown, S = D.S, T = D.T, P = D.P;
   // G = L.groups candidates per round.  With G < 8 (long trajectories) the waves beyond G shadow the last group: they compute
   // the same candidate into the same buffers (identical values), which keeps every barrier uniform.
   const int G = L.groups;
@@ -470,36 +484,150 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   double e_base = 0, step_acc = step0, pt_acc = t0;
   int k_acc = -1, evals = 0, wg = 0;
   int k_first = -1;   // candidate of group 0 in the next generic round: -1 = E(x) is still to be evaluated (it is group 0's job in that round)
-  // Round 0 in the TEAM shape (x_energy_team): waves 0-3 evaluate E(x), waves 4-7 candidate 0 -- for a robot that accepted the full step
-  // in the previous iteration (hist == 0; in the steady phase of a run that is nearly every robot, every iteration).  If candidate 0 fails
-  // the search goes on with candidates 1, 2, ... in the one-wave-per-candidate rounds below; the accepted step is the reference's either way.
+  // Rounds in the TEAM shape (x_energy_team): waves 0-3 evaluate one candidate, waves 4-7 the next.
+  //  * one block per robot (ls_help = 1: fleets of more robots than compute units): round 0 only -- E(x) and candidate 0 -- for a robot that
+  //    accepted the full step in the previous iteration (hist == 0; in the steady phase of a run that is nearly every robot, every iteration).
+  //  * SUPER-ROUNDS (ls_help = H > 1: a fleet that leaves compute units idle, 64 robots on 256 CUs): the launch carries H blocks per robot,
+  //    each on a CU of its own.  In super-round sr block h evaluates candidates 2 (h + H sr) - 1 and 2 (h + H sr) (candidate -1 = E(x): the
+  //    primary's, h = 0, in super-round 0), so one super-round decides 2H candidates in the time of ONE team evaluation (3.8 us where a
+  //    one-wave evaluation takes 8 - 10): the early iterations of a run, which back off 7 - 14 times on the velocity limit, take two super-rounds
+  //    instead of two or three rounds of eight one-wave evaluations, and no robot waits for a history.  Helpers only EVALUATE: each posts its two
+  //    energies (agent-scope stores into Dev::ls_tab; all-ones = not there yet) and then waits for the primary's word -- the next super-round
+  //    or the end.  The primary walks the candidates in the reference's order (its own two, then the helpers' as they stand in the table), takes
+  //    the first that passes and commits alone; it never depends on a helper: a post that is not there 10 us after its own evaluation (a GPU shared
+  //    with another process, helpers not resident) sends it to the one-wave rounds below.  The order of stores that makes this safe:
+  //    the primary's DONE word is performed (write-through, waited for) BEFORE any of its commit stores is issued, and a helper reads the word
+  //    AFTER its staging loads have returned -- a helper that started late either sees DONE and leaves or has staged the state of before the commit.
+  //    E(.) is a pure function of its inputs in either shape (bitwise: TJ_LS_FAST=0 / TJ_LS_HELP=1 change no bit), so it does not matter who evaluated what.
   const LsTeamUnits tu = ls_team_units(S, M);
-  if (D.ls_fast && hist == 0 && G == LS_GROUPS && in_lds && tu.total() * 64 <= 2 * S * 18) {
+  const bool team_ok = D.ls_fast && G == LS_GROUPS && in_lds && tu.total() * 64 <= 2 * S * 18;
+  const bool coop = team_ok && H > 1;
+  double step = step0; int k_done = 0;                 // step = step0 * 0.8^k_done, kept across the rounds (each thread for the candidates of its team / group)
+  bool commit_late = false;
+  if (h > 0 && (!coop || D.ls_help_mute)) goto ticket;  // (uniform) a helper of a launch that searches in the one-wave shape: nothing to do  (ls_help_mute: test hook -- helpers
+                                                        // that never post; every primary then runs into its 10 us timeout and finishes on its own)
+  if (team_ok && (coop || hist == 0)) {
     const int team = tid >> 8, tw = (tid >> 6) & 3, tl = tid & 255;
     double* tnet = sm + L.gnet + (size_t)(4 * team) * 3 * T;
     double* thull = sm + L.ghull + (size_t)(4 * team) * S * 18;
     double* tterms = sm + L.ghull + (size_t)(4 * team + 1) * S * 18;   // the buffers of the team's groups 1 and 2: 2 * S * 18 doubles
     double* tcons = sm + L.gcons + (size_t)(4 * team) * 24 * P;
-    const double pt = team ? t0 + step0 * t_dir : t0;
-    for (int i = tl; i < 3 * T; i += 256) tnet[i] = team ? net[i] + step0 * dir[i] : net[i];
-    if (tid < 2) s_bad[tid] = 0;
-    if (L.affine) { const double* hn = sm + L.hn; const double* hd = sm + L.hd; for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = team ? hn[idx] + step0 * hd[idx] : hn[idx]; }   // (needs nothing of tnet: one barrier for both)
-    else { __syncthreads(); for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = ls_hull_entry(D, sm + L.basis, tnet, idx); }
-    __syncthreads();
-    TJ_TIC(D, K_LINESEARCH, 3);
-    x_energy_team(D, sm, L, tnet, pt, thull, tterms, tcons, &s_bad[team], &res[team], M, tw, gl);
-    __syncthreads();
-    TJ_TIC(D, K_LINESEARCH, 4);
-    e_base = res[0];
-    k_first = 1;   // E(x) is known, candidate 0 has been looked at
-    if (!(e_base - 1e-4 * wolfe * step0 < res[1])) {
-      k_acc = 0; step_acc = step0; pt_acc = t0 + step0 * t_dir; evals = 2; wg = 4;
-      const double* win = sm + L.gnet + (size_t)4 * 3 * T;   // team 1's trial net = group 4's buffer
-      for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+    const unsigned epoch = (unsigned)D.ctl->epoch;
+    unsigned long long* word = D.ls_word + u;
+    double* tab = D.ls_tab + (size_t)u * LS_TAB_STRIDE;   // three sets of LS_HELP_MAX x 2 slots: super-round sr uses set sr % 3
+    // late-start guard of a helper (see above): the word is read now -- the staging barriers are behind us, every load of ls_stage has returned -- and
+    // looked at before the first post (the round trip hides behind the evaluation)
+    unsigned long long w_guard = 0;
+    if (h > 0 && tid == 0) w_guard = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int sr = 0;; sr++) {
+      const int kb = 2 * (h + H * sr) - 1, k = kb + team;   // this block's two candidates of the super-round
+      if (kb + 2 * H >= STEP_CAP) {   // (uniform; never in practice) the tail of a search that ends by rounding belongs to the one-wave rounds and their cap
+        if (h > 0) break;
+        if (tid == 0) { __hip_atomic_store(word, ((unsigned long long)epoch << 32) | LS_WORD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_s_waitcnt(0); }
+        k_first = kb;
+        break;
+      }
+      for (; k_done < k; k_done++) step *= 0.8;          // same rounding as the reference's repeated step *= 0.8
+      const double pt = k < 0 ? t0 : t0 + step * t_dir;
+      for (int i = tl; i < 3 * T; i += 256) tnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
+      if (tid < 2) s_bad[tid] = 0;
+      if (L.affine) { const double* hn = sm + L.hn; const double* hd = sm + L.hd; for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = k < 0 ? hn[idx] : hn[idx] + step * hd[idx]; }   // (needs nothing of tnet: one barrier for both)
+      else { __syncthreads(); for (int idx = tl; idx < S * 18; idx += 256) thull[idx] = ls_hull_entry(D, sm + L.basis, tnet, idx); }
+      __syncthreads();
+      if (sr == 0) TJ_TIC(D, K_LINESEARCH, 3);
+      const bool ahead = h > 0 && sr > 0;   // a helper beyond super-round 0 runs ahead of the primary's decision over the round before (below) and leaves mid-evaluation once the search is over
+      x_energy_team(D, sm, L, tnet, pt, thull, tterms, tcons, &s_bad[team], &res[team], M, tw, gl, ahead ? word : nullptr, epoch, &s_abort);
+      if (tl == 0) res[LS_GROUPS + team] = step;
+      __syncthreads();
+      if (ahead && s_abort) break;
+      if (sr == 0) TJ_TIC(D, K_LINESEARCH, 4);
+      const int set = (sr % 3) * LS_HELP_MAX * 2;
+      if (h > 0) {   // helper: post, then wait for the primary's word
+        if (sr == 0) {
+          if (tid == 0) s_accept = (unsigned)(w_guard >> 32) == epoch && (unsigned)w_guard == LS_WORD_DONE;   // (its own word: s_flag is rewritten below without a barrier in between)
+          __syncthreads();
+          if (s_accept) break;
+        }
+        if (tl == 0) __hip_atomic_store(tab + set + 2 * h + team, res[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The word permits round sr + 1 as soon as the primary's own two candidates of round sr have failed -- before it has read our posts: that
+        // evaluation runs ahead of the decision and is left at its barrier if the search ends meanwhile (x_energy_team: abort_word).
+        if (tid == 0) {
+          const long long t_end = wall_clock64() + 500000;   // 5 ms: a logic error must not hang the device
+          int leave = 0;
+          for (;;) {
+            const unsigned long long w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == epoch) { if ((unsigned)w == LS_WORD_DONE) { leave = 1; break; } if ((unsigned)w > (unsigned)sr) break; }
+            if (wall_clock64() > t_end) { leave = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          s_flag = leave;
+        }
+        __syncthreads();
+        if (s_flag) break;
+        continue;
+      }
+      // primary: the first candidate that passes, in the reference's order
+      if (sr == 0) e_base = res[0];
+      if (tid < 64) {
+        int acc_k = -1, giveup = H == 1 ? 1 : 0; double acc_st = 0;
+        for (int c = sr == 0 ? 1 : 0; c < 2 && acc_k < 0; c++) { const double st = res[LS_GROUPS + c]; if (!(e_base - 1e-4 * wolfe * st < res[c])) { acc_k = kb + c; acc_st = st; } }
+        if (sr == 0) TJ_TIC(D, K_LS_COUPLED, 0);
+        if (acc_k < 0 && H > 1) {
+          // Our own two failed: PERMIT round sr + 1 at once (word = sr + 1) -- the helpers start it while we look at their posts of this round; if one of those
+          // passes, they leave mid-evaluation.  (The set round sr + 1 posts into was emptied at the end of round sr - 2: long performed, the wait is free.)
+          __builtin_amdgcn_s_waitcnt(0);
+          if (tid == 0) __hip_atomic_store(word, ((unsigned long long)epoch << 32) | (unsigned)(sr + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          double v = 0.0;
+          const long long t_end = wall_clock64() + 1000;   // 10 us
+          for (;;) {
+            const bool mine = tid >= 2 && tid < 2 * H;
+            if (mine) v = __hip_atomic_load(tab + set + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(mine && (unsigned long long)__double_as_longlong(v) == LS_TAB_EMPTY) == 0ull) break;
+            if (wall_clock64() > t_end) { giveup = 1; break; }
+          }
+          if (!giveup) {
+            double st = res[LS_GROUPS + 1];
+            for (int l = 2; l < 2 * H; l++) {
+              st *= 0.8;
+              const double e = __shfl(v, l);
+              if (acc_k < 0 && !(e_base - 1e-4 * wolfe * st < e)) { acc_k = kb + l; acc_st = st; }
+            }
+          }
+        }
+        if (sr == 0) TJ_TIC(D, K_LS_COUPLED, 1);
+        if (H > 1) {
+          if (acc_k < 0 && !giveup) {   // on to the next super-round: empty the set just read -- it is round sr + 3's (not waited for: the permit of round sr + 2 will)
+            if (tid >= 2 && tid < 2 * H) __hip_atomic_store((unsigned long long*)tab + set + tid, LS_TAB_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            if (tid == 0) __hip_atomic_store(word, ((unsigned long long)epoch << 32) | LS_WORD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (giveup) __builtin_amdgcn_s_waitcnt(0);   // the one-wave rounds commit on their own: the word is performed before they start
+          }
+        }
+        if (tid == 0) { s_accept = acc_k; s_accst = acc_st; s_flag = giveup; }
+        if (sr == 0) TJ_TIC(D, K_LS_COUPLED, 2);
+      }
+      __syncthreads();
+      if (sr == 0) TJ_TIC(D, K_LS_COUPLED, 3);
+      const int acc = s_accept;
+      if (acc >= 0) {
+        k_acc = acc; step_acc = s_accst; pt_acc = t0 + step_acc * t_dir; evals = 2 + k_acc;
+        if (acc - kb < 2) wg = 4 * (acc - kb);   // the accepting team's buffers hold the trial net (and its hulls)
+        else {                                     // a helper's candidate: form its net here (same expression, same bits)
+          wg = 4;
+          double* wnet = sm + L.gnet + (size_t)4 * 3 * T;
+          for (int i = tid; i < 3 * T; i += LS_THREADS) wnet[i] = net[i] + step_acc * dir[i];
+          __syncthreads();
+          if (!L.affine) { double* whl = sm + L.ghull + (size_t)4 * S * 18; for (int idx = tid; idx < S * 18; idx += LS_THREADS) whl[idx] = ls_hull_entry(D, sm + L.basis, wnet, idx); }
+        }
+        TJ_TIC(D, K_LS_COUPLED, 4);
+        commit_late = true;   // the control net is stored after the hull cache (below): the DONE word has been performed by then
+        __syncthreads();
+        break;
+      }
+      if (s_flag) { k_first = kb + 2; break; }   // E(x) is known, the candidates up to kb + 1 have been looked at: one-wave rounds from here
     }
-    __syncthreads();
+    if (h > 0) goto ticket;
   }
-  double step = step0; int k_done = 0;                 // step = step0 * 0.8^k_done, kept across the rounds (a round adds G factors)
   for (int round = 0; k_acc < 0; round++, k_first += G) {
     // candidate of this group: -1 = E(x), otherwise trial index k >= 0
     const int k = k_first + g;
@@ -554,8 +682,16 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     }
     ls_publish_hullinfo(D, u, wh, tid, LS_THREADS);
   }
+  TJ_TIC(D, K_LS_COUPLED, 5);
+  if (commit_late) {   // (uniform) accepted in a team round: commit now -- with helpers about, wave 0's DONE word must have been performed before the first of these stores is issued
+    if (H > 1) { if (tid < 64) __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
+    const double* win = sm + L.gnet + (size_t)wg * 3 * T;
+    for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+  }
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; D.ls_hist[u] = k_acc; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)evals; }   // per robot: one writer, no atomic in front of the ticket
+ticket:
+  if (h > 0) __builtin_amdgcn_s_waitcnt(0);   // a helper's posts are performed before its ticket: begin_body's reset of the table cannot be overtaken by them
   if (begin_next) {
     // No fence: nothing another block of THIS kernel writes is read here (gnorm and the counters come from earlier kernels;
     // what begin_body resets was consumed by every block before its ticket), and what is written here is read by later

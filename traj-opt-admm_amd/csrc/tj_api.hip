@@ -199,7 +199,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if ((in_graph || in_phase) && d.seq_fold && !(c->split_unions && multi)) return false;   // the last block of k_ccd has done it
       if (!multi && in_graph) return false;   // single UAV: no pairs to replay, and k_xsolve has left gnorm = |g| itself -- one launch less in the chain
       hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
-    case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
+    case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED: if (coupled) for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r); return coupled;
     case K_LS_COMMIT: if (coupled) hipLaunchKernelGGL(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;
@@ -497,6 +497,14 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if (const char* e = getenv("TJ_HS_MIN")) d.spec_min = std::max(1, atoi(e));
   d.ls_fast = 1;
   if (const char* e = getenv("TJ_LS_FAST")) d.ls_fast = atoi(e) != 0;   // launch-shape switch (same bits): round 0 of k_linesearch in the team shape
+  {   // helper blocks of k_linesearch: one CU each, so as many per robot as the device has compute units to spare (64 robots on 256 CUs: 4)
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, p->device));
+    const int owned = std::max(1, d.u1 - d.u0);
+    d.ls_help = (d.ls_fast && p->mode != TJ_MODE_MULTI_COUPLED) ? std::max(1, std::min(LS_HELP_MAX, prop.multiProcessorCount / owned)) : 1;
+    if (const char* e = getenv("TJ_LS_HELP")) d.ls_help = std::max(1, std::min(LS_HELP_MAX, atoi(e)));   // launch-shape switch (same bits); 1 = no helpers
+    if (const char* e = getenv("TJ_LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
+  }
   if (c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double) > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
     return TJ_ERR_UNSUPPORTED;
@@ -531,7 +539,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.oplanes, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ocount, U * S)) ||
       (r = dalloc(c, &d.splanes, U * S * d.cap_self * 4)) || (r = dalloc(c, &d.scount, U * S)) ||
       (r = dalloc(c, &d.lg, U * P * 19)) || (r = dalloc(c, &d.lh, U * P * 361)) || (r = dalloc(c, &d.xdir, U * d.xs)) ||
-      (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) || (r = dalloc(c, &d.ls_hist, U)) ||
+      (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) || (r = dalloc(c, &d.ls_hist, U)) || (r = dalloc(c, &d.ls_tab, U * LS_TAB_STRIDE)) || (r = dalloc(c, &d.ls_word, U)) ||
       (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, ACT_CAP)) ||
       (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) || (r = dalloc(c, &d.blk_stats, U * P + U)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
@@ -744,6 +752,8 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemsetAsync(d.pair_stats, 0, (size_t)U * d.S * 2 * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(d.blk_stats, 0, ((size_t)U * d.P + U) * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(d.ls_hist, 0xff, (size_t)U * 4, c->stream));   // -1: no line search yet
+  HIPCHK(c, hipMemsetAsync(d.ls_tab, 0xff, (size_t)U * LS_TAB_STRIDE * 8, c->stream));   // LS_TAB_EMPTY
+  HIPCHK(c, hipMemsetAsync(d.ls_word, 0, (size_t)U * 8, c->stream));                        // (the words carry the epoch, which restarts at 1)
   if (d.mode >= 1) HIPCHK(c, hipMemsetAsync(d.pairstamp, 0, (size_t)d.S * U * U * 4, c->stream));  // epochs restart at 1
   HIPCHK(c, hipMemsetAsync(d.pair_ovf_list, 0, ((size_t)d.cap_work + PAIR_CONSUMERS_MAX) * 8, c->stream));                  // (entries are tagged with the epoch)
   HIPCHK(c, hipMemsetAsync(d.pair_ovf, 0, 16, c->stream));
