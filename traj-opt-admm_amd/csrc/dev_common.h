@@ -56,7 +56,8 @@ struct Ctl {
   int slack_next;      // the iteration that k_begin just started still owes its slack/dual update
   int any_pair;        // robot pairs within `offset` at full step this iteration (entries of Dev::pair_list): work of the sequential CCD replay
   int order_unresolved; // segments whose pair order mattered but could not be replayed in the reference's tree order
-  int ticket;          // k_linesearch blocks that have finished (the last one does the next iteration's k_begin work)
+  int ticket;          // k_linesearch blocks that have finished (the last one does the next iteration's k_begin work); + 65536 per robot that backed off
+  int ls_quiet;        // iterations in a row in which every robot accepted the full step (k_linesearch: helpers stay home from LS_QUIET_ITERS on)
   int gjk_prev;        // gjk_max of the iteration before the running one (k_begin): the GJK head start's threshold follows it
 
   double gnorm;        // reference global `gnorm`
@@ -90,6 +91,7 @@ enum { K_BEGIN = 0, K_HULLINFO, K_FRONT, K_SEP_OBS /* k_obs_query */, K_SEP_SELF
 constexpr int LS_HELP_MAX = 8;                 // k_linesearch: at most this many blocks per robot (16 candidates per super-round)
 constexpr int LS_TAB_STRIDE = 3 * LS_HELP_MAX * 2;   // Dev::ls_tab per robot: three rotating sets (super-round % 3) of LS_HELP_MAX blocks x 2 candidates
 constexpr unsigned LS_WORD_DONE = 0x7fffffffu;
+constexpr int LS_QUIET_ITERS = 8;
 constexpr unsigned long long LS_TAB_EMPTY = ~0ull;   // a NaN no evaluation produces (and a false "empty" only sends the primary to its own evaluation)
 constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates evaluated per launch (steps 0.8^0 .. 0.8^30)
 

@@ -416,7 +416,10 @@ __device__ __forceinline__ void ls_publish_hullinfo(const Dev& D, int u, const d
 
 // The work of k_begin, callable by any workgroup: the standalone kernel runs it before the first iteration of a batch, the
 // last k_linesearch block to finish runs it for the NEXT iteration of the same batch (one kernel boundary less per iteration).
-__device__ __forceinline__ void begin_body(const Dev& D) {
+// quiet: 1 = every robot accepted the full step (exponent 0) in the line search that has just ended (k_linesearch's tickets carry the information; the
+// standalone k_begin, which follows no line search of its batch, says 0): Ctl::ls_quiet counts such iterations in a row, and k_linesearch sends its helper
+// blocks home while the count stands at LS_QUIET_ITERS or more.
+__device__ __forceinline__ void begin_body(const Dev& D, int quiet = 0) {
   // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
   __shared__ int done;
   if (threadIdx.x == 0) {
@@ -429,6 +432,7 @@ __device__ __forceinline__ void begin_body(const Dev& D) {
     D.ctl->iter = h.iter; D.ctl->pending = h.pending; D.ctl->slack_now = h.slack_now; D.ctl->slack_next = h.slack_next;
     D.ctl->done = h.done; D.ctl->epoch = h.epoch; D.ctl->any_pair = 0;   // error bits and counters are only ever touched by atomics elsewhere
     D.ctl->gjk_max_sum = h.gjk_max_sum + (unsigned long long)h.gjk_max; D.ctl->gjk_prev = h.gjk_max; D.ctl->gjk_max = 0;
+    D.ctl->ls_quiet = quiet ? min(h.ls_quiet + 1, 1 << 20) : 0;
   }
   __syncthreads();
   if (done) return;
@@ -458,8 +462,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   __shared__ int s_abort;       // super-rounds, helper ahead of the word: the search ended during this evaluation
   __shared__ double s_accst;    // super-rounds: step of the accepted candidate
   // ls_help blocks per robot (super-rounds, below): block h of robot ui is blockIdx = ui + h * owned -- the primaries (h = 0) lead the grid
-  const int nown = D.u1 - D.u0, H = D.ls_help;
-  const int h = H > 1 ? (int)blockIdx.x / nown : 0;
+  // In the steady phase of a run (every robot takes the full step, iteration after iteration) the helpers have nothing to contribute and cost ~1 us per
+  // launch (their tickets, the table's reset): after LS_QUIET_ITERS such iterations in a row they leave at once and the primaries search on their own
+  // (H = 1 below) until a robot backs off again.
+  const int nown = D.u1 - D.u0;
+  const int H = (D.ls_help > 1 && D.ctl->ls_quiet < LS_QUIET_ITERS) ? D.ls_help : 1;
+  const int h = D.ls_help > 1 ? (int)blockIdx.x / nown : 0;
+  if (h > 0 && H == 1) return;   // (no ticket: the primaries count among themselves then)
   const int tid = threadIdx.x, u = D.u0 + (int)blockIdx.x - h * nown, S = D.S, T = D.T, P = D.P;
   // G = L.groups candidates per round.  With G < 8 (long trajectories) the waves beyond G shadow the last group: they compute
   // the same candidate into the same buffers (identical values), which keeps every barrier uniform.
@@ -699,11 +708,15 @@ ticket:
     // XCD's L2 -- ~40 KB of hull cache per block -- from every block: measured +14 us.)
     __shared__ int s_last;
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&D.ctl->ticket, 1) == (int)gridDim.x - 1;
+    // the ticket also says whether this robot backed off (bit 16 up): the last block knows it of every robot without reading anything another block wrote
+    if (tid == 0) {
+      const int add = 1 + ((h == 0 && k_acc != 0) ? 0x10000 : 0), old = atomicAdd(&D.ctl->ticket, add);
+      s_last = (old & 0xffff) == nown * H - 1 ? 1 + (((old + add) >> 16) != 0) : 0;
+    }
     __syncthreads();
     if (s_last) {
       if (tid == 0) D.ctl->ticket = 0;
-      begin_body(D);
+      begin_body(D, s_last == 1);
     }
   }
   TJ_TIC(D, K_LINESEARCH, 6);
