@@ -16,7 +16,7 @@ out = np.zeros((len(names), 65536, 8), dtype=np.int64)
 lib.tj_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
 lib.tj_debug_phase_times(s._ctx, out.ctypes.data)
 # (kernel, slot of the first stamp of a block, slots that may hold its last stamp)
-spec = [("k_front", 0, [1]), ("k_mid", 0, [1]), ("k_grad", 7, [6]), ("k_xsolve", 7, [6]), ("k_ccd", 0, [1, 2]), ("k_linesearch", 7, [5, 6])]
+spec = [("k_front", 0, [1]), ("k_mid", 0, [1]), ("k_grad", 7, [6]), ("k_xsolve", 7, [4, 6]), ("k_ccd", 0, [1, 2]), ("k_linesearch", 7, [5, 6])]
 rows = []
 for n, s0, ends in spec:
     t = out[names.index(n)]

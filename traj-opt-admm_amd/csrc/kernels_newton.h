@@ -791,6 +791,8 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   }
 #ifdef TJ_PHASE_LIGHT
   __builtin_amdgcn_s_waitcnt(0);   // the stamp after the block's stores have been acknowledged
+  TJ_STAMP_(D, K_XSOLVE, 4, XS_LOAD_THREADS - 1);   // ... and the last helper wave's: its interval pairs end ~2 us after wave 0's part (the tail is bound by the
+                                                    // CU's fp64 issue rate: 1 960 interval pairs x 6 points x ~14 instructions on seven waves -- measured, round 4)
 #endif
   TJ_TIC(D, K_XSOLVE, 6);
 }
