@@ -191,13 +191,14 @@ def test_gjk_head_start_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
-                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_GRAD_BALANCE": "1"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state
     after several iterations is bitwise the default's.  (TJ_GRAD_NPL=8 forces k_grad's plane batches through several rounds and
     its HBM staging path, TJ_GRAD_FOLD=0 the one-group k_grad behind a separate compaction; TJ_LS_HELP: blocks per robot in the line
-    search, 1 = none -- the default on this fleet is 8; TJ_LS_HELP_MUTE=1: helpers that never post, every primary times out and goes on alone.)"""
+    search, 1 = none -- the default on this fleet is 8; TJ_GRAD_BALANCE=1: k_grad's blocks in the order of their last durations, which this
+    fleet of 24 x 5 blocks on 256 units does not switch on by itself; TJ_LS_HELP_MUTE=1: helpers that never post, every primary times out and goes on alone.)"""
     scene = scenes.crossing(24, 6000, seed=17, name="crossing-U24-switches")
     for k in env:
         monkeypatch.delenv(k, raising=False)

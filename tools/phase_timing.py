@@ -56,7 +56,8 @@ def main():
     if live.any():
         t0 = t[live, 0].min(); n_obs = scene["U"] * scene["P"] * 8
         n_hs = 128 if (scene["mode"] >= 1 and os.environ.get("TJ_PAIR_HEAD_START", "1") != "0") else 0   # GJK head-start blocks lead the grid
-        for lab, lo, hi in (("gjk head start", 0, n_hs), ("obstacle query", n_hs, n_hs + n_obs), ("pair rows", n_hs + n_obs, 65536)):
+        n_ord = (scene["U"] * scene["P"] + 63) // 64 if 256 < scene["U"] * scene["P"] < 512 else 0   # k_grad's launch-order blocks lead the grid (Dev::grad_bal; 256 compute units)
+        for lab, lo, hi in (("k_grad order", 0, n_ord), ("gjk head start", n_ord, n_ord + n_hs), ("obstacle query", n_ord + n_hs, n_ord + n_hs + n_obs), ("pair rows", n_ord + n_hs + n_obs, 65536)):
             sel = live.copy(); sel[:lo] = False; sel[hi:] = False
             if sel.any():
                 st = (t[sel, 0] - t0) * 0.01; en = (t[sel, 1] - t0) * 0.01; du = en - st

@@ -213,6 +213,12 @@ struct Dev {
                                   // team shape for a robot that took the full step last time (kernels_ls.h: x_energy_team); ls_fast = 0 (TJ_LS_FAST=0): never (same bits)
   // helper workgroups of k_linesearch (kernels_ls.h, "super-rounds"): with fewer robots than compute units the launch carries ls_help blocks per
   // robot; block h of a robot evaluates candidates 2h-1 and 2h of a super-round in the team shape on a CU of its own and posts the two energies.
+  // k_grad's launch order (kernels_newton.h, grad_order_body): with more (robot, piece) blocks than compute units but fewer than twice as many, the
+  // blocks beyond the first `num_cu` share a CU with an older block and run ~20 % slower (the SIMD issues its oldest wave first) -- they set the kernel's
+  // length.  Every block leaves the wall-clock ticks it took; the next iteration's k_front ranks them and hands the late positions (and their
+  // CU mates) to the cheapest items.  Which block computes which item changes no bit of any item.
+  int grad_bal, num_cu;           // 1: k_grad maps blockIdx -> item through grad_perm; compute units of the device
+  int *grad_cost, *grad_perm;     // [owned * P] ticks of the item's last block; [owned * P] item of launch position b (always a permutation: identity at the start)
   int ls_help, ls_help_mute;      // blocks per robot (1 = none); host: compute units / owned robots, at most LS_HELP_MAX.  ls_help_mute (TJ_LS_HELP_MUTE=1, test hook): helpers leave at once
   double *ls_tab;                 // [U][3][LS_HELP_MAX][2] posted energies (set = super-round % 3) (all-ones = not there yet; reset by begin_body and, between super-rounds, by the robot's primary block)
   unsigned long long *ls_word;    // [U] (epoch << 32) | super-round the primary asks for (LS_WORD_DONE: the search is over, helpers leave)

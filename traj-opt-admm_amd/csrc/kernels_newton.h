@@ -222,6 +222,31 @@ __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, do
     return run;
 }
 
+// Launch order of k_grad's blocks (Dev::grad_bal; run by a few extra blocks of the NEXT iteration's k_front): item i = (robot, piece) has rank r = the number of
+// items that cost more last time (ties: lower index first).  n items on C compute units, L = n - C of them late:
+//   C < n < 2C   positions [0, L)  <- ranks [n - 2L, n - L)   (cheap: the CU mates of the late blocks)
+//                positions [L, C)  <- ranks [0, n - 2L)       (the expensive ones, a CU each)
+//                positions [C, n)  <- ranks [n - L, n)        (the cheapest: late, and ~20 % slower for it)
+//   otherwise    position = rank (longest first; the host only switches the order on in the case above, TJ_GRAD_BALANCE=1 forces it)
+constexpr int GRAD_ORDER_CHUNK = 2048;   // costs staged per pass (ints; the one-wave block's LDS buffer holds at least that many)
+__device__ __forceinline__ void grad_order_body(const Dev& D, int blk, int* cs) {
+  const int n = (D.u1 - D.u0) * D.P, C = D.num_cu, lane = (int)(threadIdx.x & 63), i = blk * 64 + lane;
+  const int ci = i < n ? D.grad_cost[i] : 0;
+  int r = 0;
+  for (int j0 = 0; j0 < n; j0 += GRAD_ORDER_CHUNK) {   // the costs pass through LDS (a loop over global words was 320 dependent round trips: 10 us)
+    const int m = min(GRAD_ORDER_CHUNK, n - j0);
+    blk_sync<true>();
+    for (int j = lane; j < m; j += 64) cs[j] = D.grad_cost[j0 + j];
+    blk_sync<true>();
+#pragma unroll 8
+    for (int j = 0; j < m; j++) { const int cj = cs[j]; r += (cj > ci || (cj == ci && j0 + j < i)) ? 1 : 0; }
+  }
+  if (i >= n) return;
+  int pos = r;
+  if (n > C && n < 2 * C) { const int L = n - C; pos = r < n - 2 * L ? L + r : (r < n - L ? r - (n - 2 * L) : r - (n - L) + C); }
+  D.grad_perm[pos] = i;
+}
+
 // FOLD: the block first turns the stamped candidate / partner slots of ITS OWN segments into plane lists (the work of
 // k_sep_self_compact, one wave per segment), so that kernel -- and its boundary -- drops out of the single-GPU chain.
 // The folded launch also keeps a SECOND group of three waves (B) alive: the plane terms (group A) and the velocity /
@@ -231,8 +256,11 @@ __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, do
 // Both launch forms add (sum over plane segments) + (sum over velocity/acceleration segments), so they agree bit for bit.
 template <bool FOLD>
 __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
+  const int item = D.grad_bal ? D.grad_perm[blockIdx.x] : (int)blockIdx.x;   // (robot, piece) of this launch position (grad_order_body); read BEFORE the stop
+                                                                             // test so that the two scalar loads share one round trip
   if (TJ_DONE(D)) return;
   TJ_TIC_ENTRY(D, K_GRAD);
+  const long long t_entry = wall_clock64();
   extern __shared__ double sm[];
   __shared__ int s_cnt[GRAD_MAXRES][2];   // folded launch: {obstacle planes, robot-pair planes} of the block's segments, left by its own compaction
   __shared__ int s_fits;                  // ... and whether every list fits the LDS hand-over (else the gradient reads the global lists, as the one-group launch does)
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   double* pst = sm + grad_lds_doubles(npl, D.res);   // [res][2][GRAD_PST][4] (folded launch only: its dynamic LDS is that much longer)
   double pall_v = 0, ball_v = 0;
   if constexpr (FOLD) {
-    const int u_ = D.u0 + blockIdx.x / D.P, sp_ = blockIdx.x % D.P;
+    const int u_ = D.u0 + item / D.P, sp_ = item % D.P;
     // hulls and bases of the piece's segments: issued first, so that their round trip runs under the compaction's
     if ((int)threadIdx.x < D.res * 18) pall_v = hull_entry(D, D.spline + (size_t)u_ * 3 * D.T, sp_ * D.res + threadIdx.x / 18, (threadIdx.x % 18) / 3, threadIdx.x % 3);
     if ((int)threadIdx.x < D.res * 36) ball_v = D.basis[(size_t)sp_ * D.res * 36 + threadIdx.x];
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   const bool grpB = FOLD && threadIdx.x >= GRAD_THREADS;
   const int tid = grpB ? threadIdx.x - GRAD_THREADS : threadIdx.x;   // position inside the wave group
   constexpr int NTH = FOLD ? 2 * GRAD_THREADS : GRAD_THREADS;
-  const int u = D.u0 + blockIdx.x / D.P, sp = blockIdx.x % D.P;
+  const int u = D.u0 + item / D.P, sp = item % D.P;
   const double* net = D.spline + (size_t)u * 3 * D.T;
   const double m = D.margin, pt = D.piece_time[u];
   const int res = D.res;
@@ -439,6 +467,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   if (tid < 19) og[tid] = g[tid];
   for (int idx = tid; idx < 361; idx += GRAD_THREADS) oh[idx] = H[idx];
   if (tid == 0 && s_llt == 0) D.blk_stats[(size_t)u * D.P + sp] += 1ull;   // PSD repairs of this piece: only this block writes the word
+  if (tid == 0 && D.grad_bal) D.grad_cost[item] = (int)(wall_clock64() - t_entry);   // 10 ns ticks; read by the next iteration's k_front
   TJ_TIC(D, K_GRAD, 6);
 }
 

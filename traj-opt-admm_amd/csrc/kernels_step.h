@@ -607,9 +607,13 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
   __shared__ double lds[OBS_LDS_DOUBLES > PAIR_LDS_DOUBLES ? OBS_LDS_DOUBLES : PAIR_LDS_DOUBLES];   // one buffer for whichever body this block runs
+  static_assert(sizeof(lds) >= GRAD_ORDER_CHUNK * sizeof(int), "grad_order_body stages its costs in this buffer");
   const int n_spec = D.spec ? SPEC_CAP : 0;   // GJK head starts of last iteration's slow pairs lead the grid: they are the longest blocks
-  const int b = (int)blockIdx.x - n_spec;
-  if (b < 0) spec_pair_body(D, blockIdx.x);
+  const int n_ord = D.grad_bal ? ((D.u1 - D.u0) * D.P + 63) / 64 : 0;   // the first blocks of the grid: launch order of this iteration's k_grad (kernels_newton.h; ~3 us each --
+                                                                        // as the LAST blocks they started when the first query blocks retired and ended 1 us after everything else)
+  const int b = (int)blockIdx.x - n_ord - n_spec;
+  if ((int)blockIdx.x < n_ord) grad_order_body(D, (int)blockIdx.x, (int*)lds);
+  else if (b < 0) spec_pair_body(D, (int)blockIdx.x - n_ord);
   else if (b < n_obs) obs_query_body<PRIM>(D, b, lds, true);
   else sep_self_rows_body(D, b - n_obs, lds);
   TJ_TIC(D, K_FRONT, 1);

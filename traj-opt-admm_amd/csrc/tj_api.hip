@@ -128,7 +128,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, c->n_solve_env > 0 ? c->n_solve_env : (d.U >= 192 ? 1536 : 1728)) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 1024 : 0;   // (512: SCN-E's k_mid 43.7 us, 1024: 38.3, 2048: 37.8; SCN-C indifferent)
   const int n_rows = multi ? d.S * pair_units(d.U, d.pair_rows) : 0;   // one wave per (segment, tile of pair_rows lower robots x 64 partners)
-  const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + (d.spec ? SPEC_CAP : 0);
+  const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + (d.spec ? SPEC_CAP : 0) + (d.grad_bal ? (owned * d.P + 63) / 64 : 0);
   const int n_mid_slack = owned * d.P;
   switch (kid) {
     case K_BEGIN: if (chain_pos & 1) return false; hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
@@ -501,6 +501,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, p->device));
     const int owned = std::max(1, d.u1 - d.u0);
+    d.num_cu = prop.multiProcessorCount;
+    // k_grad's launch order follows the items' last durations where blocks outnumber the compute units (kernels_newton.h: grad_order_body)
+    // -- between one and two blocks per unit, the case it was measured on: SCN-C -1.5 us per iteration, the 64 hard robots -1.4; at five blocks per unit
+    // (256 robots) longest-first ordering bought nothing in k_grad and the run was 1.5 % slower, so larger fleets keep the identity
+    d.grad_bal = (owned * d.P > d.num_cu && owned * d.P < 2 * d.num_cu) ? 1 : 0;
+    if (const char* e = getenv("TJ_GRAD_BALANCE")) d.grad_bal = (atoi(e) != 0 && owned * d.P <= 65536) ? 1 : 0;   // launch-shape switch (same bits)
     d.ls_help = (d.ls_fast && p->mode != TJ_MODE_MULTI_COUPLED) ? std::max(1, std::min(LS_HELP_MAX, prop.multiProcessorCount / owned)) : 1;
     if (const char* e = getenv("TJ_LS_HELP")) d.ls_help = std::max(1, std::min(LS_HELP_MAX, atoi(e)));   // launch-shape switch (same bits); 1 = no helpers
     if (const char* e = getenv("TJ_LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
@@ -539,7 +545,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.oplanes, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ocount, U * S)) ||
       (r = dalloc(c, &d.splanes, U * S * d.cap_self * 4)) || (r = dalloc(c, &d.scount, U * S)) ||
       (r = dalloc(c, &d.lg, U * P * 19)) || (r = dalloc(c, &d.lh, U * P * 361)) || (r = dalloc(c, &d.xdir, U * d.xs)) ||
-      (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) || (r = dalloc(c, &d.ls_hist, U)) || (r = dalloc(c, &d.ls_tab, U * LS_TAB_STRIDE)) || (r = dalloc(c, &d.ls_word, U)) ||
+      (r = dalloc(c, &d.k_obs, U)) || (r = dalloc(c, &d.k_self, U)) || (r = dalloc(c, &d.step_out, U)) || (r = dalloc(c, &d.ls_hist, U)) || (r = dalloc(c, &d.grad_cost, (d.u1 - d.u0) * P)) || (r = dalloc(c, &d.grad_perm, (d.u1 - d.u0) * P)) || (r = dalloc(c, &d.ls_tab, U * LS_TAB_STRIDE)) || (r = dalloc(c, &d.ls_word, U)) ||
       (r = dalloc(c, &d.ccdinfo, U * S * CCD_STRIDE)) || (r = dalloc(c, &d.pair_list, ACT_CAP)) ||
       (r = dalloc(c, &d.seg_stats, U * S * 6)) || (r = dalloc(c, &d.pair_stats, U * S * 2)) || (r = dalloc(c, &d.blk_stats, U * P + U)) ||
       (r = dalloc(c, &d.hullinfo, U * S * HULL_STRIDE)) || (r = dalloc(c, &d.hbox, S * 6 * U)) || (r = dalloc(c, &d.cbox, S * 6 * U)) || (r = dalloc(c, &d.pairplane, d.mode >= 1 ? S * U * U * 4 : 1)) ||
@@ -754,6 +760,13 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   HIPCHK(c, hipMemsetAsync(d.ls_hist, 0xff, (size_t)U * 4, c->stream));   // -1: no line search yet
   HIPCHK(c, hipMemsetAsync(d.ls_tab, 0xff, (size_t)U * LS_TAB_STRIDE * 8, c->stream));   // LS_TAB_EMPTY
   HIPCHK(c, hipMemsetAsync(d.ls_word, 0, (size_t)U * 8, c->stream));                        // (the words carry the epoch, which restarts at 1)
+  {   // k_grad's launch order: no history, identity
+    std::vector<int> idp((size_t)(d.u1 - d.u0) * d.P);
+    for (size_t i = 0; i < idp.size(); i++) idp[i] = (int)i;
+    HIPCHK(c, hipMemsetAsync(d.grad_cost, 0, idp.size() * 4, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.grad_perm, idp.data(), idp.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (d.mode >= 1) HIPCHK(c, hipMemsetAsync(d.pairstamp, 0, (size_t)d.S * U * U * 4, c->stream));  // epochs restart at 1
   HIPCHK(c, hipMemsetAsync(d.pair_ovf_list, 0, ((size_t)d.cap_work + PAIR_CONSUMERS_MAX) * 8, c->stream));                  // (entries are tagged with the epoch)
   HIPCHK(c, hipMemsetAsync(d.pair_ovf, 0, 16, c->stream));
