@@ -99,7 +99,7 @@ __device__ __forceinline__ void grad_velacc_records(const Dev& D, int tid, int s
     }
   }
   const unsigned long long bal = __ballot(rec_act);
-  if ((tid & 63) == 0) amask[tid >> 6] = bal;
+  if ((tid & 63) == 0 && tid < GRAD_THREADS) amask[tid >> 6] = bal;
 }
 // ... and their accumulation into this thread's entry: per segment partial sums, added in segment order; an all-inactive
 // segment adds an exact +0.  a0: Hessian entry / gradient entry / time gradient, a1: time-column entry / time Hessian.
@@ -123,18 +123,18 @@ __device__ __forceinline__ GradAcc grad_velacc_accumulate(const GradRole R, int 
         seg += (t[12 + ai] * t[12 + ak]) * t[cq];
       }
       a0 += seg;
-    } else if (vr >= 0) {
+    } else if (vr >= 0 || R.scal) {
+      // gradient / time-column entries (two products per record) and the time scalar (two plain sums) in ONE loop body -- they sit in the same wave, and
+      // a wave runs its branches one after the other: the scalar's terms are multiplied by 1.0, which changes no bit
+      const int i0 = R.scal ? 18 : 6 + qv, i1 = R.scal ? 19 : 9 + qv;
       double sg = 0, spp = 0;
       for (unsigned bits = bits0; bits; bits &= bits - 1) {
         const int b = __ffs(bits) - 1;
         const double* t = bts + b * GRAD_REC;
-        sg += t[6 + qv] * t[12 + av]; spp += t[9 + qv] * t[12 + av];
+        const double w_ = R.scal ? 1.0 : t[12 + av];
+        sg += t[i0] * w_; spp += t[i1] * w_;
       }
       a0 += sg; a1 += spp;
-    } else if (R.scal) {
-      double sg = 0, sh = 0;
-      for (unsigned bits = bits0; bits; bits &= bits - 1) { const int b = __ffs(bits) - 1; sg += bts[b * GRAD_REC + 18]; sh += bts[b * GRAD_REC + 19]; }
-      a0 += sg; a1 += sh;
     }
   }
   return GradAcc{a0, a1};
@@ -145,9 +145,9 @@ __device__ __forceinline__ GradAcc grad_velacc_accumulate(const GradRole R, int 
 // with more planes than the LDS buffer holds); one instantiation per address space, same summation order.
 // GSYNC: barrier among the three waves that do the plane work -- the whole block in the one-group launch, an LDS-counter
 // barrier in the folded launch, whose second wave group works on the velocity / acceleration terms at its own pace.
-struct GradSync { int* cnt; int target; };
+struct GradSync { int* cnt; int target; int nwaves = GRAD_THREADS / 64; };
 template <bool GSYNC>
-__device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, GRAD_THREADS / 64); else __syncthreads(); }
+__device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) group_barrier(g.cnt, g.target, g.nwaves); else __syncthreads(); }
 template <bool GSYNC>
 __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
                                                  const double* Pall, const double* Ball, const double* wseg, const int* segn, const int* segno, int* sego, double* Mv, const GradRole R, GradSync& gs, double run,
@@ -207,15 +207,11 @@ __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, do
     for (int i = sb; i < se; i++) {  // per segment: accumulate from zero, then add (reference's += of local matrices)
       if (segn[i] == 0) continue;
       const double* Bs = Ball + i * 36; const double* Ms = Mv + i * 54;
-      if (hi_ >= 0) {
+      if (hi_ >= 0 || vr >= 0) {   // one body for both kinds of entry (the wave that holds the gradient entries holds Hessian entries too): b * 1.0 == b
+        const int c1 = hi_ >= 0 ? ai : av, cm = hi_ >= 0 ? R.cq : 6 + qv;
         double seg = 0;
 #pragma unroll
-        for (int j = 0; j < 6; j++) seg += (Bs[j * 6 + ai] * Bs[j * 6 + ak]) * Ms[j * 9 + R.cq];
-        run += seg;
-      } else if (vr >= 0) {
-        double seg = 0;
-#pragma unroll
-        for (int j = 0; j < 6; j++) seg += Bs[j * 6 + av] * Ms[j * 9 + 6 + qv];
+        for (int j = 0; j < 6; j++) { const double b2 = hi_ >= 0 ? Bs[j * 6 + ak] : 1.0; seg += (Bs[j * 6 + c1] * b2) * Ms[j * 9 + cm]; }
         run += seg;
       }
     }
@@ -291,8 +287,12 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   int* sego = segn + GRAD_MAXRES;
   unsigned long long* amask = (unsigned long long*)(sego + GRAD_MAXRES);  // [3] active vel/acc records
 
+  // Group B is FOUR waves: its first three hold the 171 Hessian entries, the fourth (wave 6 of the block) the 18 gradient / time-column entries and the time
+  // scalar.  With those twenty threads in the third wave (as in group A) that wave walked the active records three times per segment -- once per kind of
+  // entry, the branches of a wave run one after the other -- and arrived at the hand-over 4 us after the other five (measured per wave, round 4).
   const bool grpB = FOLD && threadIdx.x >= GRAD_THREADS;
   const int tid = grpB ? threadIdx.x - GRAD_THREADS : threadIdx.x;   // position inside the wave group
+  const int rt = !grpB ? tid : (tid < 171 ? tid : (tid >= GRAD_THREADS && tid < GRAD_THREADS + 19 ? tid - GRAD_THREADS + 171 : 190));   // entry this thread accumulates (190: none)
   constexpr int NTH = FOLD ? 2 * GRAD_THREADS : GRAD_THREADS;
   const int u = D.u0 + item / D.P, sp = item % D.P;
   const double* net = D.spline + (size_t)u * 3 * D.T;
@@ -300,10 +300,10 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   const int res = D.res;
 
   // role of this thread
-  int hi_ = -1, hk_ = -1;  // Hessian entry (row >= col) for tid < 171
-  if (tid < 171) { int i = 0; while ((i + 1) * (i + 2) / 2 <= tid) i++; hi_ = i; hk_ = tid - i * (i + 1) / 2; }
-  const int vr = (tid >= 171 && tid < 189) ? tid - 171 : -1;  // gradient / time-column entry
-  const bool scal = tid == 189;
+  int hi_ = -1, hk_ = -1;  // Hessian entry (row >= col) for rt < 171
+  if (rt < 171) { int i = 0; while ((i + 1) * (i + 2) / 2 <= rt) i++; hi_ = i; hk_ = rt - i * (i + 1) / 2; }
+  const int vr = (rt >= 171 && rt < 189) ? rt - 171 : -1;  // gradient / time-column entry
+  const bool scal = rt == 189;
   const int ai = hi_ >= 0 ? hi_ / 3 : 0, qi = hi_ >= 0 ? hi_ % 3 : 0, ak = hk_ >= 0 ? hk_ / 3 : 0, qk = hk_ >= 0 ? hk_ % 3 : 0;
   const int av = vr >= 0 ? vr / 3 : 0, qv = vr >= 0 ? vr % 3 : 0;
   double pacc_ = 0, vb0 = 0, vb1 = 0;   // plane terms of this thread's entry; velocity / acceleration terms
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     __threadfence_block();
     __syncthreads();
     staged = s_fits != 0;
-    if (threadIdx.x >= 2 * GRAD_THREADS) return;   // waves 6, 7: the remaining barriers count surviving waves only
+    if (threadIdx.x >= 2 * GRAD_THREADS + 64) return;   // wave 7: the remaining barriers count surviving waves only
     if ((int)threadIdx.x < res) {
       if (staged) { s_no[threadIdx.x] = s_cnt[threadIdx.x][0]; segn[threadIdx.x] = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1]; }
       else {
@@ -349,14 +349,15 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   const GradRole role{tid, hi_, ai, qi, ak, qk, vr, av, qv, qhi * (qhi + 1) / 2 + qlo, scal};
   if (grpB) {
     // ---- group B (folded launch): velocity / acceleration records, then their accumulation, at its own pace ----
-    GradSync gb{&s_gsync[1], 0};
+    GradSync gb{&s_gsync[1], 0, GRAD_THREADS / 64 + 1};
     TJ_TICB(D, K_SEP_SELF_COMPACT, 0);
     grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, s_wseg, bt, amask);
     TJ_TICB(D, K_SEP_SELF_COMPACT, 1);
     grad_sync<true>(gb);
     TJ_TICB(D, K_SEP_SELF_COMPACT, 2);
     const GradAcc vb = grad_velacc_accumulate(role, res, bt, amask);
-    H[tid] = vb.a0; if (tid >= 171 && tid < 190) g[tid - 171] = vb.a1;   // hand-over: H / g are not in use yet
+    if (rt < 190) H[rt] = vb.a0;
+    if (rt >= 171 && rt < 190) g[rt - 171] = vb.a1;   // hand-over: H / g are not in use yet
     TJ_TICB(D, K_SEP_SELF_COMPACT, 3);
   } else {
     if (!FOLD) grad_velacc_records(D, tid, sp, res, m, pt, Pall, Ball, s_wseg, bt, amask);
@@ -379,6 +380,9 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     TJ_TIC(D, K_GRAD, 2);
     if (!FOLD) { __syncthreads(); const GradAcc vb = grad_velacc_accumulate(role, res, bt, amask); vb0 = vb.a0; vb1 = vb.a1; }
   }
+#ifdef TJ_PHASE_TIMING
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < TJ_TIC_BLOCKS) D.dbg[((size_t)K_CCD_PREP * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + (threadIdx.x >> 6)] = wall_clock64();   // arrival of every wave at the hand-over
+#endif
   if constexpr (FOLD) {
     __syncthreads();
     if (grpB) return;
