@@ -279,6 +279,12 @@ int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_grou
     const int rc = tj_create(&q, &c);
     if (rc) { const std::string m = std::string("rank ") + std::to_string(r) + ": " + tj_last_error(c); if (c) tj_destroy(c); return bail(rc, m); }
     g->ctx.push_back(c);
+    {   // ranks that share a device (a test arrangement) share its compute units too: k_linesearch's helper blocks (one CU each) and k_grad's launch order assume
+        // a device of their own -- off for those ranks (same bits either way)
+      int sharers = 0;
+      for (int b = 0; b < n_ranks; b++) sharers += g->dev[b] == g->dev[r] ? 1 : 0;
+      if (sharers > 1) { c->d.ls_help = 1; c->d.grad_bal = 0; }
+    }
     const int nwhat = c->d.mode == TJ_MODE_MULTI_COUPLED ? 5 : 2;
     for (int w = 0; w < nwhat; w++) {
       const GroupExchangeInfo b = group_buffer(c, w);
