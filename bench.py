@@ -148,7 +148,19 @@ def critical_path(slv, st, K, per_launch_ms, n_prims):
     while cnt > 64:
         cnt = (cnt + 7) // 8; lv += 1
     gjk_max = max(1.0, st["gjk_max_sum"] / it) if slv.mode >= 1 else 1.0
-    rounds = 1.0 + max(0.0, (st["energy_evals"] / it / U - 2.0) / 8.0)          # Armijo rounds of 8 candidates per robot
+    # Armijo rounds per robot.  One block per robot evaluates 8 candidates per round; with helper blocks on idle compute units (k_linesearch's
+    # super-rounds: min(8, CUs // robots) blocks per robot, two candidates each) a round decides 2H candidates and every round after the
+    # first adds the primary's permit and the helpers' posts: two dependent memory round trips.
+    try:
+        import torch as _t
+        cus = _t.cuda.get_device_properties(_t.cuda.current_device()).multi_processor_count
+    except Exception:
+        cus = 256
+    helpers = max(1, min(8, cus // max(1, U))) if slv.mode in (0, 1) and os.environ.get("TJ_LS_HELP", "") != "1" else 1
+    if os.environ.get("TJ_LS_HELP", "").isdigit() and int(os.environ["TJ_LS_HELP"]) >= 1:
+        helpers = min(8, int(os.environ["TJ_LS_HELP"]))
+    per_round = 2 * helpers if helpers > 1 else 8
+    rounds = 1.0 + max(0.0, (st["energy_evals"] / it / U - 2.0) / per_round)
     walk = (lv + 3) * p["mem"]                                                    # record, one box load per level, leaf primitives, work-item slot
     gjk_iter = (12 * p["fp64"] + p["readlane"]) + (21 * p["fp64"] + p["sqrt"] + p["div"] + p["branch"] + p["readlane"])   # support search + triangle step
     pair = 2 * p["mem"] + gjk_max * gjk_iter + (p["sqrt"] + 3 * p["div"] + 12 * p["fp64"]) + (p["log"] + 2 * p["div"] + 24 * p["fp64"])   # work item -> hulls, GJK, normal + offsets, one Newton round
@@ -157,7 +169,7 @@ def critical_path(slv, st, K, per_launch_ms, n_prims):
     grad = 3 * p["mem"] + (p["log"] + p["sqrt"] + 6 * p["div"] + 30 * p["fp64"]) + 2 * p["lds"] + eig   # counts -> planes -> (vel/acc record | plane terms) -> consensus -> repair
     xsolve = 2 * p["mem"] + p["lds"] + n * (p["rsq"] + 8 * p["fp64"] + p["readlane"] + 2 * p["fp64"]) + n * (p["readlane"] + 2 * p["fp64"]) + 3 * p["lds"] + p["mem"]
     evalx = p["lds"] + 7 * (p["lds"] + p["sqrt"] + p["div"] + 12 * p["fp64"]) + 2 * p["log"] + 3 * (p["lds"] + 6 * p["fp64"]) + p["log"] + 6 * p["lds"] + 2 * p["lds"] + 36 * p["fp64"]
-    ls = 2 * p["mem"] + p["lds"] + rounds * evalx + (p["lds"] + 6 * p["fp64"]) + (p["mem"] + 6 * 5 * p["fp64"]) + 2 * p["mem"]   # stage, rounds, exact hulls, intervals, store + ticket
+    ls = 2 * p["mem"] + p["lds"] + rounds * evalx + (max(0.0, rounds - 1.0) * 2 * p["mem"] if helpers > 1 else 0.0) + (p["lds"] + 6 * p["fp64"]) + (p["mem"] + 6 * 5 * p["fp64"]) + 2 * p["mem"]   # stage, rounds (+ signalling), exact hulls, intervals, store + ticket
     folded = slv.mode >= 1 and per_launch_ms.get("k_ccd_self_seq", 0.0) <= 0   # the sequential pair replay + gnorm is the tail of k_ccd: + the counter's landing and one poll
     bound = {"k_front": walk + p["mem"], "k_mid": pair, "k_grad": grad, "k_xsolve": xsolve, "k_ccd": walk + p["mem"] + (2 * p["mem"] if folded else 0.0),
              "k_ccd_self_seq": 3 * p["mem"] + 200 * p["fp64"], "k_linesearch": ls}
@@ -169,7 +181,7 @@ def critical_path(slv, st, K, per_launch_ms, n_prims):
         out["tj::" + k] = {"bound_us": b * 1e-3, "measured_us": ms * 1e3, "frac": b * 1e-3 / (ms * 1e3)}
         tb += b * 1e-3; tm += ms * 1e3
     return {"unit": "us", "kernels": out, "chain_bound_us": tb, "chain_measured_us": tm, "frac": tb / tm if tm else None,
-            "unit_counts": {"bvh_levels": lv, "longest_pair_gjk_iterations": gjk_max, "armijo_rounds": rounds, "newton_system_rows": n},
+            "unit_counts": {"bvh_levels": lv, "longest_pair_gjk_iterations": gjk_max, "armijo_rounds": rounds, "armijo_candidates_per_round": per_round, "linesearch_blocks_per_robot": helpers, "newton_system_rows": n},
             "primitives_ns": PRIM,
             "note": "dependency chain of each kernel's longest work item x measured single-wave latencies (profiles/round4_issue_probe.txt, profiles/round4_mem_probe.txt; a dependent global round trip is 240 ns measured, not the 700 ns rounds 1-3 assumed: frac fell from 0.28 to what is printed here); the rest of a launch is "
                     "instruction issue of ONE wave (one fp64 instruction per ~6.3 cycles, dependent or not) plus dispatch / drain: see DESIGN.md section 5"}
