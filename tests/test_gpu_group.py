@@ -190,6 +190,24 @@ def test_gjk_head_start_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
 
 
 @pytest.mark.gpu
+def test_coupled_search_in_one_launch_changes_no_bit(pkg, scenes, monkeypatch):
+    """coupled mode: the four evaluation rounds of the Armijo search run in ONE launch where a block per (robot, round) has a compute unit of its own
+    (the default on this fleet); TJ_LSC_WIDE=0 launches them one after the other as rounds 1 - 3 did.  Same table, same decision, same state."""
+    scene = dict(scenes.crossing(12, 4000, seed=23, name="crossing-U12-coupled"), mode=2)
+    monkeypatch.delenv("TJ_LSC_WIDE", raising=False)
+    a = pkg.Solver(scene, stop=0.0)
+    monkeypatch.setenv("TJ_LSC_WIDE", "0")
+    b = pkg.Solver(scene, stop=0.0)
+    a.iterate(12); b.iterate(12)
+    sa, sb = a.get_state(), b.get_state()
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), f"{n} differs between the one-launch and the four-launch coupled search"
+    assert a.stats()["error_bits"] == b.stats()["error_bits"]
+    assert a.stats()["energy_evals"] == b.stats()["energy_evals"]
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
                                  {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_GRAD_BALANCE": "1"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))

@@ -797,13 +797,22 @@ __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double ste
   if (lane == 0) { acc[0] = found_r; acc[1] = found_c; *accstep = found_step; }
 }
 
-__global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round) {
-  if (TJ_DONE(D)) return;
+// wide (round 4): rounds covered by THIS launch.  A fleet that leaves compute units idle (owned robots x LSC_ROUNDS blocks fit the device) evaluates all four rounds
+// at once, block (robot, h) takes round h: one launch and one decision instead of four launches of which the later ones mostly return at once (three kernel
+// boundaries, ~8 us each with their staging).  Same energies into the same table, same decision.
+// begin_next (wide launch of one context, inside a batch): the committing block also starts the NEXT iteration (begin_body), like k_linesearch's last block does
+// in the decoupled chain -- the host then omits k_begin.
+__global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round0, int wide, int begin_next) {
+  if (TJ_DONE(D)) {
+    if (begin_next && blockIdx.x == 0 && threadIdx.x == 0) { D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0; }   // (as k_linesearch: retire the slack update k_mid has just paid)
+    return;
+  }
   extern __shared__ double sm[];
   __shared__ int pref[1024];
   __shared__ int s_acc[2];
   __shared__ double s_step0, s_accstep;
-  const int tid = threadIdx.x, u = D.u0 + blockIdx.x, S = D.S, T = D.T, P = D.P;
+  const int nown = D.u1 - D.u0, hb = wide > 1 ? (int)blockIdx.x / nown : 0, round = round0 + hb;
+  const int tid = threadIdx.x, u = D.u0 + (int)blockIdx.x - hb * nown, S = D.S, T = D.T, P = D.P;
   // G = L.groups candidates side by side (8 up to piece_num = 10; 4 or 2 for long trajectories, whose hull buffers are larger): a
   // round's LS_GROUPS candidates then take LS_GROUPS / G passes.  Waves beyond G shadow the last group (same values into the same
   // buffers), which keeps every barrier uniform.
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   // control block; the launches of the later rounds (and the commit) read one word instead of every block re-deriving it.
   const bool one_ctx = D.u1 - D.u0 == D.U;
   const int epoch = D.ctl->epoch;
-  if (round > 0 && one_ctx && D.ctl->lsf_epoch == epoch) return;  // an earlier round already holds the accepted step
+  if (round0 > 0 && one_ctx && D.ctl->lsf_epoch == epoch) return;  // an earlier launch already holds the accepted step
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   const double step0 = lsc_step0(D, tid, t0, t_dir, &s_step0);
   bool in_lds;
@@ -849,9 +858,29 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   if (!s_last) return;
   if (tid == 0) D.ctl->ls_ticket = 0;
   if (tid < 64) {
-    lsc_decide<true>(D, round + 1, step0, tid, s_acc, &s_accstep, sm);   // sm: the evaluation is over
+    lsc_decide<true>(D, round0 + wide, step0, tid, s_acc, &s_accstep, sm);   // sm: the evaluation is over
     if (tid == 0 && s_acc[0] >= 0) { D.ctl->lsf_r = s_acc[0]; D.ctl->lsf_c = s_acc[1]; D.ctl->lsf_step = s_accstep; D.ctl->lsf_epoch = epoch; }   // read by LATER kernels only
   }
+  if (wide < LSC_ROUNDS) return;
+  // Every round has been evaluated and every other block is through (the ticket): this block also COMMITS -- k_ls_commit's work for all robots, 3T values
+  // each; the host omits that launch.  Same expressions as k_ls_commit.
+  __syncthreads();
+  double step = s_accstep;
+  const int kacc = s_acc[0] >= 0 ? lsc_cand_k(s_acc[0], s_acc[1]) : lsc_cand_k(LSC_ROUNDS - 1, LS_GROUPS - 1);
+  if (s_acc[0] < 0) {   // no acceptable step within the evaluated range: take the last candidate and report it
+    step = step0;
+    for (int i = 0; i < kacc; i++) step *= 0.8;
+    if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_LS_RANGE);
+  }
+  for (int idx = tid; idx < nown * 3 * T; idx += LS_THREADS) {
+    const int uu = D.u0 + idx / (3 * T), i = idx % (3 * T);
+    double* gs = D.spline + (size_t)uu * 3 * T;
+    gs[i] = gs[i] + step * D.dirp(uu)[i];
+  }
+  for (int uu = D.u0 + tid; uu < D.u1; uu += LS_THREADS) {
+    D.piece_time[uu] = D.piece_time[uu] + step * D.tdir(uu); D.step_out[uu] = step; D.blk_stats[(size_t)D.U * D.P + uu] += (unsigned long long)(2 + kacc);
+  }
+  if (begin_next) { __syncthreads(); begin_body(D); }
 }
 
 // commit: x_u += step d_u for every robot, the shared piece_time advances by step * t_direction

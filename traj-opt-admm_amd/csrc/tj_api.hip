@@ -50,6 +50,7 @@ struct tj_ctx {
   bool graph_ok[4] = {false, false, false, false};
   bool graph_failed[4] = {false, false, false, false};
   size_t lds_grad = 0, lds_xs = 0, lds_xs2 = 0, lds_ls = 0, lds_seq = 0;
+  bool lsc_wide = false;     // coupled mode: k_ls_coupled evaluates all LSC_ROUNDS rounds in one launch (kernels_ls.h)
   bool ccd_lean = true;        // which build of k_ccd the chain launches (kernels_step.h); re-decided whenever the control block is read
   unsigned ccd_found_seen = 0; long long iters_enqueued = 0, iters_seen = 0;
   bool grad_fold = true;       // k_grad compacts its own segments (one launch less); TJ_GRAD_FOLD=0 keeps k_sep_self_compact + the 192-thread k_grad
@@ -201,8 +202,13 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
     case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
-    case K_LS_COUPLED: if (coupled) for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r); return coupled;
-    case K_LS_COMMIT: if (coupled) hipLaunchKernelGGL(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;
+    case K_LS_COUPLED:
+      if (coupled) {
+        if (c->lsc_wide) hipLaunchKernelGGL(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0);   // all rounds at once, one block per (robot, round)
+        else for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r, 1, 0);
+      }
+      return coupled;
+    case K_LS_COMMIT: if (coupled && !(c->lsc_wide && owned == d.U)) hipLaunchKernelGGL(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;   // (one context, all rounds in one launch: its last block commits)
     case K_SLACK: if (in_graph) return false; hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
   }
   return false;
@@ -502,6 +508,9 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     HIPCHK(c, hipGetDeviceProperties(&prop, p->device));
     const int owned = std::max(1, d.u1 - d.u0);
     d.num_cu = prop.multiProcessorCount;
+    // coupled mode: the four evaluation rounds of the Armijo search in one launch where a block per (robot, round) gets a compute unit of its own
+    c->lsc_wide = p->mode == TJ_MODE_MULTI_COUPLED && owned * LSC_ROUNDS <= d.num_cu;
+    if (const char* e = getenv("TJ_LSC_WIDE")) c->lsc_wide = atoi(e) != 0;   // launch-shape switch (same bits)
     // k_grad's launch order follows the items' last durations where blocks outnumber the compute units (kernels_newton.h: grad_order_body)
     // -- between one and two blocks per unit, the case it was measured on: SCN-C -1.5 us per iteration, the 64 hard robots -1.4; at five blocks per unit
     // (256 robots) longest-first ordering bought nothing in k_grad and the run was 1.5 % slower, so larger fleets keep the identity
@@ -811,7 +820,8 @@ int tj_iterate_async(tj_ctx* c, int n_iters) {
   if (n_iters > 0) { int r = ensure_hull_cache(c); if (r) return r; }
   // inside a batch the begin work of iteration i+1 rides on iteration i's k_linesearch (not in coupled mode, whose line search
   // is several kernels, and not in the captured-graph replay, which is one fixed iteration)
-  const bool chain = !c->use_graph && c->d.mode != TJ_MODE_MULTI_COUPLED;
+  // (coupled mode: only where the whole search is ONE launch whose last block commits -- lsc_wide, one context)
+  const bool chain = !c->use_graph && (c->d.mode != TJ_MODE_MULTI_COUPLED || (c->lsc_wide && c->d.u1 - c->d.u0 == c->d.U));
   for (int i = 0; i < n_iters; i++) {
     const int pos = chain ? ((i > 0 ? 1 : 0) | (i + 1 < n_iters ? 2 : 0)) : 0;
     int r = launch_graph_or_eager(c, 3, pos); if (r) return r;

@@ -283,7 +283,7 @@ int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_grou
         // a device of their own -- off for those ranks (same bits either way)
       int sharers = 0;
       for (int b = 0; b < n_ranks; b++) sharers += g->dev[b] == g->dev[r] ? 1 : 0;
-      if (sharers > 1) { c->d.ls_help = 1; c->d.grad_bal = 0; }
+      if (sharers > 1) { c->d.ls_help = 1; c->d.grad_bal = 0; c->lsc_wide = false; }
     }
     const int nwhat = c->d.mode == TJ_MODE_MULTI_COUPLED ? 5 : 2;
     for (int w = 0; w < nwhat; w++) {
