@@ -32,7 +32,7 @@ def main():
     a = ap.parse_args()
     pkg = importlib.import_module("traj-opt-admm_amd")
     sc = pkg.scenes
-    scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d}[a.scene]()
+    scene = {"A": sc.scn_a, "B": sc.scn_b, "C": sc.scn_c, "D": sc.scn_d, "Dtri": sc.scn_d_tri, "E": sc.scn_e}[a.scene]()
     s = pkg.Solver(scene, stop=0.0)
     s.iterate(a.iter)
     lib = C.CDLL(os.environ["TRAJADMM_LIB"])
