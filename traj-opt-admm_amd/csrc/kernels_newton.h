@@ -115,7 +115,7 @@ __device__ __forceinline__ GradAcc grad_velacc_accumulate(const GradRole R, int 
     if (ao > 55 && aw < 2) av9 |= (aw == 0 ? am1 : am2) << (64 - ao);
     const unsigned bits0 = (unsigned)av9 & 0x1ffu;
     if (!bits0) continue;
-    if (hi_ >= 0) {
+    if (__ballot(hi_ < 0) == 0ull) {   // a wave of Hessian entries only
       double seg = 0;   // hessian += e2*d_x*d_x^T + e1*A^T*h_p*A (Gradient_admm.h:504,553), with d_x = w (x) dp
       for (unsigned bits = bits0; bits; bits &= bits - 1) {
         const int b = __ffs(bits) - 1;
@@ -123,16 +123,19 @@ __device__ __forceinline__ GradAcc grad_velacc_accumulate(const GradRole R, int 
         seg += (t[12 + ai] * t[12 + ak]) * t[cq];
       }
       a0 += seg;
-    } else if (vr >= 0 || R.scal) {
-      // gradient / time-column entries (two products per record) and the time scalar (two plain sums) in ONE loop body -- they sit in the same wave, and
-      // a wave runs its branches one after the other: the scalar's terms are multiplied by 1.0, which changes no bit
-      const int i0 = R.scal ? 18 : 6 + qv, i1 = R.scal ? 19 : 9 + qv;
+    } else if (hi_ >= 0 || vr >= 0 || R.scal) {
+      // A wave that holds more than one kind of entry (the one-group launch's third wave: 43 Hessian entries, the 18 gradient / time-column entries, the
+      // time scalar; the folded launch's fourth B wave: the latter two) walks the records ONCE -- a wave runs its branches one after the other, and three
+      // walks per segment made that wave the block's last by 4 us.  One body: a0 += (x0 * x1) * x2, a1 += x3 * x1, with 1.0 where a kind of entry has
+      // no factor -- a multiplication by 1.0 changes no bit, and a1 of a Hessian entry is never read.
+      const bool hs = hi_ >= 0;
+      const int i0 = hs ? 12 + ai : (R.scal ? 18 : 6 + qv), i1 = hs ? 12 + ak : 12 + av, i2 = cq, i3 = R.scal ? 19 : 9 + qv;
       double sg = 0, spp = 0;
       for (unsigned bits = bits0; bits; bits &= bits - 1) {
         const int b = __ffs(bits) - 1;
         const double* t = bts + b * GRAD_REC;
-        const double w_ = R.scal ? 1.0 : t[12 + av];
-        sg += t[i0] * w_; spp += t[i1] * w_;
+        const double x1 = R.scal ? 1.0 : t[i1], x2 = hs ? t[i2] : 1.0;
+        sg += (t[i0] * x1) * x2; spp += t[i3] * x1;
       }
       a0 += sg; a1 += spp;
     }
