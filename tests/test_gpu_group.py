@@ -190,6 +190,31 @@ def test_gjk_head_start_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2], ids=["decoupled", "coupled"])
+def test_round4_launch_shapes_over_a_long_run(pkg, scenes, monkeypatch, mode):
+    """150 iterations of a fleet whose robots really back off (4 robots stacked 0.13 apart: tens of Armijo steps per iteration at the start, PSD repairs,
+    acting robot pairs) with every launch shape of round 4 on -- helper blocks and super-rounds in k_linesearch, the quiet counter switching them off and on
+    again, the one-launch coupled search with its folded commit and begin -- against all of them off: same bits, same evaluation counts, no error bit.
+    (tests/devtools/soak_round4.py runs the same comparison for 300 iterations on eight scenes.)"""
+    scene = dict(scenes.hard(), mode=mode)
+    for k in ("TJ_LS_HELP", "TJ_GRAD_BALANCE", "TJ_LSC_WIDE"):
+        monkeypatch.delenv(k, raising=False)
+    a = pkg.Solver(scene, stop=0.0)
+    monkeypatch.setenv("TJ_LS_HELP", "1"); monkeypatch.setenv("TJ_GRAD_BALANCE", "0"); monkeypatch.setenv("TJ_LSC_WIDE", "0")
+    b = pkg.Solver(scene, stop=0.0)
+    for _ in range(3):
+        a.iterate(50); b.iterate(50)
+        sa, sb = a.get_state(), b.get_state()
+        for n in sa:
+            assert np.array_equal(sa[n], sb[n]), f"{n} differs"
+    ta, tb = a.stats(), b.stats()
+    assert ta["error_bits"] == 0 and tb["error_bits"] == 0
+    assert ta["energy_evals"] == tb["energy_evals"]
+    assert ta["energy_evals"] > 150 * scene["U"] * 2, "no robot ever backed off: the run compares nothing"
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_coupled_search_in_one_launch_changes_no_bit(pkg, scenes, monkeypatch):
     """coupled mode: the four evaluation rounds of the Armijo search run in ONE launch where a block per (robot, round) has a compute unit of its own
     (the default on this fleet); TJ_LSC_WIDE=0 launches them one after the other as rounds 1 - 3 did.  Same table, same decision, same state."""
