@@ -590,9 +590,16 @@ def main():
         # BASELINE configs 3 (8 UAVs) and 5 (256 UAVs x 1M triangles, one GPU's share of the 8-GPU config) under the driver's eyes:
         # same K, same protocol, GPU only; the headline fields above are untouched
         if args.scene == "C" and not (args.no_extra or args.coupled or args.optimal_plane):
+            # the headline scene beyond its timed window: 100 more iterations of the same run, the last 40 timed (the steady phase: every robot takes the full step)
+            slv.iterate_async(60); slv.sync(); torch.cuda.synchronize()
+            t1 = time.perf_counter(); slv.iterate_async(40); slv.sync(); torch.cuda.synchronize()
+            steady_ms = 1e3 * (time.perf_counter() - t1) / 40
             slv.close()
-            out["extra"] = {"configs": [extra_config(pkg, sc.scn_a(), K, W, local), extra_config(pkg, sc.scn_b(), K, W, local), extra_config(pkg, sc.scn_d_tri(), K, W, local)],
-                            "note": "BASELINE configs 2 (SCN-A), 3 (SCN-B) and one GPU's view of 5 (SCN-D-tri), timed after the headline line's window on the same process / GPU; not part of `value`"}
+            out["extra"] = {"configs": [extra_config(pkg, sc.scn_a(), K, W, local), extra_config(pkg, sc.scn_b(), K, W, local), extra_config(pkg, sc.scn_d_tri(), K, W, local),
+                                        extra_config(pkg, dict(sc.scn_c(), mode=2, name="SCN-C-coupled"), K, W, local)],
+                            "scn_c_steady_ms_per_step": steady_ms,
+                            "note": "BASELINE configs 2 (SCN-A), 3 (SCN-B) and one GPU's view of 5 (SCN-D-tri), then the headline fleet in the coupled mode (decouple:0), timed after the headline line's window on the same "
+                                    "process / GPU; scn_c_steady_ms_per_step: iterations 81 - 120 of the headline run; none of it is part of `value`"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
