@@ -433,9 +433,11 @@ def main():
         sharding = importlib.import_module("traj-opt-admm_amd.sharding")
 
         class _Eng:
+            chained = True   # sharding.run_sharded says whether another iteration follows: the next begin rides in phase 2's line search
+
             @staticmethod
-            def phase(k):
-                slv.iterate_phase(k)
+            def phase(k, more=0):
+                slv.iterate_phase(k, more)
 
         def _gather(what):  # RCCL all-gather straight on the library's device buffers (in place)
             if args.same_gpu:  # test path: device slice -> host -> gloo all-gather -> device

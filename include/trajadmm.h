@@ -14,6 +14,7 @@
  */
 #ifndef TRAJADMM_H
 #define TRAJADMM_H
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -139,6 +140,9 @@ int tj_set_stream(tj_ctx* c, void* hip_stream);
  * the name rocprofv3 reports (tj::<name>). */
 int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches);
 int tj_kernel_count(void);
+/* kernels the iteration schedules of this context have enqueued so far (tj_iterate*, tj_iterate_phase*, tj_group_iterate incl. the exchange
+ * kernels / collectives of its transports): launches per iteration of a schedule = the difference over a batch / its iterations */
+long long tj_launch_count(tj_ctx* c);
 const char* tj_kernel_name(int i);
 
 /* ---- stage-level access (teacher-forced parity tests, profiling) ---------------------------- */
@@ -238,6 +242,36 @@ int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_rob
  * Results are bitwise those of one unsharded context. */
 int tj_phase_count(tj_ctx* c);
 int tj_iterate_phase(tj_ctx* c, int phase);
+/* The same with the caller saying whether another iteration follows in this batch (more != 0).  Decoupled / single-UAV schedules then run
+ * the FUSED chain of one context inside the phases: phase 2's line search also does the next iteration's stop test and counter resets, so
+ * that iteration's phase 0 launches nothing -- 6 kernels + the caller's 2 collectives per iteration (round 4: 10 + 2).  A begin that was
+ * folded for an iteration the caller never enqueues is taken back by the next tj_sync / state access.  tj_iterate_phase(c, p) is
+ * tj_iterate_phase_chained(c, p, 0).  The caches of the robots other ranks own (hull cache, swept-hull cache) are rebuilt from the gathered
+ * buffers by extra units at the head of k_front / k_ccd (csrc/kernels_step.h), bitwise what the owner holds. */
+int tj_iterate_phase_chained(tj_ctx* c, int phase, int more);
+
+/* ---- direct exchange between sharded contexts (decoupled mode, world > 1; csrc/kernels_step.h) ---------------------------------------------
+ * Instead of a collective between the phases, the PRODUCING kernels store an owned robot's slice straight into every peer's receive block
+ * (k_linesearch / k_begin: control points for Optimization3D_multi.h:246-259 separate_self; k_xsolve: the direction record for Step.h:196-208
+ * self_step) and bump an arrival counter there; the (foreign robot, segment) units at the head of the peers' k_front / k_ccd wait for the
+ * count, read the slice and rebuild that robot's cache records.  With it a sharded iteration is the six-kernel chain of one context
+ * (tj_iterate_async / tj_iterate work on the sharded context) -- nothing on the host, no launch for the exchange.  tj_group's "flag"
+ * transport is this, wired inside one process; two or more PROCESSES (one per GPU, e.g. under torchrun) wire it through hipIpc:
+ *   every rank:  tj_xch_ipc_export(c, handle)            64-byte handle of its receive block (allocated on first use, uncached memory)
+ *                ... all-gather the handles with any host-side collective ...
+ *                tj_xch_ipc_open(c, handle_of_peer, &base) for every other rank
+ *                tj_xch_attach(c, world - 1, peer_ranks, peer_bases);  tj_xch_enable(c, 1, poll_in_kernel)
+ *   then tj_iterate_async / tj_iterate on every rank; every rank must run the same number of iterations per batch, and a host-side barrier
+ *   must separate "every rank has drained its batch" from tj_init_state (which restarts the counters) and tj_init_state from the next batch.
+ * poll_in_kernel = 1: the foreign units poll the arrival counters themselves (ranks on distinct devices); 0: a one-wave launch in front of
+ * k_front / k_ccd waits (ranks SHARING a device: polling units would hold the LDS the peer's producing kernel needs).  A push that does not
+ * arrive within 2 s fails the batch (TJ_ERR_DEVICE, error bit 512).  Results are bitwise those of one context.  UNVERIFIED ACROSS xGMI, like
+ * tj_group on distinct devices: the tests run ranks and processes on one device. */
+int tj_xch_block(tj_ctx* c, void** base, size_t* bytes);                 /* this rank's receive block (same-process wiring: hand `base` to the peers' tj_xch_attach) */
+int tj_xch_ipc_export(tj_ctx* c, void* handle64);                        /* hipIpcGetMemHandle of the block */
+int tj_xch_ipc_open(tj_ctx* c, const void* handle64, void** base);       /* hipIpcOpenMemHandle of a peer's block (closed by tj_destroy) */
+int tj_xch_attach(tj_ctx* c, int n_peers, const int* peer_ranks, void* const* peer_bases);
+int tj_xch_enable(tj_ctx* c, int on, int poll_in_kernel);
 
 /* ---- several GPUs under one process (csrc/tj_group.h) ------------------------------------------------------------------
  * What a maintainer of Main/multiPathPlanning3D.cpp would call instead of tj_create / tj_iterate to use N devices: the robots
@@ -246,12 +280,13 @@ int tj_iterate_phase(tj_ctx* c, int phase);
  * one-GPU box).  tj_group_iterate runs the phase schedule above on every rank (one host thread per rank) and exchanges the
  * tj_exchange_buffer slices through one of three transports (csrc/tj_group.h):
  *   "event"  direct peer stores + hipEventRecord / hipStreamWaitEvent: plain HIP stream semantics; THE DEFAULT
- *   "flag"   direct peer stores + a sequence flag the consumer's next kernel polls -- device to device, nothing on the host; the
- *            fastest with the ranks on one device, opt-in until it has run across xGMI (a peer whose push does not arrive
- *            within 2 s fails the batch with TJ_ERR_DEVICE / error bit 512; the foreign slices are then NOT unpacked)
+ *   "flag"   decoupled mode: the DIRECT exchange above (tj_xch_*): the producing kernels push, the consuming kernels wait -- the fused
+ *            six-kernel chain per rank, no launch and no host work for the exchange (ranks sharing a device: two one-wave wait launches);
+ *            coupled mode: peer stores + a sequence flag polled by a small unpack kernel.  Opt-in until it has run across xGMI (a push
+ *            that does not arrive within 2 s fails the batch with TJ_ERR_DEVICE / error bit 512)
  *   "rccl"   ncclCommInitAll + one in-place ncclAllGather per exchange on each rank's solver stream (the collective
  *            Optimization3D_multi's sharding would use over xGMI); librccl.so is opened at run time, only for this transport;
- *            needs distinct devices and uav_num divisible by n_ranks
+ *            needs distinct devices; uav_num not divisible by n_ranks: one grouped ncclBroadcast per owner instead
  * chosen by TJ_GROUP_TRANSPORT at tj_group_create or by tj_group_set_transport between batches.  Results are bitwise those of
  * one context.  tj_params.rank / world / device are ignored (set per rank).  Single-UAV mode has nothing to shard (n_ranks
  * must be 1).  UNVERIFIED ON HARDWARE: a group whose devices are all distinct (the configuration the feature exists for) has

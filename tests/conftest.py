@@ -35,6 +35,21 @@ def built_oracle():
     return so
 
 
+def hip_runtime():
+    """the HIP runtime instance libtrajadmm.so itself is linked against (a test that copies between the library's device buffers must use
+    THAT instance: torch bundles a second libamdhip64.so, and a bare CDLL("libamdhip64.so") returns whichever was loaded first)"""
+    import ctypes as C
+    importlib.import_module("traj-opt-admm_amd").load_library()
+    paths = []
+    for line in open("/proc/self/maps"):
+        if "libamdhip64.so" in line:
+            path = line.split()[-1]
+            if path not in paths:
+                paths.append(path)
+    pick = [q for q in paths if "/torch/" not in q] or paths
+    return C.CDLL(pick[0] if pick else "libamdhip64.so")
+
+
 def gold(name):
     return np.load(os.path.join(GOLD, name))
 

@@ -88,7 +88,8 @@ def test_coupled_mode_sharded_equals_unsharded(pkg, scenes):
     r0 = pkg.Solver(scene, stop=0.0, rank=0, world=2)
     r1 = pkg.Solver(scene, stop=0.0, rank=1, world=2)
     assert r0.phase_count() == 6
-    hip = C.CDLL("libamdhip64.so")
+    from conftest import hip_runtime
+    hip = hip_runtime()   # the runtime instance libtrajadmm.so is linked against
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
     def exchange(what):

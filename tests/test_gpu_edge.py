@@ -219,7 +219,7 @@ def test_cli_coupled_mode_and_log_data(pkg, scenes, tmp_path):
         assert mine.shape == out.shape and np.max(np.abs(mine - out)) <= 1e-12
 
 
-@pytest.mark.parametrize("P,res,mode", [(3, 8, 1), (4, 4, 1), (7, 8, 1), (8, 8, 1), (9, 8, 2), (3, 8, 2), (6, 8, 0), (10, 8, 1), (12, 8, 1), (20, 8, 1), (14, 8, 0), (31, 8, 1), (12, 8, 2), (16, 8, 2)])
+@pytest.mark.parametrize("P,res,mode", [(3, 8, 1), (4, 4, 1), (7, 8, 1), (8, 8, 1), (9, 8, 2), (3, 8, 2), (6, 8, 0), (10, 8, 1), (12, 8, 1), (20, 8, 1), (14, 8, 0), (31, 8, 1), (12, 8, 2), (16, 8, 2), (3, 16, 1), (3, 15, 1), (2, 16, 0)])
 def test_piece_counts_and_resolutions_vs_oracle(pkg, scenes, P, res, mode):
     """every size class of the per-robot Newton system: n = 9P-2 in {25,...,61} takes the register-resident
     factorisation, P = 8..10 the dense LDS one, P > 10 (the reference sizes everything from the init file,
@@ -244,6 +244,23 @@ def test_piece_counts_and_resolutions_vs_oracle(pkg, scenes, P, res, mode):
             assert maxdiff(a[n], b[n]) <= 1e-9 * max(1.0, np.abs(b[n]).max()), (it, n, maxdiff(a[n], b[n]))
     assert s.stats()["error_bits"] == 0
     s.close()
+
+
+@pytest.mark.parametrize("res", [15, 16])
+def test_folded_gradient_equals_one_group_gradient_at_max_res(pkg, scenes, res, monkeypatch):
+    """res = 15 / 16 segments per piece: 540 / 576 basis entries for the 512 threads of the folded k_grad (entries beyond 512 were
+    never staged).  The folded launch and the one-group launch (TJ_GRAD_FOLD=0) use the same association: states bitwise equal."""
+    scene = scenes.hard(4, 3000, pieces=3)
+    a = pkg.Solver(scene, {"res": res}, stop=0.0)
+    monkeypatch.setenv("TJ_GRAD_FOLD", "0")
+    b = pkg.Solver(scene, {"res": res}, stop=0.0)
+    for it in range(10):
+        a.iterate(1); b.iterate(1)
+        sa, sb = a.get_state(), b.get_state()
+        for n in STATE:
+            assert np.array_equal(sa[n], sb[n]), (it, n)
+    assert a.stats()["error_bits"] == 0 and b.stats()["error_bits"] == 0
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -59,6 +59,39 @@ def test_flag_transport_equals_one_context_bitwise(pkg, scenes, mode):
     ref.close(); grp.close()
 
 
+@pytest.mark.parametrize("poll,ranks", [("1", 2), ("0", 2), ("1", 3)])
+def test_direct_exchange_is_the_fused_chain(pkg, scenes, poll, ranks, monkeypatch):
+    """flag transport, decoupled mode = the DIRECT exchange: k_linesearch / k_begin push control points, k_xsolve pushes direction records,
+    the foreign units at the head of the peers' k_front / k_ccd wait and rebuild the caches -- a sharded iteration is the six-kernel
+    chain of one context.  TJ_XCH_POLL=1: the units poll the arrival counters themselves (what ranks on distinct devices do; a small
+    fleet can do it on a shared device); 0: two one-wave wait launches per iteration (what ranks sharing a device do).  Bitwise the
+    one-context states through batches of different length, the stop-free run, and a transport switch in between."""
+    monkeypatch.setenv("TJ_XCH_POLL", poll)
+    scene = scenes.hard(5 if ranks == 3 else 4, 4000)
+    ref = pkg.Solver(scene, stop=0.0)
+    grp = pkg.Group(scene, [0] * ranks, stop=0.0)
+    grp.set_transport("flag")
+    done = 0
+    for batch, transport in ((1, "flag"), (4, "flag"), (3, "event"), (6, "flag"), (2, "flag")):
+        if grp.transport != transport:
+            grp.set_transport(transport)
+        l0 = grp.launch_counts()
+        g0, _, _ = ref.iterate(batch)
+        g, it, cv = grp.iterate(batch)
+        l1 = grp.launch_counts()
+        done += batch
+        assert it == done and g == g0 and not cv
+        a, b = ref.get_state(), grp.get_state()
+        for n in STATE:
+            assert np.array_equal(a[n], b[n]), (n, done, transport)
+        per_iter = max((y - x) for x, y in zip(l0, l1)) / batch
+        if transport == "flag":   # six kernels (+ two wait launches on a shared device) per iteration; the batch adds k_begin, the flush and the slack update it pays
+            assert per_iter <= (6 if poll == "1" else 8) + 4.0 / batch + 1e-9, per_iter   # (+ k_hullinfo after a host write, k_begin, k_flush + k_slack at the end of the batch)
+        else:                     # event: the fused phases + push and unpack for each of the two exchanges
+            assert per_iter <= 10 + 4.0 / batch + 1e-9, per_iter
+    ref.close(); grp.close()
+
+
 def test_rccl_transport_is_refused_on_repeated_devices(pkg, scenes):
     grp = pkg.Group(scenes.hard(4, 4000), [0, 0], stop=0.0)
     with pytest.raises(pkg.TrajAdmmError) as ei:
@@ -101,8 +134,9 @@ def test_group_stop_test_and_uneven_partition(pkg, scenes):
     ref = pkg.Solver(scene)
     g0, it0, cv0 = ref.iterate(200)
     assert cv0
-    for ranks in (2, 3):
+    for ranks, transport in ((2, "event"), (3, "event"), (2, "flag"), (3, "flag")):
         grp = pkg.Group(scene, [0] * ranks)
+        grp.set_transport(transport)
         g, it, cv = grp.iterate(200)
         assert (it, cv) == (it0, cv0) and g == g0
         a, b = ref.get_state(), grp.get_state()

@@ -191,7 +191,8 @@ def test_sharded_persistent_pair_planes_equal_unsharded(pkg, scenes):
     ref = pkg.Solver(scene, stop=0.0, optimal_plane=1)
     r0 = pkg.Solver(scene, stop=0.0, rank=0, world=2, optimal_plane=1)
     r1 = pkg.Solver(scene, stop=0.0, rank=1, world=2, optimal_plane=1)
-    hip = C.CDLL("libamdhip64.so")
+    from conftest import hip_runtime
+    hip = hip_runtime()   # the runtime instance libtrajadmm.so is linked against
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
     def exchange(what):

@@ -459,7 +459,8 @@ def test_sharded_equals_unsharded(pkg, scenes):
     ref = pkg.Solver(scene, stop=0.0)
     r0 = pkg.Solver(scene, stop=0.0, rank=0, world=2)
     r1 = pkg.Solver(scene, stop=0.0, rank=1, world=2)
-    hip = C.CDLL("libamdhip64.so")  # the runtime libtrajadmm.so already loaded
+    from conftest import hip_runtime
+    hip = hip_runtime()   # the runtime instance libtrajadmm.so is linked against
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
     def exchange(what):
@@ -482,6 +483,37 @@ def test_sharded_equals_unsharded(pkg, scenes):
     for n in STATE:
         assert np.array_equal(a[n][:h], b0[n][:h]), n
         assert np.array_equal(a[n][h:], b1[n][h:]), n
+    # the same schedule CHAINED (tj_iterate_phase_chained: the next iteration's begin rides in phase 2's line search, its phase 0 launches
+    # nothing) and without the syncs in between (device-to-device copies on the ranks' own streams are the "collective"): six kernels per
+    # iteration and rank; the last batch ends with more = 1 although nothing follows -- the flush takes the folded begin back
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def exchange_async(what):
+        p0, per, f0, n0 = r0.exchange_buffer(what)
+        p1, _, f1, n1 = r1.exchange_buffer(what)
+        s0, s1 = r0.stream(), r1.stream()
+        assert hip.hipStreamSynchronize(s0) == 0 and hip.hipStreamSynchronize(s1) == 0   # (both producers done: stream sync only, no flush)
+        assert hip.hipMemcpyAsync(p0 + f1 * per * 8, p1 + f1 * per * 8, n1 * per * 8, 3, s0) == 0
+        assert hip.hipMemcpyAsync(p1 + f0 * per * 8, p0 + f0 * per * 8, n0 * per * 8, 3, s1) == 0
+        assert hip.hipStreamSynchronize(s0) == 0 and hip.hipStreamSynchronize(s1) == 0
+
+    for batch, last_more in ((5, 0), (4, 1), (3, 0)):
+        ref.iterate(batch)
+        l0 = r0.launch_count()
+        for it in range(batch):
+            more = 1 if (it + 1 < batch or last_more) else 0
+            for ph in (0, 1, 2):
+                r0.iterate_phase(ph, more); r1.iterate_phase(ph, more)
+                if ph < 2:
+                    exchange_async(ph)
+        assert (r0.launch_count() - l0) / batch <= 6 + 1.0 / batch
+        r0.sync(); r1.sync()
+        a = ref.get_state(); b0 = r0.get_state(); b1 = r1.get_state()
+        for n in STATE:
+            assert np.array_equal(a[n][:h], b0[n][:h]), (n, batch)
+            assert np.array_equal(a[n][h:], b1[n][h:]), (n, batch)
+        assert r0.stats()["iters"] == ref.stats()["iters"] and r0.stats()["error_bits"] == 0
     for x in (ref, r0, r1):
         x.close()
 

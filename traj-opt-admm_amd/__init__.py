@@ -25,7 +25,7 @@ EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_set_mesh", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes", "tj_get_candidates",
     "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_energy", "tj_get_stats", "tj_get_build_info", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_phase_count", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name",
+    "tj_iterate_phase", "tj_iterate_phase_chained", "tj_launch_count", "tj_phase_count", "tj_xch_block", "tj_xch_ipc_export", "tj_xch_ipc_open", "tj_xch_attach", "tj_xch_enable", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
     "tj_group_create", "tj_group_destroy", "tj_group_size", "tj_group_ctx", "tj_group_last_error", "tj_group_set_cloud", "tj_group_set_mesh",
     "tj_group_transport", "tj_group_set_transport", "tj_group_profile_exchange", "tj_rccl_available", "tj_group_rccl_ranks",
@@ -214,8 +214,35 @@ class Solver:
     def phase_count(self):
         return self._check(self.lib.tj_phase_count(self._ctx))
 
-    def iterate_phase(self, phase):
-        self._check(self.lib.tj_iterate_phase(self._ctx, C.c_int(phase)))
+    def launch_count(self):
+        self.lib.tj_launch_count.restype = C.c_longlong
+        return int(self.lib.tj_launch_count(self._ctx))
+
+    def iterate_phase(self, phase, more=0):
+        """more: another iteration follows in this batch (decoupled schedules then fold its begin into this one's line search)"""
+        self._check(self.lib.tj_iterate_phase_chained(self._ctx, C.c_int(phase), C.c_int(1 if more else 0)))
+
+    # ---- direct exchange between processes (include/trajadmm.h tj_xch_*) ----
+    def xch_ipc_export(self):
+        h = (C.c_ubyte * 64)()
+        self._check(self.lib.tj_xch_ipc_export(self._ctx, h))
+        return bytes(h)
+
+    def xch_attach_ipc(self, handles, poll_in_kernel=True):
+        """handles: {rank: 64-byte handle} of every OTHER rank; opens them, attaches and switches the direct exchange on"""
+        ranks = sorted(handles)
+        bases = (C.c_void_p * len(ranks))()
+        for i, r in enumerate(ranks):
+            b = C.c_void_p()
+            hb = (C.c_ubyte * 64).from_buffer_copy(handles[r])
+            self._check(self.lib.tj_xch_ipc_open(self._ctx, hb, C.byref(b)))
+            bases[i] = b.value
+        rk = np.ascontiguousarray(ranks, dtype=np.int32)
+        self._check(self.lib.tj_xch_attach(self._ctx, C.c_int(len(ranks)), _i(rk), bases))
+        self._check(self.lib.tj_xch_enable(self._ctx, C.c_int(1), C.c_int(1 if poll_in_kernel else 0)))
+
+    def xch_enable(self, on, poll_in_kernel=True):
+        self._check(self.lib.tj_xch_enable(self._ctx, C.c_int(1 if on else 0), C.c_int(1 if poll_in_kernel else 0)))
 
     # ---- stage-level views (same shapes as oracle.pyoracle.Engine) ---------------------------
     def stage_planes(self):
@@ -498,6 +525,12 @@ class Group:
     def rccl_ranks(self):
         """ranks RCCL's communicator reports for this group (0 unless the rccl transport is selected)"""
         return max(0, int(self.lib.tj_group_rccl_ranks(self._g)))
+
+    def launch_counts(self):
+        """kernels each rank's context has enqueued so far (tj_launch_count)"""
+        self.lib.tj_launch_count.restype = C.c_longlong
+        self.lib.tj_group_ctx.restype = C.c_void_p
+        return [int(self.lib.tj_launch_count(C.c_void_p(self.lib.tj_group_ctx(self._g, C.c_int(r))))) for r in range(self.n)]
 
     def profile_exchange(self, reps=50):
         """event-timed microseconds of one exchange of each buffer kind (slowest rank's average)"""

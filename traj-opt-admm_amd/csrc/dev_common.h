@@ -77,6 +77,12 @@ struct Ctl {
   // atomics on ONE address serialise at ~13 ns each); the last one runs the sequential pair replay + gnorm (Dev::seq_fold)
   int ccd_ticket, pad3;
   int ccd_sub[16];
+  // sharded contexts (world > 1): the (foreign robot, segment) units at the head of k_front [0] / k_ccd [1] that have left their cache record
+  // (sixteen sub-counters, fire and forget; zeroed by begin_body); the pair tiles of the same launch wait for all of them
+  int xf_sub[2][16];
+  // direct exchange (Dev::xch): robots whose control points [0] / direction records [1] THIS rank has pushed to its peers so far -- every rank
+  // pushes once per iteration, so a consumer expects xpush / owned rounds from every peer
+  int xpush[2];
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
@@ -121,10 +127,35 @@ constexpr int TJ_TIC_BLOCKS = 65536, TJ_TIC_SLOTS = 8;   // blocks per kernel th
 #define TJ_ORDER(v) do {} while (0)
 #endif
 
+// direct exchange between sharded contexts (tj_group "flag" transport, or processes that mapped each other's blocks through hipIpc): what a rank needs
+// to know about its peers.  Lives in device memory (Dev::xp).
+constexpr int XCH_MAX = 16;                    // ranks of a group
+struct XchPeers {
+  int n;                                       // peers (world - 1)
+  int rank[XCH_MAX];                           // their ranks
+  double* rx[XCH_MAX][2];                      // their receive buffers: [0] control points [U][3T], [1] direction records [U][xs]
+  unsigned long long* cnt[XCH_MAX];            // their arrival counters [2][XCH_MAX] (kind, source rank)
+};
+
 struct Dev {
   // ---- parameters (3D.json + hard-coded constants of the mains) ----
   int mode, U, P, res, S, T, N;
   int u0, u1;  // robots owned by this rank: [u0,u1)
+  int rank, world;
+  // Sharded contexts: the hull cache / swept-hull cache of the robots OTHER ranks own is rebuilt on this rank from their control points / directions by
+  // extra one-wave units at the head of k_front / k_ccd (kernels_step.h: xf_hull_body, xf_ccd_body); the pair tiles of the same launch wait for them.
+  // xch = 0: the foreign slices are in place when the kernel starts (an all-gather by the caller, or tj_group's event / rccl transports, ran between the launches).
+  // xch = 1: DIRECT exchange -- the producing kernels (k_linesearch / k_begin, k_xsolve) store an owned robot's slice straight into every peer's receive
+  //          buffer and count it there; the foreign units wait for the owner's count, read the slice from the receive buffer and put it in place.
+  int xf;                        // 1: foreign units lead k_front / k_ccd (world > 1 and Dev::fuse)
+  int xch, xch_poll;             // xch_poll = 1: the foreign units poll the arrival counters themselves; 0: a k_xch_wait launch in front of the kernel has (ranks sharing a device)
+  const XchPeers* xp;
+  double* rx[2];                 // this rank's receive buffers (uncached memory, written by the peers)
+  unsigned long long* xcnt;      // this rank's arrival counters [2][XCH_MAX]: robots of rank r whose slice of kind k has arrived, cumulative
+  __host__ __device__ int n_foreign() const { return U - (u1 - u0); }
+  __host__ __device__ int foreign_robot(int f) const { return f < u0 ? f : f + (u1 - u0); }            // f-th robot this rank does not own
+  __host__ __device__ int owner_of(int u) const { int r = (int)(((long long)(u + 1) * world - 1) / U); while ((long long)r * U / world > u) r--; while ((long long)(r + 1) * U / world <= u) r++; return r; }
+  __host__ __device__ int owned_by(int r) const { return (int)((long long)(r + 1) * U / world) - (int)((long long)r * U / world); }
   int xs_band;  // long trajectories (piece_num > 10): the Newton solve runs on band storage (k_xsolve_band) and the swept-hull
                 // cache comes from k_ccd_prep again
   int seq_tree; // k_ccd_self_seq has LDS for the reference's per-segment dynamic tree (dev_dyntree.h)
@@ -233,7 +264,11 @@ struct Dev {
   Ctl* ctl;
   long long* dbg;  // phase stamps (TJ_PHASE_TIMING builds only, else null)
 };
-constexpr int CCD_STRIDE = 18 + 18 + 6 + 6 + 98;  // P, D, obstacle box, pair box, 49 k-DOP intervals (lo,hi)
+// P, D, obstacle box, pair box, 49 k-DOP intervals (lo,hi): 146 values in a record of 160 doubles = ten 128-byte lines of its own.  No line is shared between
+// two records, so a record that another block of the SAME launch writes (sharded contexts: foreign units, then pair tiles) cannot sit half-stale in an L2
+// that fetched the neighbouring record earlier in the launch.
+constexpr int CCD_STRIDE = 160;
+constexpr int CCD_REC = 18 + 18 + 6 + 6 + 98;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
@@ -253,6 +288,69 @@ __device__ __forceinline__ double hull_entry(const Dev& D, const double* net, in
   for (int k = 0; k < 6; k++) acc += B[k] * col[k];
   return acc;
 }
+// ---- direct exchange between sharded contexts (Dev::xch): producer side ---------------------------------------------------------------------
+// Ordering without fences: a slice is stored with system-scope (write-through, uncached at the destination) stores, the wave then waits until every one of
+// them has been ACKNOWLEDGED (s_waitcnt vmcnt(0): the counter is per wave), and only after that -- and after a barrier if several waves stored -- the
+// arrival counter on the peer is bumped.  The consumer reads the counter and then the slice with system-scope loads (kernels_step.h: xch_wait_owner).
+// A release fence instead would write back the whole L2 of the XCD from every block (measured in k_linesearch: +14 us).
+__device__ __forceinline__ void xch_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double xch_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// robot u's slice of kind k (src[0, count), final; `per` doubles per robot in the receive buffer) to every peer, by the nth threads of one block (or one wave)
+template <bool ONE_WAVE>
+__device__ __forceinline__ void xch_push_robot(const Dev& D, int kind, int u, int per, const double* src, int count, int tid, int nth) {
+  const XchPeers* xp = D.xp;
+  const int np = xp->n;
+  for (int q = 0; q < np; q++) {
+    double* dst = xp->rx[q][kind] + (size_t)u * per;
+    for (int i = tid; i < count; i += nth) xch_store(dst + i, src[i]);
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0);
+  if constexpr (!ONE_WAVE) __syncthreads();
+  asm volatile("" ::: "memory");
+  if (tid < np) __hip_atomic_fetch_add(xp->cnt[tid] + kind * XCH_MAX + D.rank, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) atomicAdd(&D.ctl->xpush[kind], 1);
+}
+
+// ---- consumer side ----
+constexpr long long XCH_TIMEOUT_TICKS = 200000000ll;   // 2 s of the 100 MHz wall clock: a lost peer must not hang the device
+// All `need` robots of rank r have pushed their slice of kind k for the launch that is running?  (Every rank pushes once per iteration, so the rounds
+// THIS rank has pushed -- final when the kernel started -- are the rounds it may expect of a peer.)  Wave-uniform; false = timed out (error bit set).
+__device__ __forceinline__ bool xch_wait_owner(const Dev& D, int kind, int r) {
+  const unsigned long long need = (unsigned long long)(D.ctl->xpush[kind] / (D.u1 - D.u0)) * (unsigned long long)D.owned_by(r);
+  const unsigned long long* w = D.xcnt + kind * XCH_MAX + r;
+  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return true;
+  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(4);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return true;
+    if (wall_clock64() > t_end) { atomicOr(&D.ctl->error, ERR_PEER_TIMEOUT); return false; }
+  }
+}
+// Foreign-robot units (kernels_step.h) leave their records with write-through stores, wait for the acknowledgements and count themselves done; the pair
+// tiles of the same launch -- later in the grid, so every unit is resident or finished when a tile starts -- wait for the count.  Records are line
+// aligned (HULL_INFO_STRIDE, CCD_STRIDE), so what a tile then loads cannot have been fetched by its XCD's L2 earlier in the launch.
+__device__ __forceinline__ void xf_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double xf_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xf_signal(const Dev& D, int kind, int f) {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0);
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&D.ctl->xf_sub[kind][f & 15], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool xf_wait_all(const Dev& D, int kind) {   // one wave; uniform
+  const int lane = threadIdx.x & 63, want = D.n_foreign() * D.S;
+  const long long t_end = wall_clock64() + (D.xch ? XCH_TIMEOUT_TICKS + 10000000ll : 500000ll + 100ll * gridDim.x);   // (direct exchange: the units themselves may wait 2 s for a peer)
+  for (;;) {
+    int v = lane < 16 ? __hip_atomic_load(&D.ctl->xf_sub[kind][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = __shfl(v, 0);
+    if (v >= want) { asm volatile("" ::: "memory"); return true; }
+    if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); return false; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 __device__ __forceinline__ double seg_weight(const Dev& D, int tr) {
   int k = tr - D.res * div_small(tr, D.res);
   return (k + 1) / double(D.res) - k / double(D.res);

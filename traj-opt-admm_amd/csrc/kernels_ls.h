@@ -391,7 +391,7 @@ __device__ __forceinline__ int ls_stage(const Dev& D, const LsLayout& L, double*
 // 49 k-DOP intervals lo/hi), written from the hulls the accepted Armijo candidate was evaluated on -- they ARE the
 // hulls of the control net just committed, so the separate k_hullinfo launch (and its place on the critical path)
 // disappears from the single-GPU iteration graph.  Same expressions as k_hullinfo => identical bits.
-constexpr int LS_HULL_STRIDE = 18 + 6 + 98;
+constexpr int LS_HULL_STRIDE = 128;   // = HULL_INFO_STRIDE (kernels_sep.h)
 __device__ __forceinline__ void ls_publish_hullinfo(const Dev& D, int u, const double* hulls, int tid, int nth) {
   const int S = D.S;
   double* o = D.hullinfo + (size_t)u * S * LS_HULL_STRIDE;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void ls_publish_hullinfo(const Dev& D, int u, const d
 // quiet: 1 = every robot accepted the full step (exponent 0) in the line search that has just ended (k_linesearch's tickets carry the information; the
 // standalone k_begin, which follows no line search of its batch, says 0): Ctl::ls_quiet counts such iterations in a row, and k_linesearch sends its helper
 // blocks home while the count stands at LS_QUIET_ITERS or more.
-__device__ __forceinline__ void begin_body(const Dev& D, int quiet = 0) {
+__device__ __forceinline__ bool begin_body(const Dev& D, int quiet = 0) {   // returns whether the stop test has fired
   // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
   __shared__ int done;
   if (threadIdx.x == 0) {
@@ -435,14 +435,16 @@ __device__ __forceinline__ void begin_body(const Dev& D, int quiet = 0) {
     D.ctl->ls_quiet = quiet ? min(h.ls_quiet + 1, 1 << 20) : 0;
   }
   __syncthreads();
-  if (done) return;
+  if (done) return true;
   for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
   if (D.multi()) for (int i = threadIdx.x; i <= D.S; i += blockDim.x) D.pair_work_n[i] = 0;   // per-segment counts, [S] = cursor of the pair-solve waves
   if (threadIdx.x == 0) *D.obs_work_n = 0;
   if (threadIdx.x < 3 && D.multi()) D.pair_ovf[threadIdx.x] = 0;
   if (threadIdx.x < 16) D.ctl->ccd_sub[threadIdx.x] = 0;   // arrival counters of k_ccd's selection blocks (folded pair replay)
+  if (threadIdx.x < 32 && D.world > 1) (&D.ctl->xf_sub[0][0])[threadIdx.x] = 0;   // ... and of the foreign-robot units of k_front / k_ccd (sharded contexts)
   if (D.ls_help > 1) for (int i = threadIdx.x; i < (D.u1 - D.u0) * LS_TAB_STRIDE; i += blockDim.x) ((unsigned long long*)D.ls_tab)[(size_t)D.u0 * LS_TAB_STRIDE + i] = LS_TAB_EMPTY;   // k_linesearch's helper posts
   if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
+  return false;
 }
 
 // begin_next = 1: the last block to finish also starts the NEXT iteration (begin_body): the stop test and the counter resets
@@ -699,6 +701,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   }
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; D.ls_hist[u] = k_acc; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)evals; }   // per robot: one writer, no atomic in front of the ticket
+  // direct exchange (sharded contexts): the committed control net goes straight into every peer's receive buffer -- the next iteration's k_front
+  // there waits for it (inside a batch only: the first iteration of a batch is fed by k_begin, which pushes whatever the state is then)
+  if (D.xch && begin_next) xch_push_robot<false>(D, 0, u, 3 * T, sm + L.gnet + (size_t)wg * 3 * T, 3 * T, tid, LS_THREADS);
 ticket:
   if (h > 0) __builtin_amdgcn_s_waitcnt(0);   // a helper's posts are performed before its ticket: begin_body's reset of the table cannot be overtaken by them
   if (begin_next) {

@@ -265,12 +265,14 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   __shared__ int s_fits;                  // ... and whether every list fits the LDS hand-over (else the gradient reads the global lists, as the one-group launch does)
   const int npl = D.grad_npl;
   double* pst = sm + grad_lds_doubles(npl, D.res);   // [res][2][GRAD_PST][4] (folded launch only: its dynamic LDS is that much longer)
-  double pall_v = 0, ball_v = 0;
+  double pall_v = 0, ball_v = 0, ball_v2 = 0;   // ball_v2: entries [512, res * 36) of the bases (res = 15, 16: 540 / 576 entries for 512 threads)
+  static_assert(GRAD_MAXRES * 36 <= 2 * GRAD_FOLD_THREADS && GRAD_MAXRES * 18 <= GRAD_FOLD_THREADS, "folded k_grad stages the bases with two registers per thread, the hulls with one");
   if constexpr (FOLD) {
     const int u_ = D.u0 + item / D.P, sp_ = item % D.P;
     // hulls and bases of the piece's segments: issued first, so that their round trip runs under the compaction's
     if ((int)threadIdx.x < D.res * 18) pall_v = hull_entry(D, D.spline + (size_t)u_ * 3 * D.T, sp_ * D.res + threadIdx.x / 18, (threadIdx.x % 18) / 3, threadIdx.x % 3);
     if ((int)threadIdx.x < D.res * 36) ball_v = D.basis[(size_t)sp_ * D.res * 36 + threadIdx.x];
+    if ((int)threadIdx.x + GRAD_FOLD_THREADS < D.res * 36) ball_v2 = D.basis[(size_t)sp_ * D.res * 36 + GRAD_FOLD_THREADS + threadIdx.x];
     if (threadIdx.x == 0) s_fits = 1;
     __syncthreads();
     for (int i = threadIdx.x >> 6; i < D.res; i += GRAD_FOLD_THREADS / 64)
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     // ---- folded launch: hulls and bases arrived under the compaction; counts and planes come from it through LDS ----
     if ((int)threadIdx.x < res * 18) Pall[threadIdx.x] = pall_v;
     if ((int)threadIdx.x < res * 36) Ball[threadIdx.x] = ball_v;
+    if ((int)threadIdx.x + GRAD_FOLD_THREADS < res * 36) Ball[GRAD_FOLD_THREADS + threadIdx.x] = ball_v2;
     __threadfence_block();
     __syncthreads();
     staged = s_fits != 0;
@@ -644,6 +647,13 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     D.tdir(u) = x0[m];
     if (!D.multi()) D.ctl->gnorm = sqrt(g_);   // single UAV (Optimization3D_admm.h:499): what k_ccd_self_seq would copy; the chain skips that launch
   }
+  if (D.xch) {   // direct exchange (sharded contexts): the record goes straight into every peer's receive buffer, under the swept-hull tail of this block
+    blk_sync<true>();
+    for (int idx = tid; idx < 3 * T; idx += XS_THREADS) { const int row = idx % T, a = idx / T; scr[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0; }
+    if (tid == 0) { scr[3 * T] = x0[m]; scr[3 * T + 1] = -w_; scr[3 * T + 2] = sqrt(g_); }
+    blk_sync<true>();
+    xch_push_robot<true>(D, 1, u, D.xs, scr, 3 * T + 3, tid, XS_THREADS);
+  }
 }
 
 // NREG = n when the system fits one row per lane (n = 9P-2 <= 61, P <= 7: the register factorisation inlined, size known at
@@ -929,6 +939,13 @@ __global__ __launch_bounds__(XB_THREADS) void k_xsolve_band(Dev D) {
     dir[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0;
   }
   if (tid == 0) { D.wolfe(u) = -esum(scr, n); const double gnv = sqrt(esum(scr + n, n)); D.gn(u) = gnv; D.tdir(u) = y[m]; if (!D.multi()) D.ctl->gnorm = gnv; }
+  if (D.xch) {   // direct exchange (sharded contexts), as in k_xsolve
+    double* rec = scr + 2 * n;
+    for (int idx = tid; idx < 3 * T; idx += 64) { const int row = idx % T, a = idx / T; rec[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0; }
+    if (tid == 0) { rec[3 * T] = y[m]; rec[3 * T + 1] = -esum(scr, n); rec[3 * T + 2] = sqrt(esum(scr + n, n)); }
+    blk_sync<true>();
+    xch_push_robot<true>(D, 1, u, D.xs, rec, 3 * T + 3, tid, 64);
+  }
 }
 
 // Coupled mode, second half of the arrowhead solve: one wave per robot.  The Schur corner

@@ -170,13 +170,14 @@ __device__ __forceinline__ int pair_tile_filter(const double* segbox, int U, int
 }
 
 constexpr int PAIR_LDS_DOUBLES = PAIR_ROWS_MAX * 6 + PAIR_TILE_CAP / 2;   // rowbox | list
-__device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double* lds) {
+__device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double* lds, bool wait_xf = false) {
   int tr, rb, cb;
   pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
   const int lane = lane_id();
   const int U = D.U;
   double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
   const double dist = D.offset + 2 * D.margin;
+  if (wait_xf) xf_wait_all(D, 0);   // sharded contexts (union kernel): the hull cache of the other ranks' robots is written by units at the head of this launch
   const int m = pair_tile_filter(D.hbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, D.u0, D.u1,
                                  [&](int q) { return D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE; }, 24, 73, dist, rowbox, list, lane);
   if (m == 0) return;
@@ -208,7 +209,7 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
 constexpr int SPEC_CAP = 128, SPEC_GJK_MIN = 5, SPEC_GJK_WINDOW = 10, SPEC_GJK_BUDGET = 3;
 constexpr int SPEC_STATE_DOUBLES = 20, SPEC_STATE_INTS = 16;
 __device__ __forceinline__ unsigned pair_key(int tr, int p0, int q) { return (unsigned)(tr | (p0 << 9) | (q << 20)); }   // 9 + 11 + 11 bits
-__device__ __forceinline__ void spec_pair_body(const Dev& D, int b) {
+__device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds) {
   __builtin_amdgcn_s_setprio(3);   // the longest blocks of the launch, on SIMDs they share with four or five query waves
   const int lane = lane_id();
   const int epoch = D.ctl->epoch, par = epoch & 1;
@@ -221,6 +222,8 @@ __device__ __forceinline__ void spec_pair_body(const Dev& D, int b) {
   if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) D.spec_tag[b] = 0ull; return; }   // (cannot happen: the list is this context's own)
   const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_INFO_STRIDE;
   const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_INFO_STRIDE;
+  if (D.xf && (p0 < D.u0 || p0 >= D.u1 || q < D.u0 || q >= D.u1)) xf_wait_all(D, 0);   // sharded contexts: a hull of another rank's robot comes from this launch's foreign units
+  (void)lds;
   GjkState st; bool fin;
   gjk_wave_run(BodyHull{A}, BodyHull{B}, lane, st, true, D.spec_budget, fin);
   if (lane == 0) {

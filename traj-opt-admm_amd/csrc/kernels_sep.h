@@ -23,7 +23,7 @@
 namespace tj {
 
 struct QBox { double lo[3], hi[3]; };
-constexpr int HULL_INFO_STRIDE = 18 + 6 + 98;   // record of Dev::hullinfo (kernels_pairs.h HULL_STRIDE): hull, box lo/hi, 49 intervals lo/hi
+constexpr int HULL_INFO_STRIDE = 128;   // record of Dev::hullinfo (kernels_pairs.h HULL_STRIDE): hull 18, box lo/hi 6, 49 intervals lo/hi 98 = 122 values in a record of 128 doubles (eight 128-byte lines of its own, see CCD_STRIDE)
 
 __device__ __forceinline__ bool box_hit(const float* b, const QBox& q, double m) {
   // query.overlaps(node): reject if node.hi + m < q.lo or node.lo > q.hi + m on any axis

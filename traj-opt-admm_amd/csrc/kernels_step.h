@@ -30,23 +30,36 @@ namespace tj {
 
 // one (robot, segment) of the swept-hull cache, computed by ONE wave; net / dir are T x 3 column-major control nets
 // (global or LDS), sh is 72 doubles of wave-private LDS
-__device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net, const double* dir, int u, int tr, int lane, double* sh) {
+// XF (foreign-robot unit of a sharded context, xf_ccd_body): the record is read by the pair tiles of the SAME launch -- write-through stores; the direction
+// comes from the receive buffer of the direct exchange when `sysdir` (system-scope loads).  Same expressions in every form, hence the same bits.
+template <bool XF = false>
+__device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net, const double* dir, int u, int tr, int lane, double* sh, bool sysdir = false) {
   double* P = sh; double* Dh = sh + 18; double* PD = sh + 36; double* PS = sh + 54;
+  auto ldd = [&](const double* p) { return (XF && sysdir) ? xch_load(p) : *p; };
+  auto st = [&](double* p, double v) { if constexpr (XF) xf_store(p, v); else *p = v; };
   if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
-  else if (lane < 36) Dh[lane - 18] = hull_entry(D, dir, tr, (lane - 18) / 3, (lane - 18) % 3);
+  else if (lane < 36) {
+    const int j = (lane - 18) / 3, a = (lane - 18) % 3;
+    const double* B = D.basis + (size_t)tr * 36 + j * 6;
+    const double* col = dir + div_small(tr, D.res) * 3 + D.T * a;
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc += B[k] * ldd(col + k);   // = hull_entry(D, dir, ...)
+    Dh[lane - 18] = acc;
+  }
   else if (lane < 54) {  // basis * (bz + bz_d), the box the reference uses for the cloud query
     const int j = (lane - 36) / 3, a = (lane - 36) % 3;
     const double* B = D.basis + (size_t)tr * 36 + j * 6;
     const int r0 = div_small(tr, D.res) * 3 + D.T * a;
     double acc = 0;
-    for (int k = 0; k < 6; k++) acc += B[k] * (net[r0 + k] + dir[r0 + k]);
+    for (int k = 0; k < 6; k++) acc += B[k] * (net[r0 + k] + ldd(dir + r0 + k));
     PD[lane - 36] = acc;
   }
   blk_sync<true>();
   if (lane < 18) PS[lane] = P[lane] + Dh[lane];  // (P + D) used by the pair box and by the k-DOP at step 1
   blk_sync<true>();
   double* o = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
-  if (lane < 18) { o[lane] = P[lane]; o[18 + lane] = Dh[lane]; }
+  if (lane < 18) { st(o + lane, P[lane]); st(o + 18 + lane, Dh[lane]); }
   if (lane < 3) {
     double lo = INFINITY, hi = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
     for (int j = 0; j < 6; j++) {
@@ -54,24 +67,83 @@ __device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net
       v = PD[3 * j + lane]; if (v < lo) lo = v; if (v > hi) hi = v;
       v = PS[3 * j + lane]; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
     }
-    o[36 + lane] = lo; o[39 + lane] = hi; o[42 + lane] = lo2; o[45 + lane] = hi2;
-    D.cbox[((size_t)tr * 6 + lane) * D.U + u] = lo2; D.cbox[((size_t)tr * 6 + 3 + lane) * D.U + u] = hi2;
+    st(o + 36 + lane, lo); st(o + 39 + lane, hi); st(o + 42 + lane, lo2); st(o + 45 + lane, hi2);
+    st(D.cbox + ((size_t)tr * 6 + lane) * D.U + u, lo2); st(D.cbox + ((size_t)tr * 6 + 3 + lane) * D.U + u, hi2);
   }
   if (lane < 49) {
     const double x = D.kdop[3 * lane], y = D.kdop[3 * lane + 1], z = D.kdop[3 * lane + 2];
     double up = -INFINITY, lo = INFINITY;
     for (int i = 0; i < 6; i++) { const double lv = x * P[3 * i] + y * P[3 * i + 1] + z * P[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
     for (int i = 0; i < 6; i++) { const double lv = x * PS[3 * i] + y * PS[3 * i + 1] + z * PS[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
-    o[48 + lane] = lo; o[97 + lane] = up;
+    st(o + 48 + lane, lo); st(o + 97 + lane, up);
   }
   blk_sync<true>();  // sh is reused by the caller's next segment
 }
 
-__global__ __launch_bounds__(64) void k_ccd_prep(Dev D) {
+// u_first: first robot of the launch (all robots from 0; a sharded context whose foreign robots are handled inside k_ccd: its own from u0)
+__global__ __launch_bounds__(64) void k_ccd_prep(Dev D, int u_first) {
   if (TJ_DONE(D)) return;
-  const int u = blockIdx.x / D.S, tr = blockIdx.x % D.S;  // ALL robots: the pair clamp is replicated per rank
+  const int u = u_first + blockIdx.x / D.S, tr = blockIdx.x % D.S;
   __shared__ double sh[18 * 3 + 18];
   ccd_prep_segment(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane_id(), sh);
+}
+
+// ---- sharded contexts: the caches of the robots other ranks own ---------------------------------------------------------------------------------
+// One wave per (foreign robot, segment), at the head of k_front (hull cache, from the owner's control points) and of k_ccd (swept-hull cache, from its
+// direction record): the expressions of k_hullinfo / ccd_prep_segment -- which are those of ls_publish_hullinfo / k_xsolve's tail on the owner's side --
+// so every rank holds the same bits for every robot.  Direct exchange (Dev::xch): the unit first waits for the owner's push (xch_wait_owner), reads the
+// slice from the receive buffer, and the unit of segment 0 puts it in place (Dev::spline / Dev::xdir) for the kernels that follow.
+__device__ __forceinline__ void xf_hull_body(const Dev& D, int f) {
+  const int u = D.foreign_robot(f / D.S), tr = f % D.S, lane = lane_id(), T = D.T;
+  __shared__ double P[18];
+  const double* net = D.spline + (size_t)u * 3 * T;
+  if (D.xch) {
+    if (D.xch_poll) xch_wait_owner(D, 0, D.owner_of(u));   // (after a timeout the error bit fails the batch; the unit still reports, so that no tile waits in vain)
+    const double* rxn = D.rx[0] + (size_t)u * 3 * T;
+    if (tr == 0) for (int i = lane; i < 3 * T; i += 64) D.spline[(size_t)u * 3 * T + i] = xch_load(rxn + i);   // read by later kernels only (k_ccd's units)
+    if (lane < 18) {
+      const int j = lane / 3, a = lane % 3;
+      const double* B = D.basis + (size_t)tr * 36 + j * 6;
+      const double* col = rxn + div_small(tr, D.res) * 3 + T * a;
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += B[k] * xch_load(col + k);   // = hull_entry
+      P[lane] = acc;
+    }
+  } else if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
+  blk_sync<true>();
+  double* o = D.hullinfo + ((size_t)u * D.S + tr) * HULL_STRIDE;
+  if (lane < 18) xf_store(o + lane, P[lane]);
+  if (lane < 3) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int j = 0; j < 6; j++) { const double v = P[3 * j + lane]; if (v < lo) lo = v; if (v > hi) hi = v; }
+    xf_store(o + 18 + lane, lo); xf_store(o + 21 + lane, hi);
+    xf_store(D.hbox + ((size_t)tr * 6 + lane) * D.U + u, lo); xf_store(D.hbox + ((size_t)tr * 6 + 3 + lane) * D.U + u, hi);
+  }
+  if (lane < 49) {
+    const double x = D.kdop[3 * lane], y = D.kdop[3 * lane + 1], z = D.kdop[3 * lane + 2];
+    double up = -INFINITY, lo = INFINITY;
+    for (int i = 0; i < 6; i++) { const double lv = x * P[3 * i] + y * P[3 * i + 1] + z * P[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+    xf_store(o + 24 + lane, lo); xf_store(o + 73 + lane, up);
+  }
+  xf_signal(D, 0, f);
+}
+__device__ __forceinline__ void xf_ccd_body(const Dev& D, int f, double* sh) {
+  const int u = D.foreign_robot(f / D.S), tr = f % D.S, lane = lane_id(), T = D.T;
+  const double* dir = D.dirp(u);
+  if (D.xch) {
+    if (D.xch_poll) xch_wait_owner(D, 1, D.owner_of(u));
+    dir = D.rx[1] + (size_t)u * D.xs;
+    if (tr == 0) for (int i = lane; i < 3 * T + 3; i += 64) xf_store(D.xdir + (size_t)u * D.xs + i, xch_load(dir + i));   // |g| is read by this launch's finisher, the rest by k_linesearch
+  }
+  ccd_prep_segment<true>(D, D.spline + (size_t)u * 3 * T, dir, u, tr, lane, sh, D.xch != 0);
+  xf_signal(D, 1, f);
+}
+// ranks that share a device (a test arrangement): the units' polling would hold LDS and wave slots the peer's producing kernel needs -- one
+// one-wave launch in front of k_front / k_ccd waits for all peers instead (Dev::xch_poll = 0)
+__global__ __launch_bounds__(64) void k_xch_wait(Dev D, int kind) {
+  if (TJ_DONE(D)) return;
+  for (int r = 0; r < D.world; r++) if (r != D.rank) xch_wait_owner(D, kind, r);
 }
 
 constexpr int CCD_LDS_DOUBLES = 294 + (2 * FRONT_CAP + 128) / 2;   // info[146] kax[147] | fa fb cand
@@ -85,7 +157,7 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
   V3 axv{0, 0, 0}; double lo_ax = 0, hi_ax = 0;
   const double* src = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
   const TopBox topb = bvh_top_box(D);   // travels with the segment's record
-  for (int i = lane; i < CCD_STRIDE; i += 64) info[i] = src[i];
+  for (int i = lane; i < CCD_REC; i += 64) info[i] = src[i];
   __syncthreads();
   QBox q;
   for (int k = 0; k < 3; k++) { q.lo[k] = info[36 + k]; q.hi[k] = info[39 + k]; }
@@ -133,13 +205,14 @@ __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
 constexpr int ACT_CAP = 4096;                                    // acting pairs of one iteration (all segments)
 constexpr int ROBOT_BITS = 11;                                   // robot ids in packed pair keys: U <= 2048 (with S < 512 a key is 31 bits)
 __device__ __forceinline__ int act_key(int tr, int p0, int p1) { return (tr << (2 * ROBOT_BITS)) | (p0 << ROBOT_BITS) | p1; }
-__device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double* lds) {   // returns the acting pairs this tile listed
+__device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double* lds, bool wait_xf = false) {   // returns the acting pairs this tile listed
   int tr, rb, cb;
   pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
   const int lane = lane_id();
   const int U = D.U;
   const double off = D.offset;
   double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
+  if (wait_xf) xf_wait_all(D, 1);   // sharded contexts (union kernel): the swept-hull cache of the other ranks' robots is written by units at the head of this launch
   // swept boxes (lanes over partners), then swept 49-axis intervals (lanes over axes): BVH::SelfCCDCollision + CCD::SelfKDOPCCD
   const int m = pair_tile_filter(D.cbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, 0, U,
                                  [&](int q) { return D.ccdinfo + ((size_t)q * D.S + tr) * CCD_STRIDE; }, 48, 97, off, rowbox, list, lane);
@@ -611,11 +684,13 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_spec = D.spec ? SPEC_CAP : 0;   // GJK head starts of last iteration's slow pairs lead the grid: they are the longest blocks
   const int n_ord = D.grad_bal ? ((D.u1 - D.u0) * D.P + 63) / 64 : 0;   // the first blocks of the grid: launch order of this iteration's k_grad (kernels_newton.h; ~3 us each --
                                                                         // as the LAST blocks they started when the first query blocks retired and ended 1 us after everything else)
-  const int b = (int)blockIdx.x - n_ord - n_spec;
+  const int n_xf = D.xf ? D.n_foreign() * D.S : 0;   // sharded contexts: hull cache of the other ranks' robots, AHEAD of everything that reads it (head starts, pair tiles)
+  const int b = (int)blockIdx.x - n_ord - n_xf - n_spec;
   if ((int)blockIdx.x < n_ord) grad_order_body(D, (int)blockIdx.x, (int*)lds);
-  else if (b < 0) spec_pair_body(D, (int)blockIdx.x - n_ord);
+  else if ((int)blockIdx.x < n_ord + n_xf) xf_hull_body(D, (int)blockIdx.x - n_ord);
+  else if (b < 0) spec_pair_body(D, (int)blockIdx.x - n_ord - n_xf, lds);
   else if (b < n_obs) obs_query_body<PRIM>(D, b, lds, true);
-  else sep_self_rows_body(D, b - n_obs, lds);
+  else sep_self_rows_body(D, b - n_obs, lds, D.xf != 0);
   TJ_TIC(D, K_FRONT, 1);
 }
 // two waves per SIMD (<= 256 VGPRs; 244 used, no spills since the slack body was rewritten): 2 048 one-wave blocks are resident
@@ -647,9 +722,11 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   TJ_TIC(D, K_CCD, 0);
   // with the replay folded in (below) the grid has one block more: block 0 is the finisher and has no other work
   const int fin = D.seq_fold ? 1 : 0;
-  const int b = (int)blockIdx.x - fin;
-  if (b >= 0 && b < n_obs) ccd_obs_body<PRIM>(D, b, lds);
-  else if (b >= 0) found = ccd_self_pairs_body(D, b - n_obs, lds);
+  const int n_xf = D.xf ? D.n_foreign() * D.S : 0;   // sharded contexts: swept-hull cache of the other ranks' robots, ahead of the pair tiles that read it
+  const int b = (int)blockIdx.x - fin - n_xf;
+  if ((int)blockIdx.x >= fin && b < 0) xf_ccd_body(D, (int)blockIdx.x - fin, lds);
+  else if (b >= 0 && b < n_obs) ccd_obs_body<PRIM>(D, b, lds);
+  else if (b >= 0) found = ccd_self_pairs_body(D, b - n_obs, lds, D.xf != 0);
   TJ_TIC(D, K_CCD, 1);
   // The sequential replay of the acting pairs + gnorm (k_ccd_self_seq: one wave with ~1 us of work in the usual case of no acting
   // pair, 4.6 us as a launch of its own) is finished inside this launch.  A first version -- every block takes a ticket, the
@@ -662,7 +739,7 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   // in.  Their sum also tells it whether any pair acts: none, almost always, and then it is done (k_begin has zeroed k_self).
   if (!D.seq_fold) return;
   const int lane = lane_id();
-  const int n_t = (int)gridDim.x - 1 - n_obs;   // selection blocks
+  const int n_t = (int)gridDim.x - 1 - n_xf - n_obs;   // selection blocks
   if (b >= n_obs) {
     __builtin_amdgcn_s_waitcnt(0);
     if (lane == 0) atomicAdd(&D.ctl->ccd_sub[(b - n_obs) & 15], 1 + (found ? 0x10000 : 0));
@@ -678,7 +755,8 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   M.ti = D.seq_gmem_i; M.stk = M.ti + 10 * (size_t)D.U;
   M.lane0_stages = true;
   {   // gnorm: the sequential sum in robot order (Optimization3D_multi.h:57,72,750)
-    for (int i = lane; i < D.U; i += 64) M.gns[i] = D.gn(i);
+    if (D.xf) xf_wait_all(D, 1);   // sharded contexts: the other ranks' |g| values are put in place by this launch's foreign units
+    for (int i = lane; i < D.U; i += 64) M.gns[i] = D.xf ? xf_load(&D.gn(i)) : D.gn(i);
     __syncthreads();
     if (lane == 0) { double gsum = 0; for (int u = 0; u < D.U; u++) gsum += M.gns[u]; D.ctl->gnorm = gsum / double(D.U); }
     __syncthreads();
@@ -716,10 +794,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 }
 
 // ---- iteration bookkeeping ---------------------------------------------------------------------
-__global__ void k_begin(Dev D) { begin_body(D); }
+// the first iteration of a batch; direct exchange (sharded contexts): it also feeds the peers with this rank's control points as they stand now (inside a
+// batch k_linesearch does, robot by robot) -- so a tj_set_state between batches reaches every rank like it did through the all-gather
+__global__ void k_begin(Dev D) {
+  const bool done = begin_body(D);
+  if (!D.xch || done) return;
+  const XchPeers* xp = D.xp;
+  const int np = xp->n, T = D.T, own = D.u1 - D.u0;
+  const size_t off = (size_t)D.u0 * 3 * T, cnt = (size_t)own * 3 * T;
+  for (int q = 0; q < np; q++) for (size_t i = threadIdx.x; i < cnt; i += blockDim.x) xch_store(xp->rx[q][0] + off + i, D.spline[off + i]);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  asm volatile("" ::: "memory");
+  if ((int)threadIdx.x < np) __hip_atomic_fetch_add(xp->cnt[threadIdx.x] + D.rank, (unsigned long long)own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) atomicAdd(&D.ctl->xpush[0], own);
+}
 // only used by the stage API: commit the iteration counter explicitly
 // hand a still-owed slack/dual update to the next k_slack(deferred) launch without starting an iteration
-__global__ void k_flush(Dev D) {
+// cancel = 1: the last k_linesearch has already begun an iteration (begin_next) that the host then did not enqueue -- take that back: the update owed is the
+// finished iteration's (already in slack_now), nothing is pending
+__global__ void k_flush(Dev D, int cancel) {
+  if (cancel) { D.ctl->pending = 0; D.ctl->slack_next = 0; return; }
   D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0;
 }
 __global__ void k_end(Dev D) {

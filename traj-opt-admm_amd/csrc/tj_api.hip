@@ -43,6 +43,13 @@ struct tj_ctx {
   bool have_cloud = false, have_state = false;
   bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
   bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
+  bool ccd_valid = false;    // Dev::fuse: the swept-hull cache of the owned robots matches their direction records (k_xsolve's tail wrote it; tj_set_direction / tj_set_state clear it)
+  long long launches = 0;    // kernels enqueued by the iteration schedules so far (tj_launch_count)
+  bool begin_folded = false; // the last k_linesearch enqueued has already begun the next iteration (begin_next): the next phase 0 / iteration launches no k_begin
+  // direct exchange between sharded contexts (Dev::xch): this rank's receive block (uncached), the peers' blocks as mapped here, the device table
+  void* xch_block = nullptr; size_t xch_bytes = 0; bool xch_ipc_exported = false;
+  std::vector<void*> xch_ipc_opened;
+  XchPeers* xch_table = nullptr;
   // graph of one full iteration
   // hipGraphs: [0..2] the three phases of a sharded iteration, [3] one full iteration
   hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -103,6 +110,9 @@ void drop_graph(tj_ctx* c) {
   }
 }
 
+// every kernel the iteration schedules enqueue is counted (tj_launch_count: launches per iteration of a schedule, bench.py / tests)
+#define TJ_LAUNCH(...) do { c->launches++; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 // ---- kernels of one iteration, in stream order (also the unit of tj_profile_kernels) ----
 const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "k_obs_query", "k_sep_self_rows", "k_mid", "k_obs_solve", "k_sep_self_solve", "k_keep", "k_sep_self_compact",
                                            "k_grad", "k_xsolve", "k_xsolve_c2", "k_ccd_prep", "k_ccd", "k_ccd_obs", "k_ccd_self_pairs", "k_ccd_self_seq",
@@ -129,87 +139,94 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, c->n_solve_env > 0 ? c->n_solve_env : (d.U >= 192 ? 1536 : 1728)) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 1024 : 0;   // (512: SCN-E's k_mid 43.7 us, 1024: 38.3, 2048: 37.8; SCN-C indifferent)
   const int n_rows = multi ? d.S * pair_units(d.U, d.pair_rows) : 0;   // one wave per (segment, tile of pair_rows lower robots x 64 partners)
-  const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + (d.spec ? SPEC_CAP : 0) + (d.grad_bal ? (owned * d.P + 63) / 64 : 0);
+  const int n_xf = d.xf ? d.n_foreign() * d.S : 0;   // sharded contexts: one wave per (foreign robot, segment) at the head of k_front / k_ccd (kernels_step.h)
+  const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + n_xf + (d.spec ? SPEC_CAP : 0) + (d.grad_bal ? (owned * d.P + 63) / 64 : 0);
+  const bool chained = in_graph || in_phase;          // an iteration chain (one context, or the phases of a sharded schedule) as opposed to the stage API
   const int n_mid_slack = owned * d.P;
   switch (kid) {
-    case K_BEGIN: if (chain_pos & 1) return false; hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, d); return true;
-    case K_HULLINFO: if ((in_graph && d.fuse) || !multi) return false; hipLaunchKernelGGL(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // sharded phases: always (all robots, after the gather)
+    case K_BEGIN: if (chain_pos & 1) return false; TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d); return true;
+    case K_HULLINFO: if ((chained && d.fuse) || !multi) return false; TJ_LAUNCH(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // unfused sharded phases (coupled mode): always (all robots, after the gather)
     case K_FRONT: if (!in_graph && !in_phase) return false;
       if (c->split_unions && multi) {
         // hundreds of robots: the union is bound by how many one-wave blocks are resident (LDS of the BVH frontier: 14 per CU), and
         // the pair rows need none of that LDS -- two launches, the second one at full occupancy, beat one boundary saved
-        if (owned * d.S > 0) { if (tri) hipLaunchKernelGGL((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d); }
-        hipLaunchKernelGGL(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d);
+        if (owned * d.S > 0) { if (tri) TJ_LAUNCH((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else TJ_LAUNCH((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d); }
+        TJ_LAUNCH(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
-      if (tri) hipLaunchKernelGGL((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
+      if (d.xch && !d.xch_poll) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 0);   // ranks sharing a device: the wait for the peers' control points is a launch of its own
+      if (tri) TJ_LAUNCH((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else TJ_LAUNCH((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
       return true;
     case K_SEP_OBS: if (in_graph || in_phase) return false;  // stage API and sharded phase 0
-      if (tri) hipLaunchKernelGGL((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d);
+      if (tri) TJ_LAUNCH((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else TJ_LAUNCH((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d);
       return true;
     case K_OBS_SOLVE: if (in_graph || !n_obs_solve) return false;
-      if (tri) hipLaunchKernelGGL((k_obs_solve<3>), dim3(n_obs_solve), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_obs_solve<1>), dim3(n_obs_solve), dim3(64), 0, s, d);
+      if (tri) TJ_LAUNCH((k_obs_solve<3>), dim3(n_obs_solve), dim3(64), 0, s, d); else TJ_LAUNCH((k_obs_solve<1>), dim3(n_obs_solve), dim3(64), 0, s, d);
       return true;
-    case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; hipLaunchKernelGGL(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d); return true;
+    case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; TJ_LAUNCH(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d); return true;
     case K_MID: if (!in_graph && !in_phase) return false;
-      if (tri) hipLaunchKernelGGL((k_mid<3>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else hipLaunchKernelGGL((k_mid<1>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
+      if (tri) TJ_LAUNCH((k_mid<3>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else TJ_LAUNCH((k_mid<1>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
       return true;
-    case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; hipLaunchKernelGGL(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
+    case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; TJ_LAUNCH(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
-      hipLaunchKernelGGL(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
+      TJ_LAUNCH(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
     case K_SEP_SELF_COMPACT: if ((in_graph || in_phase) && c->grad_fold) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
-      hipLaunchKernelGGL(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
+      TJ_LAUNCH(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD:
-      if ((in_graph || in_phase) && c->grad_fold) hipLaunchKernelGGL((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double), s, d);
-      else hipLaunchKernelGGL((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
+      if ((in_graph || in_phase) && c->grad_fold) TJ_LAUNCH((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double), s, d);
+      else TJ_LAUNCH((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
       return true;
     case K_XSOLVE:
-      if (d.xs_band) hipLaunchKernelGGL(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
+      if (d.xs_band) TJ_LAUNCH(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
       else switch (9 * d.P - 2) {   // the register factorisation is inlined per size (kernels_newton.h); 61 rows and the LDS forms: the generic kernel
-        case 16: hipLaunchKernelGGL((k_xsolve<16>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
-        case 25: hipLaunchKernelGGL((k_xsolve<25>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
-        case 34: hipLaunchKernelGGL((k_xsolve<34>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
-        case 43: hipLaunchKernelGGL((k_xsolve<43>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
-        case 52: hipLaunchKernelGGL((k_xsolve<52>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
-        default: hipLaunchKernelGGL((k_xsolve<0>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 16: TJ_LAUNCH((k_xsolve<16>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 25: TJ_LAUNCH((k_xsolve<25>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 34: TJ_LAUNCH((k_xsolve<34>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 43: TJ_LAUNCH((k_xsolve<43>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        case 52: TJ_LAUNCH((k_xsolve<52>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
+        default: TJ_LAUNCH((k_xsolve<0>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
       }
+      if (chained && d.fuse && !d.xs_band) c->ccd_valid = true;   // its tail has left the owned robots' swept-hull cache
       return true;
     case K_XSOLVE_C2:
-      if (coupled) { if (d.xs_band) hipLaunchKernelGGL(k_xsolve_c2_band, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); else hipLaunchKernelGGL(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); }
+      if (coupled) { if (d.xs_band) TJ_LAUNCH(k_xsolve_c2_band, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); else TJ_LAUNCH(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); }
       return coupled;
-    case K_CCD_PREP: if (in_graph && d.fuse && !d.xs_band) return false;  // single-GPU chain: k_xsolve's tail leaves the swept-hull cache
-      hipLaunchKernelGGL(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d); return true;
+    case K_CCD_PREP: if (chained && d.fuse && !d.xs_band && c->ccd_valid) return false;  // fused chains: k_xsolve's tail leaves the swept-hull cache
+      if (chained && d.xf) { if (owned > 0) TJ_LAUNCH(k_ccd_prep, dim3(owned * d.S), dim3(64), 0, s, d, d.u0); }   // (the other ranks' robots: k_ccd's foreign units)
+      else TJ_LAUNCH(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d, 0);
+      return true;
     case K_CCD: if (!in_graph && !in_phase) return false;
       if (c->split_unions && multi) {
-        if (owned * d.S > 0) { if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d); }
-        hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d);
+        if (owned * d.S > 0) { if (tri) TJ_LAUNCH((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else TJ_LAUNCH((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d); }
+        TJ_LAUNCH(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
+      if (d.xch && !d.xch_poll) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 1);   // ranks sharing a device: the wait for the peers' direction records is a launch of its own
       {
-        const int g = n_ccd + (d.seq_fold ? 1 : 0);   // + the finisher of the folded pair replay (kernels_step.h)
-        if (c->ccd_lean) { if (tri) hipLaunchKernelGGL((k_ccd_lean<3>), dim3(g), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_lean<1>), dim3(g), dim3(64), 0, s, d); }
-        else { if (tri) hipLaunchKernelGGL((k_ccd<3>), dim3(g), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd<1>), dim3(g), dim3(64), 0, s, d); }
+        const int g = n_ccd + n_xf + (d.seq_fold ? 1 : 0);   // + the finisher of the folded pair replay (kernels_step.h)
+        if (c->ccd_lean) { if (tri) TJ_LAUNCH((k_ccd_lean<3>), dim3(g), dim3(64), 0, s, d); else TJ_LAUNCH((k_ccd_lean<1>), dim3(g), dim3(64), 0, s, d); }
+        else { if (tri) TJ_LAUNCH((k_ccd<3>), dim3(g), dim3(64), 0, s, d); else TJ_LAUNCH((k_ccd<1>), dim3(g), dim3(64), 0, s, d); }
       }
       return true;
     case K_CCD_OBS: if (in_graph) return false;
-      if (tri) hipLaunchKernelGGL((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else hipLaunchKernelGGL((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d);
+      if (tri) TJ_LAUNCH((k_ccd_obs<3>), dim3(owned * d.S), dim3(64), 0, s, d); else TJ_LAUNCH((k_ccd_obs<1>), dim3(owned * d.S), dim3(64), 0, s, d);
       return true;
-    case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; hipLaunchKernelGGL(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d); return true;
+    case K_CCD_SELF_PAIRS: if (in_graph || !multi) return false; TJ_LAUNCH(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d); return true;
     case K_CCD_SELF_SEQ:
       if ((in_graph || in_phase) && d.seq_fold && !(c->split_unions && multi)) return false;   // the last block of k_ccd has done it
       if (!multi && in_graph) return false;   // single UAV: no pairs to replay, and k_xsolve has left gnorm = |g| itself -- one launch less in the chain
-      hipLaunchKernelGGL(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
-    case K_LINESEARCH: if (!coupled) hipLaunchKernelGGL(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
+      TJ_LAUNCH(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
+    case K_LINESEARCH: if (!coupled) TJ_LAUNCH(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED:
       if (coupled) {
-        if (c->lsc_wide) hipLaunchKernelGGL(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0);   // all rounds at once, one block per (robot, round)
-        else for (int r = 0; r < LSC_ROUNDS; r++) hipLaunchKernelGGL(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r, 1, 0);
+        if (c->lsc_wide) TJ_LAUNCH(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0);   // all rounds at once, one block per (robot, round)
+        else for (int r = 0; r < LSC_ROUNDS; r++) TJ_LAUNCH(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r, 1, 0);
       }
       return coupled;
-    case K_LS_COMMIT: if (coupled && !(c->lsc_wide && owned == d.U)) hipLaunchKernelGGL(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;   // (one context, all rounds in one launch: its last block commits)
-    case K_SLACK: if (in_graph) return false; hipLaunchKernelGGL(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
+    case K_LS_COMMIT: if (coupled && !(c->lsc_wide && owned == d.U)) TJ_LAUNCH(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;   // (one context, all rounds in one launch: its last block commits)
+    case K_SLACK: if (in_graph) return false; TJ_LAUNCH(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
   }
   return false;
 }
@@ -250,11 +267,14 @@ int enqueue_iteration(tj_ctx* c, int chain_pos = 0) {
   return TJ_OK;
 }
 
+int ensure_hull_cache(tj_ctx* c);
+
 // Pay a deferred slack/dual update (no-op kernels if nothing is owed).
 int flush_deferred(tj_ctx* c) {
   if (!c->maybe_deferred) return TJ_OK;
   const Dev& d = c->d;
-  hipLaunchKernelGGL(k_flush, dim3(1), dim3(1), 0, c->stream, d);
+  TJ_LAUNCH(k_flush, dim3(1), dim3(1), 0, c->stream, d, c->begin_folded ? 1 : 0);   // (a begin folded into the last line search whose iteration was never enqueued is taken back)
+  c->begin_folded = false;
   launch_kernel(c, K_SLACK, c->stream, 1);
   HIPCHK(c, hipGetLastError());
   c->maybe_deferred = false;
@@ -293,7 +313,8 @@ int enqueue_body(tj_ctx* c, int which, int chain_pos = 0, bool whole_iteration =
     case 4: list = pc4; n = 1; break;
     case 5: list = pc5; n = 1; break;
   }
-  for (int i = 0; i < n; i++) launch_kernel(c, list[i], m, 0, false, true);
+  if (which == 1 && c->d.fuse) { int hr = ensure_hull_cache(c); if (hr) return hr; }   // fused phases: k_linesearch keeps the owned robots' hull cache; after a host write it is rebuilt once
+  for (int i = 0; i < n; i++) launch_kernel(c, list[i], m, 0, false, true, chain_pos);
   HIPCHK(c, hipGetLastError());
   if (which == (cpl ? 5 : 2)) c->maybe_deferred = true;  // this iteration's slack/dual update is owed to the next k_mid (or the flush)
   return TJ_OK;
@@ -438,7 +459,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   memset(&d, 0, sizeof(d));
   d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0; d.prim = 1;
   c->use_graph = getenv("TJ_USE_GRAPH") != nullptr;
-  d.fuse = (p->world == 1 && p->mode != TJ_MODE_MULTI_COUPLED) ? 1 : 0;
+  // the fused chain (k_linesearch leaves the hull cache, k_xsolve's tail the swept-hull cache) -- sharded contexts too since round 5: the other ranks' robots
+  // are handled by foreign units inside k_front / k_ccd (Dev::xf).  Coupled mode keeps its own kernels (and, sharded, k_hullinfo / k_ccd_prep for all robots).
+  const bool split_env = getenv("TJ_SPLIT_UNIONS") && atoi(getenv("TJ_SPLIT_UNIONS")) != 0;
+  d.fuse = (p->mode != TJ_MODE_MULTI_COUPLED && !(p->world > 1 && (split_env || getenv("TJ_SHARD_UNFUSED")))) ? 1 : 0;
+  d.rank = p->rank; d.world = p->world;
+  d.xf = (p->world > 1 && d.fuse && p->mode == TJ_MODE_MULTI_DECOUPLE) ? 1 : 0;
   d.u0 = (int)((long long)p->rank * d.U / p->world); d.u1 = (int)((long long)(p->rank + 1) * d.U / p->world);
   d.lambda = p->lambda; d.margin = p->margin; d.offset = p->offset; d.mu = p->mu; d.vel_limit = p->vel_limit; d.acc_limit = p->acc_limit;
   d.ks = p->ks; d.kt = p->kt; d.stop = p->stop;
@@ -580,6 +606,9 @@ int tj_create(const tj_params* p, tj_ctx** out) {
 void tj_destroy(tj_ctx* c) {
   if (!c) return;
   drop_graph(c);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->xch_ipc_opened) (void)hipIpcCloseMemHandle(p);
+  if (c->xch_block) (void)hipFree(c->xch_block);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->cloud_allocs) hipFree(p);
   if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
@@ -748,11 +777,14 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   if ((r = upload(c, d.spline, spline.data(), spline.size() * 8)) || (r = upload(c, d.p_slack, p_slack.data(), p_slack.size() * 8)) ||
       (r = upload(c, d.p_lambda, zeros.data(), zeros.size() * 8)) || (r = upload(c, d.t_slack, ts.data(), ts.size() * 8)) ||
       (r = upload(c, d.t_lambda, tz.data(), tz.size() * 8)) || (r = upload(c, d.piece_time, ptv.data(), ptv.size() * 8))) return r;
+  // direct exchange: the push / arrival counts restart (the caller has every rank drained before any rank calls this, and a barrier after:
+  // tj_group_init_state does; processes use their collective's barrier)
+  if (c->xch_block) HIPCHK(c, hipMemsetAsync(d.xcnt, 0, 2 * XCH_MAX * sizeof(unsigned long long), c->stream));
   Ctl h;
   memset(&h, 0, sizeof(h));
   h.gnorm = 1.0;  // Main/multiPathPlanning3D.cpp:594
   if ((r = upload(c, d.ctl, &h, sizeof(h)))) return r;
-  c->hull_valid = false;
+  c->hull_valid = false; c->ccd_valid = false;
   HIPCHK(c, hipMemsetAsync(d.xdir, 0, (size_t)U * d.xs * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(d.ocount, 0, (size_t)U * d.S * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(d.scount, 0, (size_t)U * d.S * 4, c->stream));
@@ -809,7 +841,7 @@ int tj_set_state(tj_ctx* c, int u, const double* spline, const double* p_slack, 
   if (t_slack && (r = upload(c, d.t_slack + (size_t)u * d.P, t_slack, d.P * 8))) return r;
   if (t_lambda && (r = upload(c, d.t_lambda + (size_t)u * d.P, t_lambda, d.P * 8))) return r;
   if ((r = upload(c, d.piece_time + u, &piece_time, 8))) return r;
-  c->hull_valid = false;
+  c->hull_valid = false; c->ccd_valid = false;
   c->have_state = true;
   return TJ_OK;
 }
@@ -823,7 +855,8 @@ int tj_iterate_async(tj_ctx* c, int n_iters) {
   // (coupled mode: only where the whole search is ONE launch whose last block commits -- lsc_wide, one context)
   const bool chain = !c->use_graph && (c->d.mode != TJ_MODE_MULTI_COUPLED || (c->lsc_wide && c->d.u1 - c->d.u0 == c->d.U));
   for (int i = 0; i < n_iters; i++) {
-    const int pos = chain ? ((i > 0 ? 1 : 0) | (i + 1 < n_iters ? 2 : 0)) : 0;
+    const int pos = chain ? (((i > 0 || c->begin_folded) ? 1 : 0) | (i + 1 < n_iters ? 2 : 0)) : 0;
+    c->begin_folded = false;
     int r = launch_graph_or_eager(c, 3, pos); if (r) return r;
   }
   c->iters_enqueued += n_iters;
@@ -881,6 +914,7 @@ int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
   return check_device_errors(c);
 }
 
+long long tj_launch_count(tj_ctx* c) { return c ? c->launches : -1; }
 int tj_kernel_count(void) { return K_COUNT; }
 const char* tj_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? kKernelNames[i] : ""; }
 
@@ -909,14 +943,24 @@ int tj_run_stage(tj_ctx* c, int stage) {
 
 int tj_phase_count(tj_ctx* c) { return c ? (c->d.mode == TJ_MODE_MULTI_COUPLED ? 6 : 3) : TJ_ERR_INVALID; }
 
-int tj_iterate_phase(tj_ctx* c, int phase) {
+int tj_iterate_phase_chained(tj_ctx* c, int phase, int more) {
   if (!c || phase < 0 || phase >= tj_phase_count(c)) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
   // eager launches: measured faster than three graph replays per iteration (a replay costs ~10-16 us of host time, a
   // plain launch ~3.5 us, and a phase has only 2-7 kernels).  No flush here: the slack/dual update an iteration owes is
   // paid by k_mid of the next iteration's phase 1 (or by tj_sync / any state access).
-  return enqueue_body(c, phase);
+  // Decoupled / single-UAV schedules fold the next iteration's begin into the last phase's k_linesearch when the caller says one follows
+  // (more != 0): that iteration's phase 0 then launches nothing.  A begin that was folded for an iteration the caller never enqueues is
+  // taken back by the next flush (tj_sync, any state access).
+  int pos = 0;
+  if (c->d.mode != TJ_MODE_MULTI_COUPLED && c->d.fuse) {
+    if (phase == 0) { pos = c->begin_folded ? 1 : 0; c->begin_folded = false; }
+    if (phase == 2 && more) { pos = 2; c->begin_folded = true; }
+  }
+  if (phase == 0) c->iters_enqueued += 1;
+  return enqueue_body(c, phase, pos);
 }
+int tj_iterate_phase(tj_ctx* c, int phase) { return tj_iterate_phase_chained(c, phase, 0); }
 
 int tj_exchange_buffer(tj_ctx* c, int what, void** dev_ptr, int* doubles_per_robot, int* first_owned, int* n_owned) {
   if (!c || what < 0 || what > 4) return TJ_ERR_INVALID;
@@ -1023,6 +1067,7 @@ int tj_set_direction(tj_ctx* c, int u, const double* direction, double t_directi
   std::vector<double> rec(d.xs, 0.0);
   memcpy(rec.data(), direction, 3 * d.T * 8);
   rec[3 * d.T] = t_direction; rec[3 * d.T + 1] = wolfe; rec[3 * d.T + 2] = gn;
+  c->ccd_valid = false;   // the swept-hull cache no longer matches: the next chained CCD stage rebuilds it (k_ccd_prep)
   return upload(c, d.xdir + (size_t)u * d.xs, rec.data(), d.xs * 8);
 }
 
@@ -1488,5 +1533,94 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
 }
 
 }  // extern "C"
+
+// ---- direct exchange between sharded contexts (Dev::xch; include/trajadmm.h "tj_xch_*") ------------------------------------------------------------
+// Each rank owns ONE uncached block: [U][3T] control points | [U][xs] direction records | [2][XCH_MAX] arrival counters.  Peers store into it (same
+// process: plain peer access; other processes: hipIpc) from inside their producing kernels; this rank's k_front / k_ccd read it.
+namespace {
+size_t xch_rx1_off(const Dev& d) { return (size_t)d.U * 3 * d.T; }
+size_t xch_cnt_off(const Dev& d) { return xch_rx1_off(d) + (size_t)d.U * d.xs; }
+size_t xch_block_bytes(const Dev& d) { return (xch_cnt_off(d) + 2 * XCH_MAX) * sizeof(double); }
+}  // namespace
+
+int tj_xch_block(tj_ctx* c, void** base, size_t* bytes) {
+  if (!c) return TJ_ERR_INVALID;
+  Dev& d = c->d;
+  if (!d.xf) { c->err = "tj_xch_block: the direct exchange exists for sharded decoupled contexts (world > 1) only"; return TJ_ERR_UNSUPPORTED; }
+  if (d.u1 - d.u0 < 1) { c->err = "tj_xch_block: this rank owns no robot (more ranks than robots)"; return TJ_ERR_UNSUPPORTED; }
+  if (d.world > XCH_MAX) { c->err = "tj_xch_block: more than 16 ranks"; return TJ_ERR_UNSUPPORTED; }
+  if (!c->xch_block) {
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const size_t nb = xch_block_bytes(d);
+    void* q = nullptr;
+    // uncached: written by a remote GPU (or another process) while this rank's kernels run, read by them with system-scope loads
+    if (hipExtMallocWithFlags(&q, nb, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipExtMallocWithFlags(&q, nb, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); c->err = "tj_xch_block: hipExtMallocWithFlags (uncached / fine-grained) failed"; return TJ_ERR_DEVICE; }
+    }
+    HIPCHK(c, hipMemset(q, 0, nb));
+    HIPCHK(c, hipDeviceSynchronize());
+    c->xch_block = q; c->xch_bytes = nb;
+    d.rx[0] = (double*)q; d.rx[1] = (double*)q + xch_rx1_off(d); d.xcnt = (unsigned long long*)((double*)q + xch_cnt_off(d));
+  }
+  if (base) *base = c->xch_block;
+  if (bytes) *bytes = c->xch_bytes;
+  return TJ_OK;
+}
+
+int tj_xch_ipc_export(tj_ctx* c, void* handle64) {
+  if (!c || !handle64) return TJ_ERR_INVALID;
+  { int r = tj_xch_block(c, nullptr, nullptr); if (r) return r; }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands the handle over as 64 bytes");
+  hipIpcMemHandle_t h;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, hipIpcGetMemHandle(&h, c->xch_block));
+  memcpy(handle64, &h, 64);
+  c->xch_ipc_exported = true;
+  return TJ_OK;
+}
+
+int tj_xch_ipc_open(tj_ctx* c, const void* handle64, void** base) {
+  if (!c || !handle64 || !base) return TJ_ERR_INVALID;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  void* p = nullptr;
+  HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  c->xch_ipc_opened.push_back(p);
+  *base = p;
+  return TJ_OK;
+}
+
+int tj_xch_attach(tj_ctx* c, int n_peers, const int* peer_ranks, void* const* peer_bases) {
+  if (!c || n_peers < 0 || n_peers >= XCH_MAX || (n_peers > 0 && (!peer_ranks || !peer_bases))) return TJ_ERR_INVALID;
+  { int r = tj_xch_block(c, nullptr, nullptr); if (r) return r; }
+  Dev& d = c->d;
+  if (n_peers != d.world - 1) { c->err = "tj_xch_attach: every other rank of the world must be attached"; return TJ_ERR_INVALID; }
+  XchPeers t;
+  memset(&t, 0, sizeof(t));
+  t.n = n_peers;
+  for (int q = 0; q < n_peers; q++) {
+    if (peer_ranks[q] < 0 || peer_ranks[q] >= d.world || peer_ranks[q] == d.rank || !peer_bases[q]) { c->err = "tj_xch_attach: bad peer"; return TJ_ERR_INVALID; }
+    t.rank[q] = peer_ranks[q];
+    double* b = (double*)peer_bases[q];
+    t.rx[q][0] = b; t.rx[q][1] = b + xch_rx1_off(d); t.cnt[q] = (unsigned long long*)(b + xch_cnt_off(d));
+  }
+  QUIESCE(c);
+  if (!c->xch_table) { int r = dalloc(c, &c->xch_table, 1); if (r) return r; }
+  { int r = upload(c, c->xch_table, &t, sizeof(t)); if (r) return r; }
+  d.xp = c->xch_table;
+  return TJ_OK;
+}
+
+int tj_xch_enable(tj_ctx* c, int on, int poll_in_kernel) {
+  if (!c) return TJ_ERR_INVALID;
+  Dev& d = c->d;
+  if (on && (!d.xp || !c->xch_block)) { c->err = "tj_xch_enable: tj_xch_attach has not been called"; return TJ_ERR_INVALID; }
+  QUIESCE(c);
+  drop_graph(c);
+  d.xch = on ? 1 : 0; d.xch_poll = poll_in_kernel ? 1 : 0;
+  return TJ_OK;
+}
 
 #include "tj_group.h"

@@ -94,6 +94,9 @@ struct RcclApi {
   int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;  // ncclAllGather
   const char* (*GetErrorString)(int) = nullptr;                                                                      // ncclGetErrorString
   int (*CommCount)(void* comm, int* count) = nullptr;                                                                // ncclCommCount (optional: reporting only)
+  int (*Broadcast)(const void* send, void* recv, size_t count, int dtype, int root, void* comm, hipStream_t stream) = nullptr;   // ncclBroadcast  } optional: unequal slices
+  int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;                                                        // ncclGroupStart / ncclGroupEnd  } (uav_num % ranks != 0)
+  bool uneven_ok() const { return Broadcast && GroupStart && GroupEnd; }
   std::string err;                                                                                                   // why the library could not be bound (taken once, where dlopen failed)
   bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GetErrorString; }
 };
@@ -117,6 +120,9 @@ RcclApi& rccl_api() {
     api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
     api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+    api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
+    api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
     if (!api.ok()) api.err = "librccl.so lacks ncclCommInitAll / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
   });
   return api;
@@ -163,8 +169,22 @@ int group_exchange(tj_group* g, int r, int what, long s) {
   const GroupExchangeInfo b = group_buffer(c, what);
   const size_t off = (size_t)d.u0 * b.per, cnt = (size_t)(d.u1 - d.u0) * b.per, total = (size_t)d.U * b.per;
   if (g->transport == TJ_TRANSPORT_RCCL) {   // in place: this rank's slice already sits at its offset of the full buffer
-    const int rc = rccl_api().AllGather(b.buf + off, b.buf, cnt, kNcclFloat64, g->comms[r], c->stream);
-    if (rc != 0) { c->err = std::string("ncclAllGather: ") + rccl_api().GetErrorString(rc); return TJ_ERR_DEVICE; }
+    RcclApi& api = rccl_api();
+    c->launches++;   // (the collective's kernel)
+    if (d.U % g->n == 0) {
+      const int rc = api.AllGather(b.buf + off, b.buf, cnt, kNcclFloat64, g->comms[r], c->stream);
+      if (rc != 0) { c->err = std::string("ncclAllGather: ") + api.GetErrorString(rc); return TJ_ERR_DEVICE; }
+      return TJ_OK;
+    }
+    // unequal slices (uav_num not divisible by the ranks): one in-place broadcast per owner, fused into one group call
+    int rc = api.GroupStart();
+    for (int q = 0; q < g->n && rc == 0; q++) {
+      const size_t qo = (size_t)((long long)q * d.U / g->n) * b.per, qc = (size_t)((long long)(q + 1) * d.U / g->n) * b.per - qo;
+      if (qc > 0) rc = api.Broadcast(b.buf + qo, b.buf + qo, qc, kNcclFloat64, q, g->comms[r], c->stream);
+    }
+    const int rc2 = api.GroupEnd();
+    if (rc == 0) rc = rc2;
+    if (rc != 0) { c->err = std::string("ncclBroadcast (unequal slices): ") + api.GetErrorString(rc); return TJ_ERR_DEVICE; }
     return TJ_OK;
   }
   GroupPeers peers; int np = 0;
@@ -172,12 +192,12 @@ int group_exchange(tj_group* g, int r, int what, long s) {
   if (g->transport == TJ_TRANSPORT_FLAG) {
     GroupPeers mine; int nm = 0;
     for (int q = 0; q < g->n; q++) if (q != r) { mine.p[nm] = nullptr; mine.flag[nm] = group_flag(g, r, what, par, q); nm++; }
-    hipLaunchKernelGGL(k_group_push_flag, dim3(1), dim3(GROUP_FLAG_THREADS), 0, c->stream, b.buf, peers, np, off, cnt, (unsigned long long)(s + 1));
-    hipLaunchKernelGGL(k_group_wait_unpack, dim3(1), dim3(GROUP_FLAG_THREADS), 0, c->stream, b.buf, g->rx[r][what][par], mine, nm, (unsigned long long)(s + 1), off, cnt, total, d.ctl);
+    TJ_LAUNCH(k_group_push_flag, dim3(1), dim3(GROUP_FLAG_THREADS), 0, c->stream, b.buf, peers, np, off, cnt, (unsigned long long)(s + 1));
+    TJ_LAUNCH(k_group_wait_unpack, dim3(1), dim3(GROUP_FLAG_THREADS), 0, c->stream, b.buf, g->rx[r][what][par], mine, nm, (unsigned long long)(s + 1), off, cnt, total, d.ctl);
     HIPCHK(c, hipGetLastError());
     return TJ_OK;
   }
-  if (cnt > 0) hipLaunchKernelGGL(k_group_push, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, peers, np, off, cnt);
+  if (cnt > 0) TJ_LAUNCH(k_group_push, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, peers, np, off, cnt);
   HIPCHK(c, hipEventRecord(g->ev[r][what][par], c->stream));
   g->recorded[r][what].store(s + 1, std::memory_order_release);
   for (int q = 0; q < g->n; q++) {
@@ -188,7 +208,7 @@ int group_exchange(tj_group* g, int r, int what, long s) {
     }
     HIPCHK(c, hipStreamWaitEvent(c->stream, g->ev[q][what][par], 0));
   }
-  hipLaunchKernelGGL(k_group_unpack, dim3((unsigned)std::min<size_t>((total + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, g->rx[r][what][par], off, cnt, total);
+  TJ_LAUNCH(k_group_unpack, dim3((unsigned)std::min<size_t>((total + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, g->rx[r][what][par], off, cnt, total);
   HIPCHK(c, hipGetLastError());
   return TJ_OK;
 }
@@ -204,11 +224,14 @@ int group_rank_loop(tj_group* g, int r, int n_iters) {
   const bool cpl = c->d.mode == TJ_MODE_MULTI_COUPLED;
   const int (*sched)[2] = cpl ? kGroupCoupled : kGroupDecoupled;
   const int nph = cpl ? 6 : 3;
+  // direct exchange (flag transport, decoupled mode): nothing between the launches -- the producing kernels push, the consuming kernels wait:
+  // the fused six-kernel chain of one context
+  if (g->n > 1 && g->transport == TJ_TRANSPORT_FLAG && c->d.xch) return tj_iterate_async(c, n_iters);
   long s[5];
   for (int w = 0; w < 5; w++) s[w] = g->issued[w];
   for (int it = 0; it < n_iters; it++)
     for (int k = 0; k < nph; k++) {
-      int rc = enqueue_body(c, sched[k][0]);
+      int rc = tj_iterate_phase_chained(c, sched[k][0], it + 1 < n_iters);   // (decoupled: the next iteration's begin rides in this one's k_linesearch)
       if (rc) return rc;
       const int what = sched[k][1];
       if (what >= 0) { rc = group_exchange(g, r, what, s[what]++); if (rc) return rc; }
@@ -225,14 +248,28 @@ const char* transport_name(int t) { return t == TJ_TRANSPORT_FLAG ? "flag" : (t 
 int group_select_transport(tj_group* g, int t) {
   if (t == TJ_TRANSPORT_RCCL) {
     if (!g->distinct) return group_fail(g, TJ_ERR_UNSUPPORTED, "transport rccl needs every rank on its own device (RCCL refuses two ranks on one GPU)");
-    if (g->ctx[0]->d.U % g->n != 0) return group_fail(g, TJ_ERR_UNSUPPORTED, "transport rccl needs the robot count to be divisible by the number of ranks (ncclAllGather gathers equal slices)");
     RcclApi& api = rccl_api();
     if (!api.ok()) return group_fail(g, TJ_ERR_DEVICE, std::string("transport rccl: librccl.so could not be bound: ") + (api.err.empty() ? std::string("symbols missing") : api.err));
+    if (g->ctx[0]->d.U % g->n != 0 && !api.uneven_ok()) return group_fail(g, TJ_ERR_UNSUPPORTED, "transport rccl: the robot count is not divisible by the number of ranks and this librccl.so lacks ncclBroadcast / ncclGroupStart / ncclGroupEnd (unequal slices go out as one grouped broadcast per owner)");
     if (g->comms.empty()) {
       g->comms.assign(g->n, nullptr);
       const int rc = api.CommInitAll(g->comms.data(), g->n, g->dev.data());
       if (rc != 0) { g->comms.clear(); return group_fail(g, TJ_ERR_DEVICE, std::string("ncclCommInitAll: ") + api.GetErrorString(rc)); }
     }
+  }
+  // flag transport, decoupled mode: the DIRECT exchange (in-kernel pushes and waits, csrc/kernels_step.h).  Ranks that share a device do not poll inside
+  // k_front / k_ccd (their waiting waves would hold the LDS the peer's producing kernel needs): a one-wave wait launch in front instead.
+  // TJ_XCH_POLL=1 / 0 overrides (test hook: small fleets can poll on a shared device).
+  for (int r = 0; r < g->n; r++) {
+    tj_ctx* c = g->ctx[r];
+    if (!c->d.xf || !c->d.xp) continue;
+    (void)hipSetDevice(g->dev[r]);
+    int sharers = 0;
+    for (int b = 0; b < g->n; b++) sharers += g->dev[b] == g->dev[r] ? 1 : 0;
+    int poll = sharers == 1 ? 1 : 0;
+    if (const char* e = getenv("TJ_XCH_POLL")) poll = atoi(e) != 0;
+    const int rc = tj_xch_enable(c, t == TJ_TRANSPORT_FLAG ? 1 : 0, poll);
+    if (rc) return group_fail(g, rc, std::string("rank ") + std::to_string(r) + ": " + tj_last_error(c));
   }
   g->transport = t;
   return TJ_OK;
@@ -295,6 +332,20 @@ int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_grou
     }
     if (!ualloc(g->dev[r], sizeof(unsigned long long) * 5 * 2 * tj::GROUP_MAX, (void**)&g->flags[r])) return bail(TJ_ERR_DEVICE, "flag allocation failed (hipExtMallocWithFlags, uncached)");
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(TJ_ERR_DEVICE, "stream synchronisation failed");
+  }
+  // direct exchange (decoupled mode): every rank's receive block, attached to every other rank (peer access is enabled above)
+  if (n_ranks > 1 && g->ctx[0]->d.xf) {
+    bool ok = true;
+    std::vector<void*> base(n_ranks, nullptr);
+    for (int r = 0; r < n_ranks && ok; r++) { (void)hipSetDevice(g->dev[r]); ok = tj_xch_block(g->ctx[r], &base[r], nullptr) == TJ_OK; }
+    for (int r = 0; r < n_ranks && ok; r++) {
+      std::vector<int> pr; std::vector<void*> pb;
+      for (int q = 0; q < n_ranks; q++) if (q != r) { pr.push_back(q); pb.push_back(base[q]); }
+      (void)hipSetDevice(g->dev[r]);
+      ok = tj_xch_attach(g->ctx[r], (int)pr.size(), pr.data(), pb.data()) == TJ_OK;
+    }
+    // (a group that cannot have it -- more ranks than robots -- keeps the legacy flag kernels; the other transports do not need it)
+    if (!ok) for (int r = 0; r < n_ranks; r++) g->ctx[r]->d.xp = nullptr;
   }
   // Default: event, on distinct devices too.  The flag transport (no host, no event on the path) is the fastest one measured with the ranks
   // on one device, but it has not crossed xGMI yet: it is opt-in (TJ_GROUP_TRANSPORT=flag / tj_group_set_transport) until
@@ -369,7 +420,7 @@ int tj_group_init_state(tj_group* g, const double* waypoints, double piece_time)
   for (int w = 0; w < 5; w++) { g->issued[w] = 0; for (int r = 0; r < g->n; r++) g->recorded[r][w].store(0); }
   for (int r = 0; r < g->n; r++) { (void)hipSetDevice(g->dev[r]); if (g->flags[r]) (void)hipMemset(g->flags[r], 0, sizeof(unsigned long long) * 5 * 2 * tj::GROUP_MAX); (void)hipDeviceSynchronize(); }
   g->poisoned = false;
-  GROUP_EACH(g, tj_init_state(c, waypoints, piece_time));
+  GROUP_EACH(g, tj_init_state(c, waypoints, piece_time));   // (also restarts the direct exchange's arrival counters: every stream is drained here)
   return TJ_OK;
 }
 

@@ -49,7 +49,8 @@ def run_sharded(engine, gather, n_iters, gather_begin=None):
     gather_begin(what) (optional) STARTS that all-gather and returns a callable that completes it.  Phase 0 touches no
     exchanged buffer and the control points are final when the previous phase 2 ends, so gather 0 may be started before
     phase 0 and completed after it."""
-    for _ in range(n_iters):
+    chained = getattr(engine, "chained", False)   # engine.phase(k, more): the HIP engine folds the next iteration's begin into phase 2 (tj_iterate_phase_chained)
+    for it in range(n_iters):
         finish = gather_begin(0) if gather_begin is not None else None
         engine.phase(0)
         if finish is not None:
@@ -58,4 +59,7 @@ def run_sharded(engine, gather, n_iters, gather_begin=None):
             gather(0)
         engine.phase(1)
         gather(1)
-        engine.phase(2)
+        if chained:
+            engine.phase(2, it + 1 < n_iters)
+        else:
+            engine.phase(2)
