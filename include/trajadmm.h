@@ -260,18 +260,19 @@ int tj_iterate_phase_chained(tj_ctx* c, int phase, int more);
  *   every rank:  tj_xch_ipc_export(c, handle)            64-byte handle of its receive block (allocated on first use, uncached memory)
  *                ... all-gather the handles with any host-side collective ...
  *                tj_xch_ipc_open(c, handle_of_peer, &base) for every other rank
- *                tj_xch_attach(c, world - 1, peer_ranks, peer_bases);  tj_xch_enable(c, 1, poll_in_kernel)
+ *                tj_xch_attach(c, world - 1, peer_ranks, peer_bases);  tj_xch_enable(c, 1, wait_mode)
  *   then tj_iterate_async / tj_iterate on every rank; every rank must run the same number of iterations per batch, and a host-side barrier
  *   must separate "every rank has drained its batch" from tj_init_state (which restarts the counters) and tj_init_state from the next batch.
- * poll_in_kernel = 1: the foreign units poll the arrival counters themselves (ranks on distinct devices); 0: a one-wave launch in front of
- * k_front / k_ccd waits (ranks SHARING a device: polling units would hold the LDS the peer's producing kernel needs).  A push that does not
- * arrive within 2 s fails the batch (TJ_ERR_DEVICE, error bit 512).  Results are bitwise those of one context.  UNVERIFIED ACROSS xGMI, like
+ * wait_mode = 1: the foreign units poll the arrival counters themselves (ranks on distinct devices); 0: a one-wave launch in front of
+ * k_front / k_ccd polls instead (ranks SHARING a device: polling units would hold the LDS the peer's producing kernel needs); 2: nobody polls --
+ * the CALLER orders the streams (tj_group's event transport: an event recorded behind the producing kernel, waited for by the consumer's stream).
+ * A push that does not arrive within 2 s fails the batch (TJ_ERR_DEVICE, error bit 512).  Results are bitwise those of one context.  UNVERIFIED ACROSS xGMI, like
  * tj_group on distinct devices: the tests run ranks and processes on one device. */
 int tj_xch_block(tj_ctx* c, void** base, size_t* bytes);                 /* this rank's receive block (same-process wiring: hand `base` to the peers' tj_xch_attach) */
 int tj_xch_ipc_export(tj_ctx* c, void* handle64);                        /* hipIpcGetMemHandle of the block */
 int tj_xch_ipc_open(tj_ctx* c, const void* handle64, void** base);       /* hipIpcOpenMemHandle of a peer's block (closed by tj_destroy) */
 int tj_xch_attach(tj_ctx* c, int n_peers, const int* peer_ranks, void* const* peer_bases);
-int tj_xch_enable(tj_ctx* c, int on, int poll_in_kernel);
+int tj_xch_enable(tj_ctx* c, int on, int wait_mode);
 
 /* ---- several GPUs under one process (csrc/tj_group.h) ------------------------------------------------------------------
  * What a maintainer of Main/multiPathPlanning3D.cpp would call instead of tj_create / tj_iterate to use N devices: the robots
@@ -279,7 +280,9 @@ int tj_xch_enable(tj_ctx* c, int on, int poll_in_kernel);
  * device devices[r] (NULL: device r; entries may repeat -- several ranks on one device, which is how the tests run it on a
  * one-GPU box).  tj_group_iterate runs the phase schedule above on every rank (one host thread per rank) and exchanges the
  * tj_exchange_buffer slices through one of three transports (csrc/tj_group.h):
- *   "event"  direct peer stores + hipEventRecord / hipStreamWaitEvent: plain HIP stream semantics; THE DEFAULT
+ *   "event"  hipEventRecord behind the producing kernel / hipStreamWaitEvent in front of the consuming one: plain HIP stream semantics; THE DEFAULT.
+ *            Decoupled mode: the slices travel by the direct exchange's in-kernel pushes (six kernels per iteration and rank, nothing launched for
+ *            the exchange); coupled mode: a push kernel and an unpack kernel per exchange
  *   "flag"   decoupled mode: the DIRECT exchange above (tj_xch_*): the producing kernels push, the consuming kernels wait -- the fused
  *            six-kernel chain per rank, no launch and no host work for the exchange (ranks sharing a device: two one-wave wait launches);
  *            coupled mode: peer stores + a sequence flag polled by a small unpack kernel.  Opt-in until it has run across xGMI (a push

@@ -87,8 +87,8 @@ def test_direct_exchange_is_the_fused_chain(pkg, scenes, poll, ranks, monkeypatc
         per_iter = max((y - x) for x, y in zip(l0, l1)) / batch
         if transport == "flag":   # six kernels (+ two wait launches on a shared device) per iteration; the batch adds k_begin, the flush and the slack update it pays
             assert per_iter <= (6 if poll == "1" else 8) + 4.0 / batch + 1e-9, per_iter   # (+ k_hullinfo after a host write, k_begin, k_flush + k_slack at the end of the batch)
-        else:                     # event: the fused phases + push and unpack for each of the two exchanges
-            assert per_iter <= 10 + 4.0 / batch + 1e-9, per_iter
+        else:                     # event: the same six kernels (the slices travel by the in-kernel pushes), events order the streams
+            assert per_iter <= 6 + 4.0 / batch + 1e-9, per_iter
     ref.close(); grp.close()
 
 

@@ -77,9 +77,6 @@ struct Ctl {
   // atomics on ONE address serialise at ~13 ns each); the last one runs the sequential pair replay + gnorm (Dev::seq_fold)
   int ccd_ticket, pad3;
   int ccd_sub[16];
-  // sharded contexts (world > 1): the (foreign robot, segment) units at the head of k_front [0] / k_ccd [1] that have left their cache record
-  // (sixteen sub-counters, fire and forget; zeroed by begin_body); the pair tiles of the same launch wait for all of them
-  int xf_sub[2][16];
   // direct exchange (Dev::xch): robots whose control points [0] / direction records [1] THIS rank has pushed to its peers so far -- every rank
   // pushes once per iteration, so a consumer expects xpush / owned rounds from every peer
   int xpush[2];
@@ -130,6 +127,7 @@ constexpr int TJ_TIC_BLOCKS = 65536, TJ_TIC_SLOTS = 8;   // blocks per kernel th
 // direct exchange between sharded contexts (tj_group "flag" transport, or processes that mapped each other's blocks through hipIpc): what a rank needs
 // to know about its peers.  Lives in device memory (Dev::xp).
 constexpr int XCH_MAX = 16;                    // ranks of a group
+constexpr int XF_SEG_STRIDE = 32;              // ints between two segments' completion counters (Dev::xf_seg): a 128-byte line each
 struct XchPeers {
   int n;                                       // peers (world - 1)
   int rank[XCH_MAX];                           // their ranks
@@ -150,6 +148,11 @@ struct Dev {
   int xf;                        // 1: foreign units lead k_front / k_ccd (world > 1 and Dev::fuse)
   int xch, xch_poll;             // xch_poll = 1: the foreign units poll the arrival counters themselves; 0: a k_xch_wait launch in front of the kernel has (ranks sharing a device)
   const XchPeers* xp;
+  // completion counters of the foreign units, one per (kind, SEGMENT), each on a 128-byte line of its own ([2][S][XF_SEG_STRIDE] ints; zeroed by
+  // begin_body): the units of segment tr add to word tr, fire and forget, and what reads that segment's records in the same launch -- its pair tiles, a
+  // head start on it -- polls that word only.  (One set of sixteen words for everything, as k_ccd's selection blocks use, was a hot line here: 1 280 adds
+  // and 450 polling waves on it made k_front 35 us long.)
+  int* xf_seg;
   double* rx[2];                 // this rank's receive buffers (uncached memory, written by the peers)
   unsigned long long* xcnt;      // this rank's arrival counters [2][XCH_MAX]: robots of rank r whose slice of kind k has arrived, cumulative
   __host__ __device__ int n_foreign() const { return U - (u1 - u0); }
@@ -332,22 +335,23 @@ __device__ __forceinline__ bool xch_wait_owner(const Dev& D, int kind, int r) {
 // aligned (HULL_INFO_STRIDE, CCD_STRIDE), so what a tile then loads cannot have been fetched by its XCD's L2 earlier in the launch.
 __device__ __forceinline__ void xf_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double xf_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void xf_signal(const Dev& D, int kind, int f) {
+__device__ __forceinline__ int* xf_word(const Dev& D, int kind, int tr) { return D.xf_seg + ((size_t)kind * D.S + tr) * XF_SEG_STRIDE; }
+__device__ __forceinline__ void xf_signal(const Dev& D, int kind, int tr) {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt(0);
   asm volatile("" ::: "memory");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&D.ctl->xf_sub[kind][f & 15], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(xf_word(D, kind, tr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool xf_wait_all(const Dev& D, int kind) {   // one wave; uniform
-  const int lane = threadIdx.x & 63, want = D.n_foreign() * D.S;
+// every foreign unit of segment tr has left its record?  one wave; uniform
+__device__ __forceinline__ bool xf_wait_seg(const Dev& D, int kind, int tr) {
+  const int want = D.n_foreign();
+  const int* w = xf_word(D, kind, tr);
+  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
   const long long t_end = wall_clock64() + (D.xch ? XCH_TIMEOUT_TICKS + 10000000ll : 500000ll + 100ll * gridDim.x);   // (direct exchange: the units themselves may wait 2 s for a peer)
   for (;;) {
-    int v = lane < 16 ? __hip_atomic_load(&D.ctl->xf_sub[kind][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    v = __shfl(v, 0);
-    if (v >= want) { asm volatile("" ::: "memory"); return true; }
-    if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); return false; }
     __builtin_amdgcn_s_sleep(2);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
+    if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); return false; }
   }
 }
 

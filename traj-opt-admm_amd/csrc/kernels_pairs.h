@@ -177,7 +177,7 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
   const int U = D.U;
   double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
   const double dist = D.offset + 2 * D.margin;
-  if (wait_xf) xf_wait_all(D, 0);   // sharded contexts (union kernel): the hull cache of the other ranks' robots is written by units at the head of this launch
+  if (wait_xf) xf_wait_seg(D, 0, tr);   // sharded contexts (union kernel): the hull cache of the other ranks' robots is written by units at the head of this launch
   const int m = pair_tile_filter(D.hbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, D.u0, D.u1,
                                  [&](int q) { return D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE; }, 24, 73, dist, rowbox, list, lane);
   if (m == 0) return;
@@ -222,7 +222,7 @@ __device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds)
   if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) D.spec_tag[b] = 0ull; return; }   // (cannot happen: the list is this context's own)
   const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_INFO_STRIDE;
   const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_INFO_STRIDE;
-  if (D.xf && (p0 < D.u0 || p0 >= D.u1 || q < D.u0 || q >= D.u1)) xf_wait_all(D, 0);   // sharded contexts: a hull of another rank's robot comes from this launch's foreign units
+  if (D.xf && (p0 < D.u0 || p0 >= D.u1 || q < D.u0 || q >= D.u1)) xf_wait_seg(D, 0, tr);   // sharded contexts: a hull of another rank's robot comes from this launch's foreign units
   (void)lds;
   GjkState st; bool fin;
   gjk_wave_run(BodyHull{A}, BodyHull{B}, lane, st, true, D.spec_budget, fin);

@@ -126,7 +126,7 @@ __device__ __forceinline__ void xf_hull_body(const Dev& D, int f) {
     for (int i = 0; i < 6; i++) { const double lv = x * P[3 * i] + y * P[3 * i + 1] + z * P[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
     xf_store(o + 24 + lane, lo); xf_store(o + 73 + lane, up);
   }
-  xf_signal(D, 0, f);
+  xf_signal(D, 0, tr);
 }
 __device__ __forceinline__ void xf_ccd_body(const Dev& D, int f, double* sh) {
   const int u = D.foreign_robot(f / D.S), tr = f % D.S, lane = lane_id(), T = D.T;
@@ -137,13 +137,27 @@ __device__ __forceinline__ void xf_ccd_body(const Dev& D, int f, double* sh) {
     if (tr == 0) for (int i = lane; i < 3 * T + 3; i += 64) xf_store(D.xdir + (size_t)u * D.xs + i, xch_load(dir + i));   // |g| is read by this launch's finisher, the rest by k_linesearch
   }
   ccd_prep_segment<true>(D, D.spline + (size_t)u * 3 * T, dir, u, tr, lane, sh, D.xch != 0);
-  xf_signal(D, 1, f);
+  xf_signal(D, 1, tr);
 }
 // ranks that share a device (a test arrangement): the units' polling would hold LDS and wave slots the peer's producing kernel needs -- one
 // one-wave launch in front of k_front / k_ccd waits for all peers instead (Dev::xch_poll = 0)
 __global__ __launch_bounds__(64) void k_xch_wait(Dev D, int kind) {
-  if (TJ_DONE(D)) return;
-  for (int r = 0; r < D.world; r++) if (r != D.rank) xch_wait_owner(D, kind, r);
+  // lane r watches rank r's counter; the counter, the stop flag and this rank's own push count are fetched in ONE round trip (three dependent ones made this launch 5 - 6 us long)
+  const int lane = lane_id();
+  const bool mine = lane < D.world && lane != D.rank;
+  const unsigned long long* w = D.xcnt + kind * XCH_MAX + (mine ? lane : 0);
+  unsigned long long got = mine ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+  const int done = D.ctl->done, pushed = D.ctl->xpush[kind];
+  if (done) return;
+  const unsigned long long need = mine ? (unsigned long long)(pushed / (D.u1 - D.u0)) * (unsigned long long)D.owned_by(lane) : 0ull;
+  if (ballot(got < need) == 0ull) return;
+  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(4);
+    if (mine) got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ballot(got < need) == 0ull) return;
+    if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_PEER_TIMEOUT); return; }
+  }
 }
 
 constexpr int CCD_LDS_DOUBLES = 294 + (2 * FRONT_CAP + 128) / 2;   // info[146] kax[147] | fa fb cand
@@ -212,7 +226,7 @@ __device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double
   const int U = D.U;
   const double off = D.offset;
   double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
-  if (wait_xf) xf_wait_all(D, 1);   // sharded contexts (union kernel): the swept-hull cache of the other ranks' robots is written by units at the head of this launch
+  if (wait_xf) xf_wait_seg(D, 1, tr);   // sharded contexts (union kernel): the swept-hull cache of the other ranks' robots is written by units at the head of this launch
   // swept boxes (lanes over partners), then swept 49-axis intervals (lanes over axes): BVH::SelfCCDCollision + CCD::SelfKDOPCCD
   const int m = pair_tile_filter(D.cbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, 0, U,
                                  [&](int q) { return D.ccdinfo + ((size_t)q * D.S + tr) * CCD_STRIDE; }, 48, 97, off, rowbox, list, lane);
@@ -755,7 +769,7 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   M.ti = D.seq_gmem_i; M.stk = M.ti + 10 * (size_t)D.U;
   M.lane0_stages = true;
   {   // gnorm: the sequential sum in robot order (Optimization3D_multi.h:57,72,750)
-    if (D.xf) xf_wait_all(D, 1);   // sharded contexts: the other ranks' |g| values are put in place by this launch's foreign units
+    if (D.xf) xf_wait_seg(D, 1, 0);   // sharded contexts: the other ranks' |g| values are put in place by this launch's foreign units of segment 0
     for (int i = lane; i < D.U; i += 64) M.gns[i] = D.xf ? xf_load(&D.gn(i)) : D.gn(i);
     __syncthreads();
     if (lane == 0) { double gsum = 0; for (int u = 0; u < D.U; u++) gsum += M.gns[u]; D.ctl->gnorm = gsum / double(D.U); }

@@ -50,6 +50,7 @@ struct tj_ctx {
   void* xch_block = nullptr; size_t xch_bytes = 0; bool xch_ipc_exported = false;
   std::vector<void*> xch_ipc_opened;
   XchPeers* xch_table = nullptr;
+  bool xch_wait_kernel = false;   // direct exchange, wait mode 0: a one-wave k_xch_wait launch in front of k_front / k_ccd
   // graph of one full iteration
   // hipGraphs: [0..2] the three phases of a sharded iteration, [3] one full iteration
   hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -154,7 +155,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
         TJ_LAUNCH(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
-      if (d.xch && !d.xch_poll) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 0);   // ranks sharing a device: the wait for the peers' control points is a launch of its own
+      if (d.xch && c->xch_wait_kernel) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 0);   // ranks sharing a device: the wait for the peers' control points is a launch of its own
       if (tri) TJ_LAUNCH((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else TJ_LAUNCH((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
       return true;
     case K_SEP_OBS: if (in_graph || in_phase) return false;  // stage API and sharded phase 0
@@ -202,7 +203,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
         TJ_LAUNCH(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
-      if (d.xch && !d.xch_poll) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 1);   // ranks sharing a device: the wait for the peers' direction records is a launch of its own
+      if (d.xch && c->xch_wait_kernel) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 1);   // ranks sharing a device: the wait for the peers' direction records is a launch of its own
       {
         const int g = n_ccd + n_xf + (d.seq_fold ? 1 : 0);   // + the finisher of the folded pair replay (kernels_step.h)
         if (c->ccd_lean) { if (tri) TJ_LAUNCH((k_ccd_lean<3>), dim3(g), dim3(64), 0, s, d); else TJ_LAUNCH((k_ccd_lean<1>), dim3(g), dim3(64), 0, s, d); }
@@ -590,7 +591,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.obs_work, 2 * U * S * d.cap_obs)) || (r = dalloc(c, &d.obs_work_n, 1)) ||
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
       (r = dalloc(c, &d.grad_scr, (size_t)(d.u1 - d.u0) * P * 16 * (size_t)(d.cap_obs + d.cap_self))) ||
-      (r = dalloc(c, &d.xs_scr, d.xs_band ? (size_t)(d.u1 - d.u0) * ((size_t)n * n + 4 * n) : 1))) return r;
+      (r = dalloc(c, &d.xs_scr, d.xs_band ? (size_t)(d.u1 - d.u0) * ((size_t)n * n + 4 * n) : 1)) ||
+      (r = dalloc(c, &d.xf_seg, d.xf ? 2 * S * XF_SEG_STRIDE : 1))) return r;
   if (d.optimal_plane) {
     const bool m0 = d.mode == 0;
     if ((r = dalloc(c, &d.kobs_id, m0 ? U * S * d.cap_obs : 1)) || (r = dalloc(c, &d.kobs_n, U * S)) || (r = dalloc(c, &d.kobs_cd, m0 ? U * S * d.cap_obs * 4 : 1)) ||
@@ -780,6 +782,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   // direct exchange: the push / arrival counts restart (the caller has every rank drained before any rank calls this, and a barrier after:
   // tj_group_init_state does; processes use their collective's barrier)
   if (c->xch_block) HIPCHK(c, hipMemsetAsync(d.xcnt, 0, 2 * XCH_MAX * sizeof(unsigned long long), c->stream));
+  if (d.xf) HIPCHK(c, hipMemsetAsync(d.xf_seg, 0, (size_t)2 * d.S * XF_SEG_STRIDE * sizeof(int), c->stream));
   Ctl h;
   memset(&h, 0, sizeof(h));
   h.gnorm = 1.0;  // Main/multiPathPlanning3D.cpp:594
@@ -1613,13 +1616,13 @@ int tj_xch_attach(tj_ctx* c, int n_peers, const int* peer_ranks, void* const* pe
   return TJ_OK;
 }
 
-int tj_xch_enable(tj_ctx* c, int on, int poll_in_kernel) {
-  if (!c) return TJ_ERR_INVALID;
+int tj_xch_enable(tj_ctx* c, int on, int wait_mode) {
+  if (!c || wait_mode < 0 || wait_mode > 2) return TJ_ERR_INVALID;
   Dev& d = c->d;
   if (on && (!d.xp || !c->xch_block)) { c->err = "tj_xch_enable: tj_xch_attach has not been called"; return TJ_ERR_INVALID; }
   QUIESCE(c);
   drop_graph(c);
-  d.xch = on ? 1 : 0; d.xch_poll = poll_in_kernel ? 1 : 0;
+  d.xch = on ? 1 : 0; d.xch_poll = (on && wait_mode == 1) ? 1 : 0; c->xch_wait_kernel = on && wait_mode == 0;
   return TJ_OK;
 }
 

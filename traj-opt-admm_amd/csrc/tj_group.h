@@ -197,7 +197,9 @@ int group_exchange(tj_group* g, int r, int what, long s) {
     HIPCHK(c, hipGetLastError());
     return TJ_OK;
   }
-  if (cnt > 0) TJ_LAUNCH(k_group_push, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, peers, np, off, cnt);
+  const bool direct = d.xch != 0;   // decoupled mode: the producing kernel itself has stored this rank's slice into the peers' receive blocks (kernels_step.h) -- the event
+                                    // only orders the consumer's stream behind it, and the foreign units of its next kernel put the slices in place
+  if (cnt > 0 && !direct) TJ_LAUNCH(k_group_push, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, peers, np, off, cnt);
   HIPCHK(c, hipEventRecord(g->ev[r][what][par], c->stream));
   g->recorded[r][what].store(s + 1, std::memory_order_release);
   for (int q = 0; q < g->n; q++) {
@@ -208,7 +210,7 @@ int group_exchange(tj_group* g, int r, int what, long s) {
     }
     HIPCHK(c, hipStreamWaitEvent(c->stream, g->ev[q][what][par], 0));
   }
-  TJ_LAUNCH(k_group_unpack, dim3((unsigned)std::min<size_t>((total + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, g->rx[r][what][par], off, cnt, total);
+  if (!direct) TJ_LAUNCH(k_group_unpack, dim3((unsigned)std::min<size_t>((total + 255) / 256, 64)), dim3(256), 0, c->stream, b.buf, g->rx[r][what][par], off, cnt, total);
   HIPCHK(c, hipGetLastError());
   return TJ_OK;
 }
@@ -266,9 +268,17 @@ int group_select_transport(tj_group* g, int t) {
     (void)hipSetDevice(g->dev[r]);
     int sharers = 0;
     for (int b = 0; b < g->n; b++) sharers += g->dev[b] == g->dev[r] ? 1 : 0;
-    int poll = sharers == 1 ? 1 : 0;
-    if (const char* e = getenv("TJ_XCH_POLL")) poll = atoi(e) != 0;
-    const int rc = tj_xch_enable(c, t == TJ_TRANSPORT_FLAG ? 1 : 0, poll);
+    // ranks sharing a device: k_linesearch's helper blocks (one compute unit each) only where the ranks run in lockstep (flag: the kernels of the ranks overlap and every
+    // helper is resident; measured with 2 x 32 robots on one device: 0.147 -> 0.137 ms) -- under the event transport, which orders whole kernels, the helpers of one rank
+    // queue behind the other rank's blocks and the primaries run into their 10 us give-up (0.166 -> 0.279 ms)
+    if (sharers > 1 && !getenv("TJ_LS_HELP") && c->d.ls_fast && c->d.mode != TJ_MODE_MULTI_COUPLED) {
+      const int owned = std::max(1, c->d.u1 - c->d.u0);
+      c->d.ls_help = t == TJ_TRANSPORT_FLAG ? std::max(1, std::min(LS_HELP_MAX, c->d.num_cu / (owned * sharers))) : 1;
+    }
+    int wait_mode = sharers == 1 ? 1 : 0;
+    if (const char* e = getenv("TJ_XCH_POLL")) wait_mode = atoi(e) != 0 ? 1 : 0;
+    if (t == TJ_TRANSPORT_EVENT) wait_mode = 2;   // events order the streams
+    const int rc = tj_xch_enable(c, t != TJ_TRANSPORT_RCCL ? 1 : 0, wait_mode);
     if (rc) return group_fail(g, rc, std::string("rank ") + std::to_string(r) + ": " + tj_last_error(c));
   }
   g->transport = t;
@@ -320,7 +330,7 @@ int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_grou
         // a device of their own -- off for those ranks (same bits either way)
       int sharers = 0;
       for (int b = 0; b < n_ranks; b++) sharers += g->dev[b] == g->dev[r] ? 1 : 0;
-      if (sharers > 1) { c->d.ls_help = 1; c->d.grad_bal = 0; c->lsc_wide = false; }
+      if (sharers > 1) { c->d.ls_help = 1; c->d.grad_bal = 0; c->lsc_wide = false; }   // (ls_help: re-decided per transport, group_select_transport)
     }
     const int nwhat = c->d.mode == TJ_MODE_MULTI_COUPLED ? 5 : 2;
     for (int w = 0; w < nwhat; w++) {
