@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--optimal-plane", action="store_true", help='time the "optimal_plane":1 variant (persistent planes refined every iteration); not the headline')
     ap.add_argument("--overlap-gather", action="store_true", help="sharded schedule: start the control-point all-gather before phase 0 and join it after (async RCCL op); "
                                                                   "off by default: with one rank it measured 13 us slower per iteration, its effect with real peers is unmeasured")
+    ap.add_argument("--no-direct", action="store_true", help="sharded runs under torchrun: do not try the direct (hipIpc, in-kernel) exchange, time the RCCL all-gathers")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded schedule + RCCL collectives even with one rank (self test)")
     ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: every rank uses device 0 and the all-gathers are staged through host memory over gloo "
                                                             "(RCCL refuses two ranks on one device); exercises the multi-process schedule on a 1-GPU box")
@@ -471,8 +472,40 @@ def main():
             work = dist.all_gather_into_tensor(views[what][0], views[what][1], async_op=True)
             return work.wait
 
+        # DIRECT exchange between the processes (include/trajadmm.h tj_xch_*): every rank's receive block is mapped into every other process through
+        # hipIpc, the producing kernels push, the consuming kernels wait -- the fused six-kernel chain per rank, no collective on the path.  Tried first
+        # (decoupled mode, more than one rank); it has to reproduce the one-rank state bit for bit like any other path, else the RCCL all-gathers are timed.
+        path = {"name": "rccl", "direct_error": None}
+        if world > 1 and not args.coupled and not args.no_direct:
+            ok_local, err = 1, None
+            try:
+                mine_h = slv.xch_ipc_export()
+            except Exception as e:   # noqa: BLE001 -- any failure sends every rank to the collective path
+                mine_h, ok_local, err = None, 0, str(e)
+            hs = [None] * world
+            dist.all_gather_object(hs, (mine_h, err))
+            if all(h[0] is not None for h in hs):
+                try:
+                    slv.xch_attach_ipc({r: hs[r][0] for r in range(world) if r != rank}, poll_in_kernel=not args.same_gpu)
+                except Exception as e:   # noqa: BLE001
+                    ok_local, err = 0, str(e)
+            else:
+                ok_local, err = 0, "; ".join(f"rank {r}: {h[1]}" for r, h in enumerate(hs) if h[1])
+            oks = [None] * world
+            dist.all_gather_object(oks, (ok_local, err))
+            if all(o[0] for o in oks):
+                path["name"] = "direct"
+            else:
+                path["direct_error"] = "; ".join(f"rank {r}: {o[1]}" for r, o in enumerate(oks) if o[1])
+                try:
+                    slv.xch_enable(False)
+                except Exception:   # noqa: BLE001
+                    pass
+
         def run(n_it):
-            if args.coupled:   # six phases, five small all-gathers per iteration (sharding.COUPLED_SCHEDULE)
+            if path["name"] == "direct":
+                slv.iterate_async(n_it)
+            elif args.coupled:   # six phases, five small all-gathers per iteration (sharding.COUPLED_SCHEDULE)
                 sharding.run_schedule(_Eng, _gather, n_it, sharding.COUPLED_SCHEDULE)
             else:
                 sharding.run_sharded(_Eng, _gather, n_it, gather_begin=_gather_begin)
@@ -492,23 +525,43 @@ def main():
     validation = None
     if sharded:
         V = args.validate_iters
-        run(V)
-        barrier()
-        st_sh = slv.get_state()
         u0, u1 = rank * scene["U"] // world, (rank + 1) * scene["U"] // world
-        bits = slv.stats()["error_bits"]
         ref = one_rank_state(pkg, scene, local, V, args.optimal_plane)
-        mine_ok = bits == 0 and states_equal(st_sh, ref, u0, u1)
-        flag = torch.tensor([1.0 if mine_ok else 0.0], dtype=torch.float64, device=f"cuda:{local}")
-        nok = flag.clone()
-        if not args.same_gpu:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN); dist.all_reduce(nok, op=dist.ReduceOp.SUM)
-        else:   # gloo stages through the host
-            fh, nh = flag.cpu(), nok.cpu()
-            dist.all_reduce(fh, op=dist.ReduceOp.MIN); dist.all_reduce(nh, op=dist.ReduceOp.SUM)
-            flag, nok = fh, nh
+        tried = {}
+        while True:
+            mine_ok, err = False, None
+            try:
+                run(V)
+                barrier()
+                st_sh = slv.get_state()
+                bits = slv.stats()["error_bits"]
+                mine_ok = bits == 0 and states_equal(st_sh, ref, u0, u1)
+                if bits:
+                    err = f"device error bits {bits}"
+            except pkg.TrajAdmmError as e:   # e.g. a peer's push that never arrived (direct exchange): recorded, the next path is tried
+                err = str(e)
+            flag = torch.tensor([1.0 if mine_ok else 0.0], dtype=torch.float64, device=f"cuda:{local}")
+            nok = flag.clone()
+            if not args.same_gpu:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN); dist.all_reduce(nok, op=dist.ReduceOp.SUM)
+            else:   # gloo stages through the host
+                fh, nh = flag.cpu(), nok.cpu()
+                dist.all_reduce(fh, op=dist.ReduceOp.MIN); dist.all_reduce(nh, op=dist.ReduceOp.SUM)
+                flag, nok = fh, nh
+            tried[path["name"]] = {"bitwise_equal_to_one_rank": bool(flag.item() == 1.0), "ranks_equal": int(nok.item()), "error_rank0": err}
+            if flag.item() == 1.0 or path["name"] != "direct":
+                break
+            # the direct exchange did not reproduce the one-rank state (or failed): every rank falls back to the collectives
+            path["name"] = "rccl"
+            try:
+                slv.xch_enable(False)
+            except pkg.TrajAdmmError:
+                pass
+            slv.reset()
+            barrier()
         validation = {"iterations": V, "reference": "one rank, default fused chain, a second context on each rank's own GPU", "checked": "every state array of the robots each rank owns",
-                      "bitwise_equal_to_one_rank": bool(flag.item() == 1.0), "ranks_equal": int(nok.item()), "ranks": world}
+                      "bitwise_equal_to_one_rank": bool(flag.item() == 1.0), "ranks_equal": int(nok.item()), "ranks": world, "paths": tried, "timed_path": path["name"],
+                      "direct_exchange_setup_error": path["direct_error"]}
         slv.reset()
         barrier()
 
@@ -552,7 +605,7 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['tris'].shape[0] if scene.get('tris') is not None else scene['cloud'].shape[0]} obstacle {'triangles (fp64 narrow phase, fp32 outward-rounded BVH boxes)' if scene.get('tris') is not None else 'points'}, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
-                          "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {5 if args.coupled else 2} RCCL all-gathers/iter on the library's exchange buffers; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else 6} kernels on one queue (union kernels), enqueued ahead, no host sync",
+                          "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {'direct exchange (in-kernel pushes / waits through hipIpc-mapped receive blocks), six kernels per iteration and rank' if sharded and path['name'] == 'direct' else str(5 if args.coupled else 2) + ' RCCL all-gathers/iter on the library exchange buffers'}; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else 6} kernels on one queue (union kernels), enqueued ahead, no host sync",
                           "iters_timed_from": "initial trajectory"}}
         if scene["name"] == "SCN-C" and not (args.coupled or args.optimal_plane):
             out["config"]["parity_pin"] = ("the timed SCN-C is pinned against the unmodified reference PER ITERATION (tests/golden/stages_scn_c.npz) and end to end only inside the reference's own "
@@ -560,7 +613,9 @@ def main():
                                            "is tested on SCN-C3 -- the same fleet and cloud stacked 0.29 apart, a spacing SEARCHED for so that the reference reproduces itself (envelope 8e-11): "
                                            "control points 1.3e-10, final energies 8.9e-8 (bar max(1e-8, 3 x the reference's own 5.8e-8 energy envelope)), tests/golden/e2e_scn_c3.npz")
         if sharded:
-            out["group"] = {"launcher": "torch.distributed.run, one process per GPU", "backend": dist.get_backend(), "transport": "gloo through host memory (TEST ONLY)" if args.same_gpu else "RCCL all_gather_into_tensor on the library's exchange buffers (zero copy)",
+            tname = ("direct exchange: in-kernel pushes into hipIpc-mapped receive blocks of the peers, in-kernel waits (six kernels per iteration and rank, no collective)" if path["name"] == "direct"
+                     else ("gloo through host memory (TEST ONLY)" if args.same_gpu else "RCCL all_gather_into_tensor on the library's exchange buffers (zero copy)"))
+            out["group"] = {"launcher": "torch.distributed.run, one process per GPU", "backend": dist.get_backend(), "transport": tname,
                             "ranks": world, "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0),
                             "bitwise_equal_to_one_rank": validation["bitwise_equal_to_one_rank"], "validation": validation,
                             "expectation": EXPECT.get(scene["name"].split("-coupled")[0], "")}

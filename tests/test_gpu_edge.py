@@ -351,6 +351,9 @@ def test_bench_two_processes_sharded_equals_single_process(tmp_path, coupled):
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["value"] > 0
     # the line validates itself: before timing, both ranks compared their robots with a one-rank run, bit for bit
     assert j["group"]["bitwise_equal_to_one_rank"] is True and j["group"]["validation"]["ranks_equal"] == 2 and j["group"]["validation"]["iterations"] == 8
+    # decoupled mode: the DIRECT exchange between the two processes (receive blocks mapped through hipIpc, in-kernel pushes; ranks sharing a device wait in
+    # a one-wave launch) is what ran and what validated; coupled mode keeps the collectives
+    assert j["group"]["validation"]["timed_path"] == ("rccl" if coupled else "direct"), j["group"]["validation"]
     # single-process checksum covers all 8 robots; recompute the halves from a library run to compare per rank
     import hashlib
     import importlib
@@ -381,7 +384,9 @@ def test_bench_group_line_validates_itself(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads(r.stdout[r.stdout.index('{"metric"'):].split("\n")[0])
     g = j["group"]
-    assert j["value"] > 0 and g["bitwise_equal_to_one_rank"] is True and g["transport"] == "flag" and g["validation"]["timed_transport"] == "flag"
+    # (every transport that validated is timed, the line carries the fastest)
+    assert j["value"] > 0 and g["bitwise_equal_to_one_rank"] is True and g["transport"] in ("flag", "event") and g["validation"]["timed_transport"] == g["transport"]
+    assert set(g["validation"]["ms_per_step_by_transport"]) == {"flag", "event"}
     tr = g["validation"]["transports"]
     assert tr["flag"]["bitwise_equal_to_one_rank"] and tr["event"]["bitwise_equal_to_one_rank"]
     assert tr["rccl"]["ran"] is False and "own device" in tr["rccl"]["error"]
