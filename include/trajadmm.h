@@ -88,8 +88,9 @@ int tj_host_tables(int piece_num, int res, double* convert, double* mdyn, double
  *                                   iteration's); there this library returns the largest first-clear exponent over the candidates
  *                                   (tests/golden/backoff_kat.npz pins the regime boundary).
  *   back-off loops                  followed to where the reference's own loop ends (step *= 0.8 to its fixed point 1e-323 after 3332 factors);
- *                                   TJ_ERR_NO_PROGRESS only where the reference would spin forever.  Exception: coupled mode ("decouple":0) searches
- *                                   the 31 steps 0.8^0 .. 0.8^30 per iteration and reports TJ_ERR_NO_PROGRESS (detail bit 32) beyond.
+ *                                   TJ_ERR_NO_PROGRESS only where the reference would spin forever -- in all three modes since round 5 (the coupled search
+ *                                   beyond 0.8^30 is continued by one block, tests/golden/coupled_long_kat.npz).  Exception: a SHARDED coupled context
+ *                                   (world > 1) decides on the 31 steps its exchange carries and reports TJ_ERR_NO_PROGRESS (detail bit 32) beyond.
  *   cap_obs / cap_self / cap_pairs  list capacities of tj_params; an overflow is TJ_ERR_CAPACITY with the bit that says which. */
 int tj_create(const tj_params* p, tj_ctx** out);
 void tj_destroy(tj_ctx* c);
@@ -197,6 +198,8 @@ typedef struct tj_stats {
                            kernel (pairs that were slow in the previous iteration; same bits either way) */
   unsigned long long gjk_max_sum; /* sum over the iterations of the longest robot-pair GJK (iterations of openGJK's main loop; pairs below 6
                                      do not report): / iters = unit count of the pair stage's critical path */
+  int ls_giveups;         /* line search, helper blocks: primaries that found a helper's post missing after 10 us and searched on alone (same result) */
+  int ls_helper_timeouts; /* ... helper blocks that left after 5 ms without a word from their primary.  Both 0 on a GPU of the solver's own */
 } tj_stats;
 int tj_get_stats(tj_ctx* c, tj_stats* s);
 /* the obstacle BVH of the last tj_set_cloud / tj_set_mesh: device time of the build (Morton keys, radix sort, box pyramid;

@@ -23,12 +23,13 @@ n = sys.argv[1] if len(sys.argv) > 1 else "300"
 bad = 0
 for name in ("tiny", "hard", "A", "B", "C", "Bc", "Cc", "E"):
     outs = []
-    for off in (False, True):
+    # default | everything off | helpers that start 10 us late (TJ_LS_HELP_LATE) | helpers that never post (TJ_LS_HELP_MUTE): round 5 added the two hooks
+    for extra in ({}, dict(TJ_LS_HELP="1", TJ_GRAD_BALANCE="0", TJ_LSC_WIDE="0"), dict(TJ_LS_HELP_LATE="10"), dict(TJ_LS_HELP_MUTE="1")):
         env = dict(os.environ)
-        if off: env.update(TJ_LS_HELP="1", TJ_GRAD_BALANCE="0", TJ_LSC_WIDE="0")
+        env.update(extra)
         r = subprocess.run([sys.executable, "-c", code, name, n, ROOT], env=env, capture_output=True, text=True)
         outs.append(r.stdout.strip() or ("ERR " + r.stderr[-300:]))
-    ok = outs[0] == outs[1] and outs[0].split()[1:2] == ["0"]
+    ok = all(o == outs[0] for o in outs) and outs[0].split()[1:2] == ["0"]
     bad += 0 if ok else 1
-    print(f"{name:6s} {n} iterations: {'same bits, no error bit' if ok else 'MISMATCH'}   default: {outs[0]}   plain: {outs[1]}", flush=True)
+    print(f"{name:6s} {n} iterations: {'same bits, no error bit' if ok else 'MISMATCH'}   default: {outs[0]}   plain: {outs[1]}   late: {outs[2]}   mute: {outs[3]}", flush=True)
 sys.exit(1 if bad else 0)

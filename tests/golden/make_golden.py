@@ -564,7 +564,50 @@ def make_planner():
                         edges=edges, prior=prior, hit_cloud=e.edge_collision(edges), hit_all=e.edge_collision(edges, prior))
 
 
+def coupled_long_case(U, amp, seed, dz):
+    """A coupled-mode state whose Armijo search on the summed energy (Optimization3D_multi.h:605-636) takes far more than the 31 back-offs the HIP
+    path's evaluation launches cover: a crossing fleet with the cloud and the other robots out of reach (no CCD clamp takes the exponent), three
+    ordinary iterations, then the slack blocks z displaced by `amp` -- the Newton direction is then ~amp long and only a step of ~1/amp keeps the
+    velocity limits.  The same construction is used by tests/test_gpu_coupled.py."""
+    scene = dict(pkg_scenes.crossing(U, 2000, seed=seed, dz=dz), mode=2)
+    scene["cloud"] = scene["cloud"] + np.array([0.0, 0.0, 1e9])
+    scene["name"] = f"coupled-long-U{U}"
+    return scene, amp, seed
+
+
+def make_coupled_long():
+    """42 ... 63 Armijo back-offs of the coupled search, from the unmodified reference: pre state, state after update_spline, after the slack update"""
+    rec = {}
+    cases = [(4, 1e3, 11, 1e7), (4, 1e5, 11, 1e7), (3, 1e4, 11, 1e6)]
+    rec["cases"] = np.array(cases)
+    for ci, (U, amp, seed, dz) in enumerate(cases):
+        scene, amp, seed = coupled_long_case(U, amp, seed, dz)
+        e = Engine("ref", scene)
+        for _ in range(3):
+            e.iterate()
+        st = e.get_state()
+        rng = np.random.default_rng(seed)
+        st["p_slack"] = st["p_slack"] + amp * rng.normal(0, 1, st["p_slack"].shape)
+        e.set_state(st)
+        pre = e.get_state()
+        e.stage_planes()
+        gnorm, wolfe = e.stage_update_spline()
+        mid = e.get_state()
+        e.stage_slack()
+        post = e.get_state()
+        k = f"c{ci}_"
+        for n_, v in pre.items(): rec[k + "pre_" + n_] = v
+        rec[k + "gnorm"] = np.array(gnorm); rec[k + "wolfe"] = np.array(wolfe)
+        rec[k + "mid_spline"] = mid["spline"]; rec[k + "mid_piece_time"] = mid["piece_time"]
+        for n_, v in post.items(): rec[k + "post_" + n_] = v
+        rec[k + "cloud_sum"] = np.array([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()])
+    np.savez_compressed(os.path.join(HERE, "coupled_long_kat.npz"), **rec)
+
+
 if __name__ == "__main__":
+    if "--coupled-long-only" in sys.argv:
+        make_coupled_long()
+        sys.exit(0)
     if "--coupled-only" in sys.argv:
         make_stages_coupled("hard_coupled", coupled(pkg_scenes.hard()), 12, {0, 3, 4, 5, 8, 11})
         make_e2e("scn_b_coupled", coupled(pkg_scenes.scn_b()))
@@ -610,4 +653,5 @@ if __name__ == "__main__":
     make_bvh_kat()
     make_single_solve()
     make_backoff()
+    make_coupled_long()
     print("golden vectors written to", HERE)

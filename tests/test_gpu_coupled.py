@@ -115,3 +115,43 @@ def test_coupled_mode_sharded_equals_unsharded(pkg, scenes):
     assert ref.stats()["error_bits"] == 0 and r0.stats()["error_bits"] == 0 and r1.stats()["error_bits"] == 0
     for x in (ref, r0, r1):
         x.close()
+
+
+def test_coupled_armijo_search_follows_the_reference_beyond_31_steps(pkg, scenes):
+    """The coupled Armijo search on the summed energy (Optimization3D_multi.h:605-636) has no bound in the reference; the HIP path's evaluation launches cover
+    the steps 0.8^0 .. 0.8^30 and round 4 reported TJ_ERR_NO_PROGRESS beyond.  Now the deciding block goes on alone (kernels_ls.h: lsc_continue) to the
+    reference's own end.  Fixture from the unmodified reference (tests/golden/make_golden.py: make_coupled_long): three teacher-forced states whose search
+    takes 42, 63 and 51 back-offs -- the state after update_spline (a different exponent would move piece_time by 20 %), gnorm, wolfe, and the state after
+    the slack update; the evaluation count says the continuation really ran.  Tolerances as in test_coupled_stages_teacher_forced_vs_reference."""
+    g = gold("coupled_long_kat.npz")
+    for ci, (U, amp, seed, dz) in enumerate(g["cases"]):
+        scene = dict(scenes.crossing(int(U), 2000, seed=int(seed), dz=float(dz)), mode=2)
+        scene["cloud"] = scene["cloud"] + np.array([0.0, 0.0, 1e9])
+        k = f"c{ci}_"
+        assert np.allclose([scene["cloud"].sum(), np.abs(scene["cloud"]).sum()], g[k + "cloud_sum"], rtol=1e-13)
+        s = pkg.Solver(scene, stop=0.0)
+        s.set_state({n: g[k + "pre_" + n] for n in STATE})
+        s.stage_planes()
+        e0 = s.stats()["energy_evals"]
+        gnorm, wolfe = s.stage_update_spline()
+        assert abs(gnorm - g[k + "gnorm"]) <= 1e-11 * max(1.0, float(g[k + "gnorm"]))
+        assert abs(wolfe - g[k + "wolfe"]) <= 1e-9 * max(1.0, abs(float(g[k + "wolfe"])))
+        st = s.get_state()
+        evals = (s.stats()["energy_evals"] - e0) // int(U)            # 2 + accepted exponent, per robot
+        assert evals - 2 > 31, (ci, evals)
+        scale = max(1.0, np.abs(g[k + "mid_spline"]).max())
+        assert maxdiff(st["spline"], g[k + "mid_spline"]) <= 1e-9 * scale, (ci, maxdiff(st["spline"], g[k + "mid_spline"]))
+        assert maxdiff(st["piece_time"], g[k + "mid_piece_time"]) <= 1e-9, (ci, st["piece_time"][0], g[k + "mid_piece_time"][0], evals)
+        assert s.stats()["error_bits"] == 0, ci
+        # ... and the whole iteration through the chain (one-launch search, its last block continuing, committing and beginning the next iteration)
+        s.close()
+        s = pkg.Solver(scene, stop=0.0)   # (a fresh context: the stage calls above left a slack update owed)
+        s.set_state({n: g[k + "pre_" + n] for n in STATE})
+        s.iterate(1)
+        st = s.get_state()
+        # (robots 1e7 apart: a control point carries ~4e-9 of absolute rounding, which the slack update's Newton step on the displaced z amplifies -- the exact
+        #  comparison is the stage-level one above; this one says the chain reaches the same state: a different exponent would be 20 % off)
+        for n in STATE:
+            assert maxdiff(st[n], g[k + "post_" + n]) <= 1e-6 * max(1.0, np.abs(g[k + "post_" + n]).max()), (ci, n, maxdiff(st[n], g[k + "post_" + n]))
+        assert s.stats()["error_bits"] == 0, ci
+        s.close()

@@ -249,6 +249,47 @@ def test_round4_launch_shapes_over_a_long_run(pkg, scenes, monkeypatch, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["scn_c", "hard64"])
+def test_helper_blocks_that_start_late_change_no_bit(pkg, scenes, monkeypatch, which):
+    """k_linesearch's helper protocol, the case its late-start guard exists for: TJ_LS_HELP_LATE=<us> makes every helper block idle that long
+    before it stages its robot -- by then the primary has decided, stored DONE and (in most iterations) committed the new control net.  A late helper must
+    either see DONE and leave or have staged the state of before the commit; what it posts is never looked at.  150 iterations, four delays from "inside the
+    primary's first super-round" to "long after its commit": states bitwise those of a run without helpers, no error bit, and the helpers really were there
+    (give-ups counted: a primary that finds no post after 10 us searches on alone).  TJ_LS_HELP_MUTE=1 (helpers that never post) likewise."""
+    scene = scenes.scn_c() if which == "scn_c" else scenes.hard(64, 20000)
+    for k in ("TJ_LS_HELP", "TJ_LS_HELP_LATE", "TJ_LS_HELP_MUTE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TJ_LS_HELP", "1")
+    ref = pkg.Solver(scene, stop=0.0)
+    ref.iterate(150)
+    want = ref.get_state()
+    ref.close()
+    monkeypatch.delenv("TJ_LS_HELP")
+    base = pkg.Solver(scene, stop=0.0)
+    base.iterate(150)
+    sb, tb = base.get_state(), base.stats()
+    base.close()
+    for n in want:
+        assert np.array_equal(want[n], sb[n]), n
+    assert tb["error_bits"] == 0 and tb["ls_helper_timeouts"] == 0
+    for env in ({"TJ_LS_HELP_LATE": "2"}, {"TJ_LS_HELP_LATE": "6"}, {"TJ_LS_HELP_LATE": "15"}, {"TJ_LS_HELP_LATE": "60"}, {"TJ_LS_HELP_MUTE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = pkg.Solver(scene, stop=0.0)
+        s.iterate(150)
+        st, ts = s.get_state(), s.stats()
+        s.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        for n in want:
+            assert np.array_equal(want[n], st[n]), (n, env)
+        assert ts["error_bits"] == 0 and ts["ls_helper_timeouts"] == 0, env
+        assert ts["energy_evals"] == tb["energy_evals"], env
+        if "TJ_LS_HELP_MUTE" in env or int(env.get("TJ_LS_HELP_LATE", 0)) >= 15:
+            assert ts["ls_giveups"] > 0, (env, "the late / mute helpers were never waited for: the run proves nothing")
+
+
+@pytest.mark.gpu
 def test_coupled_search_in_one_launch_changes_no_bit(pkg, scenes, monkeypatch):
     """coupled mode: the four evaluation rounds of the Armijo search run in ONE launch where a block per (robot, round) has a compute unit of its own
     (the default on this fleet); TJ_LSC_WIDE=0 launches them one after the other as rounds 1 - 3 did.  Same table, same decision, same state."""

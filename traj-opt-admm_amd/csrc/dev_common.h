@@ -30,7 +30,8 @@ enum : int {
   ERR_NOT_SPD = 16,          // coupled mode: the arrowhead Newton system is not positive definite (the reference's
                              // SimplicialLLT has no fallback there either, Optimization3D_multi.h:553-557)
   // detail bits, set together with ERR_LOOP_CAP
-  ERR_LS_RANGE = 32,         // coupled mode: no step among the 8 * LSC_ROUNDS evaluated Armijo candidates (0.8^0 .. 0.8^30) was accepted
+  ERR_LS_RANGE = 32,         // coupled mode, SHARDED context: no step among the 8 * LSC_ROUNDS Armijo candidates its exchange carries (0.8^0 .. 0.8^30) was accepted
+                             // (one context goes on to the reference's own end: kernels_ls.h lsc_continue)
   ERR_CCD_STUCK = 128,       // a CCD clamp found a contact at every step down to 0.8^STEP_CAP (the fixed point of step *= 0.8): the state itself is in collision (the
                              // reference spins forever there, Step.h:83-97)
   ERR_SLACK_ARMIJO = 256,    // the slack update's Armijo loop
@@ -80,6 +81,9 @@ struct Ctl {
   // direct exchange (Dev::xch): robots whose control points [0] / direction records [1] THIS rank has pushed to its peers so far -- every rank
   // pushes once per iteration, so a consumer expects xpush / owned rounds from every peer
   int xpush[2];
+  // k_linesearch's helper protocol: primaries that gave up waiting for a post (10 us) and searched on alone / helpers that left after 5 ms without a word.
+  // Both are zero on a GPU of the solver's own; a regression to the always-timeout path shows here (tj_stats) instead of only as a slower run.
+  int ls_giveups, ls_helper_timeouts;
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
@@ -253,6 +257,7 @@ struct Dev {
   // CU mates) to the cheapest items.  Which block computes which item changes no bit of any item.
   int grad_bal, num_cu;           // 1: k_grad maps blockIdx -> item through grad_perm; compute units of the device
   int *grad_cost, *grad_perm;     // [owned * P] ticks of the item's last block; [owned * P] item of launch position b (always a permutation: identity at the start)
+  int ls_help_late;               // TJ_LS_HELP_LATE=<us> (test hook, same bits): helper blocks idle that long before they stage -- they then start AFTER the primary's commit, the case the late-start guard exists for
   int ls_help, ls_help_mute;      // blocks per robot (1 = none); host: compute units / owned robots, at most LS_HELP_MAX.  ls_help_mute (TJ_LS_HELP_MUTE=1, test hook): helpers leave at once
   double *ls_tab;                 // [U][3][LS_HELP_MAX][2] posted energies (set = super-round % 3) (all-ones = not there yet; reset by begin_body and, between super-rounds, by the robot's primary block)
   unsigned long long *ls_word;    // [U] (epoch << 32) | super-round the primary asks for (LS_WORD_DONE: the search is over, helpers leave)

@@ -487,6 +487,10 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   const double t_dir = D.tdir(u), t0 = D.piece_time[u];
   double step0 = D.pow08[min(STEP_CAP, max(D.k_obs[u], D.k_self[u]))];
   const int hist = D.ls_hist[u];   // exponent this robot accepted in the previous iteration (-1: none yet): the round-0 shape follows it
+  if (h > 0 && D.ls_help_late > 0) {   // test hook (TJ_LS_HELP_LATE): this helper starts its staging late -- typically after the primary has committed
+    const long long t_go = wall_clock64() + 100ll * D.ls_help_late;
+    while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(32);
+  }
   bool in_lds;
   const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
   TJ_TIC(D, K_LINESEARCH, 2);
@@ -529,7 +533,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     // late-start guard of a helper (see above): the word is read now -- the staging barriers are behind us, every load of ls_stage has returned -- and
     // looked at before the first post (the round trip hides behind the evaluation)
     unsigned long long w_guard = 0;
+    asm volatile("" ::: "memory");   // (compiler: the guard load stays behind ls_stage's loads and barriers; hardware: those loads have returned -- their values went through LDS and two s_barriers)
     if (h > 0 && tid == 0) w_guard = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");
     for (int sr = 0;; sr++) {
       const int kb = 2 * (h + H * sr) - 1, k = kb + team;   // this block's two candidates of the super-round
       if (kb + 2 * H >= STEP_CAP) {   // (uniform; never in practice) the tail of a search that ends by rounding belongs to the one-wave rounds and their cap
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
           for (;;) {
             const unsigned long long w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(w >> 32) == epoch) { if ((unsigned)w == LS_WORD_DONE) { leave = 1; break; } if ((unsigned)w > (unsigned)sr) break; }
-            if (wall_clock64() > t_end) { leave = 1; break; }
+            if (wall_clock64() > t_end) { leave = 1; atomicAdd(&D.ctl->ls_helper_timeouts, 1); break; }
             __builtin_amdgcn_s_sleep(1);
           }
           s_flag = leave;
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
             const bool mine = tid >= 2 && tid < 2 * H;
             if (mine) v = __hip_atomic_load(tab + set + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__ballot(mine && (unsigned long long)__double_as_longlong(v) == LS_TAB_EMPTY) == 0ull) break;
-            if (wall_clock64() > t_end) { giveup = 1; break; }
+            if (wall_clock64() > t_end) { giveup = 1; if (tid == 0) atomicAdd(&D.ctl->ls_giveups, 1); break; }
           }
           if (!giveup) {
             double st = res[LS_GROUPS + 1];
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   }
   TJ_TIC(D, K_LS_COUPLED, 5);
   if (commit_late) {   // (uniform) accepted in a team round: commit now -- with helpers about, wave 0's DONE word must have been performed before the first of these stores is issued
-    if (H > 1) { if (tid < 64) __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
+    if (H > 1) { asm volatile("" ::: "memory"); if (tid < 64) __builtin_amdgcn_s_waitcnt(0); __syncthreads(); asm volatile("" ::: "memory"); }   // (s_waitcnt vmcnt(0): wave 0's DONE store has been acknowledged; the barrier hands that to the other waves; the compiler keeps the commit stores below)
     const double* win = sm + L.gnet + (size_t)wg * 3 * T;
     for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
   }
@@ -802,6 +808,65 @@ __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double ste
   if (lane == 0) { acc[0] = found_r; acc[1] = found_c; *accstep = found_step; }
 }
 
+// The search BEYOND the rounds the launches evaluated (steps 0.8^31 and smaller): the reference's loop (Optimization3D_multi.h:623) has no bound, it ends by rounding
+// like the decoupled one.  Met in no ordinary iteration (nine scenes, 30 iterations each: at most 24 back-offs) -- so it is the job of ONE block, which walks the
+// robots one after the other (stage, evaluate eight candidates, add to the eight totals in robot order: the reference's e += spline_energy(i)), round after round,
+// until a candidate passes or the step reaches the fixed point of `step *= 0.8`.  Slow (a round costs ~13 us per robot) and exact.  One context only: a sharded
+// context decides on the gathered four-round table and still reports ERR_LS_RANGE beyond it.
+__device__ __forceinline__ void lsc_continue(const Dev& D, const LsLayout& L, double* sm, int* pref, double step0, int tid, int* acc, double* accstep) {
+  __shared__ double s_tot[LS_GROUPS], s_e0;
+  __shared__ int s_hit;
+  const int S = D.S, T = D.T, P = D.P, G = L.groups;
+  const int g = min(tid / LS_GSIZE, G - 1), gl = tid % LS_GSIZE;
+  const bool shadow = tid / LS_GSIZE >= G;
+  double* net = sm + L.net; double* dir = sm + L.dir;
+  double* gnet = sm + L.gnet + (size_t)g * 3 * T;
+  double* ghull = sm + L.ghull + (size_t)g * S * 18;
+  const double wolfe = D.ctl->wolfe_c;
+  if (tid == 0) {   // E(x) summed in robot order: column (round 0, slot 0) of the table (written by other blocks of this launch with agent-scope stores)
+    double e0 = 0;
+    for (int u = 0; u < D.U; u++) e0 += __hip_atomic_load(&D.ls_e[((size_t)u * LSC_ROUNDS + 0) * LS_GROUPS + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_e0 = e0;
+  }
+  int k_first = lsc_cand_k(LSC_ROUNDS - 1, LS_GROUPS - 1) + 1;   // 31
+  double step_first = step0;
+  for (int i = 0; i < k_first; i++) step_first *= 0.8;            // same rounding as the reference's repeated step *= 0.8
+  for (int round = LSC_ROUNDS;; round++, k_first += LS_GROUPS) {
+    if (tid < LS_GROUPS) s_tot[tid] = 0.0;
+    __syncthreads();
+    for (int u = D.u0; u < D.u1; u++) {
+      bool in_lds;
+      const int M = ls_stage(D, L, sm, pref, u, tid, LS_THREADS, in_lds);
+      const double t_dir = D.tdir(u), t0 = D.piece_time[u];
+      for (int pass = 0; pass < LS_GROUPS / G; pass++) {
+        const int slot = pass * G + g;
+        double step = step_first;
+        for (int i = 0; i < slot; i++) step *= 0.8;
+        const double pt = t0 + step * t_dir;
+        __syncthreads();
+        for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = net[i] + step * dir[i];
+        __syncthreads();
+        const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, 1, step);
+        if (gl == 0 && !shadow) s_tot[slot] += e;   // one writer per slot, robots in order
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      int hit = -1; double st = step_first, hst = 0;
+      for (int c = 0; c < LS_GROUPS; c++) { if (hit < 0 && !(s_e0 - 1e-4 * wolfe * st < s_tot[c])) { hit = c; hst = st; } st *= 0.8; }
+      if (hit < 0 && k_first + LS_GROUPS - 1 >= STEP_CAP) {   // the fixed point of step *= 0.8: the reference's loop would never end -- take the last candidate and report
+        atomicOr(&D.ctl->error, ERR_LOOP_CAP);
+        hit = LS_GROUPS - 1; hst = step_first; for (int i = 0; i < hit; i++) hst *= 0.8;
+      }
+      s_hit = hit;
+      if (hit >= 0) { acc[0] = round; acc[1] = hit; *accstep = hst; }
+    }
+    __syncthreads();
+    if (s_hit >= 0) return;
+    for (int i = 0; i < LS_GROUPS; i++) step_first *= 0.8;
+  }
+}
+
 // wide (round 4): rounds covered by THIS launch.  A fleet that leaves compute units idle (owned robots x LSC_ROUNDS blocks fit the device) evaluates all four rounds
 // at once, block (robot, h) takes round h: one launch and one decision instead of four launches of which the later ones mostly return at once (three kernel
 // boundaries, ~8 us each with their staging).  Same energies into the same table, same decision.
@@ -862,21 +927,17 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   __syncthreads();
   if (!s_last) return;
   if (tid == 0) D.ctl->ls_ticket = 0;
-  if (tid < 64) {
-    lsc_decide<true>(D, round0 + wide, step0, tid, s_acc, &s_accstep, sm);   // sm: the evaluation is over
-    if (tid == 0 && s_acc[0] >= 0) { D.ctl->lsf_r = s_acc[0]; D.ctl->lsf_c = s_acc[1]; D.ctl->lsf_step = s_accstep; D.ctl->lsf_epoch = epoch; }   // read by LATER kernels only
-  }
+  if (tid < 64) lsc_decide<true>(D, round0 + wide, step0, tid, s_acc, &s_accstep, sm);   // sm: the evaluation is over
+  __syncthreads();
+  // none of the 31 steps of the evaluated rounds passes (never met outside constructed states): this block goes on alone, to the reference's own end
+  if (s_acc[0] < 0 && round0 + wide >= LSC_ROUNDS) { lsc_continue(D, L, sm, pref, step0, tid, s_acc, &s_accstep); __syncthreads(); }
+  if (tid == 0 && s_acc[0] >= 0) { D.ctl->lsf_r = s_acc[0]; D.ctl->lsf_c = s_acc[1]; D.ctl->lsf_step = s_accstep; D.ctl->lsf_epoch = epoch; }   // read by LATER kernels only
   if (wide < LSC_ROUNDS) return;
   // Every round has been evaluated and every other block is through (the ticket): this block also COMMITS -- k_ls_commit's work for all robots, 3T values
   // each; the host omits that launch.  Same expressions as k_ls_commit.
   __syncthreads();
-  double step = s_accstep;
-  const int kacc = s_acc[0] >= 0 ? lsc_cand_k(s_acc[0], s_acc[1]) : lsc_cand_k(LSC_ROUNDS - 1, LS_GROUPS - 1);
-  if (s_acc[0] < 0) {   // no acceptable step within the evaluated range: take the last candidate and report it
-    step = step0;
-    for (int i = 0; i < kacc; i++) step *= 0.8;
-    if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_LS_RANGE);
-  }
+  const double step = s_accstep;
+  const int kacc = lsc_cand_k(s_acc[0], s_acc[1]);   // (lsc_continue always leaves a decision)
   for (int idx = tid; idx < nown * 3 * T; idx += LS_THREADS) {
     const int uu = D.u0 + idx / (3 * T), i = idx % (3 * T);
     double* gs = D.spline + (size_t)uu * 3 * T;

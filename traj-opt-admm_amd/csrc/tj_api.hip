@@ -375,7 +375,7 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
   }
   if (h.error & ERR_LOOP_CAP) {
     c->err = "a device back-off/Newton/Armijo loop hit its cap (infeasible state)";
-    if (h.error & ERR_LS_RANGE) c->err += ": coupled mode, no acceptable step among the 31 evaluated Armijo back-offs (step < 1.2e-3: no progress)";
+    if (h.error & ERR_LS_RANGE) c->err += ": coupled mode on a SHARDED context, no acceptable step among the 31 Armijo back-offs its exchange carries (one context follows the search to the reference's own end)";
     if (h.error & ERR_CCD_STUCK) c->err += ": a CCD clamp found contact at every step (the state itself is in collision; the reference loops forever here)";
     if (h.error & ERR_SLACK_ARMIJO) c->err += ": the slack update's Armijo search";
     if (h.error & ERR_PLANE_REFINE) c->err += ": optimal_plane, a plane refinement did not terminate within its caps";
@@ -545,6 +545,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     if (const char* e = getenv("TJ_GRAD_BALANCE")) d.grad_bal = (atoi(e) != 0 && owned * d.P <= 65536) ? 1 : 0;   // launch-shape switch (same bits)
     d.ls_help = (d.ls_fast && p->mode != TJ_MODE_MULTI_COUPLED) ? std::max(1, std::min(LS_HELP_MAX, prop.multiProcessorCount / owned)) : 1;
     if (const char* e = getenv("TJ_LS_HELP")) d.ls_help = std::max(1, std::min(LS_HELP_MAX, atoi(e)));   // launch-shape switch (same bits); 1 = no helpers
+    if (const char* e = getenv("TJ_LS_HELP_LATE")) d.ls_help_late = std::max(0, std::min(4000, atoi(e)));   // test hook (same bits): helper blocks idle that many microseconds before staging
     if (const char* e = getenv("TJ_LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
   }
   if (c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double) > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
@@ -1531,6 +1532,7 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   s->pair_tests = d.mode >= 1 ? s->iters * (unsigned long long)(d.u1 - d.u0) * d.S * d.U : 0;
   s->order_ambiguous = h.order_ambiguous; s->error_bits = h.error; s->order_unresolved = h.order_unresolved;
   s->gjk_max_sum = h.gjk_max_sum + (unsigned long long)h.gjk_max;
+  s->ls_giveups = h.ls_giveups; s->ls_helper_timeouts = h.ls_helper_timeouts;
   s->head_starts = h.spec_taken;
   return TJ_OK;
 }
