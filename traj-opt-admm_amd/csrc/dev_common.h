@@ -186,6 +186,7 @@ struct Dev {
   const double* tri;            // [N][9] sorted triangles, three vertices row-major (prim == 3)
   const float* leafbox;         // [N][6] outward-rounded fp32 box of each triangle: pre-filter before the exact fp64 test (prim == 3)
   int nlevels;                  // level 0 = boxes over 8 consecutive primitives; top level has <= 64 boxes
+  int bvh_skip;                 // 1: the walk takes two levels per step while its frontier is small (kernels_sep.h bvh_query; TJ_BVH_SKIP=0: off -- same candidates, same order)
   int lvl_off[MAX_LEVELS], lvl_n[MAX_LEVELS];
   // Inner boxes are fp32, rounded OUTWARD (lo down, hi up): 24 B instead of 48 B per box visited.  A conservative box can
   // only add visits, never lose a primitive, and the leaf predicate is evaluated in fp64 on the primitive itself
@@ -215,6 +216,8 @@ struct Dev {
   int* ccd_found;                  // [64] obstacle primitives the CCD stage found inside swept boxes, cumulative, spread over 64 counters (block & 63) so that no
                                    // address is hot; the host sums them when it reads the control block and picks k_ccd's build from the rate
   int pair_rows;                   // rows per tile of the robot-pair broad phase (kernels_pairs.h)
+  int pair_prio;      // large fleets: producer waves of k_mid run at wave priority 3 (TJ_PAIR_PRIO=0: off)
+  int pair_lpw;       // large fleets, one pair per lane: pairs a producer wave of k_mid takes per pass (64 = every lane; TJ_PAIR_LPW)
   int pair_pass_on;   // 1 (default): large fleets pass long pair solves on to idle waves; TJ_PAIR_PASS_ON=0 keeps every pair on its lane (test hook: same bits either way)
   int* pair_ovf; unsigned long long* pair_ovf_list;   // large fleets: [0] pairs passed on by the lane solve, [1] producer waves done, [2] consumer cursor; entries (epoch << 32 | q << 20 | p0 << 9 | segment), cap_work of them
   int *pair_work; int *pair_work_n; int cap_work;  // (segment, p0, p1) triples that passed box + k-DOP this iteration

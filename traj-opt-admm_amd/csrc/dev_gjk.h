@@ -41,6 +41,12 @@ struct BodyHull {  // 6 control points of one Bezier segment, row-major [6][3] (
   static constexpr int N = 6;
   __device__ __forceinline__ V3 get(int i) const { return V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
 };
+template <int STRIDE>
+struct BodyHullT {  // the same, one hull per LANE in a transposed LDS tile: entry e of this lane's hull at p[e * STRIDE] (p already points at the lane's column)
+  const double* p;
+  static constexpr int N = 6;
+  __device__ __forceinline__ V3 get(int i) const { return V3{p[(3 * i) * STRIDE], p[(3 * i + 1) * STRIDE], p[(3 * i + 2) * STRIDE]}; }
+};
 struct BodySwept {  // conv{P, P + t*D}: 12 points (CCD.h:119-120), never stored
   const double* p; const double* d; double t;
   static constexpr int N = 12;

@@ -265,7 +265,12 @@ __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
 }
 
 // one wavefront per robot pair (stride over the work list: wave bid of nwaves), solved cooperatively by its lanes (plane_pair_wave)
-__device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int nwaves, bool head_start = false) {   // head_start: k_mid only -- the k_front of the same iteration ran in front of it
+// tile (large fleets, one pair per lane): PAIR_TILE_DOUBLES doubles of LDS in which every lane keeps its pair's two hulls, transposed (entry e of lane l at
+// tile[e * lpw + l]: conflict-free).  The per-lane GJK and the offset Newton read a hull entry dozens of times; from global memory that was 36 scattered
+// 8-byte loads per lane and GJK iteration -- the producers' GJK phase took 4 ... 58 us depending on what else the memory pipeline was doing (phase stamps,
+// round 5), from LDS it does not depend on it.
+constexpr int PAIR_TILE_LANES = 32, PAIR_TILE_DOUBLES = 36 * PAIR_TILE_LANES;
+__device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int nwaves, bool head_start, double* tile) {   // head_start: k_mid only -- the k_front of the same iteration ran in front of it
   const int lane = lane_id();
   __shared__ double A[18], B[18];
   __shared__ int wpre[513];
@@ -291,7 +296,8 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     // address) and starve the producers -- measured.  The producer that counts itself done last writes nc STOP entries behind
     // the list, so every consumer's next word turns valid.  An append's returning add has been performed before its wave
     // counts itself done; no fence (= no L2 write-back) is needed anywhere.
-    const int np = min(nwaves, (n + 63) / 64);            // waves that own a chunk of the list ("producers")
+    const int lpw = min(D.pair_lpw, PAIR_TILE_LANES);   // pairs (= active lanes) per producer wave (TJ_PAIR_LPW; 64 .. 8 lanes measured alike without the tile)
+    const int np = min(nwaves, (n + lpw - 1) / lpw);      // waves that own a chunk of the list ("producers")
     const int nc = min(nwaves - np, PAIR_CONSUMERS_MAX);
     const bool pass_on = D.pair_pass_on && 2 * np <= nwaves;
     const int kcap = pass_on ? PAIR_LANE_GJK_CAP : 50;
@@ -332,16 +338,24 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     }
     unsigned long long nit_sum = 0, solved = 0; bool any_capped = false;
     TJ_TIC(D, K_SEP_SELF_SOLVE, 0);
-    for (int base = bid * 64; base < n; base += nwaves * 64) {
+    if (D.pair_prio) __builtin_amdgcn_s_setprio(3);   // the ~160 producer waves set k_mid's length at hundreds of robots: ahead of whatever shares their SIMD (TJ_PAIR_PRIO)
+    for (int base = bid * lpw; base < n; base += nwaves * lpw) {
       const int w = base + lane;
-      if (w < n) {
+      if (w < n && lane < lpw) {
         const size_t sl = (size_t)pair_work_slot(D, wpre, w);
         const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
         const double* Ag = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
         const double* Bg = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
+        constexpr int hst = PAIR_TILE_LANES;
+        {   // this lane's column of the tile (private to the lane: no synchronisation)
+          double* col = tile + lane;
+#pragma unroll 6
+          for (int e = 0; e < 18; e++) { col[e * hst] = Ag[e]; col[(18 + e) * hst] = Bg[e]; }
+          Ag = col; Bg = col + 18 * hst;
+        }
         double e0, e1c, e2c, dpl; bool capped; int nit = 0;
         int gkl = 0; bool cut = false;
-        const V3 vw = gjk(BodyHull{Ag}, BodyHull{Bg}, &gkl, kcap, &cut);
+        const V3 vw = gjk(BodyHullT<hst>{Ag}, BodyHullT<hst>{Bg}, &gkl, kcap, &cut);
 #ifdef TJ_PHASE_TIMING
         if (!cut) atomicAdd((unsigned long long*)&D.dbg[((size_t)K_SEP_SELF_ROWS * TJ_TIC_BLOCKS + min(gkl, 63)) * TJ_TIC_SLOTS], 1ull);   // histogram of GJK iterations per pair (lane path)
 #endif
@@ -352,7 +366,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
           if (slot < D.cap_work) __hip_atomic_store(&D.pair_ovf_list[slot], ((unsigned long long)(unsigned)epoch << 32) | (unsigned long long)(tr | (p0 << 9) | (q << 20)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);   // cannot happen (the list holds cap_work entries and there are at most that many pairs); never drop a pair silently
         }
-        if (!cut && plane_pair_finish(vw, Ag, Bg, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit)) {
+        if (!cut && plane_pair_finish(vw, Ag, Bg, dist, m, off, true, e0, e1c, e2c, dpl, capped, &nit, hst)) {
           nit_sum += (unsigned long long)nit; solved++; any_capped = any_capped || capped;
           const size_t s0 = ((size_t)tr * U + p0) * U + q, s1 = ((size_t)tr * U + q) * U + p0;
           double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
@@ -500,7 +514,8 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
 }
 __global__ __launch_bounds__(64) void k_sep_self_solve(Dev D) {
   if (TJ_DONE(D)) return;
-  sep_self_solve_body(D, blockIdx.x, gridDim.x);
+  __shared__ double tile[PAIR_TILE_DOUBLES];
+  sep_self_solve_body(D, blockIdx.x, gridDim.x, false, tile);
 }
 
 // per (owned robot, segment): obstacle planes from the stamped candidate slots (slot order), then -- multi-robot modes --

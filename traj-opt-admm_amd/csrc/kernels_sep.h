@@ -54,6 +54,7 @@ template <> struct PrimOf<3> {
 // The top level's boxes do not depend on the query: a caller can fetch its lane's box (bvh_top_box) TOGETHER with the record that
 // holds the query box and hand it in -- one dependent round trip less at the head of the walk.
 struct TopBox { float b[6]; };
+constexpr int BVH_SKIP_MAX = 8;   // frontier nodes up to which a level pair is taken in one step (64 boxes per node)
 __device__ __forceinline__ TopBox bvh_top_box(const Dev& D) {
   TopBox t{{0, 0, 0, 0, 0, 0}};
   if (D.N == 0) return t;
@@ -82,6 +83,44 @@ __device__ int bvh_query(const Dev& D, const QBox& q, double m, int* fa, int* fb
   if (count == 0) { if (visits) *visits += nv; return 0; }   // wave-uniform: nothing of the obstacle set is near this box (the common case)
   __syncthreads();
   int* cur = fa; int* nxt = fb;
+  // DOUBLE STEPS while the frontier is small (the top of a deep pyramid: 1 M primitives are five levels): the 64 GRANDchildren of a frontier node are tested by
+  // the 64 lanes at once -- one dependent round trip per two levels instead of two.  A box contains its children's boxes (unions, rounded outward monotonically),
+  // so a grandchild that is hit has a hit parent: the survivors at level lv - 1 are the same nodes in the same (ascending) order as after two single steps.
+  while (top >= 2 && count <= BVH_SKIP_MAX && D.bvh_skip) {
+    const int lv = top - 2, nl = D.lvl_n[lv];
+    const float* lvl = D.boxes + (size_t)D.lvl_off[lv] * 6;
+    int ncount = 0; bool overflow = false;
+    for (int base = 0; base < count && !overflow; base += BQ_UNROLL) {
+      int gc[BQ_UNROLL]; bool live[BQ_UNROLL]; float bx[BQ_UNROLL][6];
+#pragma unroll
+      for (int c = 0; c < BQ_UNROLL; c++) {
+        const int node = cur[min(base + c, count - 1)];
+        gc[c] = node * 64 + lane;
+        live[c] = base + c < count && gc[c] < nl;
+        const float* b = lvl + (size_t)min(gc[c], nl - 1) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) bx[c][k] = b[k];
+      }
+#pragma unroll
+      for (int c = 0; c < BQ_UNROLL; c++) {
+        if (base + c >= count) break;
+        bool hit = live[c];
+#pragma unroll
+        for (int k = 0; k < 3; k++) hit = hit & !(((double)bx[c][3 + k] + m < q.lo[k]) | ((double)bx[c][k] > q.hi[k] + m));
+        const unsigned long long mask = ballot(hit);
+        const int tot = __popcll(mask);
+        if (ncount + tot > FRONT_CAP) { if (lane == 0) atomicOr(&D.ctl->error, ERR_FRONT_OVERFLOW); overflow = true; break; }
+        if (hit) nxt[ncount + prefix_count(mask)] = gc[c];
+        ncount += tot;
+        nv += 64;
+      }
+    }
+    __syncthreads();
+    int* t = cur; cur = nxt; nxt = t;
+    count = ncount;
+    top -= 2;
+    if (count == 0) break;
+  }
   // Each step of the walk is a dependent global load (~0.7 us).  BQ_UNROLL chunks of 8 frontier nodes are therefore
   // fetched together: all box loads of the group are issued first (branch-free, clamped addresses), then the chunks are
   // tested and compacted one by one in frontier order (the order of the survivors, and with it of the candidate list,
@@ -308,26 +347,27 @@ __device__ inline bool kdop_hulls_pass(const Dev& D, const double* A, const doub
 // second half of plane_pair: from the GJK witness vector to the plane (separate so that a caller can act between the halves)
 // cr_log out of line: the per-lane pair path lives in k_mid at its 256-register cap, where the inlined double-double pieces spill
 __device__ __noinline__ double cr_log_call(double x) { return cr_log(x); }
-__device__ inline bool plane_pair_finish(const V3& v, const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters = nullptr);
+__device__ inline bool plane_pair_finish(const V3& v, const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters = nullptr, int st = 1);
 __device__ inline bool plane_pair(const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters = nullptr, int* gjk_iters = nullptr) {
   const V3 v = gjk(BodyHull{A}, BodyHull{Bq}, gjk_iters);
   return plane_pair_finish(v, A, Bq, dist, m, off, refine, e0, e1c, e2c, dpl, capped, newton_iters);
 }
-__device__ inline bool plane_pair_finish(const V3& v, const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters) {
+// st: stride between the entries of A / Bq (1: row-major [6][3] in global memory or LDS; the lane-per-pair path of large fleets keeps a transposed tile, BodyHullT)
+__device__ inline bool plane_pair_finish(const V3& v, const double* A, const double* Bq, double dist, double m, double off, bool refine, double& e0, double& e1c, double& e2c, double& dpl, bool& capped, int* newton_iters, int st) {
   capped = false;
   const double cn = norm3(v.x, v.y, v.z);
   if (cn > dist) return false;
   e0 = v.x / cn; e1c = v.y / cn; e2c = v.z / cn;
   double d0 = INFINITY, d1 = -INFINITY;
-  for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, Bq + 3 * i); if (d0 > t) d0 = t; }
-  for (int i = 0; i < 6; i++) { const double t = -dot_fixed3(e0, e1c, e2c, A + 3 * i); if (d1 < t) d1 = t; }
+  for (int i = 0; i < 6; i++) { const double t = -(e0 * Bq[(3 * i) * st] + (e1c * Bq[(3 * i + 1) * st] + e2c * Bq[(3 * i + 2) * st])); if (d0 > t) d0 = t; }   // dot_fixed3's order (Eigen unrolled 3-term, Separate.h:268,276)
+  for (int i = 0; i < 6; i++) { const double t = -(e0 * A[(3 * i) * st] + (e1c * A[(3 * i + 1) * st] + e2c * A[(3 * i + 2) * st])); if (d1 < t) d1 = t; }
   dpl = 0.5 * (d0 + d1);
   if (!refine) return true;
   int it = 0;
   for (; it < NEWTON_CAP; it++) {  // Newton on the offset until |grad| < 1e-2
     double grad = 0, hess = 0;
     for (int j = 0; j < 6; j++) {
-      const double ds = (A[3 * j] * e0 + A[3 * j + 1] * e1c + A[3 * j + 2] * e2c) + dpl - 0.5 * off;
+      const double ds = (A[(3 * j) * st] * e0 + A[(3 * j + 1) * st] * e1c + A[(3 * j + 2) * st] * e2c) + dpl - 0.5 * off;
       if (ds < m) {
         const double lg = cr_log_call(ds / m);   // rounds like glibc's log (dev_crmath.h): the offset is then the reference's bit for bit
         const double g1 = -(2 * (ds - m) * lg + (ds - m) * (ds - m) / ds);
@@ -336,7 +376,7 @@ __device__ inline bool plane_pair_finish(const V3& v, const double* A, const dou
       }
     }
     for (int j = 0; j < 6; j++) {
-      const double ds = -(Bq[3 * j] * e0 + Bq[3 * j + 1] * e1c + Bq[3 * j + 2] * e2c) - dpl - 0.5 * off;
+      const double ds = -(Bq[(3 * j) * st] * e0 + Bq[(3 * j + 1) * st] * e1c + Bq[(3 * j + 2) * st] * e2c) - dpl - 0.5 * off;
       if (ds < m) {
         const double lg = cr_log_call(ds / m);
         const double g1 = -(2 * (ds - m) * lg + (ds - m) * (ds - m) / ds);

@@ -550,11 +550,13 @@ __device__ __forceinline__ double z_energy_wave(const Dev& D, const double* md, 
 // per lane, v_readlane broadcasts: the LDS form pays three barriers per pivot) -> Armijo search with the objective evaluated by
 // the whole wave (z_energy_wave) and every pow() of a pass taken on different lanes at once (the scalar loop on one lane was
 // a third of the 27 us this body took; it is the whole of k_mid for one or a few robots).
-__device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) {
+constexpr int SLACK_LDS_DOUBLES = 5 * 18 + 19 + 2 * 361 + 2 * 19 + 4 * 19 + 36 + 36;   // 1017
+__device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred, double* lds) {   // lds: SLACK_LDS_DOUBLES doubles the KERNEL owns (k_mid overlays them with the pair tile)
   const int tid = threadIdx.x;
   const int u = D.u0 + bid / D.P, sp = bid % D.P;
   const int P6 = 6 * D.P, T = D.T;
-  __shared__ double cx[18], z[18], lam[18], zt[18], dirz[18], g[19], H[361], L[361], g0[19], x0[19], scr[4 * 19], md[36], w18[36];
+  double* cx = lds; double* z = cx + 18; double* lam = z + 18; double* zt = lam + 18; double* dirz = zt + 18; double* g = dirz + 18; double* H = g + 19; double* L = H + 361;
+  double* g0 = L + 361; double* x0 = g0 + 19; double* scr = x0 + 19; double* md = scr + 4 * 19; double* w18 = md + 36;
   const double* net = D.spline + (size_t)u * 3 * T;
   const double* C = D.convert + (size_t)sp * 36;
   const double pt = D.piece_time[u];
@@ -676,7 +678,8 @@ __device__ __forceinline__ void slack_body(const Dev& D, int bid, int deferred) 
 }
 __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
   if (deferred ? !D.ctl->slack_now : TJ_DONE(D)) return;
-  slack_body(D, blockIdx.x, deferred);
+  __shared__ double lds[SLACK_LDS_DOUBLES];
+  slack_body(D, blockIdx.x, deferred, lds);
 }
 
 // ---- union kernels of the single-GPU iteration graph ---------------------------------------------------------------
@@ -699,10 +702,11 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_ord = D.grad_bal ? ((D.u1 - D.u0) * D.P + 63) / 64 : 0;   // the first blocks of the grid: launch order of this iteration's k_grad (kernels_newton.h; ~3 us each --
                                                                         // as the LAST blocks they started when the first query blocks retired and ended 1 us after everything else)
   const int n_xf = D.xf ? D.n_foreign() * D.S : 0;   // sharded contexts: hull cache of the other ranks' robots, AHEAD of everything that reads it (head starts, pair tiles)
-  const int b = (int)blockIdx.x - n_ord - n_xf - n_spec;
-  if ((int)blockIdx.x < n_ord) grad_order_body(D, (int)blockIdx.x, (int*)lds);
-  else if ((int)blockIdx.x < n_ord + n_xf) xf_hull_body(D, (int)blockIdx.x - n_ord);
-  else if (b < 0) spec_pair_body(D, (int)blockIdx.x - n_ord - n_xf, lds);
+  const int bx = (int)blockIdx.x;
+  const int b = bx - n_ord - n_xf - n_spec;
+  if (bx < n_ord) grad_order_body(D, bx, (int*)lds);
+  else if (bx < n_ord + n_xf) xf_hull_body(D, bx - n_ord);
+  else if (b < 0) spec_pair_body(D, bx - n_ord - n_xf, lds);
   else if (b < n_obs) obs_query_body<PRIM>(D, b, lds, true);
   else sep_self_rows_body(D, b - n_obs, lds, D.xf != 0);
   TJ_TIC(D, K_FRONT, 1);
@@ -722,9 +726,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     D.dbg[((size_t)K_MID * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
   }
 #endif
-  if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
+  __shared__ double mid_lds[SLACK_LDS_DOUBLES > PAIR_TILE_DOUBLES ? SLACK_LDS_DOUBLES : PAIR_TILE_DOUBLES];   // one buffer for whichever body this block runs: the slack system, or the pair tile
+  if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1, mid_lds); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
   else if (TJ_DONE(D)) return;
-  else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves, D.spec != 0);
+  else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves, D.spec != 0, mid_lds);
   else obs_solve_body<PRIM>(D, b - n_slack - n_pair_waves, n_obs_waves);
   TJ_TIC(D, K_MID, 1);
 }

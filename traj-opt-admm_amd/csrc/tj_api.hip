@@ -507,6 +507,12 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   // plus a separate compaction launch is faster once there are more pieces than that (SCN-D: k_grad 109 -> 72 + 14 us)
   c->grad_fold = (d.u1 - d.u0) * d.P <= 512;
   if (const char* e = getenv("TJ_GRAD_FOLD")) c->grad_fold = atoi(e) != 0;
+  d.bvh_skip = 0;    // decided when the obstacle set is known (set_obstacles); TJ_BVH_SKIP=0 / 1 forces it (launch-shape switch, same bits)
+  if (const char* e = getenv("TJ_BVH_SKIP")) d.bvh_skip = atoi(e) != 0;
+  d.pair_prio = 1;
+  if (const char* e = getenv("TJ_PAIR_PRIO")) d.pair_prio = atoi(e) != 0;   // launch-shape switch (same bits)
+  d.pair_lpw = 64;
+  if (const char* e = getenv("TJ_PAIR_LPW")) { const int r = atoi(e); if (r == 8 || r == 16 || r == 32 || r == 64) d.pair_lpw = r; }   // launch-shape switch (same bits)
   d.pair_pass_on = 1;
   if (const char* e = getenv("TJ_PAIR_PASS_ON")) d.pair_pass_on = atoi(e) != 0;
   if (const char* e = getenv("TJ_SPLIT_UNIONS")) c->split_unions = atoi(e) != 0;
@@ -651,7 +657,7 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
   QUIESCE(c);
   drop_graph(c);
   c->have_cloud = false;
-  d.N = 0; d.nlevels = 0; d.px = d.py = d.pz = d.tri = nullptr; d.boxes = d.leafbox = nullptr;
+  d.N = 0; d.nlevels = 0; if (!getenv("TJ_BVH_SKIP")) d.bvh_skip = 0; d.px = d.py = d.pz = d.tri = nullptr; d.boxes = d.leafbox = nullptr;
   for (void* p : c->cloud_allocs) hipFree(p);
   c->cloud_allocs.clear();
   c->cloud_order.clear();
@@ -713,6 +719,9 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
     c->cloud_order.swap(order);
     d.boxes = boxes; d.px = px; d.py = py; d.pz = pz; d.tri = tri; d.leafbox = lb;
     d.nlevels = (int)lvl_n.size();
+    // two levels per step at the top of the walk (kernels_sep.h): pays where the pyramid is deep AND the query waves outnumber the resident slots, i.e. where a
+    // query's latency is the launch's throughput (256 robots x 1 M primitives: k_front 40.2 -> 36.3 us, k_ccd 34.0 -> 31.0); 64 robots through 1 M points: no change
+    if (!getenv("TJ_BVH_SKIP")) d.bvh_skip = (d.nlevels >= 5 && (d.u1 - d.u0) * d.S > 3584) ? 1 : 0;
     for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = lvl_off[i]; d.lvl_n[i] = lvl_n[i]; }
     d.N = n;
   }
