@@ -213,6 +213,11 @@ struct Dev {
   // one component of 64 partners with one coalesced load instead of 64 strided 8-byte loads
   double *hbox, *cbox;
   double *pairplane; int *pairstamp;  // [S][U][U][4] plane of robot a against partner b, [S][U][U] epoch stamp
+  // index of the stamped slots: bit b of word [S][U][ceil(U/64)] = "the slot of partner b may carry this iteration's stamp" -- set (atomicOr) by whoever stamps a
+  // slot, read AND cleared by the one wave that compacts the row, which therefore looks at the stamps and planes of the set bits only (the dense row scan was
+  // 1 KB of stamps + 2 KB of speculative planes per segment: 16.8 MB per launch at 256 robots).  A superset is enough: the stamp still decides.
+  unsigned long long* pairbits;
+  __device__ __forceinline__ void pair_mark(int tr, int a, int b) const { atomicOr(&pairbits[((size_t)tr * U + a) * ((U + 63) >> 6) + (b >> 6)], 1ull << (b & 63)); }
   int* ccd_found;                  // [64] obstacle primitives the CCD stage found inside swept boxes, cumulative, spread over 64 counters (block & 63) so that no
                                    // address is hot; the host sums them when it reads the control block and picks k_ccd's build from the rate
   int pair_rows;                   // rows per tile of the robot-pair broad phase (kernels_pairs.h)
@@ -258,6 +263,7 @@ struct Dev {
   // blocks beyond the first `num_cu` share a CU with an older block and run ~20 % slower (the SIMD issues its oldest wave first) -- they set the kernel's
   // length.  Every block leaves the wall-clock ticks it took; the next iteration's k_front ranks them and hands the late positions (and their
   // CU mates) to the cheapest items.  Which block computes which item changes no bit of any item.
+  int grad_cfold;                 // 1: the 192-thread k_grad compacts its own segments (chains of large fleets; the 512-thread folded launch does by construction)
   int grad_bal, num_cu;           // 1: k_grad maps blockIdx -> item through grad_perm; compute units of the device
   int *grad_cost, *grad_perm;     // [owned * P] ticks of the item's last block; [owned * P] item of launch position b (always a permutation: identity at the start)
   int ls_help_late;               // TJ_LS_HELP_LATE=<us> (test hook, same bits): helper blocks idle that long before they stage -- they then start AFTER the primary's commit, the case the late-start guard exists for

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     q0[0] = cx; q0[1] = cy; q0[2] = cz; q0[3] = d - 0.5 * off;
     q1[0] = -cx; q1[1] = -cy; q1[2] = -cz; q1[3] = -d - 0.5 * off;
     }
-    D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+    D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch; D.pair_mark(tr, p0, q); D.pair_mark(tr, q, p0);
   };
   // statistics of this mode (tj_stats): newton_iters / pair_solves = Newton rounds / planes refined (Optimal_plane::self_optimal_cd's outer loop),
   // gjk_max_sum = sum over the iterations of the longest refinement of a launch, in rounds -- the unit count of k_keep's critical path

@@ -332,7 +332,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
           double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
           q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
           q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
-          D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+          D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch; D.pair_mark(tr, p0, q); D.pair_mark(tr, q, p0);
         }
       }
     }
@@ -372,7 +372,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
           double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
           q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
           q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
-          D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+          D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch; D.pair_mark(tr, p0, q); D.pair_mark(tr, q, p0);
         }
       }
     }
@@ -430,7 +430,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
       double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
       q0[0] = e0; q0[1] = e1c; q0[2] = e2c; q0[3] = dpl - 0.5 * off;
       q1[0] = -e0; q1[1] = -e1c; q1[2] = -e2c; q1[3] = -dpl - 0.5 * off;
-      D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch;
+      D.pairstamp[s0] = epoch; D.pairstamp[s1] = epoch; D.pair_mark(tr, p0, q); D.pair_mark(tr, q, p0);
     }
   };
   if (dedicated) {
@@ -531,32 +531,27 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
   const bool obs_part = !(D.optimal_plane && !D.multi());  // single-UAV "optimal_plane":1 -- k_keep wrote the obstacle plane list itself
   const bool pair_part = D.multi();
   const int n = obs_part ? D.ocand_n[seg] : 0;
-  // partner stamps of the first four chunks (all of them up to 256 robots)
-  int pst[4];
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const int q = 64 * c + lane;
-    pst[c] = (pair_part && q < U) ? D.pairstamp[((size_t)tr * U + u) * U + q] : 0;
-  }
-  // The planes of the first 64 partner slots travel WITH the stamps (stamped or not: 2 KB per segment), and a candidate's plane
-  // with its stamp: two dependent round trips instead of three at the head of every k_grad block.
-  double pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0;
-  if (pair_part && lane < U) { const double* p = D.pairplane + 4 * (((size_t)tr * U + u) * U + lane); pp0 = p[0]; pp1 = p[1]; pp2 = p[2]; pp3 = p[3]; }
+  // the row's index words (Dev::pairbits): one per 64 partners, fetched with the candidate count -- the stamps and planes of the SET bits follow in the second trip
+  const int W = (U + 63) >> 6;
+  unsigned long long* bw = D.pairbits + ((size_t)tr * U + u) * W;
+  unsigned long long wbits = 0;   // lane w: word w (W <= 32)
+  if (pair_part && lane < W) wbits = bw[lane];
   double* outp = D.splanes + seg * D.cap_self * 4;
   int pbase = 0;
   if (pair_part) {
     for (int q0 = 0; q0 < U; q0 += 64) {
+      const unsigned long long word = __shfl(wbits, q0 >> 6);
+      if (word == 0ull) continue;   // (uniform) nobody stamped a slot of this chunk
       const int q = q0 + lane;
+      const bool bit = (word >> lane) & 1ull;
       const size_t slot = ((size_t)tr * U + u) * U + min(q, U - 1);
-      const int st = q0 < 256 ? pst[q0 >> 6] : (q < U ? D.pairstamp[slot] : 0);
-      const bool ok = q < U && q != u && st == epoch;
+      int st = 0; double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+      if (bit && q < U) { st = D.pairstamp[slot]; const double* p = D.pairplane + 4 * slot; v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; }   // stamp and plane in one trip
+      const bool ok = bit && q < U && q != u && st == epoch;
       const unsigned long long mask = ballot(ok);
       const int idx = pbase + prefix_count(mask);
       if (ok) {
         if (idx < D.cap_self) {
-          double v0, v1, v2, v3;
-          if (q0 == 0) { v0 = pp0; v1 = pp1; v2 = pp2; v3 = pp3; }
-          else { const double* p = D.pairplane + 4 * slot; v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; }
           outp[4 * idx] = v0; outp[4 * idx + 1] = v1; outp[4 * idx + 2] = v2; outp[4 * idx + 3] = v3;
           if (pst_s && idx < pst_cap) { pst_s[4 * idx] = v0; pst_s[4 * idx + 1] = v1; pst_s[4 * idx + 2] = v2; pst_s[4 * idx + 3] = v3; }
         }
@@ -564,6 +559,7 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
       }
       pbase += __popcll(mask);
     }
+    if (lane < W && wbits != 0ull) bw[lane] = 0ull;   // read: cleared for the next iteration (its writers run in a later kernel; this wave is the row's only reader)
   }
   if (obs_part) {
     double* out = D.oplanes + seg * D.cap_obs * 4;
