@@ -263,7 +263,6 @@ struct Dev {
   // blocks beyond the first `num_cu` share a CU with an older block and run ~20 % slower (the SIMD issues its oldest wave first) -- they set the kernel's
   // length.  Every block leaves the wall-clock ticks it took; the next iteration's k_front ranks them and hands the late positions (and their
   // CU mates) to the cheapest items.  Which block computes which item changes no bit of any item.
-  int grad_cfold;                 // 1: the 192-thread k_grad compacts its own segments (chains of large fleets; the 512-thread folded launch does by construction)
   int grad_bal, num_cu;           // 1: k_grad maps blockIdx -> item through grad_perm; compute units of the device
   int *grad_cost, *grad_perm;     // [owned * P] ticks of the item's last block; [owned * P] item of launch position b (always a permutation: identity at the start)
   int ls_help_late;               // TJ_LS_HELP_LATE=<us> (test hook, same bits): helper blocks idle that long before they stage -- they then start AFTER the primary's commit, the case the late-start guard exists for

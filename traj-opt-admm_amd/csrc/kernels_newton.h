@@ -154,7 +154,7 @@ __device__ __forceinline__ void grad_sync(GradSync& g) { if constexpr (GSYNC) gr
 template <bool GSYNC>
 __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, double* E1b, double* E2b, int sb, int se, int tot, int u, int sp, int res, double m,
                                                  const double* Pall, const double* Ball, const double* wseg, const int* segn, const int* segno, int* sego, double* Mv, const GradRole R, GradSync& gs, double run,
-                                                 const double* pst = nullptr, bool coh = false) {   // run: this thread's running sum (Hessian or gradient entry) in, updated sum out; pst: the planes are in LDS already (folded launch); coh: the global lists were written by THIS block a moment ago -- read them past the CU's L1
+                                                 const double* pst = nullptr) {   // run: this thread's running sum (Hessian or gradient entry) in, updated sum out; pst: the planes are in LDS already (folded launch)
   const int tid = R.tid, hi_ = R.hi, ai = R.ai, ak = R.ak, vr = R.vr, av = R.av, qv = R.qv;
     // offsets of the batch's segments: every wave writes the same values itself (lanes over segments), so only wave-local
     // ordering is needed -- no barrier, no serial loop on one thread
@@ -167,10 +167,8 @@ __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, do
       int i = sb; while (i + 1 < se && sego[i + 1] <= w) i++;
       const int tr = sp * res + i, k = w - sego[i], no = segno[i];
       if (pst) pcb[it] = k < no ? pst[((size_t)(2 * i) * GRAD_PST + k) * 4 + c] : pst[((size_t)(2 * i + 1) * GRAD_PST + (k - no)) * 4 + c];
-      else {
-        const double* src = k < no ? &D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c] : &D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
-        pcb[it] = coh ? xf_load(src) : *src;
-      }
+      else pcb[it] = k < no ? D.oplanes[(((size_t)u * D.S + tr) * D.cap_obs + k) * 4 + c]
+                           : D.splanes[(((size_t)u * D.S + tr) * D.cap_self + (k - no)) * 4 + c];
     }
     grad_sync<GSYNC>(gs);
     TJ_TIC(D, K_SEP_SELF_COMPACT, 4);
@@ -344,21 +342,10 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
     // ---- stage every segment of the piece once: hull, basis, plane counts ----
     for (int idx = threadIdx.x; idx < res * 18; idx += NTH) Pall[idx] = hull_entry(D, net, sp * res + idx / 18, (idx % 18) / 3, idx % 3);
     for (int idx = threadIdx.x; idx < res * 36; idx += NTH) Ball[idx] = D.basis[(size_t)sp * res * 36 + idx];
-    if (D.grad_cfold) {
-      // hundreds of robots (five of these blocks per compute unit): the block's three waves first compact ITS segments (k_sep_self_compact's work -- with the index
-      // words of Dev::pairbits two short round trips per segment), so that launch drops out of the chain here too.  The lists go through global memory: written,
-      // acknowledged, barrier, then read past the L1 (counts and planes with agent-scope loads) -- no LDS hand-over, which would cost this launch a block per CU.
-      for (int i = threadIdx.x >> 6; i < res; i += GRAD_THREADS / 64) compact_segment(D, u, sp * res + i, threadIdx.x & 63);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      asm volatile("" ::: "memory");
-    }
     if (threadIdx.x < res) {
-      const int* oc = &D.ocount[u * D.S + sp * res + threadIdx.x]; const int* scn = &D.scount[u * D.S + sp * res + threadIdx.x];
-      const int no = D.grad_cfold ? __hip_atomic_load(oc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *oc;
+      const int no = D.ocount[u * D.S + sp * res + threadIdx.x];
       s_no[threadIdx.x] = no;
-      segn[threadIdx.x] = no + (D.multi() ? (D.grad_cfold ? __hip_atomic_load(scn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *scn) : 0);
+      segn[threadIdx.x] = no + (D.multi() ? D.scount[u * D.S + sp * res + threadIdx.x] : 0);
     }
     __syncthreads();
   }
@@ -390,9 +377,8 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
       int se = sb, tot = 0;
       while (se < res && (se == sb || tot + segn[se] <= npl)) { tot += segn[se]; se++; }  // uniform: same LDS words for all threads
       if (tot > 0) {
-        const bool coh = !FOLD && D.grad_cfold;
-        if (tot <= npl) pacc_ = grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_, staged ? pst : nullptr, coh);
-        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); pacc_ = grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_, nullptr, coh); }
+        if (tot <= npl) pacc_ = grad_plane_batch<FOLD>(D, pc, E1, E2, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_, staged ? pst : nullptr);
+        else { double* gs = D.grad_scr + (size_t)blockIdx.x * 16 * (size_t)(D.cap_obs + D.cap_self); pacc_ = grad_plane_batch<FOLD>(D, gs, gs + 4 * (size_t)tot, gs + 10 * (size_t)tot, sb, se, tot, u, sp, res, m, Pall, Ball, s_wseg, segn, s_no, sego, Mv, role, ga, pacc_); }
       }
       sb = se;
     }

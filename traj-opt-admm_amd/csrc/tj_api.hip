@@ -61,7 +61,6 @@ struct tj_ctx {
   bool lsc_wide = false;     // coupled mode: k_ls_coupled evaluates all LSC_ROUNDS rounds in one launch (kernels_ls.h)
   bool ccd_lean = true;        // which build of k_ccd the chain launches (kernels_step.h); re-decided whenever the control block is read
   unsigned ccd_found_seen = 0; long long iters_enqueued = 0, iters_seen = 0;
-  bool grad_cfold = false;     // chains of large fleets: the 192-thread k_grad compacts its own segments (TJ_GRAD_CFOLD=0: a k_sep_self_compact launch in front, as in round 4)
   bool grad_fold = true;       // k_grad compacts its own segments (one launch less); TJ_GRAD_FOLD=0 keeps k_sep_self_compact + the 192-thread k_grad
   int n_solve_env = 0;         // TJ_N_SOLVE: pair-solve waves of k_mid (launch-shape switch)
   bool split_unions = false;   // k_front / k_ccd as two launches each (hundreds of robots), see launch_kernel
@@ -173,15 +172,11 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
       TJ_LAUNCH(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
-    case K_SEP_SELF_COMPACT: if ((in_graph || in_phase) && (c->grad_fold || c->grad_cfold)) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
+    case K_SEP_SELF_COMPACT: if ((in_graph || in_phase) && c->grad_fold) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
       TJ_LAUNCH(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD:
       if ((in_graph || in_phase) && c->grad_fold) TJ_LAUNCH((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double), s, d);
-      else {
-        Dev dg = d;
-        dg.grad_cfold = ((in_graph || in_phase) && c->grad_cfold) ? 1 : 0;   // (the stage API's k_grad follows a stand-alone compaction)
-        TJ_LAUNCH((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, dg);
-      }
+      else TJ_LAUNCH((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
       return true;
     case K_XSOLVE:
       if (d.xs_band) TJ_LAUNCH(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
@@ -512,8 +507,6 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   // plus a separate compaction launch is faster once there are more pieces than that (SCN-D: k_grad 109 -> 72 + 14 us)
   c->grad_fold = (d.u1 - d.u0) * d.P <= 512;
   if (const char* e = getenv("TJ_GRAD_FOLD")) c->grad_fold = atoi(e) != 0;
-  c->grad_cfold = !c->grad_fold;
-  if (const char* e = getenv("TJ_GRAD_CFOLD")) c->grad_cfold = !c->grad_fold && atoi(e) != 0;   // launch-shape switch (same bits)
   d.bvh_skip = 0;    // decided when the obstacle set is known (set_obstacles); TJ_BVH_SKIP=0 / 1 forces it (launch-shape switch, same bits)
   if (const char* e = getenv("TJ_BVH_SKIP")) d.bvh_skip = atoi(e) != 0;
   d.pair_prio = 1;
