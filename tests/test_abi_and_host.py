@@ -170,8 +170,8 @@ def test_hot_kernels_use_no_scratch_memory(pkg, tmp_path):
         m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
         if m and name:
             seen[name] = int(m.group(1))
-    hot = [k for k in seen if re.search(r"tj\d+(k_grad|k_xsolve|k_xsolve_band|k_linesearch|k_front|k_mid|k_slack)(I|E)", k)]
-    assert len(hot) >= 8, f"expected the chain's kernels in the metadata, found {sorted(seen)[:5]}..."
+    hot = [k for k in seen if re.search(r"tj\d+(k_grad|k_xsolve|k_xsolve_band|k_linesearch|k_front|k_mid|k_slack|k_ccd_lean)(I|E)", k)]   # k_ccd_lean: the chain's build of k_ccd (round 5: no spills)
+    assert len(hot) >= 10, f"expected the chain's kernels in the metadata, found {sorted(seen)[:5]}..."
     bad = {k: seen[k] for k in hot if seen[k] != 0}
     if bad:
         # A private segment that is DECLARED but never touched (round 4: k_linesearch, 68 bytes -- the frame objects of its SGPR spills, which all
@@ -185,10 +185,17 @@ def test_hot_kernels_use_no_scratch_memory(pkg, tmp_path):
                 cur = m.group(1); body[cur] = []
             elif cur:
                 body[cur].append(line)
+        # (the parse is checked on every kernel looked at: the first token of a line must be the mnemonic -- a body without s_endpgm or global_load would mean the
+        #  filter below matches nothing and passes vacuously.)  Exemptions are per kernel: k_linesearch's declared-but-untouched frame; k_ccd_lean's finisher keeps the
+        #  stack of the reference's tree query for the order-dependent pair replay in private memory (a cold path: taken when two acting pairs of a segment share a robot)
+        allow_touch = {"k_ccd_lean": 128}
         for k in list(bad):
             insts = [l.split()[0] for l in body.get(k, []) if l.strip()]
             assert insts, f"{k} not found in the disassembly"
-            if bad[k] <= 128 and not any(i.startswith(("scratch_", "buffer_load", "buffer_store")) for i in insts):
+            assert "s_endpgm" in insts and any(i.startswith("global_load") for i in insts), f"disassembly of {k} not parsed into mnemonics"
+            touched = any(i.startswith(("scratch_", "buffer_load", "buffer_store")) for i in insts)
+            cold = next((lim for nm, lim in allow_touch.items() if nm in k), 0)
+            if bad[k] <= 128 and (not touched or bad[k] <= cold):
                 del bad[k]
     assert not bad, f"scratch memory in hot kernels: {bad}"
 

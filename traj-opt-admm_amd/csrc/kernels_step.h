@@ -161,7 +161,16 @@ __global__ __launch_bounds__(64) void k_xch_wait(Dev D, int kind) {
 }
 
 constexpr int CCD_LDS_DOUBLES = 294 + (2 * FRONT_CAP + 128) / 2;   // info[146] kax[147] | fa fb cand
-template <int PRIM>
+// the candidate a lane holds, handed to the whole wave
+__device__ __forceinline__ V3 bcast_v3(const V3& v, int l) { return V3{readlane_f64(v.x, l), readlane_f64(v.y, l), readlane_f64(v.z, l)}; }
+__device__ __forceinline__ BodyPoint bcast_body(const BodyPoint& b, int l) { return BodyPoint{bcast_v3(b.q, l)}; }
+__device__ __forceinline__ BodyTri bcast_body(const BodyTri& b, int l) { return BodyTri{bcast_v3(b.a, l), bcast_v3(b.b, l), bcast_v3(b.c, l)}; }
+// LEAN (k_ccd_lean, the build for scenes whose swept boxes meet next to no obstacle): the candidates that pass the k-DOP cull are taken ONE AFTER THE OTHER by the whole
+// wave (wave-cooperative GJK, the form the robot-pair replay uses: same witness vectors bit for bit) instead of one per lane.  The per-lane swept-hull GJK needs ~240
+// registers; compiled for three waves per SIMD (168) it spilled 216 of them -- 416 bytes of scratch per lane, 2.3 MB of spill traffic per launch on the headline scene,
+// whose walks almost never reach it (rounds 2 - 4).  The cooperative form fits the budget without a spill; it is slower per candidate, which is why the host only
+// picks this build while the candidates are few (tj_api.hip: choose_builds).
+template <int PRIM, bool LEAN = false>
 __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
@@ -187,6 +196,24 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
     const int ncand = __popcll(ballot(pt >= 0));   // candidates sit in lanes [0, ncand)
     const typename PrimOf<PRIM>::Body qb = PrimOf<PRIM>::load(D, max(pt, 0));
     const bool pass = kdop_cull_wave(qb, ncand, axv, lo_ax, hi_ax, off, lane);
+    if constexpr (LEAN) {
+      unsigned long long pm = ballot(pass && pt >= 0);
+      if (pm) {
+        int k = max(kmax, __builtin_amdgcn_readfirstlane(atomicAdd(&D.k_obs[u], 0)));   // any earlier value is a valid lower bound (uniform)
+        while (pm) {
+          const int l = __ffsll((long long)pm) - 1;
+          pm &= pm - 1ull;
+          const typename PrimOf<PRIM>::Body qu = bcast_body(qb, l);
+          while (k < STEP_CAP) {
+            const V3 v = gjk_wave(BodySwept{info, info + 18, D.pow08[k]}, qu, lane);
+            if (!(v.x * v.x + v.y * v.y + v.z * v.z <= off * off)) break;
+            k++;
+          }
+        }
+        if (k >= STEP_CAP && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_CCD_STUCK);
+        if (k > kmax) { kmax = k; if (lane == 0) atomicMax(&D.k_obs[u], k); }
+      }
+    } else
     if (pt >= 0) {
       if (pass) {
         int k = max(kmax, atomicAdd(&D.k_obs[u], 0));  // any earlier value is a valid lower bound
@@ -219,6 +246,7 @@ __global__ __launch_bounds__(64) void k_ccd_obs(Dev D) {
 constexpr int ACT_CAP = 4096;                                    // acting pairs of one iteration (all segments)
 constexpr int ROBOT_BITS = 11;                                   // robot ids in packed pair keys: U <= 2048 (with S < 512 a key is 31 bits)
 __device__ __forceinline__ int act_key(int tr, int p0, int p1) { return (tr << (2 * ROBOT_BITS)) | (p0 << ROBOT_BITS) | p1; }
+template <bool LEAN = false>   // LEAN: the survivors of the box + k-DOP filter one after the other by the whole wave (see ccd_obs_body)
 __device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double* lds, bool wait_xf = false) {   // returns the acting pairs this tile listed
   int tr, rb, cb;
   pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
@@ -236,6 +264,23 @@ __device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double
   // nested in the step (conv{P, P+tD} shrinks with t), and the replay evaluates them at steps <= 1.  Deciding that
   // here, in parallel over all tiles (one surviving pair per lane), leaves the one-wave replay kernel with the (rare)
   // colliding pairs only.
+  if constexpr (LEAN) {
+    for (int i = 0; i < m; i++) {   // (uniform)
+      const int p0 = list[i] >> 16, p1 = list[i] & 0xffff;
+      const double* a = D.ccdinfo + ((size_t)p0 * D.S + tr) * CCD_STRIDE;
+      const double* b = D.ccdinfo + ((size_t)p1 * D.S + tr) * CCD_STRIDE;
+      const V3 v = gjk_wave(BodySwept{a, a + 18, D.pow08[0]}, BodySwept{b, b + 18, D.pow08[0]}, lane);
+      if (v.x * v.x + v.y * v.y + v.z * v.z <= off * off) {
+        found++;
+        if (lane == 0) {
+          const int w = atomicAdd(&D.ctl->any_pair, 1);
+          if (w < ACT_CAP) __hip_atomic_store(&D.pair_list[w], act_key(tr, p0, p1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
+        }
+      }
+    }
+    return found;
+  }
   for (int i0 = 0; i0 < m; i0 += 64) {
     bool ok = false;
     int p0 = 0, p1 = 0;
@@ -265,7 +310,7 @@ __device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double
 __global__ __launch_bounds__(64) void k_ccd_self_pairs(Dev D) {
   if (TJ_DONE(D)) return;
   __shared__ double lds[PAIR_LDS_DOUBLES];
-  ccd_self_pairs_body(D, blockIdx.x, lds);
+  ccd_self_pairs_body<false>(D, blockIdx.x, lds);
 }
 
 // Phase B + gnorm.  One workgroup of one wave; control flow is wave uniform.
@@ -733,7 +778,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   else obs_solve_body<PRIM>(D, b - n_slack - n_pair_waves, n_obs_waves);
   TJ_TIC(D, K_MID, 1);
 }
-template <int PRIM>
+template <int PRIM, bool LEAN>
 __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   const int n_obs = (D.u1 - D.u0) * D.S;
   __shared__ double lds[CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES];
@@ -744,8 +789,8 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   const int n_xf = D.xf ? D.n_foreign() * D.S : 0;   // sharded contexts: swept-hull cache of the other ranks' robots, ahead of the pair tiles that read it
   const int b = (int)blockIdx.x - fin - n_xf;
   if ((int)blockIdx.x >= fin && b < 0) xf_ccd_body(D, (int)blockIdx.x - fin, lds);
-  else if (b >= 0 && b < n_obs) ccd_obs_body<PRIM>(D, b, lds);
-  else if (b >= 0) found = ccd_self_pairs_body(D, b - n_obs, lds, D.xf != 0);
+  else if (b >= 0 && b < n_obs) ccd_obs_body<PRIM, LEAN>(D, b, lds);
+  else if (b >= 0) found = ccd_self_pairs_body<LEAN>(D, b - n_obs, lds, D.xf != 0);
   TJ_TIC(D, K_CCD, 1);
   // The sequential replay of the acting pairs + gnorm (k_ccd_self_seq: one wave with ~1 us of work in the usual case of no acting
   // pair, 4.6 us as a launch of its own) is finished inside this launch.  A first version -- every block takes a ticket, the
@@ -804,12 +849,12 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_ccd(Dev D) {
   if (TJ_DONE(D)) return;
-  ccd_union_body<PRIM>(D);
+  ccd_union_body<PRIM, false>(D);
 }
 template <int PRIM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ccd_lean(Dev D) {
   if (TJ_DONE(D)) return;
-  ccd_union_body<PRIM>(D);
+  ccd_union_body<PRIM, true>(D);
 }
 
 // ---- iteration bookkeeping ---------------------------------------------------------------------
