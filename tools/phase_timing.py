@@ -77,10 +77,19 @@ def main():
             continue
         t = t[live]
         nph = len(PHASES[name])
+        # a block that leaves early (helper blocks of k_linesearch after the DONE word, k_front's empty units, retired waves) has no later stamps: zeros there made
+        # the differences garbage (round 4: "block total mean -35325103373.4").  Only blocks that left every stamp enter the phase statistics.
+        full = (t[:, :nph + 1] != 0).all(axis=1)
+        n_early = int((~full).sum())
+        span = (t[:, :nph + 1].max() - t[:, 0].min()) * 0.01
+        if not full.any():
+            print(f"{name}: {live.sum()} blocks, all of them left before their last stamp; first start -> last stamp {span:.1f} us")
+            continue
+        live_idx = np.flatnonzero(live)[full]
+        t = t[full]
         d = np.diff(t[:, :nph + 1], axis=1) * 0.01   # us
         tot = d.sum(1)
-        span = (t[:, :nph + 1].max() - t[:, 0].min()) * 0.01
-        print(f"{name}: {live.sum()} blocks, first start -> last stamp {span:.1f} us, block total mean {tot.mean():.1f} max {tot.max():.1f} us")
+        print(f"{name}: {live.sum()} blocks ({n_early} left early and are not in the phase statistics), first start -> last stamp {span:.1f} us, block total mean {tot.mean():.1f} max {tot.max():.1f} us")
         print("   phase        " + " ".join(f"{p:>12s}" for p in PHASES[name]))
         print("   mean us      " + " ".join(f"{x:12.2f}" for x in d.mean(0)))
         print("   max us       " + " ".join(f"{x:12.2f}" for x in d.max(0)))
@@ -106,7 +115,7 @@ def main():
             print(f"   psd split: LLT check mean {llt.mean():.2f} max {llt.max():.2f} us; after the check: {failed.sum()} blocks repair, mean {rest[failed].mean() if failed.any() else 0:.2f} max {rest.max():.2f} us")
         worst = np.argsort(-tot)[:3]
         for w in worst:
-            print(f"   slow block {np.flatnonzero(live)[w]:5d}: " + " ".join(f"{x:12.2f}" for x in d[w]))
+            print(f"   slow block {live_idx[w]:5d}: " + " ".join(f"{x:12.2f}" for x in d[w]))
 
 
 if __name__ == "__main__":
