@@ -294,14 +294,14 @@ def test_large_fleet_launch_shapes_change_no_bit(pkg, scenes, monkeypatch):
     """256 robots x 1 M obstacle points (the one-pair-per-lane path of k_mid, the deep BVH): the launch-shape switches of round 5 -- pairs per producer wave
     (TJ_PAIR_LPW, the LDS tile of their hulls), producer priority, two BVH levels per step -- against the defaults: three iterations, states bitwise equal"""
     scene = scenes.scn_d()
-    for k in ("TJ_PAIR_LPW", "TJ_PAIR_PRIO", "TJ_BVH_SKIP"):
+    for k in ("TJ_PAIR_LPW", "TJ_PAIR_PRIO", "TJ_BVH_SKIP", "TJ_MID_ORDER"):
         monkeypatch.delenv(k, raising=False)
     a = pkg.Solver(scene, stop=0.0)
     a.iterate(3)
     sa = a.get_state()
     assert a.stats()["error_bits"] == 0
     a.close()
-    for env in ({"TJ_PAIR_LPW": "8", "TJ_PAIR_PRIO": "0"}, {"TJ_BVH_SKIP": "0"}, {"TJ_PAIR_LPW": "16", "TJ_BVH_SKIP": "1"}):
+    for env in ({"TJ_PAIR_LPW": "8", "TJ_PAIR_PRIO": "0"}, {"TJ_BVH_SKIP": "0"}, {"TJ_PAIR_LPW": "16", "TJ_BVH_SKIP": "1"}, {"TJ_MID_ORDER": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         b = pkg.Solver(scene, stop=0.0)
@@ -335,7 +335,7 @@ def test_coupled_search_in_one_launch_changes_no_bit(pkg, scenes, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
-                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_GRAD_BALANCE": "1"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}, {"TJ_BVH_SKIP": "1"}, {"TJ_BVH_SKIP": "0"}],
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_GRAD_BALANCE": "1"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}, {"TJ_BVH_SKIP": "1"}, {"TJ_BVH_SKIP": "0"}, {"TJ_MID_ORDER": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state

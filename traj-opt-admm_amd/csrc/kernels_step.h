@@ -772,6 +772,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 #endif
   __shared__ double mid_lds[SLACK_LDS_DOUBLES > PAIR_TILE_DOUBLES ? SLACK_LDS_DOUBLES : PAIR_TILE_DOUBLES];   // one buffer for whichever body this block runs: the slack system, or the pair tile
+  if (D.mid_order) {
+    // Hundreds of robots (TJ_MID_ORDER): pair waves | obstacle solves | slack.  Blocks b and b + 1024 share a SIMD (two waves per SIMD, 1 024 SIMDs); with the slack
+    // blocks leading, every producer wave of the one-pair-per-lane path had a slack wave as its mate and both took 80 - 100 us where they take 12 + 30 alone (phase
+    // stamps + HW_ID, round 5).  With the pair waves leading, a producer's mate is a consumer that spins until pairs are passed on, the obstacle solves fill the
+    // remaining slots and the slack waves follow as those retire: config 5's k_mid 76.5 -> 61 us.  Small fleets keep slack first (their k_mid is its slowest pair).
+    const int s0 = n_pair_waves + n_obs_waves;
+    if (b >= s0) { if (D.ctl->slack_now) slack_body(D, b - s0, 1, mid_lds); TJ_TIC(D, K_MID, 1); return; }
+    if (TJ_DONE(D)) return;
+    if (b < n_pair_waves) sep_self_solve_body(D, b, n_pair_waves, D.spec != 0, mid_lds);
+    else obs_solve_body<PRIM>(D, b - n_pair_waves, n_obs_waves);
+    TJ_TIC(D, K_MID, 1);
+    return;
+  }
   if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1, mid_lds); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
   else if (TJ_DONE(D)) return;
   else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves, D.spec != 0, mid_lds);

@@ -513,6 +513,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.bvh_skip = 0;    // decided when the obstacle set is known (set_obstacles); TJ_BVH_SKIP=0 / 1 forces it (launch-shape switch, same bits)
   if (const char* e = getenv("TJ_BVH_SKIP")) d.bvh_skip = atoi(e) != 0;
   d.pair_prio = 1;
+  d.mid_order = (d.mode >= 1 && d.U >= 192) ? 1 : 0;   // k_mid's grid order (kernels_step.h): config 5 -15 us; small fleets: nothing or slightly worse
+  if (const char* e = getenv("TJ_MID_ORDER")) d.mid_order = atoi(e) != 0;   // launch-shape switch (same bits)
   if (const char* e = getenv("TJ_PAIR_PRIO")) d.pair_prio = atoi(e) != 0;   // launch-shape switch (same bits)
   d.pair_lpw = 64;
   if (const char* e = getenv("TJ_PAIR_LPW")) { const int r = atoi(e); if (r == 8 || r == 16 || r == 32 || r == 64) d.pair_lpw = r; }   // launch-shape switch (same bits)
