@@ -155,3 +155,29 @@ def test_coupled_armijo_search_follows_the_reference_beyond_31_steps(pkg, scenes
             assert maxdiff(st[n], g[k + "post_" + n]) <= 1e-6 * max(1.0, np.abs(g[k + "post_" + n]).max()), (ci, n, maxdiff(st[n], g[k + "post_" + n]))
         assert s.stats()["error_bits"] == 0, ci
         s.close()
+
+
+def test_coupled_chain_with_cache_units_changes_no_bit(pkg, scenes, monkeypatch):
+    """coupled mode, one context: every robot's hull cache / swept-hull cache is built by units at the head of k_front / k_ccd (round 5: the k_hullinfo and
+    k_ccd_prep launches drop out of the chain: 10 -> 8 kernels per iteration); TJ_COUPLED_UNITS=0 launches the two kernels as before.  Same bits."""
+    scene = dict(scenes.crossing(12, 4000, seed=23, name="crossing-U12-coupled"), mode=2)
+    monkeypatch.delenv("TJ_COUPLED_UNITS", raising=False)
+    a = pkg.Solver(scene, stop=0.0)
+    l0 = a.launch_count(); a.iterate(12); la = a.launch_count() - l0
+    monkeypatch.setenv("TJ_COUPLED_UNITS", "0")
+    b = pkg.Solver(scene, stop=0.0)
+    l0 = b.launch_count(); b.iterate(12); lb = b.launch_count() - l0
+    sa, sb = a.get_state(), b.get_state()
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), n
+    assert a.stats()["error_bits"] == 0 and b.stats()["error_bits"] == 0
+    assert lb - la == 2 * 12 and la <= 6 * 12 + 4, (la, lb)    # k_front, k_mid, k_grad, k_xsolve (finishes the arrowhead solve itself), k_ccd (replays the pairs itself), k_ls_coupled
+    # ... and with the corner solve / the pair replay as launches of their own (TJ_C2_FOLD=0, TJ_SEQ_FOLD=0): same bits
+    monkeypatch.setenv("TJ_C2_FOLD", "0"); monkeypatch.setenv("TJ_SEQ_FOLD", "0")
+    c = pkg.Solver(scene, stop=0.0)
+    l0 = c.launch_count(); c.iterate(12); lc = c.launch_count() - l0
+    sc = c.get_state()
+    for n in sa:
+        assert np.array_equal(sa[n], sc[n]), n
+    assert lc - lb == 2 * 12
+    a.close(); b.close(); c.close()

@@ -84,6 +84,7 @@ struct Ctl {
   // k_linesearch's helper protocol: primaries that gave up waiting for a post (10 us) and searched on alone / helpers that left after 5 ms without a word.
   // Both are zero on a GPU of the solver's own; a regression to the always-timeout path shows here (tj_stats) instead of only as a slower run.
   int ls_giveups, ls_helper_timeouts;
+  int c2_cnt;          // coupled chain with the corner solve folded into k_xsolve (Dev::c2_fold): robots whose Schur-corner terms have been written (zeroed by begin_body)
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
@@ -149,7 +150,14 @@ struct Dev {
   // xch = 0: the foreign slices are in place when the kernel starts (an all-gather by the caller, or tj_group's event / rccl transports, ran between the launches).
   // xch = 1: DIRECT exchange -- the producing kernels (k_linesearch / k_begin, k_xsolve) store an owned robot's slice straight into every peer's receive
   //          buffer and count it there; the foreign units wait for the owner's count, read the slice from the receive buffer and put it in place.
-  int xf;                        // 1: foreign units lead k_front / k_ccd (world > 1 and Dev::fuse)
+  int xf;                        // 1: cache units lead k_front / k_ccd: the other ranks' robots (world > 1 and Dev::fuse), or -- xf_all -- ALL robots
+  int c2_fold;                   // coupled mode, one context, every robot's k_xsolve block resident at once: the block waits for all corner terms and finishes the arrowhead solve itself (no k_xsolve_c2 launch)
+  int xf_all;                    // coupled mode, one context: nobody publishes a hull / swept-hull cache there (one block commits every robot, the direction comes from k_xsolve_c2),
+                                 // so the obstacle units of k_front / k_ccd -- one per (robot, segment) -- publish that record themselves (write-through + the segment's counter) before
+                                 // they walk, and the k_hullinfo / k_ccd_prep launches drop out of the chain
+  __host__ __device__ int xf_want() const { return xf_all ? U : U - (u1 - u0); }                           // robots the units cover (= units per segment)
+  __host__ __device__ int xf_units() const { return (xf && !xf_all) ? xf_want() * S : 0; }   // extra one-wave units in the grid (xf_all: the obstacle units of k_front / k_ccd publish their own robot's record instead)
+  __host__ __device__ int xf_robot(int i) const { return xf_all ? i : (i < u0 ? i : i + (u1 - u0)); }
   int xch, xch_poll;             // xch_poll = 1: the foreign units poll the arrival counters themselves; 0: a k_xch_wait launch in front of the kernel has (ranks sharing a device)
   const XchPeers* xp;
   // completion counters of the foreign units, one per (kind, SEGMENT), each on a 128-byte line of its own ([2][S][XF_SEG_STRIDE] ints; zeroed by
@@ -358,7 +366,7 @@ __device__ __forceinline__ void xf_signal(const Dev& D, int kind, int tr) {
 }
 // every foreign unit of segment tr has left its record?  one wave; uniform
 __device__ __forceinline__ bool xf_wait_seg(const Dev& D, int kind, int tr) {
-  const int want = D.n_foreign();
+  const int want = D.xf_want();
   const int* w = xf_word(D, kind, tr);
   if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
   const long long t_end = wall_clock64() + (D.xch ? XCH_TIMEOUT_TICKS + 10000000ll : 500000ll + 100ll * gridDim.x);   // (direct exchange: the units themselves may wait 2 s for a peer)

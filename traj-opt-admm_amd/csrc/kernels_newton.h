@@ -600,6 +600,69 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
       if (tid == 0) { atomicAdd(&D.ctl->llt_fail_robot, 1ull); atomicOr(&D.ctl->error, ERR_NOT_SPD); }
     }
     blk_sync<true>();
+    if (D.c2_fold) {
+      // One context, every robot's block resident at once (round 5): the corner terms go out written through, the block counts itself in, waits until all uav_num are there
+      // and finishes the arrowhead solve itself -- k_xsolve_c2's operations on the factor that is still in LDS (that launch re-read 15 KB per robot): the corner summed in
+      // robot order, its pivot, the back substitution, the direction record.  Same operations in the same order, hence the same bits (TJ_C2_FOLD=0: the separate launch).
+      double* oc = D.xcorner + (size_t)u * 4;
+      if (tid == 0) { xf_store(oc, L[m * n + m]); xf_store(oc + 1, x0[m]); xf_store(oc + 2, g0[m]); xf_store(oc + 3, 0.0); }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0);
+      asm volatile("" ::: "memory");
+      if (tid == 0) __hip_atomic_fetch_add(&D.ctl->c2_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      {
+        const long long t_end = wall_clock64() + 500000;   // 5 ms: a logic error must not hang the device
+        while (__hip_atomic_load(&D.ctl->c2_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < D.U) {
+          if (wall_clock64() > t_end) { if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+      }
+      double* s_cstage = scr; double* s_red = scr + 64;   // (the scratch of the solve, >= 96 doubles and idle here: static arrays would push the 88-row system over the LDS limit)
+      {
+        double acc = 0;
+        for (int r0 = 0; r0 < D.U; r0 += 16) {   // sixteen robots per pass; the sums run in robot order whatever the chunking
+          const int nr = min(16, D.U - r0);
+          blk_sync<true>();
+          for (int i = tid; i < 4 * nr; i += XS_THREADS) s_cstage[i] = xf_load(D.xcorner + (size_t)r0 * 4 + i);
+          blk_sync<true>();
+          if (tid < 3) for (int r = 0; r < nr; r++) acc += s_cstage[4 * r + tid];
+        }
+        blk_sync<true>();
+        if (tid < 3) s_red[tid] = acc;
+      }
+      blk_sync<true>();
+      const double corner = s_red[0], rhs = s_red[1];
+      blk_sync<true>();
+      if (!(corner > 0) && tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_NOT_SPD);
+      const double lc = pivot_rsqrt(corner);
+      double* y = x0;
+      if (tid == 0) { L[m * n + m] = lc; y[m] = rhs * lc; }
+      blk_sync<true>();
+      if (n <= 64) {
+        double yv = y[min(tid, n - 1)];
+        yv = xs_backsolve(L, n, yv, tid);
+        blk_sync<true>();
+        if (tid < n) y[tid] = yv;
+        blk_sync<true>();
+      } else chol_arrow_backsolve_lds<true, true>(L, n, XS_BAND, y, tid, XS_THREADS);
+      for (int i = tid; i < n; i += XS_THREADS) y[i] = -y[i];
+      blk_sync<true>();
+      for (int i = tid; i < m; i += XS_THREADS) { scr[i] = y[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
+      blk_sync<true>();
+      double* dirc = D.dirp(u);
+      for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
+        const int row = idx % T, a = idx / T;
+        dirc[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0;
+      }
+      if (tid == 0) {
+        D.wolfe(u) = esum(scr, m);
+        D.gn(u) = esum(scr + n, m);
+        D.tdir(u) = y[m];
+        D.xdir[(size_t)u * D.xs + 3 * T + 3] = g0[m];
+      }
+      return;
+    }
     double* oL = D.xL + (size_t)u * n * n; double* oy = D.xy + (size_t)u * n; double* og = D.xg + (size_t)u * n;
     for (int idx = tid; idx < n * n; idx += XS_THREADS) oL[idx] = L[idx];
     for (int i = tid; i < n; i += XS_THREADS) { oy[i] = x0[i]; og[i] = g0[i]; }

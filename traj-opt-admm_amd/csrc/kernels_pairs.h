@@ -222,8 +222,11 @@ __device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds)
   if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) D.spec_tag[b] = 0ull; return; }   // (cannot happen: the list is this context's own)
   const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_INFO_STRIDE;
   const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_INFO_STRIDE;
-  if (D.xf && (p0 < D.u0 || p0 >= D.u1 || q < D.u0 || q >= D.u1)) xf_wait_seg(D, 0, tr);   // sharded contexts: a hull of another rank's robot comes from this launch's foreign units
-  (void)lds;
+  if (D.xf_all) {   // coupled chain: the records are being written by this launch's obstacle units (LATER in the grid: not waited for) -- the two hulls straight from the control nets
+    if (lane < 36) { const int r = lane < 18 ? p0 : q, e = lane < 18 ? lane : lane - 18; lds[lane] = hull_entry(D, D.spline + (size_t)r * 3 * D.T, tr, e / 3, e % 3); }
+    blk_sync<true>();
+    A = lds; B = lds + 18;
+  } else if (D.xf && (p0 < D.u0 || p0 >= D.u1 || q < D.u0 || q >= D.u1)) xf_wait_seg(D, 0, tr);   // sharded contexts: a hull of another rank's robot comes from this launch's foreign units
   GjkState st; bool fin;
   gjk_wave_run(BodyHull{A}, BodyHull{B}, lane, st, true, D.spec_budget, fin);
   if (lane == 0) {

@@ -478,8 +478,10 @@ constexpr int OBS_LDS_DOUBLES = 264 + (2 * FRONT_CAP + 128) / 2;   // P[18] klo[
 // use_cache: the hull cache (hullinfo: hull, box, 49 intervals -- the same expressions, written by k_linesearch / k_hullinfo) is
 // valid for this robot; taking the record from there is ONE memory latency where recomputing costs two plus the projections.
 // True in the iteration chains of the multi-robot modes, false in the stage API (the cache is rebuilt after this stage there).
+// publish (coupled chain, Dev::xf_all; implies !use_cache): the unit also leaves the hull-cache record of its (robot, segment) -- what k_hullinfo would -- written through,
+// and counts itself done on the segment's counter: the pair tiles of this launch wait for it
 template <int PRIM>
-__device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* lds, bool use_cache) {
+__device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* lds, bool use_cache, bool publish = false) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   double* P = lds; double* klo = P + 18; double* khi = klo + 49;
@@ -508,6 +510,17 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
     }
   }
   __syncthreads();
+  if (publish) {
+    double* o = D.hullinfo + ((size_t)u * D.S + tr) * HULL_INFO_STRIDE;
+    if (lane < 18) xf_store(o + lane, P[lane]);
+    if (lane < 3) {
+      const double lo = lane == 0 ? q.lo[0] : (lane == 1 ? q.lo[1] : q.lo[2]), hi = lane == 0 ? q.hi[0] : (lane == 1 ? q.hi[1] : q.hi[2]);
+      xf_store(o + 18 + lane, lo); xf_store(o + 21 + lane, hi);
+      xf_store(D.hbox + ((size_t)tr * 6 + lane) * D.U + u, lo); xf_store(D.hbox + ((size_t)tr * 6 + 3 + lane) * D.U + u, hi);
+    }
+    if (lane < 49) { xf_store(o + 24 + lane, klo[lane]); xf_store(o + 73 + lane, khi[lane]); }
+    xf_signal(D, 0, tr);
+  }
   TJ_TIC(D, K_SEP_OBS, 1);
   const double dist = D.offset + D.margin;
   const size_t seg = (size_t)u * D.S + tr;

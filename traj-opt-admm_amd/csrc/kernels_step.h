@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void k_ccd_prep(Dev D, int u_first) {
 // so every rank holds the same bits for every robot.  Direct exchange (Dev::xch): the unit first waits for the owner's push (xch_wait_owner), reads the
 // slice from the receive buffer, and the unit of segment 0 puts it in place (Dev::spline / Dev::xdir) for the kernels that follow.
 __device__ __forceinline__ void xf_hull_body(const Dev& D, int f) {
-  const int u = D.foreign_robot(f / D.S), tr = f % D.S, lane = lane_id(), T = D.T;
+  const int u = D.xf_robot(f / D.S), tr = f % D.S, lane = lane_id(), T = D.T;
   __shared__ double P[18];
   const double* net = D.spline + (size_t)u * 3 * T;
   if (D.xch) {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void xf_hull_body(const Dev& D, int f) {
   xf_signal(D, 0, tr);
 }
 __device__ __forceinline__ void xf_ccd_body(const Dev& D, int f, double* sh) {
-  const int u = D.foreign_robot(f / D.S), tr = f % D.S, lane = lane_id(), T = D.T;
+  const int u = D.xf_robot(f / D.S), tr = f % D.S, lane = lane_id(), T = D.T;
   const double* dir = D.dirp(u);
   if (D.xch) {
     if (D.xch_poll) xch_wait_owner(D, 1, D.owner_of(u));
@@ -171,7 +171,7 @@ __device__ __forceinline__ BodyTri bcast_body(const BodyTri& b, int l) { return 
 // whose walks almost never reach it (rounds 2 - 4).  The cooperative form fits the budget without a spill; it is slower per candidate, which is why the host only
 // picks this build while the candidates are few (tj_api.hip: choose_builds).
 template <int PRIM, bool LEAN = false>
-__device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds) {
+__device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds, bool publish = false) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
   double* info = lds;
@@ -180,6 +180,11 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds)
   V3 axv{0, 0, 0}; double lo_ax = 0, hi_ax = 0;
   const double* src = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
   const TopBox topb = bvh_top_box(D);   // travels with the segment's record
+  if (publish) {   // coupled chain (Dev::xf_all): this unit builds its (robot, segment)'s swept-hull record itself -- what k_ccd_prep would --, written through for the pair tiles
+    ccd_prep_segment<true>(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane, lds);
+    xf_signal(D, 1, tr);
+    for (int i = lane; i < CCD_REC; i += 64) info[i] = xf_load(src + i);   // (its own write-through stores, acknowledged: read back past the L1)
+  } else
   for (int i = lane; i < CCD_REC; i += 64) info[i] = src[i];
   __syncthreads();
   QBox q;
@@ -746,13 +751,13 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_spec = D.spec ? SPEC_CAP : 0;   // GJK head starts of last iteration's slow pairs lead the grid: they are the longest blocks
   const int n_ord = D.grad_bal ? ((D.u1 - D.u0) * D.P + 63) / 64 : 0;   // the first blocks of the grid: launch order of this iteration's k_grad (kernels_newton.h; ~3 us each --
                                                                         // as the LAST blocks they started when the first query blocks retired and ended 1 us after everything else)
-  const int n_xf = D.xf ? D.n_foreign() * D.S : 0;   // sharded contexts: hull cache of the other ranks' robots, AHEAD of everything that reads it (head starts, pair tiles)
+  const int n_xf = D.xf_units();   // sharded contexts: hull cache of the other ranks' robots (coupled chain: of every robot), AHEAD of everything that reads it (head starts, pair tiles)
   const int bx = (int)blockIdx.x;
   const int b = bx - n_ord - n_xf - n_spec;
   if (bx < n_ord) grad_order_body(D, bx, (int*)lds);
   else if (bx < n_ord + n_xf) xf_hull_body(D, bx - n_ord);
   else if (b < 0) spec_pair_body(D, bx - n_ord - n_xf, lds);
-  else if (b < n_obs) obs_query_body<PRIM>(D, b, lds, true);
+  else if (b < n_obs) obs_query_body<PRIM>(D, b, lds, !D.xf_all, D.xf_all != 0);   // (xf_all: the query forms its hull itself and publishes the record)
   else sep_self_rows_body(D, b - n_obs, lds, D.xf != 0);
   TJ_TIC(D, K_FRONT, 1);
 }
@@ -799,10 +804,10 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   TJ_TIC(D, K_CCD, 0);
   // with the replay folded in (below) the grid has one block more: block 0 is the finisher and has no other work
   const int fin = D.seq_fold ? 1 : 0;
-  const int n_xf = D.xf ? D.n_foreign() * D.S : 0;   // sharded contexts: swept-hull cache of the other ranks' robots, ahead of the pair tiles that read it
+  const int n_xf = D.xf_units();   // sharded contexts: swept-hull cache of the other ranks' robots (coupled chain: of every robot), ahead of what reads it
   const int b = (int)blockIdx.x - fin - n_xf;
   if ((int)blockIdx.x >= fin && b < 0) xf_ccd_body(D, (int)blockIdx.x - fin, lds);
-  else if (b >= 0 && b < n_obs) ccd_obs_body<PRIM, LEAN>(D, b, lds);
+  else if (b >= 0 && b < n_obs) ccd_obs_body<PRIM, LEAN>(D, b, lds, D.xf_all != 0);
   else if (b >= 0) found = ccd_self_pairs_body<LEAN>(D, b - n_obs, lds, D.xf != 0);
   TJ_TIC(D, K_CCD, 1);
   // The sequential replay of the acting pairs + gnorm (k_ccd_self_seq: one wave with ~1 us of work in the usual case of no acting
@@ -835,7 +840,26 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
     if (D.xf) xf_wait_seg(D, 1, 0);   // sharded contexts: the other ranks' |g| values are put in place by this launch's foreign units of segment 0
     for (int i = lane; i < D.U; i += 64) M.gns[i] = D.xf ? xf_load(&D.gn(i)) : D.gn(i);
     __syncthreads();
-    if (lane == 0) { double gsum = 0; for (int u = 0; u < D.U; u++) gsum += M.gns[u]; D.ctl->gnorm = gsum / double(D.U); }
+    if (!D.coupled()) { if (lane == 0) { double gsum = 0; for (int u = 0; u < D.U; u++) gsum += M.gns[u]; D.ctl->gnorm = gsum / double(D.U); } }
+    else {
+      // coupled mode (one context; round 5: the replay is folded here too): gnorm = |G| / uav_num and wolfe = -x0.G over the whole arrowhead system
+      // (Optimization3D_multi.h:558,580) from k_xsolve_c2's per-robot partial sums, the shared-time entries added in robot order -- what k_ccd_self_seq forms
+      __shared__ double s_cp[2][64];
+      double gt = 0, xg = 0;
+      for (int u0 = 0; u0 < D.U; u0 += 64) {
+        const int nu = min(64, D.U - u0);
+        __syncthreads();
+        if (lane < nu) { s_cp[0][lane] = D.xdir[(size_t)(u0 + lane) * D.xs + 3 * D.T + 3]; s_cp[1][lane] = D.wolfe(u0 + lane); }
+        __syncthreads();
+        if (lane == 0) for (int j = 0; j < nu; j++) { gt += s_cp[0][j]; xg += s_cp[1][j]; }
+      }
+      if (lane == 0) {
+        double gsum = 0;
+        for (int u = 0; u < D.U; u++) gsum += M.gns[u];
+        D.ctl->gnorm = sqrt(gsum + gt * gt) / double(D.U);
+        D.ctl->wolfe_c = -(xg + D.tdir(0) * gt);
+      }
+    }
     __syncthreads();
   }
   int any_act = 0;

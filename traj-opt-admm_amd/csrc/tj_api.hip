@@ -140,13 +140,13 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_solve = (multi && !d.optimal_plane) ? std::min(d.cap_work, c->n_solve_env > 0 ? c->n_solve_env : (d.U >= 192 ? 1536 : 1728)) : 0;  // "optimal_plane":1 -- k_keep finds and refines the pair planes
   const int n_obs_solve = d.N > 0 ? 1024 : 0;   // (512: SCN-E's k_mid 43.7 us, 1024: 38.3, 2048: 37.8; SCN-C indifferent)
   const int n_rows = multi ? d.S * pair_units(d.U, d.pair_rows) : 0;   // one wave per (segment, tile of pair_rows lower robots x 64 partners)
-  const int n_xf = d.xf ? d.n_foreign() * d.S : 0;   // sharded contexts: one wave per (foreign robot, segment) at the head of k_front / k_ccd (kernels_step.h)
+  const int n_xf = d.xf_units();   // sharded contexts: one wave per (foreign robot, segment) at the head of k_front / k_ccd (kernels_step.h); coupled chain: per (robot, segment)
   const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + n_xf + (d.spec ? SPEC_CAP : 0) + (d.grad_bal ? (owned * d.P + 63) / 64 : 0);
   const bool chained = in_graph || in_phase;          // an iteration chain (one context, or the phases of a sharded schedule) as opposed to the stage API
   const int n_mid_slack = owned * d.P;
   switch (kid) {
     case K_BEGIN: if (chain_pos & 1) return false; TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d); return true;
-    case K_HULLINFO: if ((chained && d.fuse) || !multi) return false; TJ_LAUNCH(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // unfused sharded phases (coupled mode): always (all robots, after the gather)
+    case K_HULLINFO: if ((chained && (d.fuse || d.xf_all)) || !multi) return false; TJ_LAUNCH(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // unfused sharded phases (coupled mode): always (all robots, after the gather)
     case K_FRONT: if (!in_graph && !in_phase) return false;
       if (c->split_unions && multi) {
         // hundreds of robots: the union is bound by how many one-wave blocks are resident (LDS of the BVH frontier: 14 per CU), and
@@ -178,7 +178,10 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if ((in_graph || in_phase) && c->grad_fold) TJ_LAUNCH((k_grad<true>), dim3(owned * d.P), dim3(GRAD_FOLD_THREADS), c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double), s, d);
       else TJ_LAUNCH((k_grad<false>), dim3(owned * d.P), dim3(GRAD_THREADS), c->lds_grad, s, d);
       return true;
-    case K_XSOLVE:
+    case K_XSOLVE: {
+      Dev dx = d;
+      if (!chained) dx.c2_fold = 0;   // (the stage API's solve is followed by k_xsolve_c2)
+      const Dev& d = dx;
       if (d.xs_band) TJ_LAUNCH(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
       else switch (9 * d.P - 2) {   // the register factorisation is inlined per size (kernels_newton.h); 61 rows and the LDS forms: the generic kernel
         case 16: TJ_LAUNCH((k_xsolve<16>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
@@ -190,10 +193,13 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       }
       if (chained && d.fuse && !d.xs_band) c->ccd_valid = true;   // its tail has left the owned robots' swept-hull cache
       return true;
+    }
     case K_XSOLVE_C2:
+      if (coupled && chained && d.c2_fold) return false;   // k_xsolve has finished the arrowhead solve itself
       if (coupled) { if (d.xs_band) TJ_LAUNCH(k_xsolve_c2_band, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); else TJ_LAUNCH(k_xsolve_c2, dim3(owned), dim3(XS_THREADS), c->lds_xs2, s, d); }
       return coupled;
-    case K_CCD_PREP: if (chained && d.fuse && !d.xs_band && c->ccd_valid) return false;  // fused chains: k_xsolve's tail leaves the swept-hull cache
+    case K_CCD_PREP: if (chained && d.xf_all) return false;                                // coupled chain: k_ccd's units build every robot's record
+      if (chained && d.fuse && !d.xs_band && c->ccd_valid) return false;  // fused chains: k_xsolve's tail leaves the swept-hull cache
       if (chained && d.xf) { if (owned > 0) TJ_LAUNCH(k_ccd_prep, dim3(owned * d.S), dim3(64), 0, s, d, d.u0); }   // (the other ranks' robots: k_ccd's foreign units)
       else TJ_LAUNCH(k_ccd_prep, dim3(d.U * d.S), dim3(64), 0, s, d, 0);
       return true;
@@ -469,6 +475,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.fuse = (p->mode != TJ_MODE_MULTI_COUPLED && !(p->world > 1 && (split_env || getenv("TJ_SHARD_UNFUSED")))) ? 1 : 0;
   d.rank = p->rank; d.world = p->world;
   d.xf = (p->world > 1 && d.fuse && p->mode == TJ_MODE_MULTI_DECOUPLE) ? 1 : 0;
+  // coupled mode, one context: every robot's cache records by units inside k_front / k_ccd (two launches less per iteration; TJ_COUPLED_UNITS=0: k_hullinfo / k_ccd_prep)
+  if (p->mode == TJ_MODE_MULTI_COUPLED && p->world == 1 && !split_env && !(getenv("TJ_COUPLED_UNITS") && atoi(getenv("TJ_COUPLED_UNITS")) == 0)) { d.xf = 1; d.xf_all = 1; }
   d.u0 = (int)((long long)p->rank * d.U / p->world); d.u1 = (int)((long long)(p->rank + 1) * d.U / p->world);
   d.lambda = p->lambda; d.margin = p->margin; d.offset = p->offset; d.mu = p->mu; d.vel_limit = p->vel_limit; d.acc_limit = p->acc_limit;
   d.ks = p->ks; d.kt = p->kt; d.stop = p->stop;
@@ -527,7 +535,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   // k_ccd's last block finishes with the sequential pair replay + gnorm (kernels_step.h): decoupled mode, when the replay's small
   // arrays fit k_ccd's static LDS buffer with room for at least 256 acting-pair keys (the value is that capacity)
   d.seq_fold = 0;
-  if (d.mode == TJ_MODE_MULTI_DECOUPLE && !c->split_unions) {
+  if ((d.mode == TJ_MODE_MULTI_DECOUPLE || (d.mode == TJ_MODE_MULTI_COUPLED && p->world == 1)) && !c->split_unions) {   // (coupled: one context only -- a sharded one exports its obstacle-CCD exponents from k_ccd_self_seq)
     const size_t buf = sizeof(double) * (size_t)(CCD_LDS_DOUBLES > PAIR_LDS_DOUBLES ? CCD_LDS_DOUBLES : PAIR_LDS_DOUBLES);
     int cap = 4096;
     while (cap >= 256 && seq_fold_lds_bytes(d.U, cap) > buf) cap >>= 1;
@@ -548,6 +556,9 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     d.num_cu = prop.multiProcessorCount;
     // coupled mode: the four evaluation rounds of the Armijo search in one launch where a block per (robot, round) gets a compute unit of its own
     c->lsc_wide = p->mode == TJ_MODE_MULTI_COUPLED && owned * LSC_ROUNDS <= d.num_cu;
+    // ... and the corner solve inside k_xsolve where every robot's block is resident at once (one block per compute unit: 242 registers x 8 waves), dense storage
+    d.c2_fold = (p->mode == TJ_MODE_MULTI_COUPLED && p->world == 1 && d.U <= d.num_cu && !d.xs_band) ? 1 : 0;
+    if (const char* e = getenv("TJ_C2_FOLD")) d.c2_fold = d.c2_fold && atoi(e) != 0;   // launch-shape switch (same bits)
     if (const char* e = getenv("TJ_LSC_WIDE")) c->lsc_wide = atoi(e) != 0;   // launch-shape switch (same bits)
     // k_grad's launch order follows the items' last durations where blocks outnumber the compute units (kernels_newton.h: grad_order_body)
     // -- between one and two blocks per unit, the case it was measured on: SCN-C -1.5 us per iteration, the 64 hard robots -1.4; at five blocks per unit
