@@ -134,7 +134,7 @@ PRIM = {"fp64": 2.6,        # issue_probe:2-3   one fp64 VALU instruction, depen
                             #                   same recurrence with a select (which also pays a second fma): 64.6 - 26.8 = 37.8; round 3 priced it at 10
 
 
-def critical_path(slv, st, K, per_launch_ms, n_prims):
+def critical_path(slv, st, K, per_launch_ms, n_prims, batch_us=None):
     """roofline.critical_path: per chain kernel the DEPENDENCY CHAIN of its longest work item -- the operations that must follow
     one another whatever the parallel width -- priced with the measured single-wave latencies above.  It is the bound this
     latency-dominated path can be judged against (the HBM roofline is kept beside it as SURVEY 8(d) demands): `frac` =
@@ -180,7 +180,10 @@ def critical_path(slv, st, K, per_launch_ms, n_prims):
             continue
         out["tj::" + k] = {"bound_us": b * 1e-3, "measured_us": ms * 1e3, "frac": b * 1e-3 / (ms * 1e3)}
         tb += b * 1e-3; tm += ms * 1e3
-    return {"unit": "us", "kernels": out, "chain_bound_us": tb, "chain_measured_us": tm, "frac": tb / tm if tm else None,
+    # frac: against the BATCH CLOCK (the iteration as the timed window measured it) -- the sum of the per-kernel hipEvent times carries ~1 - 2 us of event
+    # overhead per kernel and exceeds it; frac_vs_event_sum keeps the old figure
+    den = batch_us if batch_us else tm
+    return {"unit": "us", "kernels": out, "chain_bound_us": tb, "chain_measured_us": tm, "iteration_batch_clock_us": batch_us, "frac": tb / den if den else None, "frac_vs_event_sum": tb / tm if tm else None,
             "unit_counts": {"bvh_levels": lv, "longest_pair_gjk_iterations": gjk_max, "armijo_rounds": rounds, "armijo_candidates_per_round": per_round, "linesearch_blocks_per_robot": helpers, "newton_system_rows": n},
             "primitives_ns": PRIM,
             "note": "dependency chain of each kernel's longest work item x measured single-wave latencies (profiles/round4_issue_probe.txt, profiles/round4_mem_probe.txt; a dependent global round trip is 240 ns measured, not the 700 ns rounds 1-3 assumed: frac fell from 0.28 to what is printed here); the rest of a launch is "
@@ -654,7 +657,7 @@ def main():
                            "whole_iteration": {"algorithmic_bytes": alg_total, "achieved_GBps": alg_total / (dt / K) / 1e9, "frac": alg_total / (dt / K) / 1e9 / 8000.0,
                                                "implementation_bytes": impl_total, "implementation_frac": impl_total / (dt / K) / 1e9 / 8000.0},
                            "kernel_ms_per_launch": per_launch_ms, "source_id": source_id(),
-                           "critical_path": critical_path(slv, st2, K, per_launch_ms, scene["tris"].shape[0] if scene.get("tris") is not None else scene["cloud"].shape[0])}
+                           "critical_path": critical_path(slv, st2, K, per_launch_ms, scene["tris"].shape[0] if scene.get("tris") is not None else scene["cloud"].shape[0], batch_us=1e6 * dt / K)}
         out["timed_window_ms"] = 1e3 * dt
         out["stats_per_iter"] = {k: (v / K if k not in ("error_bits", "order_ambiguous", "iters") else v) for k, v in st2.items()}
         if not args.no_cpu:

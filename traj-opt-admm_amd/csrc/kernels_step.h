@@ -869,11 +869,17 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
       int v = lane < 16 ? __hip_atomic_load(&D.ctl->ccd_sub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
       v = __shfl(v, 0);
-      if ((v & 0xffff) == n_t) { any_act = v >> 16; break; }
+      if ((v & 0xffff) == n_t) {
+        any_act = v >> 16;
+        // every selection block of THIS launch is in: take exactly what was observed back out, so that a launch that is repeated without a begin in between
+        // (tj_iterate_phase on the CCD phase twice, a re-run after an error) starts from zero instead of finding the counters full.  Not after a
+        // time-out: late blocks may still be adding (the next begin_body zeroes the words anyway).
+        if (lane < 16) { const int mine = __hip_atomic_load(&D.ctl->ccd_sub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (mine) atomicSub(&D.ctl->ccd_sub[lane], mine); }
+        break;
+      }
       if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); break; }
       __builtin_amdgcn_s_sleep(8);
     }
-    // (the counters are zeroed by the next iteration's begin_body, not here: after a timeout late blocks may still be adding)
   }
   if (any_act > 0) ccd_self_seq_body<true>(D, M, false);   // (reads the pairs' count and keys with agent-scope loads)
   TJ_TIC(D, K_CCD, 2);

@@ -50,6 +50,7 @@ struct tj_ctx {
   void* xch_block = nullptr; size_t xch_bytes = 0; bool xch_ipc_exported = false;
   std::vector<void*> xch_ipc_opened;
   XchPeers* xch_table = nullptr;
+  bool xf_used[2] = {false, false};   // the cache units of k_front [0] / k_ccd [1] have counted themselves done since the last begin: a repeat of that launch before the next begin first zeroes the counters
   bool xch_wait_kernel = false;   // direct exchange, wait mode 0: a one-wave k_xch_wait launch in front of k_front / k_ccd
   // graph of one full iteration
   // hipGraphs: [0..2] the three phases of a sharded iteration, [3] one full iteration
@@ -145,7 +146,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const bool chained = in_graph || in_phase;          // an iteration chain (one context, or the phases of a sharded schedule) as opposed to the stage API
   const int n_mid_slack = owned * d.P;
   switch (kid) {
-    case K_BEGIN: if (chain_pos & 1) return false; TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d); return true;
+    case K_BEGIN: if (chain_pos & 1) return false; TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d); c->xf_used[0] = c->xf_used[1] = false; return true;
     case K_HULLINFO: if ((chained && (d.fuse || d.xf_all)) || !multi) return false; TJ_LAUNCH(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // unfused sharded phases (coupled mode): always (all robots, after the gather)
     case K_FRONT: if (!in_graph && !in_phase) return false;
       if (c->split_unions && multi) {
@@ -155,6 +156,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
         TJ_LAUNCH(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
+      if (d.xf) { if (c->xf_used[0]) (void)hipMemsetAsync(d.xf_seg, 0, (size_t)d.S * XF_SEG_STRIDE * sizeof(int), s); c->xf_used[0] = true; }
       if (d.xch && c->xch_wait_kernel) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 0);   // ranks sharing a device: the wait for the peers' control points is a launch of its own
       if (tri) TJ_LAUNCH((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else TJ_LAUNCH((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
       return true;
@@ -209,6 +211,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
         TJ_LAUNCH(k_ccd_self_pairs, dim3(n_rows), dim3(64), 0, s, d);
         return true;
       }
+      if (d.xf) { if (c->xf_used[1]) (void)hipMemsetAsync(d.xf_seg + (size_t)d.S * XF_SEG_STRIDE, 0, (size_t)d.S * XF_SEG_STRIDE * sizeof(int), s); c->xf_used[1] = true; }
       if (d.xch && c->xch_wait_kernel) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 1);   // ranks sharing a device: the wait for the peers' direction records is a launch of its own
       {
         const int g = n_ccd + n_xf + (d.seq_fold ? 1 : 0);   // + the finisher of the folded pair replay (kernels_step.h)
@@ -224,11 +227,12 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if ((in_graph || in_phase) && d.seq_fold && !(c->split_unions && multi)) return false;   // the last block of k_ccd has done it
       if (!multi && in_graph) return false;   // single UAV: no pairs to replay, and k_xsolve has left gnorm = |g| itself -- one launch less in the chain
       TJ_LAUNCH(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
-    case K_LINESEARCH: if (!coupled) TJ_LAUNCH(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); return !coupled;
+    case K_LINESEARCH: if (!coupled) { TJ_LAUNCH(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // (its last block runs begin_body)
+      return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED:
       if (coupled) {
-        if (c->lsc_wide) TJ_LAUNCH(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0);   // all rounds at once, one block per (robot, round)
+        if (c->lsc_wide) { TJ_LAUNCH(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // all rounds at once, one block per (robot, round)
         else for (int r = 0; r < LSC_ROUNDS; r++) TJ_LAUNCH(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r, 1, 0);
       }
       return coupled;
@@ -566,7 +570,11 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     d.grad_bal = (owned * d.P > d.num_cu && owned * d.P < 2 * d.num_cu) ? 1 : 0;
     if (const char* e = getenv("TJ_GRAD_BALANCE")) d.grad_bal = (atoi(e) != 0 && owned * d.P <= 65536) ? 1 : 0;   // launch-shape switch (same bits)
     d.ls_help = (d.ls_fast && p->mode != TJ_MODE_MULTI_COUPLED) ? std::max(1, std::min(LS_HELP_MAX, prop.multiProcessorCount / owned)) : 1;
-    if (const char* e = getenv("TJ_LS_HELP")) d.ls_help = std::max(1, std::min(LS_HELP_MAX, atoi(e)));   // launch-shape switch (same bits); 1 = no helpers
+    if (const char* e = getenv("TJ_LS_HELP")) {   // launch-shape switch (same bits); 1 = no helpers.  More blocks per robot than the compute units hold at once would leave helpers waiting for a
+                                                  // unit while every primary runs into its 10 us give-up per super-round: clamped unless TJ_LS_HELP_FORCE=1 says so
+      d.ls_help = std::max(1, std::min(LS_HELP_MAX, atoi(e)));
+      if (!getenv("TJ_LS_HELP_FORCE")) d.ls_help = std::min(d.ls_help, std::max(1, prop.multiProcessorCount / owned));
+    }
     if (const char* e = getenv("TJ_LS_HELP_LATE")) d.ls_help_late = std::max(0, std::min(4000, atoi(e)));   // test hook (same bits): helper blocks idle that many microseconds before staging
     if (const char* e = getenv("TJ_LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
   }
