@@ -414,6 +414,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_gpu and world > 1:
+        # Processes SHARING a GPU (test arrangement): the device runs one process's waves at a time, so a kernel that sleeps on a word which another queue of its process
+        # is to write (the asynchronous Newton solve of the one-rank reference contexts below) shuts the other process out -- and with both processes doing it, each other.
+        os.environ["TJ_XS_ASYNC"] = "0"
     group_devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else None
     if world == 1 and args.gpus > 1 and group_devices is None:
         group_devices = list(range(args.gpus))   # not under torchrun: the library shards by itself

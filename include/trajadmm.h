@@ -190,7 +190,7 @@ typedef struct tj_stats {
   int order_ambiguous; /* segments whose inter-robot clamp depended on pair order (two acting pairs sharing a robot): replayed in the
                           order of the reference's per-segment dynamic AABB tree (Step.h:213-251, AABB.cc:669-734) */
   int error_bits;      /* 1 plane list overflow, 2 BVH frontier overflow, 4 a loop hit its cap (detail: 32 coupled Armijo range, 64 plane
-                          refinement, 128 CCD contact at every step = state in collision, 256 slack Armijo, 1024 a wait for passed-on pairs timed out), 8 pair list overflow,
+                          refinement, 128 CCD contact at every step = state in collision, 256 slack Armijo, 1024 a wait for passed-on pairs timed out, 2048 a wait of the asynchronous Newton solve timed out), 8 pair list overflow,
                           16 coupled Newton system not SPD, 512 tj_group: a peer's slice did not arrive */
   int order_unresolved; /* such segments for which the tree order could NOT be established (result may differ from the reference's;
                            tj_iterate returns TJ_ERR_UNSUPPORTED) -- 0 unless uav_num is in the thousands */

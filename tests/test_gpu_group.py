@@ -290,18 +290,46 @@ def test_helper_blocks_that_start_late_change_no_bit(pkg, scenes, monkeypatch, w
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["scn_c", "scn_a", "hard"])
+def test_asynchronous_newton_solve_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
+    """Round 5: in the one-context chain k_xsolve runs on a second hardware queue next to k_grad (tickets per robot, a one-wave gate in front of the launch) and k_ccd's
+    units wait for the robots' flags and build the swept-hull records themselves.  Against the one-queue chain (TJ_XS_ASYNC=0): same state bit for bit over 60 iterations
+    from the initial trajectory (through the back-off regime into the steady one), no error bit, the same number of energy evaluations -- and the launch count shows that
+    the second queue was really in use (one gate launch per iteration on top of the six kernels)."""
+    scene = {"scn_c": scenes.scn_c, "scn_a": scenes.scn_a, "hard": lambda: scenes.hard(8, 8000)}[scene_name]()   # hard: robots that meet -- CCD candidates, acting pairs, the replay
+    for k in ("TJ_XS_ASYNC", "TJ_XS_ONE_QUEUE"):
+        monkeypatch.delenv(k, raising=False)
+    n_it = 60
+    a = pkg.Solver(scene, stop=0.0)
+    l0 = a.launch_count(); a.iterate_async(n_it); a.sync(); la = a.launch_count() - l0
+    sa, ta = a.get_state(), a.stats()
+    a.close()
+    monkeypatch.setenv("TJ_XS_ASYNC", "0")
+    b = pkg.Solver(scene, stop=0.0)
+    l0 = b.launch_count(); b.iterate_async(n_it); b.sync(); lb = b.launch_count() - l0
+    sb, tb = b.get_state(), b.stats()
+    b.close()
+    monkeypatch.delenv("TJ_XS_ASYNC")
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), f"{n} differs between the asynchronous solve and the one-queue chain"
+    assert ta["error_bits"] == 0 and tb["error_bits"] == 0
+    assert ta["energy_evals"] == tb["energy_evals"]
+    assert la == lb + n_it, f"expected one gate launch per iteration on top of the chain ({lb} launches): {la}"
+
+
+@pytest.mark.gpu
 def test_large_fleet_launch_shapes_change_no_bit(pkg, scenes, monkeypatch):
     """256 robots x 1 M obstacle points (the one-pair-per-lane path of k_mid, the deep BVH): the launch-shape switches of round 5 -- pairs per producer wave
     (TJ_PAIR_LPW, the LDS tile of their hulls), producer priority, two BVH levels per step -- against the defaults: three iterations, states bitwise equal"""
     scene = scenes.scn_d()
-    for k in ("TJ_PAIR_LPW", "TJ_PAIR_PRIO", "TJ_BVH_SKIP", "TJ_MID_ORDER"):
+    for k in ("TJ_PAIR_LPW", "TJ_PAIR_PRIO", "TJ_BVH_SKIP", "TJ_MID_ORDER", "TJ_XS_ASYNC"):
         monkeypatch.delenv(k, raising=False)
     a = pkg.Solver(scene, stop=0.0)
     a.iterate(3)
     sa = a.get_state()
     assert a.stats()["error_bits"] == 0
     a.close()
-    for env in ({"TJ_PAIR_LPW": "8", "TJ_PAIR_PRIO": "0"}, {"TJ_BVH_SKIP": "0"}, {"TJ_PAIR_LPW": "16", "TJ_BVH_SKIP": "1"}, {"TJ_MID_ORDER": "0"}):
+    for env in ({"TJ_PAIR_LPW": "8", "TJ_PAIR_PRIO": "0"}, {"TJ_BVH_SKIP": "0"}, {"TJ_PAIR_LPW": "16", "TJ_BVH_SKIP": "1"}, {"TJ_MID_ORDER": "0"}, {"TJ_XS_ASYNC": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         b = pkg.Solver(scene, stop=0.0)
@@ -335,7 +363,8 @@ def test_coupled_search_in_one_launch_changes_no_bit(pkg, scenes, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"TJ_CCD_LEAN": "0"}, {"TJ_CCD_LEAN": "1"}, {"TJ_GRAD_FOLD": "0"}, {"TJ_GRAD_NPL": "8"}, {"TJ_SPLIT_UNIONS": "1"},
-                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_GRAD_BALANCE": "1"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}, {"TJ_BVH_SKIP": "1"}, {"TJ_BVH_SKIP": "0"}, {"TJ_MID_ORDER": "1"}],
+                                 {"TJ_USE_GRAPH": "1"}, {"TJ_PAIR_ROWS": "4"}, {"TJ_N_SOLVE": "96"}, {"TJ_N_SOLVE": "96", "TJ_HS_MIN": "1"}, {"TJ_SEQ_FOLD": "0"}, {"TJ_LS_FAST": "0"}, {"TJ_GRAD_BALANCE": "1"}, {"TJ_LS_HELP": "1"}, {"TJ_LS_HELP": "2"}, {"TJ_LS_HELP": "3"}, {"TJ_LS_HELP_MUTE": "1"}, {"TJ_HS_BUDGET": "1", "TJ_HS_MIN": "2"}, {"TJ_HS_BUDGET": "40", "TJ_HS_MIN": "1"}, {"TJ_BVH_SKIP": "1"}, {"TJ_BVH_SKIP": "0"}, {"TJ_MID_ORDER": "1"}, {"TJ_XS_ASYNC": "0"}, {"TJ_XS_ONE_QUEUE": "1"},
+                                 {"TJ_XS_ASYNC": "0", "TJ_SPLIT_UNIONS": "1"}, {"TJ_XS_ASYNC": "0", "TJ_CCD_LEAN": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
     """The launch-shape switches of tj_create select other builds / groupings of the same arithmetic: the state

@@ -39,6 +39,7 @@ enum : int {
   ERR_PEER_TIMEOUT = 512,    // tj_group, flag transport: a peer's push did not arrive within 2 s (tj_group.h)
   ERR_PASS_TIMEOUT = 1024,   // large fleets: a wave waiting for passed-on robot pairs gave up after 5 ms (the queue was descheduled, e.g. several
                              // processes on one GPU); the pairs it would have taken are unsolved -- set together with ERR_LOOP_CAP
+  ERR_XS_TIMEOUT = 2048,     // asynchronous Newton solve: a wait between the two queues of the context (tickets, gate, flags, the records k_ccd's units build) ran out (2 s)
 };
 
 #ifdef TJ_NO_DONE_CHECK
@@ -155,7 +156,7 @@ struct Dev {
   int xf_all;                    // coupled mode, one context: nobody publishes a hull / swept-hull cache there (one block commits every robot, the direction comes from k_xsolve_c2),
                                  // so the obstacle units of k_front / k_ccd -- one per (robot, segment) -- publish that record themselves (write-through + the segment's counter) before
                                  // they walk, and the k_hullinfo / k_ccd_prep launches drop out of the chain
-  __host__ __device__ int xf_want() const { return xf_all ? U : U - (u1 - u0); }                           // robots the units cover (= units per segment)
+  __host__ __device__ int xf_want() const { return (xf_all || xs_async) ? U : U - (u1 - u0); }                           // robots the units cover (= units per segment)
   __host__ __device__ int xf_units() const { return (xf && !xf_all) ? xf_want() * S : 0; }   // extra one-wave units in the grid (xf_all: the obstacle units of k_front / k_ccd publish their own robot's record instead)
   __host__ __device__ int xf_robot(int i) const { return xf_all ? i : (i < u0 ? i : i + (u1 - u0)); }
   int xch, xch_poll;             // xch_poll = 1: the foreign units poll the arrival counters themselves; 0: a k_xch_wait launch in front of the kernel has (ranks sharing a device)
@@ -171,6 +172,18 @@ struct Dev {
   __host__ __device__ int foreign_robot(int f) const { return f < u0 ? f : f + (u1 - u0); }            // f-th robot this rank does not own
   __host__ __device__ int owner_of(int u) const { int r = (int)(((long long)(u + 1) * world - 1) / U); while ((long long)r * U / world > u) r--; while ((long long)(r + 1) * U / world <= u) r++; return r; }
   __host__ __device__ int owned_by(int r) const { return (int)((long long)(r + 1) * U / world) - (int)((long long)r * U / world); }
+  // ASYNCHRONOUS Newton solve (round 5; single-GPU chain, decoupled / single-UAV modes): k_xsolve runs on a SECOND hardware queue, released when k_mid has finished,
+  // i.e. next to k_grad.  Its block of robot u sleeps until the robot's P piece blocks of k_grad have stored their 19 x 19 blocks (write-through) and taken a ticket,
+  // solves, leaves direction record and swept-hull cache with write-through stores and raises the robot's flag; k_ccd -- next on the FIRST queue behind k_grad --
+  // waits for the flags in its units.  The two kernel boundaries grad -> xsolve -> ccd (each ~5 us between the last useful instruction of one kernel and the first
+  // of the next) disappear from the chain.  xs_sync: ints [U][32] tickets | [U][32] flags | [32] robots done | [32] xs_go -- a 128-byte line each; all but the last zeroed by begin_body.
+  // The second queue's launch is released by a one-wave gate kernel in front of it (k_xs_gate: it sleeps on the word xs_go until k_grad's first block has stored this
+  // chain link's sequence number xs_seq there -- an event recorded between k_mid and k_grad instead costs a 7 us marker on the first queue, measured).
+  int xs_async, xs_seq; int* xs_sync;
+  __host__ __device__ int* xs_go() const { return xs_sync + ((size_t)2 * U + 1) * 32; }
+  __host__ __device__ int* xs_ticket(int u) const { return xs_sync + (size_t)u * 32; }
+  __host__ __device__ int* xs_flag(int u) const { return xs_sync + ((size_t)U + u) * 32; }
+  __host__ __device__ int* xs_done() const { return xs_sync + (size_t)2 * U * 32; }
   int xs_band;  // long trajectories (piece_num > 10): the Newton solve runs on band storage (k_xsolve_band) and the swept-hull
                 // cache comes from k_ccd_prep again
   int seq_tree; // k_ccd_self_seq has LDS for the reference's per-segment dynamic tree (dev_dyntree.h)
@@ -369,13 +382,28 @@ __device__ __forceinline__ bool xf_wait_seg(const Dev& D, int kind, int tr) {
   const int want = D.xf_want();
   const int* w = xf_word(D, kind, tr);
   if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
-  const long long t_end = wall_clock64() + (D.xch ? XCH_TIMEOUT_TICKS + 10000000ll : 500000ll + 100ll * gridDim.x);   // (direct exchange: the units themselves may wait 2 s for a peer)
+  const long long t_end = wall_clock64() + ((D.xch || D.xs_async) ? XCH_TIMEOUT_TICKS + 10000000ll : 500000ll + 100ll * gridDim.x);   // (direct exchange: the units themselves may wait 2 s for a peer)
   for (;;) {
     __builtin_amdgcn_s_sleep(2);
     if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
     if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); return false; }
   }
 }
+
+// asynchronous Newton solve (Dev::xs_async): wait until word *w has reached `want`.  One wave, uniform; false = timed out (error bit set).
+template <int SLEEP = 2>
+__device__ __forceinline__ bool xs_wait(const Dev& D, const int* w, int want) {
+  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
+  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s: a logic error must not hang the device -- but a GPU shared with another process may leave the
+                                                                // other queue of this context off the hardware for whole time slices (5 ms was too short for that)
+  for (;;) {
+    __builtin_amdgcn_s_sleep(SLEEP);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
+    if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return false; }
+  }
+}
+// a value that a kernel running at the same time on the other queue will read: written through when the solve is asynchronous
+__device__ __forceinline__ void xs_out(bool wt, double* p, double v) { if (wt) xf_store(p, v); else *p = v; }
 
 __device__ __forceinline__ double seg_weight(const Dev& D, int tr) {
   int k = tr - D.res * div_small(tr, D.res);

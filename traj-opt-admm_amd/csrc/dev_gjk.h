@@ -35,6 +35,15 @@ struct BodyTri {  // one obstacle triangle held in registers (body 2 of the refe
   V3 a, b, c;
   static constexpr int N = 3;
   __device__ __forceinline__ V3 get(int i) const { return i == 0 ? a : (i == 1 ? b : c); }
+  // the same for an index that differs from lane to lane (gjk_wave_run: lane -> vertex): component-wise selects on values pinned in registers.  Left to itself the
+  // compiler turns the selects of a triangle that sits in memory into ONE load through a selected address -- a private array, i.e. scratch memory (k_mid<3>: 80 bytes
+  // per lane and three scratch round trips at the head of every wave query).
+  __device__ __forceinline__ V3 get_dyn(int i) const {
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z, cx = c.x, cy = c.y, cz = c.z;
+    asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz), "+v"(cx), "+v"(cy), "+v"(cz));
+    const bool i0 = i == 0, i1 = i == 1;
+    return V3{i0 ? ax : (i1 ? bx : cx), i0 ? ay : (i1 ? by : cy), i0 ? az : (i1 ? bz : cz)};
+  }
 };
 struct BodyHull {  // 6 control points of one Bezier segment, row-major [6][3] (LDS or global)
   const double* p;
@@ -289,11 +298,20 @@ template <class Body>
 __device__ __forceinline__ void support(const Body& body, const V3& dir, V3& cur) {
   double best = dot(cur, dir);
   V3 pick = cur;
+  if constexpr (Body::N <= 3) {   // a point or a triangle held in registers: written out -- a loop over its vertices indexes them at run time, i.e. through a private array (scratch memory)
+#pragma unroll
+    for (int i = 0; i < Body::N; ++i) {
+      const V3 p = body.get(i);
+      const double sd = dot(p, dir);
+      if (sd > best) { best = sd; pick = p; }
+    }
+  } else {
 #pragma unroll 1
-  for (int i = 0; i < Body::N; ++i) {
-    const V3 p = body.get(i);
-    const double sd = dot(p, dir);
-    if (sd > best) { best = sd; pick = p; }
+    for (int i = 0; i < Body::N; ++i) {
+      const V3 p = body.get(i);
+      const double sd = dot(p, dir);
+      if (sd > best) { best = sd; pick = p; }
+    }
   }
   cur = pick;
 }
@@ -573,6 +591,8 @@ __device__ __forceinline__ void gjk_tri_uni(Simplex& s, int lane) {
 // wave-uniform.  gjk_wave_run leaves the loop after iteration k_stop if the query has not ended by then (finished = false)
 // and continues from a saved state (fresh = false) with the same instruction sequence -- the iterations of a query may be
 // spread over two kernels (kernels_pairs.h: spec_pair_body) and arrive at the same bits.
+template <class B> __device__ __forceinline__ V3 body_get_dyn(const B& b, int i) { return b.get(i); }
+__device__ __forceinline__ V3 body_get_dyn(const BodyTri& b, int i) { return b.get_dyn(i); }
 struct GjkState { Simplex s; V3 v; double wmax2; int c1, c2, k; };
 template <class B1, class B2>
 __device__ __forceinline__ V3 gjk_wave_run(const B1& b1, const B2& b2, int lane, GjkState& st, bool fresh, int k_stop, bool& finished, long long* prof = nullptr) {   // prof (timing builds): [0] support, [1..3] segment / triangle / tetrahedron steps (100 MHz ticks), [4..6] their counts
@@ -583,8 +603,8 @@ __device__ __forceinline__ V3 gjk_wave_run(const B1& b1, const B2& b2, int lane,
   const int idx = lane & 15;
   const bool valid = (row1 && idx < B1::N) || (row2 && idx < B2::N);
   V3 p{0, 0, 0};
-  if (row1 && idx < B1::N) p = b1.get(idx);
-  if (row2 && idx < B2::N) p = b2.get(idx);
+  if (row1 && idx < B1::N) p = body_get_dyn(b1, idx);
+  if (row2 && idx < B2::N) p = body_get_dyn(b2, idx);
   const unsigned sgn = row1 ? 0x80000000u : 0u;   // body 1 is searched along -v, body 2 along v
   // the sticky supports as lane indices: a support is always a vertex of its body, and dot(vertex, dir) of the kept one is
   // bit for bit the `best` the reference starts its scan with -- so "some vertex is strictly better" == "the kept lane is not

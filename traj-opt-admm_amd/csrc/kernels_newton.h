@@ -257,6 +257,7 @@ template <bool FOLD>
 __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_grad(Dev D) {
   const int item = D.grad_bal ? D.grad_perm[blockIdx.x] : (int)blockIdx.x;   // (robot, piece) of this launch position (grad_order_body); read BEFORE the stop
                                                                              // test so that the two scalar loads share one round trip
+  if (D.xs_seq > 0 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(D.xs_go(), D.xs_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // opens the gate in front of k_xsolve on the other queue (also when the run has converged)
   if (TJ_DONE(D)) return;
   TJ_TIC_ENTRY(D, K_GRAD);
   const long long t_entry = wall_clock64();
@@ -474,10 +475,18 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   TJ_TIC(D, K_GRAD, 5);
   double* og = D.lg + ((size_t)u * D.P + sp) * 19;
   double* oh = D.lh + ((size_t)u * D.P + sp) * 361;
-  if (tid < 19) og[tid] = g[tid];
-  for (int idx = tid; idx < 361; idx += GRAD_THREADS) oh[idx] = H[idx];
+  const bool wt = D.xs_async != 0;   // the solve is waiting on the other queue: the block goes out written through, then the robot's ticket
+  if (tid < 19) xs_out(wt, og + tid, g[tid]);
+  for (int idx = tid; idx < 361; idx += GRAD_THREADS) xs_out(wt, oh + idx, H[idx]);
   if (tid == 0 && s_llt == 0) D.blk_stats[(size_t)u * D.P + sp] += 1ull;   // PSD repairs of this piece: only this block writes the word
   if (tid == 0 && D.grad_bal) D.grad_cost[item] = (int)(wall_clock64() - t_entry);   // 10 ns ticks; read by the next iteration's k_front
+  if (wt) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);   // every store of this wave has been acknowledged ...
+    __syncthreads();                 // ... and of the other two
+    asm volatile("" ::: "memory");
+    if (tid == 0) __hip_atomic_fetch_add(D.xs_ticket(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   TJ_TIC(D, K_GRAD, 6);
 }
 
@@ -698,17 +707,18 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
   blk_sync<true>();
   for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
   blk_sync<true>();
+  const bool wt = D.xs_async != 0;
   double* dir = D.dirp(u);
   for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
     const int row = idx % T, a = idx / T;
-    dir[idx] = (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0;
+    xs_out(wt, dir + idx, (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0);
   }
   const double w_ = esum_wave(scr, n, tid), g_ = esum_wave(scr + n, n, tid);
   if (tid == 0) {
-    D.wolfe(u) = -w_;
-    D.gn(u) = sqrt(g_);
-    D.tdir(u) = x0[m];
-    if (!D.multi()) D.ctl->gnorm = sqrt(g_);   // single UAV (Optimization3D_admm.h:499): what k_ccd_self_seq would copy; the chain skips that launch
+    xs_out(wt, &D.wolfe(u), -w_);
+    xs_out(wt, &D.gn(u), sqrt(g_));
+    xs_out(wt, &D.tdir(u), x0[m]);
+    if (!D.multi()) xs_out(wt, &D.ctl->gnorm, sqrt(g_));   // single UAV (Optimization3D_admm.h:499): what k_ccd_self_seq would copy; the chain skips that launch
   }
   if (D.xch) {   // direct exchange (sharded contexts): the record goes straight into every peer's receive buffer, under the swept-hull tail of this block
     blk_sync<true>();
@@ -716,6 +726,16 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     if (tid == 0) { scr[3 * T] = x0[m]; scr[3 * T + 1] = -w_; scr[3 * T + 2] = sqrt(g_); }
     blk_sync<true>();
     xch_push_robot<true>(D, 1, u, D.xs, scr, 3 * T + 3, tid, XS_THREADS);
+  }
+}
+
+// asynchronous solve: the gate in front of k_xsolve on the second queue (one wave, no LDS: it may sit there through the rest of the previous iteration)
+__global__ __launch_bounds__(64) void k_xs_gate(Dev D, int seq) {
+  const int* w = D.xs_go();
+  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq < 0) {
+    if (wall_clock64() > t_end) { if (threadIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
+    __builtin_amdgcn_s_sleep(16);
   }
 }
 
@@ -747,11 +767,25 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   if (tid == 0) s_grp = 0;
   double* lhu = scr + 6 * n;          // [P*361]
   double* lgu = lhu + D.P * 361;      // [P*19]
+  const bool wt = D.xs_async != 0;   // asynchronous solve (Dev::xs_async): this launch started next to k_grad, on the other queue
+  if (wt) {
+    // the robot's P piece blocks are in (each took a ticket after its write-through stores were acknowledged): wave 0 sleeps on the word, the others at the barrier
+    if (tid < 64) xs_wait(D, D.xs_ticket(u), D.P);
+    __syncthreads();
+#ifndef TJ_PHASE_LIGHT
+    TJ_TIC(D, K_XSOLVE, 7);
+#endif
+  }
   {
     const double* gh = D.lh + (size_t)u * D.P * 361;
     const double* gg = D.lg + (size_t)u * D.P * 19;
-    for (int i = tid; i < D.P * 361; i += XS_LOAD_THREADS) lhu[i] = gh[i];
-    for (int i = tid; i < D.P * 19; i += XS_LOAD_THREADS) lgu[i] = gg[i];
+    if (wt) {
+      for (int i = tid; i < D.P * 361; i += XS_LOAD_THREADS) lhu[i] = xf_load(gh + i);
+      for (int i = tid; i < D.P * 19; i += XS_LOAD_THREADS) lgu[i] = xf_load(gg + i);
+    } else {
+      for (int i = tid; i < D.P * 361; i += XS_LOAD_THREADS) lhu[i] = gh[i];
+      for (int i = tid; i < D.P * 19; i += XS_LOAD_THREADS) lgu[i] = gg[i];
+    }
   }
   __syncthreads();
   TJ_TIC(D, K_XSOLVE, 1);
@@ -789,7 +823,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   // not depend on the direction: the control net in LDS, the hull of every segment, and -- carried in registers across the
   // wait -- the k-DOP intervals of the current hull for the (segment, axis) pairs each helper thread will finish afterwards.
   // The helpers synchronise among themselves through an LDS counter (wave 0 is busy and must not be waited for).
-  const bool tail = D.fuse != 0;
+  const bool tail = D.fuse != 0 && !wt;   // (asynchronous solve: k_ccd's units build the swept-hull records from the direction -- the serial tail here would sit on the chain)
   if (tid >= XS_THREADS && !tail) return;
   const int S = D.S;
   double* netl = sm + xsolve_front_doubles(n);   // [3T] control net, [3T] direction (rows 0,1,T-2,T-1 are zero)
@@ -799,7 +833,21 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   const bool pre = tail && S * 49 <= XS_HELP * XS_KPT && (size_t)S * 54 <= 2 * (size_t)n * n + 8 * (size_t)n && S * 18 <= D.P * 361;   // uniform
   double klo[XS_KPT], kup[XS_KPT];
   const int ht = tid - XS_THREADS;
-  if (tid < XS_THREADS) { __builtin_amdgcn_s_setprio(3); xs_wave0<NREG>(D, u, tid, n, m, H, L, g0, x0, scr); __builtin_amdgcn_s_setprio(0); }   // the factorisation: ahead of the helper wave on its SIMD
+  if (tid < XS_THREADS) {
+    __builtin_amdgcn_s_setprio(3); xs_wave0<NREG>(D, u, tid, n, m, H, L, g0, x0, scr); __builtin_amdgcn_s_setprio(0);   // the factorisation: ahead of the helper wave on its SIMD
+    if (wt) {
+      // the direction record is out (write-through) and acknowledged: the robot's flag and the count -- k_ccd's units on the other queue are waiting for them
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0);
+      asm volatile("" ::: "memory");
+      if (tid == 0) {
+        __hip_atomic_store(D.xs_flag(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(D.xs_done(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      TJ_TIC(D, K_XSOLVE, 6);
+      return;
+    }
+  }
   else if (pre) {
     int target = 0;
     for (int idx = ht; idx < 3 * T; idx += XS_HELP) netl[idx] = gnet[idx];
@@ -854,7 +902,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     __syncthreads();
     for (int idx = tid; idx < S * 36; idx += XS_LOAD_THREADS) {   // P, Dh
       const int tr = idx / 36, e = idx % 36;
-      D.ccdinfo[((size_t)u * S + tr) * CCD_STRIDE + e] = Ph[tr * 54 + e];
+      xs_out(wt, D.ccdinfo + ((size_t)u * S + tr) * CCD_STRIDE + e, Ph[tr * 54 + e]);
     }
     for (int idx = tid; idx < S * 3; idx += XS_LOAD_THREADS) {    // obstacle box over {P, PD}, pair box over {P, P + Dh}
       const int tr = idx / 3, a = idx % 3;
@@ -866,8 +914,8 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
         v = q[3 * j + a] + q[18 + 3 * j + a]; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
       }
       double* o = D.ccdinfo + ((size_t)u * S + tr) * CCD_STRIDE;
-      o[36 + a] = lo; o[39 + a] = hi; o[42 + a] = lo2; o[45 + a] = hi2;
-      D.cbox[((size_t)tr * 6 + a) * D.U + u] = lo2; D.cbox[((size_t)tr * 6 + 3 + a) * D.U + u] = hi2;
+      xs_out(wt, o + 36 + a, lo); xs_out(wt, o + 39 + a, hi); xs_out(wt, o + 42 + a, lo2); xs_out(wt, o + 45 + a, hi2);
+      xs_out(wt, D.cbox + ((size_t)tr * 6 + a) * D.U + u, lo2); xs_out(wt, D.cbox + ((size_t)tr * 6 + 3 + a) * D.U + u, hi2);
     }
     // 49-axis intervals of the swept hull at step 1: min / max over the 6 hull points and the 6 points P + Dh.  With the
     // hull's part already known (helpers), only the second half is left -- min and max do not depend on the order.
@@ -883,7 +931,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
             double up = kup[q_], lo = klo[q_];
             for (int i = 0; i < 6; i++) { const double lv = x * (q[3 * i] + q[18 + 3 * i]) + y * (q[3 * i + 1] + q[18 + 3 * i + 1]) + z * (q[3 * i + 2] + q[18 + 3 * i + 2]); if (lv < lo) lo = lv; if (lv > up) up = lv; }
             double* o = D.ccdinfo + ((size_t)u * S + tr) * CCD_STRIDE;
-            o[48 + k] = lo; o[97 + k] = up;
+            xs_out(wt, o + 48 + k, lo); xs_out(wt, o + 97 + k, up);
           }
         }
       }
@@ -895,7 +943,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
       for (int i = 0; i < 6; i++) { const double lv = x * q[3 * i] + y * q[3 * i + 1] + z * q[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
       for (int i = 0; i < 6; i++) { const double lv = x * (q[3 * i] + q[18 + 3 * i]) + y * (q[3 * i + 1] + q[18 + 3 * i + 1]) + z * (q[3 * i + 2] + q[18 + 3 * i + 2]); if (lv < lo) lo = lv; if (lv > up) up = lv; }
       double* o = D.ccdinfo + ((size_t)u * S + tr) * CCD_STRIDE;
-      o[48 + k] = lo; o[97 + k] = up;
+      xs_out(wt, o + 48 + k, lo); xs_out(wt, o + 97 + k, up);
     }
   }
 #ifdef TJ_PHASE_LIGHT

@@ -33,9 +33,10 @@ namespace tj {
 // XF (foreign-robot unit of a sharded context, xf_ccd_body): the record is read by the pair tiles of the SAME launch -- write-through stores; the direction
 // comes from the receive buffer of the direct exchange when `sysdir` (system-scope loads).  Same expressions in every form, hence the same bits.
 template <bool XF = false>
-__device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net, const double* dir, int u, int tr, int lane, double* sh, bool sysdir = false) {
+__device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net, const double* dir, int u, int tr, int lane, double* sh, int sysdir = 0) {   // sysdir: 1 = system-scope loads of the
+  // direction (receive buffer of the direct exchange), 2 = agent-scope loads (asynchronous solve: the records of two robots share cache lines, and a neighbour's line may have been fetched before its owner wrote it)
   double* P = sh; double* Dh = sh + 18; double* PD = sh + 36; double* PS = sh + 54;
-  auto ldd = [&](const double* p) { return (XF && sysdir) ? xch_load(p) : *p; };
+  auto ldd = [&](const double* p) { return (XF && sysdir == 1) ? xch_load(p) : ((XF && sysdir == 2) ? xf_load(p) : *p); };
   auto st = [&](double* p, double v) { if constexpr (XF) xf_store(p, v); else *p = v; };
   if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
   else if (lane < 36) {
@@ -78,6 +79,67 @@ __device__ __forceinline__ void ccd_prep_segment(const Dev& D, const double* net
     st(o + 48 + lane, lo); st(o + 97 + lane, up);
   }
   blk_sync<true>();  // sh is reused by the caller's next segment
+}
+
+// Asynchronous Newton solve (Dev::xs_async): the obstacle unit of (robot, segment) in k_ccd builds the record itself -- and it was launched before the robot's solve has
+// finished.  What does not depend on the direction (the segment's basis rows, the control points) is fetched BEFORE the wait for the robot's flag; afterwards one
+// round trip for the direction entries (agent-scope loads: the records of two robots share cache lines), the sums of ccd_prep_segment in its order (same bits), the
+// record into `info` (LDS: the unit's own walk reads it there, no read-back) and out to the cache written through for the pair tiles of the launch.  sh: 72 doubles.
+__device__ __forceinline__ void ccd_record_async(const Dev& D, int u, int tr, int lane, double* info, double* sh) {
+  double* P = sh; double* Dh = sh + 18; double* PD = sh + 36; double* PS = sh + 54;
+  const double* net = D.spline + (size_t)u * 3 * D.T; const double* dir = D.dirp(u);
+  double bk[6] = {0, 0, 0, 0, 0, 0}, nk[6] = {0, 0, 0, 0, 0, 0}, dk[6] = {0, 0, 0, 0, 0, 0};
+  const int e = lane % 18, r0 = div_small(tr, D.res) * 3 + D.T * (e % 3);
+  if (lane < 54) {
+    const double* B = D.basis + (size_t)tr * 36 + (e / 3) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { bk[k] = B[k]; nk[k] = net[r0 + k]; }
+  }
+  const double kx = D.kdop[3 * min(lane, 48)], ky = D.kdop[3 * min(lane, 48) + 1], kz = D.kdop[3 * min(lane, 48) + 2];
+  xs_wait<4>(D, D.xs_flag(u), 1);
+  TJ_TIC(D, K_CCD, 3);
+  if (lane >= 18 && lane < 54) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) dk[k] = xf_load(dir + r0 + k);
+  }
+  {
+    double acc = 0;
+    if (lane < 18) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += bk[k] * nk[k];
+      P[lane] = acc;
+    } else if (lane < 36) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += bk[k] * dk[k];
+      Dh[lane - 18] = acc;
+    } else if (lane < 54) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += bk[k] * (nk[k] + dk[k]);
+      PD[lane - 36] = acc;
+    }
+  }
+  blk_sync<true>();
+  if (lane < 18) { PS[lane] = P[lane] + Dh[lane]; info[lane] = P[lane]; info[18 + lane] = Dh[lane]; }
+  blk_sync<true>();
+  if (lane < 3) {
+    double lo = INFINITY, hi = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
+    for (int j = 0; j < 6; j++) {
+      double v = P[3 * j + lane]; if (v < lo) lo = v; if (v > hi) hi = v; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
+      v = PD[3 * j + lane]; if (v < lo) lo = v; if (v > hi) hi = v;
+      v = PS[3 * j + lane]; if (v < lo2) lo2 = v; if (v > hi2) hi2 = v;
+    }
+    info[36 + lane] = lo; info[39 + lane] = hi; info[42 + lane] = lo2; info[45 + lane] = hi2;
+    xf_store(D.cbox + ((size_t)tr * 6 + lane) * D.U + u, lo2); xf_store(D.cbox + ((size_t)tr * 6 + 3 + lane) * D.U + u, hi2);
+  }
+  if (lane < 49) {
+    double up = -INFINITY, lo = INFINITY;
+    for (int i = 0; i < 6; i++) { const double lv = kx * P[3 * i] + ky * P[3 * i + 1] + kz * P[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+    for (int i = 0; i < 6; i++) { const double lv = kx * PS[3 * i] + ky * PS[3 * i + 1] + kz * PS[3 * i + 2]; if (lv < lo) lo = lv; if (lv > up) up = lv; }
+    info[48 + lane] = lo; info[97 + lane] = up;
+  }
+  blk_sync<true>();
+  double* o = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
+  for (int i = lane; i < CCD_REC; i += 64) xf_store(o + i, info[i]);
 }
 
 // u_first: first robot of the launch (all robots from 0; a sharded context whose foreign robots are handled inside k_ccd: its own from u0)
@@ -136,7 +198,7 @@ __device__ __forceinline__ void xf_ccd_body(const Dev& D, int f, double* sh) {
     dir = D.rx[1] + (size_t)u * D.xs;
     if (tr == 0) for (int i = lane; i < 3 * T + 3; i += 64) xf_store(D.xdir + (size_t)u * D.xs + i, xch_load(dir + i));   // |g| is read by this launch's finisher, the rest by k_linesearch
   }
-  ccd_prep_segment<true>(D, D.spline + (size_t)u * 3 * T, dir, u, tr, lane, sh, D.xch != 0);
+  ccd_prep_segment<true>(D, D.spline + (size_t)u * 3 * T, dir, u, tr, lane, sh, D.xch != 0 ? 1 : 0);
   xf_signal(D, 1, tr);
 }
 // ranks that share a device (a test arrangement): the units' polling would hold LDS and wave slots the peer's producing kernel needs -- one
@@ -180,7 +242,13 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds,
   V3 axv{0, 0, 0}; double lo_ax = 0, hi_ax = 0;
   const double* src = D.ccdinfo + ((size_t)u * D.S + tr) * CCD_STRIDE;
   const TopBox topb = bvh_top_box(D);   // travels with the segment's record
-  if (publish) {   // coupled chain (Dev::xf_all): this unit builds its (robot, segment)'s swept-hull record itself -- what k_ccd_prep would --, written through for the pair tiles
+  if (D.xs_async) {   // asynchronous Newton solve: the record is built here, once this robot's block (on the other queue) has left its direction
+    ccd_record_async(D, u, tr, lane, info, lds + 148);
+    TJ_TIC(D, K_CCD, 4);
+    xf_signal(D, 1, tr);   // (its write-through stores acknowledged) -> the pair tiles of the segment
+    TJ_TIC(D, K_CCD, 5);
+  } else
+  if (publish) {   // coupled chain (Dev::xf_all), asynchronous solve: this unit builds its (robot, segment)'s swept-hull record itself -- what k_ccd_prep would --, written through for the pair tiles
     ccd_prep_segment<true>(D, D.spline + (size_t)u * 3 * D.T, D.dirp(u), u, tr, lane, lds);
     xf_signal(D, 1, tr);
     for (int i = lane; i < CCD_REC; i += 64) info[i] = xf_load(src + i);   // (its own write-through stores, acknowledged: read back past the L1)
@@ -259,7 +327,7 @@ __device__ __forceinline__ int ccd_self_pairs_body(const Dev& D, int bid, double
   const int U = D.U;
   const double off = D.offset;
   double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
-  if (wait_xf) xf_wait_seg(D, 1, tr);   // sharded contexts (union kernel): the swept-hull cache of the other ranks' robots is written by units at the head of this launch
+  if (wait_xf || D.xs_async) { xf_wait_seg(D, 1, tr); TJ_TIC(D, K_CCD, 6); }   // (asynchronous Newton solve: the obstacle units of this launch build the records once their robot's direction is there)   // sharded contexts (union kernel): the swept-hull cache of the other ranks' robots is written by units at the head of this launch
   // swept boxes (lanes over partners), then swept 49-axis intervals (lanes over axes): BVH::SelfCCDCollision + CCD::SelfKDOPCCD
   const int m = pair_tile_filter(D.cbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, 0, U,
                                  [&](int q) { return D.ccdinfo + ((size_t)q * D.S + tr) * CCD_STRIDE; }, 48, 97, off, rowbox, list, lane);
@@ -837,8 +905,9 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   M.ti = D.seq_gmem_i; M.stk = M.ti + 10 * (size_t)D.U;
   M.lane0_stages = true;
   {   // gnorm: the sequential sum in robot order (Optimization3D_multi.h:57,72,750)
+    if (D.xs_async) xs_wait(D, D.xs_done(), D.u1 - D.u0);   // asynchronous Newton solve: every robot's |g| is in
     if (D.xf) xf_wait_seg(D, 1, 0);   // sharded contexts: the other ranks' |g| values are put in place by this launch's foreign units of segment 0
-    for (int i = lane; i < D.U; i += 64) M.gns[i] = D.xf ? xf_load(&D.gn(i)) : D.gn(i);
+    for (int i = lane; i < D.U; i += 64) M.gns[i] = (D.xf || D.xs_async) ? xf_load(&D.gn(i)) : D.gn(i);
     __syncthreads();
     if (!D.coupled()) { if (lane == 0) { double gsum = 0; for (int u = 0; u < D.U; u++) gsum += M.gns[u]; D.ctl->gnorm = gsum / double(D.U); } }
     else {
@@ -864,7 +933,8 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   }
   int any_act = 0;
   {
-    const long long t_end = wall_clock64() + 500000 + 100ll * gridDim.x;   // 5 ms + 1 us per block of the launch: a logic error must not hang the device
+    const long long t_end = wall_clock64() + (D.xs_async ? XCH_TIMEOUT_TICKS : 500000 + 100ll * gridDim.x);   // 5 ms + 1 us per block of the launch: a logic error must not hang the device
+                                                                                                                // (asynchronous solve: the tiles themselves wait for units that wait for the other queue -- 2 s, like them)
     for (;;) {
       int v = lane < 16 ? __hip_atomic_load(&D.ctl->ccd_sub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -41,6 +41,8 @@ struct tj_ctx {
   std::vector<void*> allocs;
   std::string err;
   bool have_cloud = false, have_state = false;
+  // asynchronous Newton solve (Dev::xs_async): k_xsolve goes to a second hardware queue, behind an event that k_mid's completion fires
+  hipStream_t stream2 = nullptr; int xs_seq = 0, xs_seq_gated = 0; bool xs_two_queues = false, xs_same_queue_now = false;
   bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
   bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
   bool ccd_valid = false;    // Dev::fuse: the swept-hull cache of the owned robots matches their direction records (k_xsolve's tail wrote it; tj_set_direction / tj_set_state clear it)
@@ -128,7 +130,11 @@ const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "
 // begin work was done by the previous iteration's k_linesearch (no k_begin launch); bit 2 = this iteration's k_linesearch also
 // does the next iteration's begin work.
 bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false, bool in_phase = false, int chain_pos = 0) {
-  const Dev& d = c->d;
+  Dev d_ = c->d;
+  if (!in_graph) d_.xs_async = 0;   // the asynchronous solve's tickets and flags belong to the single-GPU chain (begin -> k_grad -> k_xsolve -> k_ccd, every iteration); stage API and phases: plain
+  d_.xs_seq = 0;
+  if (kid == K_GRAD && d_.xs_async && c->xs_two_queues && !c->xs_same_queue_now && !c->use_graph) d_.xs_seq = ++c->xs_seq;   // this k_grad opens the gate of its k_xsolve
+  const Dev& d = d_;
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2, tri = d.prim == 3;
   // Waves striding over the two device-built work lists.  k_mid holds ~1 wave per SIMD (VGPR bound), i.e. 1024 resident
@@ -184,6 +190,11 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       Dev dx = d;
       if (!chained) dx.c2_fold = 0;   // (the stage API's solve is followed by k_xsolve_c2)
       const Dev& d = dx;
+      if (c->xs_seq_gated != c->xs_seq) {   // asynchronous solve: on the second queue, behind a gate that this iteration's k_grad opens (profiling, graphs: it simply follows k_grad on this queue)
+        c->xs_seq_gated = c->xs_seq;
+        s = c->stream2;
+        TJ_LAUNCH(k_xs_gate, dim3(1), dim3(64), 0, s, d, c->xs_seq);
+      }
       if (d.xs_band) TJ_LAUNCH(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
       else switch (9 * d.P - 2) {   // the register factorisation is inlined per size (kernels_newton.h); 61 rows and the LDS forms: the generic kernel
         case 16: TJ_LAUNCH((k_xsolve<16>), dim3(owned), dim3(XS_LOAD_THREADS), c->lds_xs, s, d); break;
@@ -298,6 +309,7 @@ int flush_deferred(tj_ctx* c) {
     int qr_ = flush_deferred(c);                                \
     if (qr_) return qr_;                                        \
     HIPCHK(c, hipStreamSynchronize((c)->stream));               \
+    if ((c)->stream2) HIPCHK(c, hipStreamSynchronize((c)->stream2)); \
   } while (0)
 
 // Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two all-gathers), 3 = one full
@@ -392,6 +404,7 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
     if (h.error & ERR_CCD_STUCK) c->err += ": a CCD clamp found contact at every step (the state itself is in collision; the reference loops forever here)";
     if (h.error & ERR_SLACK_ARMIJO) c->err += ": the slack update's Armijo search";
     if (h.error & ERR_PLANE_REFINE) c->err += ": optimal_plane, a plane refinement did not terminate within its caps";
+    if (h.error & ERR_XS_TIMEOUT) c->err += ": NOT an infeasible state -- a wait between the two queues of the asynchronous Newton solve ran out after 2 s (GPU shared with other processes?); TJ_XS_ASYNC=0 keeps the solve on the chain's queue";
     if (h.error & ERR_PASS_TIMEOUT) c->err += ": NOT an infeasible state -- a wave waiting for passed-on robot pairs timed out after 5 ms (GPU queue descheduled / shared with other processes); re-run the iteration or set TJ_PAIR_PASS_ON=0";
     return TJ_ERR_NO_PROGRESS;
   }
@@ -568,6 +581,38 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     // -- between one and two blocks per unit, the case it was measured on: SCN-C -1.5 us per iteration, the 64 hard robots -1.4; at five blocks per unit
     // (256 robots) longest-first ordering bought nothing in k_grad and the run was 1.5 % slower, so larger fleets keep the identity
     d.grad_bal = (owned * d.P > d.num_cu && owned * d.P < 2 * d.num_cu) ? 1 : 0;
+    // asynchronous Newton solve (dev_common.h, Dev::xs_async): one context, decoupled / single-UAV chain with the swept-hull tail in k_xsolve.  TJ_XS_ASYNC=0: the
+    // solve stays a link of the one-queue chain (launch-shape switch: same bits)
+    d.xs_async = (d.fuse && p->world == 1 && p->mode != TJ_MODE_MULTI_COUPLED && !d.xs_band) ? 1 : 0;
+    if (d.xs_async) {
+      // Liveness: k_xsolve's blocks hold registers and LDS while they sleep on their tickets, and the k_grad blocks that hand the tickets out may still be waiting
+      // for a compute unit.  Safe when the sleepers can never shut k_grad out: at most half as many robots as compute units (half the device stays free whatever
+      // the dispatcher does), or at most one robot per unit AND a k_grad block fits a unit next to one k_xsolve block (a unit with two sleepers then implies a
+      // unit with none).  Larger fleets keep the solve on the chain's queue (1 500 robots: the sleepers filled the device and every wait ran into its 5 ms limit).
+      bool fits = false;
+      {
+        const void* fx = nullptr;
+        switch (9 * d.P - 2) {
+          case 16: fx = (const void*)k_xsolve<16>; break; case 25: fx = (const void*)k_xsolve<25>; break; case 34: fx = (const void*)k_xsolve<34>; break;
+          case 43: fx = (const void*)k_xsolve<43>; break; case 52: fx = (const void*)k_xsolve<52>; break; default: fx = (const void*)k_xsolve<0>; break;
+        }
+        const void* fg = c->grad_fold ? (const void*)k_grad<true> : (const void*)k_grad<false>;
+        hipFuncAttributes ax, ag;
+        if (hipFuncGetAttributes(&ax, fx) == hipSuccess && hipFuncGetAttributes(&ag, fg) == hipSuccess) {
+          auto gran = [](int r) { return (r + 7) / 8 * 8; };
+          const int wx = XS_LOAD_THREADS / 64, wg = (c->grad_fold ? GRAD_FOLD_THREADS : GRAD_THREADS) / 64;
+          const size_t lx = c->lds_xs + ax.sharedSizeBytes, lg = c->lds_grad + (c->grad_fold ? grad_fold_extra_doubles(d.res) * sizeof(double) : 0) + ag.sharedSizeBytes;
+          fits = ((wx + 3) / 4) * gran(ax.numRegs) + ((wg + 3) / 4) * gran(ag.numRegs) <= 512 && lx + lg <= (size_t)160 * 1024 && (wx + 3) / 4 + (wg + 3) / 4 <= 8;
+        } else (void)hipGetLastError();
+      }
+      if (!(2 * owned <= d.num_cu || (owned <= d.num_cu && fits))) d.xs_async = 0;
+    }
+    if (const char* e = getenv("TJ_XS_ASYNC")) d.xs_async = d.xs_async && atoi(e) != 0;
+    if (d.xs_async) {
+      const bool ok = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); c->stream2 = nullptr; }   // (the tickets and flags work on one queue as well)
+      c->xs_two_queues = ok && getenv("TJ_XS_ONE_QUEUE") == nullptr;
+    }
     if (const char* e = getenv("TJ_GRAD_BALANCE")) d.grad_bal = (atoi(e) != 0 && owned * d.P <= 65536) ? 1 : 0;   // launch-shape switch (same bits)
     d.ls_help = (d.ls_fast && p->mode != TJ_MODE_MULTI_COUPLED) ? std::max(1, std::min(LS_HELP_MAX, prop.multiProcessorCount / owned)) : 1;
     if (const char* e = getenv("TJ_LS_HELP")) {   // launch-shape switch (same bits); 1 = no helpers.  More blocks per robot than the compute units hold at once would leave helpers waiting for a
@@ -623,7 +668,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
       (r = dalloc(c, &d.grad_scr, (size_t)(d.u1 - d.u0) * P * 16 * (size_t)(d.cap_obs + d.cap_self))) ||
       (r = dalloc(c, &d.xs_scr, d.xs_band ? (size_t)(d.u1 - d.u0) * ((size_t)n * n + 4 * n) : 1)) ||
-      (r = dalloc(c, &d.xf_seg, d.xf ? 2 * S * XF_SEG_STRIDE : 1))) return r;
+      (r = dalloc(c, &d.xf_seg, 2 * S * XF_SEG_STRIDE)) || (r = dalloc(c, &d.xs_sync, (2 * U + 2) * 32))) return r;
   if (d.optimal_plane) {
     const bool m0 = d.mode == 0;
     if ((r = dalloc(c, &d.kobs_id, m0 ? U * S * d.cap_obs : 1)) || (r = dalloc(c, &d.kobs_n, U * S)) || (r = dalloc(c, &d.kobs_cd, m0 ? U * S * d.cap_obs * 4 : 1)) ||
@@ -640,6 +685,7 @@ void tj_destroy(tj_ctx* c) {
   if (!c) return;
   drop_graph(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   for (void* p : c->xch_ipc_opened) (void)hipIpcCloseMemHandle(p);
   if (c->xch_block) (void)hipFree(c->xch_block);
   for (void* p : c->allocs) hipFree(p);
@@ -817,6 +863,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   // tj_group_init_state does; processes use their collective's barrier)
   if (c->xch_block) HIPCHK(c, hipMemsetAsync(d.xcnt, 0, 2 * XCH_MAX * sizeof(unsigned long long), c->stream));
   if (d.xf) HIPCHK(c, hipMemsetAsync(d.xf_seg, 0, (size_t)2 * d.S * XF_SEG_STRIDE * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(d.xs_sync, 0, ((size_t)2 * d.U + 1) * 32 * sizeof(int), c->stream));
   Ctl h;
   memset(&h, 0, sizeof(h));
   h.gnorm = 1.0;  // Main/multiPathPlanning3D.cpp:594
@@ -928,6 +975,7 @@ int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
   std::vector<hipEvent_t> ev((size_t)n_iters * (K_COUNT + 1));
   for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
   std::vector<int> ran(K_COUNT, 0);
+  c->xs_same_queue_now = true;   // per-kernel events on one queue: the asynchronous solve follows k_grad there (its own time is then what the events show)
   for (int it = 0; it < n_iters; it++) {
     hipEvent_t* e = &ev[(size_t)it * (K_COUNT + 1)];
     HIPCHK(c, hipEventRecord(e[0], c->stream));
@@ -938,6 +986,7 @@ int tj_profile_kernels(tj_ctx* c, int n_iters, double* ms, int* launches) {
       HIPCHK(c, hipEventRecord(e[k + 1], c->stream));
     }
   }
+  c->xs_same_queue_now = false;
   if (n_iters > 0) c->maybe_deferred = true;  // the last iteration's slack/dual update is still owed (paid by the flush below)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int k = 0; k < K_COUNT; k++) ms[k] = 0;
