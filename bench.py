@@ -418,6 +418,7 @@ def main():
         # Processes SHARING a GPU (test arrangement): the device runs one process's waves at a time, so a kernel that sleeps on a word which another queue of its process
         # is to write (the asynchronous Newton solve of the one-rank reference contexts below) shuts the other process out -- and with both processes doing it, each other.
         os.environ["TJ_XS_ASYNC"] = "0"
+        os.environ["TJ_KEEP_ASYNC"] = "0"
     group_devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else None
     if world == 1 and args.gpus > 1 and group_devices is None:
         group_devices = list(range(args.gpus))   # not under torchrun: the library shards by itself
@@ -612,7 +613,8 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['tris'].shape[0] if scene.get('tris') is not None else scene['cloud'].shape[0]} obstacle {'triangles (fp64 narrow phase, fp32 outward-rounded BVH boxes)' if scene.get('tris') is not None else 'points'}, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
-                          "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {'direct exchange (in-kernel pushes / waits through hipIpc-mapped receive blocks), six kernels per iteration and rank' if sharded and path['name'] == 'direct' else str(5 if args.coupled else 2) + ' RCCL all-gathers/iter on the library exchange buffers'}; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else f"1 GPU, whole iteration resident on the device: a linear chain of {13 if args.coupled else 6} kernels on one queue (union kernels), enqueued ahead, no host sync",
+                          "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {'direct exchange (in-kernel pushes / waits through hipIpc-mapped receive blocks), six kernels per iteration and rank' if sharded and path['name'] == 'direct' else str(5 if args.coupled else 2) + ' RCCL all-gathers/iter on the library exchange buffers'}; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else (f"1 GPU, whole iteration resident on the device: a linear chain of 6 kernels on one queue (union kernels), enqueued ahead, no host sync" if args.coupled or os.environ.get("TJ_XS_ASYNC") == "0"
+                                           else "1 GPU, whole iteration resident on the device: six kernels per iteration enqueued ahead, no host sync -- five in a chain on one queue, the Newton solve on a second queue next to the gradient kernel (in-kernel tickets / flags; TJ_XS_ASYNC=0: all six on one queue)"),
                           "iters_timed_from": "initial trajectory"}}
         if scene["name"] == "SCN-C" and not (args.coupled or args.optimal_plane):
             out["config"]["parity_pin"] = ("the timed SCN-C is pinned against the unmodified reference PER ITERATION (tests/golden/stages_scn_c.npz) and end to end only inside the reference's own "

@@ -298,3 +298,31 @@ def test_degenerate_frame_and_nan_planes_stay_inert(pkg, scenes):
     assert np.isfinite(s.get_state()["spline"]).all()
     on_d, _ = s.get_pair_cache(); on_o, _ = o.get_pair_cache()
     assert on_d.sum() > 0 and s.stats()["error_bits"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["scn_b", "scn_c"])
+def test_asynchronous_plane_refinement_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
+    """Round 5: the refinement of the planes stored before an iteration (k_keep part 2: as long as its slowest plane's Newton chain) runs on a queue of its own from the
+    start of the iteration, next to k_front / k_mid; k_grad's compaction waits for the waves' completion counters.  Against one k_keep launch between k_mid and k_grad
+    (TJ_KEEP_ASYNC=0): state and persistent tables bit for bit over 40 iterations, no error bit, and the launch count shows the third queue in use (gate + part 2)."""
+    scene = {"scn_b": scenes.scn_b, "scn_c": scenes.scn_c}[scene_name]()
+    for k in ("TJ_KEEP_ASYNC", "TJ_XS_ASYNC"):
+        monkeypatch.delenv(k, raising=False)
+    n_it = 40
+    a = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    l0 = a.launch_count(); a.iterate_async(n_it); a.sync(); la = a.launch_count() - l0
+    sa, ta = a.get_state(), a.stats(); on_a, cd_a = a.get_pair_cache()
+    a.close()
+    monkeypatch.setenv("TJ_KEEP_ASYNC", "0")
+    b = pkg.Solver(scene, stop=0.0, optimal_plane=1)
+    l0 = b.launch_count(); b.iterate_async(n_it); b.sync(); lb = b.launch_count() - l0
+    sb, tb = b.get_state(), b.stats(); on_b, cd_b = b.get_pair_cache()
+    b.close()
+    monkeypatch.delenv("TJ_KEEP_ASYNC")
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), f"{n} differs between the asynchronous refinement and the one-launch k_keep"
+    assert np.array_equal(on_a, on_b) and np.array_equal(cd_a, cd_b, equal_nan=True)
+    assert ta["error_bits"] == 0 and tb["error_bits"] == 0
+    assert ta["newton_iters"] == tb["newton_iters"] and ta["pair_solves"] == tb["pair_solves"]
+    assert la == lb + 2 * n_it, f"expected a gate and a part-2 launch per iteration on top of the chain ({lb} launches): {la}"

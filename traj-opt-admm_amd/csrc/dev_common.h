@@ -184,6 +184,12 @@ struct Dev {
   __host__ __device__ int* xs_ticket(int u) const { return xs_sync + (size_t)u * 32; }
   __host__ __device__ int* xs_flag(int u) const { return xs_sync + ((size_t)U + u) * 32; }
   __host__ __device__ int* xs_done() const { return xs_sync + (size_t)2 * U * 32; }
+  // "optimal_plane":1, multi-UAV, one context: the refinement of the planes stored before this iteration (k_keep part 2) needs nothing of this iteration's broad
+  // phase -- only the committed control points -- and is as long as its slowest plane (tens of Newton rounds).  It runs on a THIRD queue from the start of the
+  // iteration (gate: k_front's first block has started), next to k_front and k_mid; k_grad (its compaction reads the planes) waits for the waves' sixteen completion
+  // counters.  keep_sync: ints [16][32] counters (zeroed by begin_body) | [32] go word.
+  int keep_async, keep_seq, keep_waves; int* keep_sync;
+  __host__ __device__ int* keep_go() const { return keep_sync + 16 * 32; }
   int xs_band;  // long trajectories (piece_num > 10): the Newton solve runs on band storage (k_xsolve_band) and the swept-hull
                 // cache comes from k_ccd_prep again
   int seq_tree; // k_ccd_self_seq has LDS for the reference's per-segment dynamic tree (dev_dyntree.h)
@@ -401,6 +407,25 @@ __device__ __forceinline__ bool xs_wait(const Dev& D, const int* w, int want) {
     if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
     if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return false; }
   }
+}
+// asynchronous plane refinement (Dev::keep_async): every wave of the refinement launch (third queue) has left its planes?  Called by all threads of a block; uniform.
+__device__ __forceinline__ void keep_wait(const Dev& D) {
+  __shared__ int s_keep_ok;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s (a refinement of thousands of rounds is legitimate: the reference spins on such planes as well)
+    for (;;) {
+      int v = lane < 16 ? __hip_atomic_load(D.keep_sync + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      v = __shfl(v, 0);
+      if (v >= D.keep_waves) break;
+      if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (lane == 0) s_keep_ok = 1;
+  }
+  __syncthreads();
+  asm volatile("" ::: "memory");
 }
 // a value that a kernel running at the same time on the other queue will read: written through when the solve is asynchronous
 __device__ __forceinline__ void xs_out(bool wt, double* p, double v) { if (wt) xf_store(p, v); else *p = v; }

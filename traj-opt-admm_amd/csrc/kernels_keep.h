@@ -21,7 +21,18 @@
 
 namespace tj {
 
-__global__ __launch_bounds__(64) void k_keep(Dev D) {
+// part: 0 = everything (the one-queue chain, the stage API), 1 = new pairs only, 2 = the planes stored before this iteration only (asynchronous refinement, Dev::keep_async:
+// launched on a queue of its own at the start of the iteration; its planes go out written through, every wave counts itself done)
+__global__ __launch_bounds__(64) void k_keep_gate(Dev D, int seq) {
+  const int* w = D.keep_go();
+  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq < 0) {
+    if (wall_clock64() > t_end) { if (threadIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+__global__ __launch_bounds__(64) void k_keep(Dev D, int part) {
+  const bool wt = part == 2;
   if (TJ_DONE(D)) return;
   const int lane = lane_id();
   const int epoch = D.ctl->epoch;
@@ -77,6 +88,14 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     k[0] = cx; k[1] = cy; k[2] = cz; k[3] = d;
     const size_t s1 = ((size_t)tr * U + q) * U + p0;
     double* q0 = D.pairplane + 4 * s0; double* q1 = D.pairplane + 4 * s1;
+    if (wt) {   // read by k_grad's compaction on another queue, possibly before this launch has ended: written through (same values as below)
+      const bool fin = isfinite(cx) && isfinite(cy) && isfinite(cz) && isfinite(d);
+      xf_store(q0, fin ? cx : 0.0); xf_store(q0 + 1, fin ? cy : 0.0); xf_store(q0 + 2, fin ? cz : 0.0); xf_store(q0 + 3, fin ? d - 0.5 * off : 1e300);
+      xf_store(q1, fin ? -cx : 0.0); xf_store(q1 + 1, fin ? -cy : 0.0); xf_store(q1 + 2, fin ? -cz : 0.0); xf_store(q1 + 3, fin ? -d - 0.5 * off : 1e300);
+      __hip_atomic_store(&D.pairstamp[s0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&D.pairstamp[s1], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      D.pair_mark(tr, p0, q); D.pair_mark(tr, q, p0);
+      return;
+    }
     if (!(isfinite(cx) && isfinite(cy) && isfinite(cz) && isfinite(d))) {
       // The reference's refinement can return NaN (its gradient takes log(dist/m) of a point on the wrong side).  Every consumer
       // of the reference tests `dist < margin` / `dist <= 0` first, which a NaN fails: such a plane is inert but stays in the
@@ -99,11 +118,19 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
   };
   __shared__ int wpre[513];
   __shared__ double s_te[64];   // opt_plane_pair_wave: the energy terms of five Armijo candidates
-  const int nwork = pair_work_prefix(D, wpre, lane), nold = D.kpair_n[1];
+  const int nwork = part == 2 ? 0 : pair_work_prefix(D, wpre, lane), nold = D.kpair_n[1];   // (part 2 alone runs while k_front is still writing this iteration's work list: it does not look at it)
   // Few planes (up to a handful per wave of the grid): one WAVE per plane -- the 12 barrier terms of a Newton round on 12
   // lanes (opt_plane_pair_wave), a quarter of the dependent chain; the kernel is as long as its slowest plane.  Many planes
   // (hundreds of robots): one plane per LANE, the same arithmetic bit for bit, for throughput.  The switch is grid-uniform.
+  auto count_done = [&]() {   // asynchronous refinement: this wave's planes are out (acknowledged) -> one of sixteen counters, fire and forget
+    if (!wt) return;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(D.keep_sync + (blockIdx.x & 15) * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   if (nwork + nold <= 4 * (int)gridDim.x) {
+    if (part != 2)
     for (int w = blockIdx.x; w < nwork; w += gridDim.x) {    // part 1 (Optimization3D_multi.h:276-290)
       const size_t sl = (size_t)pair_work_slot(D, wpre, w);
       const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
@@ -118,6 +145,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
       capped |= !opt_plane_pair_wave(A, B, m, off, lane, cx, cy, cz, d, s_te, &rounds, D.dbg ? D.dbg + ((size_t)K_KEEP * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS : nullptr);
       if (lane == 0) { publish(s0, tr, p0, q, cx, cy, cz, d); note_rounds(tr, p0, rounds); }
     }
+    if (part != 1)
     for (int w = blockIdx.x; w < nold; w += gridDim.x) {     // part 2 (:310-338)
       const size_t s0 = (size_t)D.kpair_list[w];
       const int tr = (int)(s0 / ((size_t)U * U)), p0 = (int)((s0 / U) % U), q = (int)(s0 % U);
@@ -130,9 +158,11 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
       if (lane == 0) { publish(s0, tr, p0, q, cx, cy, cz, d); note_rounds(tr, p0, rounds); }
     }
     if (capped && lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PLANE_REFINE);
+    count_done();
     return;
   }
   // part 1 (Optimization3D_multi.h:276-290): pairs that passed box + k-DOP this iteration and have no plane yet
+  if (part != 2)
   for (int w = blockIdx.x * 64 + lane; w < nwork; w += gridDim.x * 64) {
     const size_t sl = (size_t)pair_work_slot(D, wpre, w);
     const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
@@ -148,6 +178,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     publish(s0, tr, p0, q, cx, cy, cz, d);
   }
   // part 2 (:310-338): every plane stored before this iteration
+  if (part != 1)
   for (int w = blockIdx.x * 64 + lane; w < nold; w += gridDim.x * 64) {
     const size_t s0 = (size_t)D.kpair_list[w];
     const int tr = (int)(s0 / ((size_t)U * U)), p0 = (int)((s0 / U) % U), q = (int)(s0 % U);
@@ -159,6 +190,7 @@ __global__ __launch_bounds__(64) void k_keep(Dev D) {
     publish(s0, tr, p0, q, cx, cy, cz, d);
   }
   if (capped) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PLANE_REFINE);
+  count_done();
 }
 
 }  // namespace tj

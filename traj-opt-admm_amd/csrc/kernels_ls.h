@@ -445,6 +445,7 @@ __device__ __forceinline__ bool begin_body(const Dev& D, int quiet = 0) {   // r
   if (D.xs_sync) for (int i = threadIdx.x; i <= 2 * D.U; i += blockDim.x) D.xs_sync[(size_t)i * 32] = 0;   // tickets, flags and the count of the asynchronous Newton solve
   if (D.xf || D.xs_async) for (int i = threadIdx.x; i < 2 * D.S; i += blockDim.x) D.xf_seg[(size_t)i * XF_SEG_STRIDE] = 0;   // ... and of the foreign-robot units of k_front / k_ccd (sharded contexts)
   if (D.ls_help > 1) for (int i = threadIdx.x; i < (D.u1 - D.u0) * LS_TAB_STRIDE; i += blockDim.x) ((unsigned long long*)D.ls_tab)[(size_t)D.u0 * LS_TAB_STRIDE + i] = LS_TAB_EMPTY;   // k_linesearch's helper posts
+  if (D.keep_sync && threadIdx.x < 16) D.keep_sync[threadIdx.x * 32] = 0;   // completion counters of the asynchronous plane refinement
   if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
   return false;
 }

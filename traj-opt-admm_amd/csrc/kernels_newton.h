@@ -260,6 +260,7 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   if (D.xs_seq > 0 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(D.xs_go(), D.xs_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // opens the gate in front of k_xsolve on the other queue (also when the run has converged)
   if (TJ_DONE(D)) return;
   TJ_TIC_ENTRY(D, K_GRAD);
+  if (D.keep_async) keep_wait(D);   // "optimal_plane":1: the stored planes' refinement runs on a queue of its own since the start of the iteration; the compaction below reads its planes
   const long long t_entry = wall_clock64();
   extern __shared__ double sm[];
   __shared__ int s_cnt[GRAD_MAXRES][2];   // folded launch: {obstacle planes, robot-pair planes} of the block's segments, left by its own compaction

@@ -592,6 +592,7 @@ __device__ __forceinline__ void compact_segment(const Dev& D, int u, int tr, int
 }
 __global__ __launch_bounds__(64) void k_sep_self_compact(Dev D) {
   if (TJ_DONE(D)) return;
+  if (D.keep_async) keep_wait(D);   // (see k_grad)
   compact_segment(D, D.u0 + blockIdx.x / D.S, blockIdx.x % D.S, lane_id());
 }
 

@@ -811,6 +811,7 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
 //   k_ccd    obstacle CCD clamp (owned * S)  |  robot-pair CCD selection (S * U)
 template <int PRIM>
 __global__ __launch_bounds__(64) void k_front(Dev D) {
+  if (D.keep_seq > 0 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(D.keep_go(), D.keep_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // opens the gate of the asynchronous plane refinement
   if (TJ_DONE(D)) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);

@@ -3,9 +3,10 @@
 //
 // One iteration = the stage sequence of Optimization3D_multi::optimization_decouple
 // (Optimization3D_multi.h:29-118) / Optimization3D_admm::optimization (Optimization3D_admm.h:29-67),
-// enqueued as a linear chain on ONE HIP stream with no host synchronisation inside or between iterations; one
-// iteration is captured once into a hipGraph and replayed.  The stop test of the mains runs on
-// the device (k_begin), so a converged problem turns the remaining replays into early-exit kernels.
+// enqueued with plain launches and no host synchronisation inside or between iterations: a linear chain on the context's
+// stream, plus -- one context, decoupled / single-UAV mode -- the Newton solve on a second stream next to the gradient
+// kernel (Dev::xs_async, dev_common.h; TJ_USE_GRAPH=1 replays a captured hipGraph instead).  The stop test of the mains
+// runs on the device (begin_body), so a converged problem turns the remaining launches into early-exit kernels.
 //
 // There is deliberately no CPU path in this file: every entry point either runs HIP kernels or
 // fails with TJ_ERR_DEVICE.
@@ -42,6 +43,7 @@ struct tj_ctx {
   std::string err;
   bool have_cloud = false, have_state = false;
   // asynchronous Newton solve (Dev::xs_async): k_xsolve goes to a second hardware queue, behind an event that k_mid's completion fires
+  hipStream_t stream3 = nullptr; int keep_seq = 0; bool keep_two_queues = false;   // asynchronous plane refinement (Dev::keep_async)
   hipStream_t stream2 = nullptr; int xs_seq = 0, xs_seq_gated = 0; bool xs_two_queues = false, xs_same_queue_now = false;
   bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
   bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
@@ -132,7 +134,9 @@ const char* const kKernelNames[K_COUNT] = {"k_begin", "k_hullinfo", "k_front", "
 bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bool in_graph = false, bool in_phase = false, int chain_pos = 0) {
   Dev d_ = c->d;
   if (!in_graph) d_.xs_async = 0;   // the asynchronous solve's tickets and flags belong to the single-GPU chain (begin -> k_grad -> k_xsolve -> k_ccd, every iteration); stage API and phases: plain
-  d_.xs_seq = 0;
+  d_.xs_seq = 0; d_.keep_seq = 0;
+  const bool keep2q = in_graph && c->keep_two_queues && !c->xs_same_queue_now && !c->use_graph;
+  if (!keep2q) d_.keep_async = 0;
   if (kid == K_GRAD && d_.xs_async && c->xs_two_queues && !c->xs_same_queue_now && !c->use_graph) d_.xs_seq = ++c->xs_seq;   // this k_grad opens the gate of its k_xsolve
   const Dev& d = d_;
   const int owned = d.u1 - d.u0;
@@ -164,7 +168,13 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       }
       if (d.xf) { if (c->xf_used[0]) (void)hipMemsetAsync(d.xf_seg, 0, (size_t)d.S * XF_SEG_STRIDE * sizeof(int), s); c->xf_used[0] = true; }
       if (d.xch && c->xch_wait_kernel) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 0);   // ranks sharing a device: the wait for the peers' control points is a launch of its own
+      if (keep2q) d_.keep_seq = ++c->keep_seq;   // this k_front opens the gate of the iteration's plane refinement (third queue)
       if (tri) TJ_LAUNCH((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else TJ_LAUNCH((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
+      if (keep2q) {
+        d_.keep_seq = 0;
+        TJ_LAUNCH(k_keep_gate, dim3(1), dim3(64), 0, c->stream3, d, c->keep_seq);
+        TJ_LAUNCH(k_keep, dim3(d.keep_waves), dim3(64), 0, c->stream3, d, 2);
+      }
       return true;
     case K_SEP_OBS: if (in_graph || in_phase) return false;  // stage API and sharded phase 0
       if (tri) TJ_LAUNCH((k_obs_query<3>), dim3(owned * d.S), dim3(64), 0, s, d); else TJ_LAUNCH((k_obs_query<1>), dim3(owned * d.S), dim3(64), 0, s, d);
@@ -179,7 +189,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; TJ_LAUNCH(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
     case K_KEEP:  // "optimal_plane":1 only; single UAV: a wave per segment, multi UAV: lanes over the switched-on pair slots
       if (!d.optimal_plane || (multi ? false : d.N == 0)) return false;
-      TJ_LAUNCH(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d); return true;
+      TJ_LAUNCH(k_keep, dim3(multi ? 1024 : owned * d.S), dim3(64), 0, s, d, keep2q ? 1 : 0); return true;   // (asynchronous refinement: the new pairs only)
     case K_SEP_SELF_COMPACT: if ((in_graph || in_phase) && c->grad_fold) return false;   // iteration chains (single GPU and sharded phases): folded into k_grad
       TJ_LAUNCH(k_sep_self_compact, dim3(owned * d.S), dim3(64), 0, s, d); return true;
     case K_GRAD:
@@ -310,6 +320,7 @@ int flush_deferred(tj_ctx* c) {
     if (qr_) return qr_;                                        \
     HIPCHK(c, hipStreamSynchronize((c)->stream));               \
     if ((c)->stream2) HIPCHK(c, hipStreamSynchronize((c)->stream2)); \
+    if ((c)->stream3) HIPCHK(c, hipStreamSynchronize((c)->stream3)); \
   } while (0)
 
 // Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two all-gathers), 3 = one full
@@ -613,6 +624,14 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       if (!ok) { (void)hipGetLastError(); c->stream2 = nullptr; }   // (the tickets and flags work on one queue as well)
       c->xs_two_queues = ok && getenv("TJ_XS_ONE_QUEUE") == nullptr;
     }
+    // asynchronous plane refinement ("optimal_plane":1, multi-UAV decoupled mode, one context; TJ_KEEP_ASYNC=0: k_keep stays one launch between k_mid and k_grad -- same bits)
+    d.keep_async = (d.optimal_plane && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && !c->split_unions) ? 1 : 0;
+    if (const char* e = getenv("TJ_KEEP_ASYNC")) d.keep_async = d.keep_async && atoi(e) != 0;
+    d.keep_waves = 1024;
+    if (d.keep_async) {
+      if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) == hipSuccess) c->keep_two_queues = true;
+      else { (void)hipGetLastError(); c->stream3 = nullptr; d.keep_async = 0; }
+    }
     if (const char* e = getenv("TJ_GRAD_BALANCE")) d.grad_bal = (atoi(e) != 0 && owned * d.P <= 65536) ? 1 : 0;   // launch-shape switch (same bits)
     d.ls_help = (d.ls_fast && p->mode != TJ_MODE_MULTI_COUPLED) ? std::max(1, std::min(LS_HELP_MAX, prop.multiProcessorCount / owned)) : 1;
     if (const char* e = getenv("TJ_LS_HELP")) {   // launch-shape switch (same bits); 1 = no helpers.  More blocks per robot than the compute units hold at once would leave helpers waiting for a
@@ -668,7 +687,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
       (r = dalloc(c, &d.grad_scr, (size_t)(d.u1 - d.u0) * P * 16 * (size_t)(d.cap_obs + d.cap_self))) ||
       (r = dalloc(c, &d.xs_scr, d.xs_band ? (size_t)(d.u1 - d.u0) * ((size_t)n * n + 4 * n) : 1)) ||
-      (r = dalloc(c, &d.xf_seg, 2 * S * XF_SEG_STRIDE)) || (r = dalloc(c, &d.xs_sync, (2 * U + 2) * 32))) return r;
+      (r = dalloc(c, &d.xf_seg, 2 * S * XF_SEG_STRIDE)) || (r = dalloc(c, &d.xs_sync, (2 * U + 2) * 32)) || (r = dalloc(c, &d.keep_sync, 17 * 32))) return r;
   if (d.optimal_plane) {
     const bool m0 = d.mode == 0;
     if ((r = dalloc(c, &d.kobs_id, m0 ? U * S * d.cap_obs : 1)) || (r = dalloc(c, &d.kobs_n, U * S)) || (r = dalloc(c, &d.kobs_cd, m0 ? U * S * d.cap_obs * 4 : 1)) ||
@@ -686,6 +705,7 @@ void tj_destroy(tj_ctx* c) {
   drop_graph(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   for (void* p : c->xch_ipc_opened) (void)hipIpcCloseMemHandle(p);
   if (c->xch_block) (void)hipFree(c->xch_block);
   for (void* p : c->allocs) hipFree(p);
