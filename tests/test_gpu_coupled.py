@@ -162,8 +162,18 @@ def test_coupled_chain_with_cache_units_changes_no_bit(pkg, scenes, monkeypatch)
     k_ccd_prep launches drop out of the chain: 10 -> 8 kernels per iteration); TJ_COUPLED_UNITS=0 launches the two kernels as before.  Same bits."""
     scene = dict(scenes.crossing(12, 4000, seed=23, name="crossing-U12-coupled"), mode=2)
     monkeypatch.delenv("TJ_COUPLED_UNITS", raising=False)
+    # the default since the second half of round 5: the Newton solve on a second queue next to k_grad (one gate launch more per iteration) -- same bits as the one-queue chain
+    monkeypatch.delenv("TJ_XS_ASYNC", raising=False)
+    e = pkg.Solver(scene, stop=0.0)
+    l0 = e.launch_count(); e.iterate(12); le = e.launch_count() - l0
+    se, te = e.get_state(), e.stats()
+    e.close()
+    monkeypatch.setenv("TJ_XS_ASYNC", "0")   # (the launch counts below are those of the one-queue chain)
     a = pkg.Solver(scene, stop=0.0)
     l0 = a.launch_count(); a.iterate(12); la = a.launch_count() - l0
+    for n in se:
+        assert np.array_equal(se[n], a.get_state()[n]), f"{n} differs between the asynchronous solve and the one-queue coupled chain"
+    assert te["error_bits"] == 0 and le == la + 12, (le, la)
     monkeypatch.setenv("TJ_COUPLED_UNITS", "0")
     b = pkg.Solver(scene, stop=0.0)
     l0 = b.launch_count(); b.iterate(12); lb = b.launch_count() - l0

@@ -660,16 +660,17 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
       blk_sync<true>();
       for (int i = tid; i < m; i += XS_THREADS) { scr[i] = y[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
       blk_sync<true>();
+      const bool wtc = D.xs_async != 0;   // asynchronous solve: k_ccd's units (other queue) read the record while this launch is still running
       double* dirc = D.dirp(u);
       for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
         const int row = idx % T, a = idx / T;
-        dirc[idx] = (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0;
+        xs_out(wtc, dirc + idx, (row >= 2 && row < T - 2) ? y[3 * (row - 2) + a] : 0.0);
       }
       if (tid == 0) {
-        D.wolfe(u) = esum(scr, m);
-        D.gn(u) = esum(scr + n, m);
-        D.tdir(u) = y[m];
-        D.xdir[(size_t)u * D.xs + 3 * T + 3] = g0[m];
+        xs_out(wtc, &D.wolfe(u), esum(scr, m));
+        xs_out(wtc, &D.gn(u), esum(scr + n, m));
+        xs_out(wtc, &D.tdir(u), y[m]);
+        xs_out(wtc, D.xdir + (size_t)u * D.xs + 3 * T + 3, g0[m]);
       }
       return;
     }

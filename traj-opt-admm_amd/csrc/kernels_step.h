@@ -919,7 +919,10 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
       for (int u0 = 0; u0 < D.U; u0 += 64) {
         const int nu = min(64, D.U - u0);
         __syncthreads();
-        if (lane < nu) { s_cp[0][lane] = D.xdir[(size_t)(u0 + lane) * D.xs + 3 * D.T + 3]; s_cp[1][lane] = D.wolfe(u0 + lane); }
+        if (lane < nu) {
+          const double* pg = D.xdir + (size_t)(u0 + lane) * D.xs + 3 * D.T + 3;
+          s_cp[0][lane] = D.xs_async ? xf_load(pg) : *pg; s_cp[1][lane] = D.xs_async ? xf_load(&D.wolfe(u0 + lane)) : D.wolfe(u0 + lane);   // (asynchronous solve: records of two robots share cache lines)
+        }
         __syncthreads();
         if (lane == 0) for (int j = 0; j < nu; j++) { gt += s_cp[0][j]; xg += s_cp[1][j]; }
       }
@@ -927,7 +930,7 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
         double gsum = 0;
         for (int u = 0; u < D.U; u++) gsum += M.gns[u];
         D.ctl->gnorm = sqrt(gsum + gt * gt) / double(D.U);
-        D.ctl->wolfe_c = -(xg + D.tdir(0) * gt);
+        D.ctl->wolfe_c = -(xg + (D.xs_async ? xf_load(&D.tdir(0)) : D.tdir(0)) * gt);
       }
     }
     __syncthreads();
