@@ -594,7 +594,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     d.grad_bal = (owned * d.P > d.num_cu && owned * d.P < 2 * d.num_cu) ? 1 : 0;
     // asynchronous Newton solve (dev_common.h, Dev::xs_async): one context, decoupled / single-UAV chain with the swept-hull tail in k_xsolve.  TJ_XS_ASYNC=0: the
     // solve stays a link of the one-queue chain (launch-shape switch: same bits)
-    d.xs_async = (p->world == 1 && !d.xs_band && (p->mode != TJ_MODE_MULTI_COUPLED ? d.fuse != 0 : (d.c2_fold && d.xf_all))) ? 1 : 0;   // (coupled chain: with the corner solve in k_xsolve and k_ccd's units building the records already)
+    d.xs_async = (p->world == 1 && !d.xs_band && (p->mode != TJ_MODE_MULTI_COUPLED ? d.fuse != 0 : (d.c2_fold && d.xf_all))) ? 1 : 0;   // (coupled chain: with the corner solve in k_xsolve and k_ccd's units building the records already;
+                                                                                                                                               //  sharded contexts keep the one-queue chain: tried in round 5, a tj_group of two ranks aborted -- not pursued)
     if (d.xs_async) {
       // Liveness: k_xsolve's blocks hold registers and LDS while they sleep on their tickets, and the k_grad blocks that hand the tickets out may still be waiting
       // for a compute unit.  Safe when the sleepers can never shut k_grad out: at most half as many robots as compute units (half the device stays free whatever
