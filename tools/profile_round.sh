@@ -19,6 +19,10 @@ DB=$(find $OUT/kt -name '*_results.db' | head -1)
 python3 $REPO/tools/rocpd_timeline.py "$DB" --csv $OUT/kernel_stats.csv --regime 303:20 > $OUT/timeline.txt 2>&1      # statistics over the TIMED window only (300 ramp + 3 warm-up iterations come first)
 python3 $REPO/tools/rocpd_timeline.py "$DB" --csv $OUT/kernel_stats_all_launches.csv > /dev/null 2>&1
 python3 $REPO/tools/rocpd_periter.py "$DB" --regime 303:20 > $OUT/per_iteration.txt 2>&1                               # one row per timed iteration, one column per kernel
+# Counter collection SERIALISES the dispatches of all queues -- in an order of its own: the gate kernel of the asynchronous solve can be held back behind the very k_grad it
+# waits for, and every wait then runs into its 2 s limit.  The counter passes therefore run the one-queue chain (TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0: same arithmetic, same bits;
+# per kernel the swept-hull records are then written by k_xsolve's tail instead of k_ccd's units).
+export TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o x -- python3 $REPO/bench.py $ARGS > $OUT/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o x -- python3 $REPO/bench.py $ARGS > $OUT/pw.log 2>&1
 F=$(find $OUT/pf -name '*_results.db' | head -1); W=$(find $OUT/pw -name '*_results.db' | head -1)
@@ -28,6 +32,15 @@ python3 $REPO/tools/pmc_traffic.py "$F" "$W" --scene "$SCENE" --command "python3
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY -d $OUT/ps -o x -- python3 $REPO/bench.py $ARGS > $OUT/ps.log 2>&1
 S=$(find $OUT/ps -name '*_results.db' | head -1)
 python3 $REPO/tools/pmc_sq.py "$S" --out $OUT/sq.json > $OUT/sq.txt 2>&1
+unset TJ_XS_ASYNC TJ_KEEP_ASYNC
+python3 - "$OUT/pmc.json" <<'PYEOF'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1])); d["note"] = (d.get("note") or "") + " | counter passes ran the one-queue chain (TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0): counter collection serialises dispatches across queues, which the asynchronous solve's gate does not survive; same arithmetic, the swept-hull records are written by k_xsolve there"
+    json.dump(d, open(sys.argv[1], "w"), indent=1)
+except Exception as e:
+    print("pmc.json not annotated:", e)
+PYEOF
 # 4. what one wave pays per instruction (the unit of bench.py's critical_path)
 hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Wno-unused-result -o $OUT/issue_probe $REPO/tools/micro/issue_probe.hip 2>/dev/null && $OUT/issue_probe > $OUT/issue_probe.txt 2>&1; rm -f $OUT/issue_probe
 hipcc -O3 --offload-arch=gfx950 -Wno-unused-result -o $OUT/mem_probe $REPO/tools/micro/mem_probe.hip 2>/dev/null && $OUT/mem_probe > $OUT/mem_probe.txt 2>&1; rm -f $OUT/mem_probe

@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <strings.h>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/trajadmm.h"
@@ -619,6 +621,11 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       }
       if (!(2 * owned <= d.num_cu || (owned <= d.num_cu && fits))) d.xs_async = 0;
     }
+    // rocprofv3's counter collection (--pmc) serialises the dispatches of ALL queues, in an order of its own: a gate held back behind the kernel it waits for would run every
+    // wait into its 2 s limit.  Under it the context keeps everything on the one queue (an explicit TJ_XS_ASYNC=1 / TJ_KEEP_ASYNC=1 overrides).
+    const char* cc_ = getenv("ROCPROF_COUNTER_COLLECTION");
+    const bool counters_on = cc_ && cc_[0] && strcmp(cc_, "0") != 0 && strcasecmp(cc_, "false") != 0;
+    if (counters_on && !getenv("TJ_XS_ASYNC")) d.xs_async = 0;
     if (const char* e = getenv("TJ_XS_ASYNC")) d.xs_async = d.xs_async && atoi(e) != 0;
     if (d.xs_async) {
       const bool ok = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
@@ -627,6 +634,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     }
     // asynchronous plane refinement ("optimal_plane":1, multi-UAV decoupled mode, one context; TJ_KEEP_ASYNC=0: k_keep stays one launch between k_mid and k_grad -- same bits)
     d.keep_async = (d.optimal_plane && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && !c->split_unions) ? 1 : 0;
+    if (counters_on && !getenv("TJ_KEEP_ASYNC")) d.keep_async = 0;
     if (const char* e = getenv("TJ_KEEP_ASYNC")) d.keep_async = d.keep_async && atoi(e) != 0;
     d.keep_waves = 1024;
     if (d.keep_async) {
