@@ -29,7 +29,12 @@ def main():
         if len(b_all) >= r0 + rc:
             lo = b_all[r0]; hi = b_all[r0 + rc] if len(b_all) > r0 + rc else len(rows)
             stat_rows = rows[lo:hi]
-            print(f"# statistics over iterations [{r0}, {r0 + rc}) of the run: {len(stat_rows)} launches, span {1e-3 * (stat_rows[-1][2] - stat_rows[0][1]):.1f} us = {1e-3 * (stat_rows[-1][2] - stat_rows[0][1]) / rc:.2f} us per iteration under the profiler")
+            ends = [r[2] for r in stat_rows if short(r[0]) in ("k_linesearch", "k_ls_coupled", "k_ls_commit")]   # an iteration ends with its line search (what follows the last one -- the batch's flush, copies, a gate already waiting for the next batch -- is not part of the window)
+            t_end = max(ends) if ends else stat_rows[-1][2]
+            print(f"# statistics over iterations [{r0}, {r0 + rc}) of the run: {len(stat_rows)} launches, span {1e-3 * (t_end - stat_rows[0][1]):.1f} us = {1e-3 * (t_end - stat_rows[0][1]) / rc:.2f} us per iteration under the profiler")
+            if any(short(r[0]) == "k_xs_gate" for r in stat_rows):
+                print("# asynchronous solve: k_xs_gate / k_xsolve run on a second queue; the gate's duration is one wave asleep until k_grad starts, k_xsolve's includes its blocks' sleep on the tickets,")
+                print("# k_ccd's the units' sleep on the robots' flags -- durations overlap and do not add up to the iteration (see the timeline below; TJ_XS_ASYNC=0: the one-queue chain)")
         else:
             print(f"# --regime {a.regime}: the run has only {len(b_all)} iterations; statistics over all launches")
     st = {}

@@ -707,14 +707,22 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
   TJ_TIC(D, K_XSOLVE, 4);
   for (int i = tid; i < n; i += XS_THREADS) { x0[i] = -x0[i]; scr[i] = 0; }
   blk_sync<true>();
-  for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
-  blk_sync<true>();
   const bool wt = D.xs_async != 0;
   double* dir = D.dirp(u);
   for (int idx = tid; idx < 3 * T; idx += XS_THREADS) {
     const int row = idx % T, a = idx / T;
     xs_out(wt, dir + idx, (row >= 2 && row < T - 2) ? x0[3 * (row - 2) + a] : 0.0);
   }
+  if (wt) {
+    // asynchronous solve: k_ccd's units of this robot wait for the DIRECTION only -- its flag goes up as soon as those stores are acknowledged; wolfe, |g| and the
+    // time direction (read by k_ccd's finisher after the count below, and by k_linesearch) follow
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("" ::: "memory");
+    if (tid == 0) __hip_atomic_store(D.xs_flag(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
+  blk_sync<true>();
   const double w_ = esum_wave(scr, n, tid), g_ = esum_wave(scr + n, n, tid);
   if (tid == 0) {
     xs_out(wt, &D.wolfe(u), -w_);
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
       __builtin_amdgcn_s_waitcnt(0);
       asm volatile("" ::: "memory");
       if (tid == 0) {
-        __hip_atomic_store(D.xs_flag(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(D.xs_flag(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (decoupled / single: raised earlier, right behind the direction)
         __hip_atomic_fetch_add(D.xs_done(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       TJ_TIC(D, K_XSOLVE, 6);
