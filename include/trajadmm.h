@@ -91,7 +91,14 @@ int tj_host_tables(int piece_num, int res, double* convert, double* mdyn, double
  *                                   TJ_ERR_NO_PROGRESS only where the reference would spin forever -- in all three modes since round 5 (the coupled search
  *                                   beyond 0.8^30 is continued by one block, tests/golden/coupled_long_kat.npz).  Exception: a SHARDED coupled context
  *                                   (world > 1) decides on the 31 steps its exchange carries and reports TJ_ERR_NO_PROGRESS (detail bit 32) beyond.
- *   cap_obs / cap_self / cap_pairs  list capacities of tj_params; an overflow is TJ_ERR_CAPACITY with the bit that says which. */
+ *   cap_obs / cap_self / cap_pairs  list capacities of tj_params; an overflow is TJ_ERR_CAPACITY with the bit that says which.
+ *   one process per GPU             one context (world == 1) of a fleet up to about one robot per compute unit enqueues its Newton solve on a SECOND stream of its
+ *                                   own, next to the gradient kernel, and "optimal_plane":1 its stored planes' refinement on a third: kernels of one
+ *                                   queue sleep on words kernels of the other write.  Streams of ONE process run side by side; two PROCESSES that both do this on one
+ *                                   GPU shut each other out (the device runs one process's waves at a time) until the 2 s limits of the waits fire:
+ *                                   TJ_ERR_NO_PROGRESS with error bit 2048 and a message that names the switch -- TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0 in the environment
+ *                                   of tj_create keep everything on the context's stream (same results bit for bit).  Under rocprofv3's counter collection
+ *                                   (which serialises dispatches across queues) the library does that by itself. */
 int tj_create(const tj_params* p, tj_ctx** out);
 void tj_destroy(tj_ctx* c);
 const char* tj_last_error(const tj_ctx* c);
@@ -133,7 +140,9 @@ int tj_iterate_async(tj_ctx* c, int n_iters);
 int tj_sync(tj_ctx* c);
 /* Stream the context enqueues on (hipStream_t as void*), for event timing by the caller. */
 void* tj_stream(tj_ctx* c);
-/* Enqueue on a caller-owned stream instead (e.g. the stream a collective library orders against). */
+/* Enqueue on a caller-owned stream instead (e.g. the stream a collective library orders against).  (The asynchronous solve's second stream, where it is
+ * in use, stays the context's own; whatever is enqueued on the caller's stream behind tj_iterate_async sees the iterations' results as on one stream --
+ * the chain's last kernels wait for the second stream's inside the kernels.) */
 int tj_set_stream(tj_ctx* c, void* hip_stream);
 /* Runs n_iters iterations with a hipEvent pair around EVERY KERNEL on the context's stream and
  * returns the summed device time per kernel in milliseconds (ms[tj_kernel_count()]) and how often each
