@@ -410,7 +410,6 @@ __device__ __forceinline__ bool xs_wait(const Dev& D, const int* w, int want) {
 }
 // asynchronous plane refinement (Dev::keep_async): every wave of the refinement launch (third queue) has left its planes?  Called by all threads of a block; uniform.
 __device__ __forceinline__ void keep_wait(const Dev& D) {
-  __shared__ int s_keep_ok;
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s (a refinement of thousands of rounds is legitimate: the reference spins on such planes as well)
@@ -422,7 +421,6 @@ __device__ __forceinline__ void keep_wait(const Dev& D) {
       if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
       __builtin_amdgcn_s_sleep(8);
     }
-    if (lane == 0) s_keep_ok = 1;
   }
   __syncthreads();
   asm volatile("" ::: "memory");

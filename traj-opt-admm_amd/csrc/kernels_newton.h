@@ -715,7 +715,8 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
   }
   if (wt) {
     // asynchronous solve: k_ccd's units of this robot wait for the DIRECTION only -- its flag goes up as soon as those stores are acknowledged; wolfe, |g| and the
-    // time direction (read by k_ccd's finisher after the count below, and by k_linesearch) follow
+    // time direction (read by k_ccd's finisher and by k_linesearch) follow and are counted (xs_done) -- k_ccd does not end before the count is full: its finisher
+    // waits for it, and so does every robot's unit of segment 0 when its walk is over (a single UAV's k_ccd has no finisher)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0);
     asm volatile("" ::: "memory");

@@ -305,6 +305,9 @@ __device__ __forceinline__ void ccd_obs_body(const Dev& D, int bid, double* lds,
     atomicAdd(&st[2], visits); atomicAdd(&st[3], (unsigned long long)found);
     if (found > 0) atomicAdd(&D.ccd_found[blockIdx.x & 63], found);
   }
+  // asynchronous solve: a robot's flag goes up behind its direction, a few stores (wolfe, |g|, the time direction) BEFORE its block is through -- this launch must not end
+  // before every block is: the unit of segment 0 looks at the count once its own work is done (it is full by then; the folded finisher waits for it as well)
+  if (D.xs_async && tr == 0) xs_wait<8>(D, D.xs_done(), D.u1 - D.u0);
 }
 
 template <int PRIM>
