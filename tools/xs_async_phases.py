@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Per-block phase stamps of the asynchronous Newton solve (development tool, GPU only): when k_grad's blocks end, when k_xsolve's blocks see their tickets, load,
+assemble, factor, solve and raise their flags, and what k_ccd's units do after the flag (flag seen, record built, signalled, walk) -- all on one time axis that starts
+with k_grad's first block.  Needs the timing build:  make -C traj-opt-admm_amd/csrc timing ;  python tools/xs_async_phases.py   (TJ_XS_ASYNC=0 python ...: the one-queue
+chain for comparison).  Output of round 5: profiles/round5_xs_async_phase_stamps.txt."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
