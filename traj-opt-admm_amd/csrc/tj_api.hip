@@ -44,7 +44,8 @@ struct tj_ctx {
   std::vector<void*> allocs;
   std::string err;
   bool have_cloud = false, have_state = false;
-  // asynchronous Newton solve (Dev::xs_async): k_xsolve goes to a second hardware queue, behind an event that k_mid's completion fires
+  // asynchronous Newton solve (Dev::xs_async): k_xsolve goes to a second hardware queue, behind a one-wave gate kernel that the iteration's k_grad opens (xs_seq: the
+  // sequence number of that pairing; xs_seq_gated: the last one a gate was launched for; xs_same_queue_now: tj_profile_kernels keeps everything on one queue)
   hipStream_t stream3 = nullptr; int keep_seq = 0; bool keep_two_queues = false;   // asynchronous plane refinement (Dev::keep_async)
   hipStream_t stream2 = nullptr; int xs_seq = 0, xs_seq_gated = 0; bool xs_two_queues = false, xs_same_queue_now = false;
   bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
@@ -417,7 +418,7 @@ int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
     if (h.error & ERR_CCD_STUCK) c->err += ": a CCD clamp found contact at every step (the state itself is in collision; the reference loops forever here)";
     if (h.error & ERR_SLACK_ARMIJO) c->err += ": the slack update's Armijo search";
     if (h.error & ERR_PLANE_REFINE) c->err += ": optimal_plane, a plane refinement did not terminate within its caps";
-    if (h.error & ERR_XS_TIMEOUT) c->err += ": NOT an infeasible state -- a wait between the two queues of the asynchronous Newton solve ran out after 2 s (GPU shared with other processes?); TJ_XS_ASYNC=0 keeps the solve on the chain's queue";
+    if (h.error & ERR_XS_TIMEOUT) c->err += ": NOT an infeasible state -- a wait between the queues of the context (asynchronous Newton solve / plane refinement) ran out after 2 s (GPU shared with other processes?); TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0 keep everything on the chain's queue";
     if (h.error & ERR_PASS_TIMEOUT) c->err += ": NOT an infeasible state -- a wave waiting for passed-on robot pairs timed out after 5 ms (GPU queue descheduled / shared with other processes); re-run the iteration or set TJ_PAIR_PASS_ON=0";
     return TJ_ERR_NO_PROGRESS;
   }
