@@ -138,7 +138,26 @@ __device__ inline double x_energy_group(const Dev& D, int u, const double* sm, c
   if (planes_in_lds) {
     // one (plane, hull point) term per lane and pass: a robot of the headline scene carries ~30 planes, so a lane per PLANE left
     // half the wave idle while the others took six logarithms one after the other
-    for (int it = gl; it < 6 * M; it += LS_GSIZE) {
+    // FOUR passes at a time while every lane has a term in each of them: a pass is a chain of two dependent LDS reads, a dot product and a logarithm (~0.5 us on its
+    // own), and a robot next to an obstacle slab walks 45 of them per candidate (config 5: 28 us per round of eight).  The four terms are formed side by side --
+    // an inactive one is +0.0, which changes no bit of the sum (x + 0.0 == x; the sums start at +0 and every term is positive) -- and added in pass order.
+    int pass = 0;
+    const int full = (6 * M) / LS_GSIZE;
+    for (; pass + 4 <= full; pass += 4) {
+      double t4[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int it = gl + LS_GSIZE * (pass + q);
+        const int ip = it / 6, j = it - 6 * ip, tr = pltr[ip];
+        const double* Pp = hulls + tr * 18 + 3 * j; const double* pl = pl_lds + 4 * ip;
+        const double d = Pp[0] * pl[0] + Pp[1] * pl[1] + Pp[2] * pl[2] + pl[3];
+        if (d <= 0) bad = 1;
+        const double b = barrier(wsg[tr], d, m);
+        t4[q] = (d > 0 && d < m) ? b : 0.0;
+      }
+      part += t4[0]; part += t4[1]; part += t4[2]; part += t4[3];
+    }
+    for (int it = gl + LS_GSIZE * pass; it < 6 * M; it += LS_GSIZE) {
       const int ip = it / 6, j = it - 6 * ip, tr = pltr[ip];
       const double* Pp = hulls + tr * 18 + 3 * j; const double* pl = pl_lds + 4 * ip;
       const double d = Pp[0] * pl[0] + Pp[1] * pl[1] + Pp[2] * pl[2] + pl[3];
