@@ -101,6 +101,7 @@ constexpr int LS_HELP_MAX = 8;                 // k_linesearch: at most this man
 constexpr int LS_TAB_STRIDE = 3 * LS_HELP_MAX * 2;   // Dev::ls_tab per robot: three rotating sets (super-round % 3) of LS_HELP_MAX blocks x 2 candidates
 constexpr unsigned LS_WORD_DONE = 0x7fffffffu;
 constexpr int LS_QUIET_ITERS = 8;
+constexpr int LS_NARROW_MIN_PLANES = 160;      // k_linesearch: a robot with at least this many planes evaluates a narrow first round (kernels_ls.h)
 constexpr unsigned long long LS_TAB_EMPTY = ~0ull;   // a NaN no evaluation produces (and a false "empty" only sends the primary to its own evaluation)
 constexpr int LSC_ROUNDS = 4;  // coupled Armijo search: rounds of 8 candidates evaluated per launch (steps 0.8^0 .. 0.8^30)
 

@@ -539,6 +539,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   const LsTeamUnits tu = ls_team_units(S, M);
   const bool team_ok = D.ls_fast && G == LS_GROUPS && in_lds && tu.total() * 64 <= 2 * S * 18;
   const bool coop = team_ok && H > 1;
+  // A robot with hundreds of planes (next to an obstacle slab; the team shape does not hold its terms) is not a latency chain here but the fp64 issue rate of its compute
+  // unit as well: a round of eight candidates takes it 57 us in the early iterations of config 5 (and ~30 later) where a round of TWO takes 29 (measured: ~20 us is one
+  // wave's chain of 45 passes, ~4.7 us every further candidate on the unit).  In the steady phase of a run -- every robot of the fleet accepted the full step in the previous
+  // iteration -- its FIRST round therefore evaluates only E(x) and the full step, the other waves idle at the barriers; if that fails, full rounds follow.  (Sizing the
+  // first round by the robot's own last exponent while the fleet still backs off was measured too: a wrong guess costs what a right one saves.)  Which candidates share a
+  // round changes no energy and not the order they are looked at in: same step.
+  const bool narrow = !team_ok && G == LS_GROUPS && M >= LS_NARROW_MIN_PLANES && hist == 0 && D.ctl->ls_quiet >= 1 && D.ls_fast;
+  int W = G;   // candidates of the current round
   double step = step0; int k_done = 0;                 // step = step0 * 0.8^k_done, kept across the rounds (each thread for the candidates of its team / group)
   bool commit_late = false;
   if (h > 0 && (!coop || D.ls_help_mute)) goto ticket;  // (uniform) a helper of a launch that searches in the one-wave shape: nothing to do  (ls_help_mute: test hook -- helpers
@@ -667,22 +675,26 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     }
     if (h > 0) goto ticket;
   }
-  for (int round = 0; k_acc < 0; round++, k_first += G) {
+  for (int round = 0; k_acc < 0; round++, k_first += W) {
+    W = (narrow && round == 0 && k_first < 0) ? hist + 2 : G;
+    const bool act = g < W;
     // candidate of this group: -1 = E(x), otherwise trial index k >= 0
     const int k = k_first + g;
-    for (; k_done < k; k_done++) step *= 0.8;          // same rounding as the reference's repeated step *= 0.8
+    if (act) for (; k_done < k; k_done++) step *= 0.8;          // same rounding as the reference's repeated step *= 0.8
     const double pt = k < 0 ? t0 : t0 + step * t_dir;
-    for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
+    if (act) for (int i = gl; i < 3 * T; i += LS_GSIZE) gnet[i] = k < 0 ? net[i] : net[i] + step * dir[i];
     __syncthreads();
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 3);
-    const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
+    double e = 0.0;
+    if (act) e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
+    else __syncthreads();   // (the function's one block barrier)
     if (round == 0) TJ_TIC(D, K_LINESEARCH, 4);
-    if (gl == 0 && !shadow) { res[g] = e; res[LS_GROUPS + g] = step; }
+    if (gl == 0 && !shadow && act) { res[g] = e; res[LS_GROUPS + g] = step; }
     if (tid == 0) s_accept = -1;
     __syncthreads();
     if (k_first < 0) e_base = res[0];
     if (tid == 0) {
-      for (int c = (k_first < 0 ? 1 : 0); c < G; c++) {
+      for (int c = (k_first < 0 ? 1 : 0); c < W; c++) {
         const double st = res[LS_GROUPS + c];
         if (!(e_base - 1e-4 * wolfe * st < res[c])) { s_accept = c; break; }
       }
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
       wg = acc;
       const double* win = sm + L.gnet + (size_t)acc * 3 * T;
       for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
-    } else if (k_first + G - 1 >= STEP_CAP) {
+    } else if (W == G && k_first + G - 1 >= STEP_CAP) {
       // no acceptable step although step *= 0.8 has reached its fixed point (every further candidate is this one again): the
       // reference's loop would never end (Optimization3D_multi.h:792).  Take the last candidate and report.
       if (tid == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP);
