@@ -386,3 +386,46 @@ def test_launch_shape_switches_change_no_bit(pkg, scenes, monkeypatch, env):
         assert np.array_equal(sa[n], sb[n]), f"{n} differs with {env}"
     assert a.stats()["error_bits"] == 0 and b.stats()["error_bits"] == 0
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_narrow_first_round_of_plane_heavy_robots_changes_no_bit(pkg, scenes, monkeypatch):
+    """config 5 (256 UAVs x 1 M triangles): the two robots next to the obstacle slabs carry hundreds of planes -- too many terms for the team shape -- and, once the fleet is
+    in its steady phase (every robot took the full step in the previous iteration: from iteration 13 on here), evaluate a NARROW first round (E(x) and the full step, six
+    waves idle at the barriers) instead of eight candidates side by side.  TJ_LS_FAST=0 switches that (and the team shape) off: 18 iterations, same state bit for bit, same
+    number of energy evaluations."""
+    scene = scenes.scn_d_tri()
+    monkeypatch.delenv("TJ_LS_FAST", raising=False)
+    a = pkg.Solver(scene, stop=0.0)
+    a.iterate_async(18); a.sync()
+    sa, ta = a.get_state(), a.stats()
+    a.close()
+    monkeypatch.setenv("TJ_LS_FAST", "0")
+    b = pkg.Solver(scene, stop=0.0)
+    b.iterate_async(18); b.sync()
+    sb, tb = b.get_state(), b.stats()
+    b.close()
+    monkeypatch.delenv("TJ_LS_FAST")
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), n
+    assert ta["error_bits"] == 0 and tb["error_bits"] == 0 and ta["energy_evals"] == tb["energy_evals"]
+
+
+@pytest.mark.gpu
+def test_counter_collection_keeps_the_one_queue_chain(pkg, scenes, monkeypatch):
+    """rocprofv3 --pmc serialises the dispatches of all queues (in an order of its own): a context created under it (the profiler exports ROCPROF_COUNTER_COLLECTION) keeps
+    the Newton solve on the chain's queue -- no gate launch -- unless TJ_XS_ASYNC=1 says otherwise; results are the same either way."""
+    scene = scenes.crossing(8, 4000, seed=3, name="crossing-U8-counters")
+    for k in ("TJ_XS_ASYNC", "ROCPROF_COUNTER_COLLECTION"):
+        monkeypatch.delenv(k, raising=False)
+    a = pkg.Solver(scene, stop=0.0)
+    l0 = a.launch_count(); a.iterate_async(10); a.sync(); la = a.launch_count() - l0
+    sa = a.get_state(); a.close()
+    monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
+    b = pkg.Solver(scene, stop=0.0)
+    l0 = b.launch_count(); b.iterate_async(10); b.sync(); lb = b.launch_count() - l0
+    sb = b.get_state(); b.close()
+    monkeypatch.delenv("ROCPROF_COUNTER_COLLECTION")
+    assert la == lb + 10, (la, lb)
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), n
