@@ -299,6 +299,7 @@ def test_asynchronous_newton_solve_changes_no_bit(pkg, scenes, monkeypatch, scen
     scene = {"scn_c": scenes.scn_c, "scn_a": scenes.scn_a, "hard": lambda: scenes.hard(8, 8000)}[scene_name]()   # hard: robots that meet -- CCD candidates, acting pairs, the replay
     for k in ("TJ_XS_ASYNC", "TJ_XS_ONE_QUEUE"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TJ_FRONT_ASYNC", "0")   # (round 6's asynchronous front rides on the second queue too and has a gate of its own: its test is below)
     n_it = 60
     a = pkg.Solver(scene, stop=0.0)
     l0 = a.launch_count(); a.iterate_async(n_it); a.sync(); la = a.launch_count() - l0
@@ -315,6 +316,43 @@ def test_asynchronous_newton_solve_changes_no_bit(pkg, scenes, monkeypatch, scen
     assert ta["error_bits"] == 0 and tb["error_bits"] == 0
     assert ta["energy_evals"] == tb["energy_evals"]
     assert la == lb + n_it, f"expected one gate launch per iteration on top of the chain ({lb} launches): {la}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["scn_c", "scn_b", "hard", "fleet100"])
+def test_asynchronous_front_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
+    """Round 6: inside a batch the NEXT iteration's k_front runs on the second hardware queue next to k_linesearch (residency gate, per-robot commit flags behind the
+    written-through control nets, units that form and publish the hull records, done counters), and -- where k_front's whole grid is resident at once -- k_mid starts while
+    k_front still runs and waits for it in its solve waves (watcher block, go words, reads past the caches).  Against TJ_FRONT_ASYNC=0 (k_linesearch publishes the hull cache,
+    k_front follows on the chain's queue) and against TJ_FRONT_ASYNC_MID=0 (k_linesearch waits for k_front's end): the same state bit for bit over 60 iterations in batches of
+    uneven length, no error bit, the same number of energy evaluations; the launch count shows the gate (one per pairing = per iteration that has a successor in its batch).
+    fleet100: 100 robots -- one k_linesearch block per robot, k_front's grid too large to be resident at once (k_mid follows plainly)."""
+    scene = {"scn_c": scenes.scn_c, "scn_b": scenes.scn_b, "hard": lambda: scenes.hard(8, 8000), "fleet100": lambda: scenes.crossing(100, 20000, seed=121)}[scene_name]()
+    for k in ("TJ_XS_ASYNC", "TJ_XS_ONE_QUEUE", "TJ_FRONT_ASYNC", "TJ_FRONT_ASYNC_MID"):
+        monkeypatch.delenv(k, raising=False)
+    batches = (1, 7, 20, 2, 30)
+    def run():
+        s = pkg.Solver(scene, stop=0.0)
+        l0 = s.launch_count()
+        for b in batches:
+            s.iterate_async(b); s.sync()
+        n = s.launch_count() - l0
+        st, ts = s.get_state(), s.stats()
+        s.close()
+        return st, ts, n
+    sa, ta, la = run()
+    monkeypatch.setenv("TJ_FRONT_ASYNC_MID", "0")
+    sm, tm, lm = run()
+    monkeypatch.delenv("TJ_FRONT_ASYNC_MID")
+    monkeypatch.setenv("TJ_FRONT_ASYNC", "0")
+    sb, tb, lb = run()
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), f"{n} differs between the asynchronous front and the one-queue front"
+        assert np.array_equal(sm[n], sb[n]), f"{n} differs between the asynchronous front (k_linesearch waits for its end) and the one-queue front"
+    assert ta["error_bits"] == 0 and tm["error_bits"] == 0 and tb["error_bits"] == 0
+    assert ta["energy_evals"] == tb["energy_evals"] == tm["energy_evals"]
+    pairings = sum(b - 1 for b in batches)
+    assert la == lb + pairings and lm == lb + pairings, f"expected one gate launch per pairing ({pairings}) on top of {lb} launches: {la}, {lm}"
 
 
 @pytest.mark.gpu
@@ -414,7 +452,8 @@ def test_narrow_first_round_of_plane_heavy_robots_changes_no_bit(pkg, scenes, mo
 @pytest.mark.gpu
 def test_counter_collection_keeps_the_one_queue_chain(pkg, scenes, monkeypatch):
     """rocprofv3 --pmc serialises the dispatches of all queues (in an order of its own): a context created under it (the profiler exports ROCPROF_COUNTER_COLLECTION) keeps
-    the Newton solve on the chain's queue -- no gate launch -- unless TJ_XS_ASYNC=1 says otherwise; results are the same either way."""
+    the Newton solve -- and with it the asynchronous front, which rides on the same second queue -- on the chain's queue: no gate launches, unless TJ_XS_ASYNC=1 says
+    otherwise; results are the same either way."""
     scene = scenes.crossing(8, 4000, seed=3, name="crossing-U8-counters")
     for k in ("TJ_XS_ASYNC", "ROCPROF_COUNTER_COLLECTION"):
         monkeypatch.delenv(k, raising=False)
@@ -426,6 +465,6 @@ def test_counter_collection_keeps_the_one_queue_chain(pkg, scenes, monkeypatch):
     l0 = b.launch_count(); b.iterate_async(10); b.sync(); lb = b.launch_count() - l0
     sb = b.get_state(); b.close()
     monkeypatch.delenv("ROCPROF_COUNTER_COLLECTION")
-    assert la == lb + 10, (la, lb)
+    assert la == lb + 10 + 9, (la, lb)   # without counters: one gate per iteration for the solve + one per pairing k_linesearch(i) / k_front(i + 1) of the batch for the asynchronous front (round 6)
     for n in sa:
         assert np.array_equal(sa[n], sb[n]), n

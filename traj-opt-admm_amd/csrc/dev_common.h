@@ -157,7 +157,7 @@ struct Dev {
   int xf_all;                    // coupled mode, one context: nobody publishes a hull / swept-hull cache there (one block commits every robot, the direction comes from k_xsolve_c2),
                                  // so the obstacle units of k_front / k_ccd -- one per (robot, segment) -- publish that record themselves (write-through + the segment's counter) before
                                  // they walk, and the k_hullinfo / k_ccd_prep launches drop out of the chain
-  __host__ __device__ int xf_want() const { return (xf_all || xs_async) ? U : U - (u1 - u0); }                           // robots the units cover (= units per segment)
+  __host__ __device__ int xf_want() const { return (xf_all || xs_async || fa) ? U : U - (u1 - u0); }                           // robots the units cover (= units per segment)
   __host__ __device__ int xf_units() const { return (xf && !xf_all) ? xf_want() * S : 0; }   // extra one-wave units in the grid (xf_all: the obstacle units of k_front / k_ccd publish their own robot's record instead)
   __host__ __device__ int xf_robot(int i) const { return xf_all ? i : (i < u0 ? i : i + (u1 - u0)); }
   int xch, xch_poll;             // xch_poll = 1: the foreign units poll the arrival counters themselves; 0: a k_xch_wait launch in front of the kernel has (ranks sharing a device)
@@ -191,6 +191,32 @@ struct Dev {
   // counters.  keep_sync: ints [16][32] counters (zeroed by begin_body) | [32] go word.
   int keep_async, keep_seq, keep_waves; int* keep_sync;
   __host__ __device__ int* keep_go() const { return keep_sync + 16 * 32; }
+  // ASYNCHRONOUS FRONT (round 6; one context, decoupled mode, every k_linesearch block resident at once): the NEXT iteration's k_front runs on the second
+  // hardware queue next to this iteration's k_linesearch.  Its launch is held back by a one-wave gate (k_fa_gate) until every block of k_linesearch has
+  // started (residency counters: all of them are resident then, so a k_front block that sleeps on a flag can never keep a k_linesearch block off a compute
+  // unit); the primary block of robot u stores the accepted control net written through and raises the robot's COMMIT FLAG; k_front's obstacle unit of
+  // (u, segment) prefetches what does not depend on the net, waits for the flag, forms hull / box / k-DOP intervals itself (the expressions of k_hullinfo:
+  // same bits), publishes the record written through and counts itself on the segment's completion counter (xf_seg, kind 0) -- the pair tiles of the
+  // launch wait for that count, a GJK head start for its two robots' flags.  k_linesearch no longer writes a hull cache at all (Dev::fa: 976 B x S per robot
+  // and launch).  Everything k_front leaves for later kernels goes out written through and every block counts itself done behind its acknowledged stores;
+  // the LAST block of k_linesearch -- the one that begins the next iteration -- waits for that count, so k_linesearch does not end before k_front has: k_mid
+  // follows on the first queue as before, and the two kernel boundaries k_linesearch -> k_front -> k_mid become one.
+  //   fa      context switch: k_front's units build and publish the hull records (with or without the second queue), k_linesearch publishes none
+  //   fa_seq  > 0: THIS launch is part of pairing number fa_seq (k_linesearch(i) <-> k_front(i + 1) [<-> k_mid(i + 1)]); all words below are monotonic in it -- nothing is reset
+  //   fa_mid  (with fa_seq; grids of k_front that are resident all at once next to the last k_linesearch block): k_linesearch only waits until every k_front block has
+  //           STARTED -- so that k_mid's waves, which then follow at once, can never keep a k_front block off the device -- and k_mid<FA> waits for k_front's end ITSELF: its
+  //           first block (the watcher) polls the done counters and raises 64 go words, the pair / obstacle solve waves sleep on one of them and then read what k_front
+  //           left past the caches; the slack blocks need nothing of k_front and start at once.  The second boundary (k_linesearch -> k_mid) then overlaps k_front's tail.
+  //   fa_sync ints, a 128-byte line per word: [16] k_linesearch blocks started | [16] k_front blocks done | [16] k_front blocks started | [64] go words of k_mid |
+  //           [U] commit flags | record {-, epoch, done} of the begun iteration
+  int fa, fa_seq, fa_mid, fa_nls, fa_nfront; int* fa_sync;
+  __host__ __device__ int* fa_res(int i) const { return fa_sync + (size_t)(i & 15) * 32; }
+  __host__ __device__ int* fa_fdone(int i) const { return fa_sync + (size_t)(16 + (i & 15)) * 32; }
+  __host__ __device__ int* fa_fstart(int i) const { return fa_sync + (size_t)(32 + (i & 15)) * 32; }
+  __host__ __device__ int* fa_go(int i) const { return fa_sync + (size_t)(48 + (i & 63)) * 32; }
+  __host__ __device__ int* fa_commit(int u) const { return fa_sync + (size_t)(112 + u) * 32; }
+  __host__ __device__ int* fa_rec() const { return fa_sync + (size_t)(112 + U) * 32; }
+  __host__ __device__ static size_t fa_sync_ints(int U_) { return (size_t)(113 + U_) * 32; }
   int xs_band;  // long trajectories (piece_num > 10): the Newton solve runs on band storage (k_xsolve_band) and the swept-hull
                 // cache comes from k_ccd_prep again
   int seq_tree; // k_ccd_self_seq has LDS for the reference's per-segment dynamic tree (dev_dyntree.h)
@@ -426,6 +452,38 @@ __device__ __forceinline__ void keep_wait(const Dev& D) {
   __syncthreads();
   asm volatile("" ::: "memory");
 }
+// asynchronous front (Dev::fa_seq): the sixteen words at `base` (a 128-byte line each) sum to at least `want`?  One wave, uniform; false = timed out (error bit set).
+__device__ __forceinline__ bool fa_wait16(const Dev& D, const int* base, int want) {
+  const int lane = threadIdx.x & 63;
+  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+  for (;;) {
+    int v = lane < 16 ? __hip_atomic_load(base + (size_t)lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = __shfl(v, 0);
+    if (v - want >= 0) { asm volatile("" ::: "memory"); return true; }
+    if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return false; }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+// ... one word has reached `want` (a robot's commit flag)
+__device__ __forceinline__ bool fa_wait_flag(const Dev& D, const int* w, int want) {
+  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0) { asm volatile("" ::: "memory"); return true; }
+  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(4);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0) { asm volatile("" ::: "memory"); return true; }
+    if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return false; }
+  }
+}
+// a block's stores (write-through) have been acknowledged -> it counts itself on one of sixteen words (fire and forget)
+__device__ __forceinline__ void fa_count(int* w) {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0);
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xf_store_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int xf_load_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // a value that a kernel running at the same time on the other queue will read: written through when the solve is asynchronous
 __device__ __forceinline__ void xs_out(bool wt, double* p, double v) { if (wt) xf_store(p, v); else *p = v; }
 

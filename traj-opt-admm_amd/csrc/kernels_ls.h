@@ -438,7 +438,9 @@ __device__ __forceinline__ void ls_publish_hullinfo(const Dev& D, int u, const d
 // quiet: 1 = every robot accepted the full step (exponent 0) in the line search that has just ended (k_linesearch's tickets carry the information; the
 // standalone k_begin, which follows no line search of its batch, says 0): Ctl::ls_quiet counts such iterations in a row, and k_linesearch sends its helper
 // blocks home while the count stands at LS_QUIET_ITERS or more.
-__device__ __forceinline__ bool begin_body(const Dev& D, int quiet = 0) {   // returns whether the stop test has fired
+// fa_started (asynchronous front, Dev::fa_seq): the iteration's k_front is already running on the other queue -- what IT counts with (the work-list counters, the hull
+// records' completion counters) was reset by fa_early_begin before it was launched and is left alone here.
+__device__ __forceinline__ bool begin_body(const Dev& D, int quiet = 0, bool fa_started = false) {   // returns whether the stop test has fired
   // stop test of the mains: iter>1 && gnorm<stop (Main/multiPathPlanning3D.cpp:633)
   __shared__ int done;
   if (threadIdx.x == 0) {
@@ -456,22 +458,52 @@ __device__ __forceinline__ bool begin_body(const Dev& D, int quiet = 0) {   // r
   __syncthreads();
   if (done) return true;
   for (int i = threadIdx.x; i < D.U; i += blockDim.x) { D.k_obs[i] = 0; D.k_self[i] = 0; }
-  if (D.multi()) for (int i = threadIdx.x; i <= D.S; i += blockDim.x) D.pair_work_n[i] = 0;   // per-segment counts, [S] = cursor of the pair-solve waves
-  if (threadIdx.x == 0) *D.obs_work_n = 0;
+  if (D.multi() && !fa_started) for (int i = threadIdx.x; i <= D.S; i += blockDim.x) D.pair_work_n[i] = 0;   // per-segment counts, [S] = cursor of the pair-solve waves
+  if (threadIdx.x == 0 && !fa_started) *D.obs_work_n = 0;
   if (threadIdx.x < 3 && D.multi()) D.pair_ovf[threadIdx.x] = 0;
   if (threadIdx.x < 16) D.ctl->ccd_sub[threadIdx.x] = 0;   // arrival counters of k_ccd's selection blocks (folded pair replay)
   if (threadIdx.x == 0) D.ctl->c2_cnt = 0;
   if (D.xs_sync) for (int i = threadIdx.x; i <= 2 * D.U; i += blockDim.x) D.xs_sync[(size_t)i * 32] = 0;   // tickets, flags and the count of the asynchronous Newton solve
-  if (D.xf || D.xs_async) for (int i = threadIdx.x; i < 2 * D.S; i += blockDim.x) D.xf_seg[(size_t)i * XF_SEG_STRIDE] = 0;   // ... and of the foreign-robot units of k_front / k_ccd (sharded contexts)
+  if (D.xf || D.xs_async) for (int i = threadIdx.x + (fa_started ? D.S : 0); i < 2 * D.S; i += blockDim.x) D.xf_seg[(size_t)i * XF_SEG_STRIDE] = 0;   // ... and of the foreign-robot units of k_front / k_ccd (sharded contexts)
   if (D.ls_help > 1) for (int i = threadIdx.x; i < (D.u1 - D.u0) * LS_TAB_STRIDE; i += blockDim.x) ((unsigned long long*)D.ls_tab)[(size_t)D.u0 * LS_TAB_STRIDE + i] = LS_TAB_EMPTY;   // k_linesearch's helper posts
   if (D.keep_sync && threadIdx.x < 16) D.keep_sync[threadIdx.x * 32] = 0;   // completion counters of the asynchronous plane refinement
   if (threadIdx.x == 0 && D.optimal_plane && D.multi()) D.kpair_n[1] = D.kpair_n[0];  // planes stored before this iteration (k_keep part 2)
   return false;
 }
 
+// Asynchronous front (Dev::fa_seq > 0): what the NEXT iteration's k_front needs of its begin, by one block of k_linesearch at its very start -- before that
+// block counts itself started, hence before the gate in front of k_front opens.  The stop test's inputs (iter, pending, gnorm: left by k_ccd) do not change
+// while k_linesearch runs, so the decision is the one begin_body takes at the kernel's end; the control block itself is not touched (the blocks of this
+// launch still read it).  Record: [1] epoch of the iteration k_front works for, [2] its stop flag.  What k_front counts with is zeroed here (consumed by
+// k_mid of the running iteration, long finished): work-list counters and the hull records' completion counters.  Everything written through and waited for.
+__device__ __forceinline__ void fa_early_begin(const Dev& D) {
+  __shared__ int s_fdone;
+  if (threadIdx.x == 0) {
+    const Ctl h = *D.ctl;
+    const int iter = h.iter + (h.pending ? 1 : 0);
+    const int done = (h.done || (D.stop > 0 && iter > 1 && h.gnorm < D.stop)) ? 1 : 0;
+    xf_store_i(D.fa_rec() + 1, done ? h.epoch : h.epoch + 1); xf_store_i(D.fa_rec() + 2, done);
+    s_fdone = done;
+  }
+  __syncthreads();
+  if (!s_fdone) {
+    if (D.multi()) for (int i = threadIdx.x; i <= D.S; i += blockDim.x) xf_store_i(D.pair_work_n + i, 0);
+    if (threadIdx.x == 0) xf_store_i(D.obs_work_n, 0);
+    for (int i = threadIdx.x; i < D.S; i += blockDim.x) xf_store_i(D.xf_seg + (size_t)i * XF_SEG_STRIDE, 0);
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  asm volatile("" ::: "memory");
+}
+
 // begin_next = 1: the last block to finish also starts the NEXT iteration (begin_body): the stop test and the counter resets
 // need every block of this kernel to be done, which the ticket establishes; the host then omits the k_begin launch.
 __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, int begin_next) {
+  if (D.fa_seq > 0) {   // asynchronous front: the early begin (last block of the grid: a helper where there are helpers), then every block counts itself started
+    if (blockIdx.x == gridDim.x - 1) fa_early_begin(D);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(D.fa_res(blockIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (TJ_DONE(D)) {
     // converged: the only begin work left for the next iteration is to retire the slack/dual update that k_mid has just paid
     if (begin_next && blockIdx.x == 0 && threadIdx.x == 0) { D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0; }
@@ -709,7 +741,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
       // commit: the accepting group's trial net is the new control net
       wg = acc;
       const double* win = sm + L.gnet + (size_t)acc * 3 * T;
-      for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+      if (D.fa_seq > 0) commit_late = true;   // asynchronous front: one commit site (below), written through and followed by the robot's flag
+      else for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
     } else if (W == G && k_first + G - 1 >= STEP_CAP) {
       // no acceptable step although step *= 0.8 has reached its fixed point (every further candidate is this one again): the
       // reference's loop would never end (Optimization3D_multi.h:792).  Take the last candidate and report.
@@ -720,11 +753,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
       evals = 2 + k_acc;
       wg = G - 1;
       const double* win = sm + L.gnet + (size_t)(G - 1) * 3 * T;
-      for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+      if (D.fa_seq > 0) commit_late = true;
+      else for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
     }
     __syncthreads();
   }
-  if (D.fuse && D.multi()) {
+  if (D.fuse && D.multi() && !D.fa) {   // (Dev::fa: the next k_front's units form the records themselves, from the committed control net; written through from here the
+                                          //  40 KB per robot put ~4 us in front of every commit flag -- measured)
     double* wh = sm + L.ghull + (size_t)wg * S * 18;
     if (L.affine) {   // the published hulls are exactly basis * (accepted control net), like k_hullinfo's
       const double* win = sm + L.gnet + (size_t)wg * 3 * T;
@@ -737,7 +772,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   if (commit_late) {   // (uniform) accepted in a team round: commit now -- with helpers about, wave 0's DONE word must have been performed before the first of these stores is issued
     if (H > 1) { asm volatile("" ::: "memory"); if (tid < 64) __builtin_amdgcn_s_waitcnt(0); __syncthreads(); asm volatile("" ::: "memory"); }   // (s_waitcnt vmcnt(0): wave 0's DONE store has been acknowledged; the barrier hands that to the other waves; the compiler keeps the commit stores below)
     const double* win = sm + L.gnet + (size_t)wg * 3 * T;
-    for (int i = tid; i < 3 * T; i += LS_THREADS) gspline[i] = win[i];
+    for (int i = tid; i < 3 * T; i += LS_THREADS) xs_out(D.fa_seq > 0, gspline + i, win[i]);
+  }
+  if (D.fa_seq > 0) {   // (uniform) asynchronous front: the control net is out (written through) and acknowledged -> the robot's commit flag; k_front's units on the other queue wait for it
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    if (tid == 0) __hip_atomic_store(D.fa_commit(u), D.fa_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; D.ls_hist[u] = k_acc; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)evals; }   // per robot: one writer, no atomic in front of the ticket
@@ -761,7 +803,11 @@ ticket:
     __syncthreads();
     if (s_last) {
       if (tid == 0) D.ctl->ticket = 0;
-      begin_body(D, s_last == 1);
+      begin_body(D, s_last == 1, D.fa_seq > 0);
+      // asynchronous front: this launch does not end before the k_front it feeds has -- every block of it has counted itself done behind its acknowledged
+      // (write-through) stores; k_mid, next on this queue, then finds everything in memory
+      // (Dev::fa_mid: k_mid waits for k_front's end itself; here only until every k_front block has STARTED, i.e. is resident -- k_mid's waves cannot shut one out then)
+      if (D.fa_seq > 0 && tid < 64) fa_wait16(D, D.fa_mid ? D.fa_fstart(0) : D.fa_fdone(0), (int)((unsigned)D.fa_seq * (unsigned)D.fa_nfront));
     }
   }
   TJ_TIC(D, K_LINESEARCH, 6);

@@ -228,6 +228,7 @@ __device__ __forceinline__ double grad_plane_batch(const Dev& D, double* pcb, do
 //                positions [C, n)  <- ranks [n - L, n)        (the cheapest: late, and ~20 % slower for it)
 //   otherwise    position = rank (longest first; the host only switches the order on in the case above, TJ_GRAD_BALANCE=1 forces it)
 constexpr int GRAD_ORDER_CHUNK = 2048;   // costs staged per pass (ints; the one-wave block's LDS buffer holds at least that many)
+template <bool FA = false>   // FA (asynchronous front): the permutation goes out written through
 __device__ __forceinline__ void grad_order_body(const Dev& D, int blk, int* cs) {
   const int n = (D.u1 - D.u0) * D.P, C = D.num_cu, lane = (int)(threadIdx.x & 63), i = blk * 64 + lane;
   const int ci = i < n ? D.grad_cost[i] : 0;
@@ -243,7 +244,7 @@ __device__ __forceinline__ void grad_order_body(const Dev& D, int blk, int* cs) 
   if (i >= n) return;
   int pos = r;
   if (n > C && n < 2 * C) { const int L = n - C; pos = r < n - 2 * L ? L + r : (r < n - L ? r - (n - 2 * L) : r - (n - L) + C); }
-  D.grad_perm[pos] = i;
+  if constexpr (FA) xf_store_i(D.grad_perm + pos, i); else D.grad_perm[pos] = i;
 }
 
 // FOLD: the block first turns the stamped candidate / partner slots of ITS OWN segments into plane lists (the work of

@@ -89,12 +89,13 @@ constexpr int PAIR_TILE_CAP = PAIR_ROWS_MAX * 64;
 // the plane stage of k_front was bound by that, not by its work.  Consumers index the concatenation: wprefix() leaves the
 // exclusive prefix of the (clamped) counts in LDS, wslot() maps an item number to its slot.
 __device__ __forceinline__ int pair_work_cap_seg(const Dev& D) { return D.cap_work / D.S; }
+template <bool FA = false>   // FA: the counts were written while this launch was running (asynchronous front, Dev::fa_mid): read past the caches
 __device__ __forceinline__ int pair_work_prefix(const Dev& D, int* pre, int lane) {   // one wave; pre[0..S]; returns the total
   const int S = D.S, cap = pair_work_cap_seg(D);
   int run = 0;
   for (int base = 0; base < S; base += 64) {
     const int tr = base + lane;
-    const int c = tr < S ? min(D.pair_work_n[tr], cap) : 0;
+    const int c = tr < S ? min(FA ? xf_load_i(D.pair_work_n + tr) : D.pair_work_n[tr], cap) : 0;
     int x = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
@@ -119,15 +120,16 @@ __device__ __forceinline__ int pair_work_slot(const Dev& D, const int* pre, int 
 // forms (CCD.h:535-587), hence the same decisions.  Returns the number of pairs left in list[].
 //   segbox  [6][U] lo.xyz, hi.xyz of every robot for this segment      rec(q) -> robot q's record, intervals lo at LO, hi at HI
 //   [own0, own1): robots of this rank -- a pair is skipped unless it touches one (sharded contexts; pass 0, U otherwise)
-template <class RecOf>
+template <bool FA = false, class RecOf>   // FA (asynchronous front): boxes and records were written (through) by blocks of a kernel that runs at the same time -- read past the caches
 __device__ __forceinline__ int pair_tile_filter(const double* segbox, int U, int rb, int R, int cb, int own0, int own1, RecOf rec, int LO, int HI, double d,
                                                 double* rowbox, int* list, int lane) {
-  for (int i = lane; i < R * 6; i += 64) rowbox[i] = segbox[(size_t)(i % 6) * U + min(rb + i / 6, U - 1)];
+  auto ldd = [&](const double* p) { if constexpr (FA) return xf_load(p); else return *p; };
+  for (int i = lane; i < R * 6; i += 64) rowbox[i] = ldd(segbox + (size_t)(i % 6) * U + min(rb + i / 6, U - 1));
   const int p1 = cb + lane;
   const int pc = min(p1, U - 1);
   double bv[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) bv[k] = segbox[(size_t)k * U + pc];   // independent loads, no branch between them
+  for (int k = 0; k < 6; k++) bv[k] = ldd(segbox + (size_t)k * U + pc);   // independent loads, no branch between them
   const bool own1p = p1 >= own0 && p1 < own1;
   blk_sync<true>();
   int n = 0;
@@ -152,7 +154,7 @@ __device__ __forceinline__ int pair_tile_filter(const double* segbox, int U, int
 #pragma unroll
     for (int c = 0; c < PT_FLIGHT; c++) {
       const double* a = rec(pr[c] >> 16); const double* b = rec(pr[c] & 0xffff);
-      alo[c] = a[LO + ax]; ahi[c] = a[HI + ax]; blo[c] = b[LO + ax]; bhi[c] = b[HI + ax];
+      alo[c] = ldd(a + LO + ax); ahi[c] = ldd(a + HI + ax); blo[c] = ldd(b + LO + ax); bhi[c] = ldd(b + HI + ax);
     }
     blk_sync<true>();   // every lane has read this batch's list entries before the compaction overwrites earlier slots
 #pragma unroll
@@ -170,6 +172,7 @@ __device__ __forceinline__ int pair_tile_filter(const double* segbox, int U, int
 }
 
 constexpr int PAIR_LDS_DOUBLES = PAIR_ROWS_MAX * 6 + PAIR_TILE_CAP / 2;   // rowbox | list
+template <bool FA = false>   // FA (asynchronous front): the work items go out written through
 __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double* lds, bool wait_xf = false) {
   int tr, rb, cb;
   pair_unit(D.U, D.pair_rows, bid, tr, rb, cb);
@@ -178,7 +181,7 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
   double* rowbox = lds; int* list = (int*)(lds + PAIR_ROWS_MAX * 6);
   const double dist = D.offset + 2 * D.margin;
   if (wait_xf) xf_wait_seg(D, 0, tr);   // sharded contexts (union kernel): the hull cache of the other ranks' robots is written by units at the head of this launch
-  const int m = pair_tile_filter(D.hbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, D.u0, D.u1,
+  const int m = pair_tile_filter<FA>(D.hbox + (size_t)tr * 6 * U, U, rb, D.pair_rows, cb, D.u0, D.u1,   // (FA: boxes and interval records read past the caches -- a box line holds sixteen robots' entries, written by sixteen units)
                                  [&](int q) { return D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE; }, 24, 73, dist, rowbox, list, lane);
   if (m == 0) return;
   // hand the remaining pairs to the solve stage (k_mid / k_sep_self_solve): one work item per pair.  Solving them here,
@@ -189,7 +192,11 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
   const int cap = pair_work_cap_seg(D);
   for (int i = lane; i < m; i += 64) {
     const int w = base + i;
-    if (w < cap) { const size_t sl = (size_t)tr * cap + w; D.pair_work[3 * sl] = tr; D.pair_work[3 * sl + 1] = list[i] >> 16; D.pair_work[3 * sl + 2] = list[i] & 0xffff; }
+    if (w < cap) {
+      const size_t sl = (size_t)tr * cap + w;
+      if constexpr (FA) { xf_store_i(D.pair_work + 3 * sl, tr); xf_store_i(D.pair_work + 3 * sl + 1, list[i] >> 16); xf_store_i(D.pair_work + 3 * sl + 2, list[i] & 0xffff); }
+      else { D.pair_work[3 * sl] = tr; D.pair_work[3 * sl + 1] = list[i] >> 16; D.pair_work[3 * sl + 2] = list[i] & 0xffff; }
+    }
     else atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW);
   }
 }
@@ -209,20 +216,43 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
 constexpr int SPEC_CAP = 128, SPEC_GJK_MIN = 5, SPEC_GJK_WINDOW = 10, SPEC_GJK_BUDGET = 3;
 constexpr int SPEC_STATE_DOUBLES = 20, SPEC_STATE_INTS = 16;
 __device__ __forceinline__ unsigned pair_key(int tr, int p0, int q) { return (unsigned)(tr | (p0 << 9) | (q << 20)); }   // 9 + 11 + 11 bits
-__device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds) {
+// FA (asynchronous front): the launch runs next to the k_linesearch that commits the control nets -- the epoch is the begun iteration's (fa_early_begin's record, the
+// control block still shows the running one), the block waits for its two robots' commit flags and forms the hulls from the nets read past the caches, and what
+// it leaves for k_mid goes out written through.
+template <bool FA = false>
+__device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds, int fa_epoch = 0) {
   __builtin_amdgcn_s_setprio(3);   // the longest blocks of the launch, on SIMDs they share with four or five query waves
   const int lane = lane_id();
-  const int epoch = D.ctl->epoch, par = epoch & 1;
-  if (b == 0 && lane == 0) D.spec_n[par] = 0;   // the list this iteration's k_mid fills
+  const int epoch = FA ? fa_epoch : D.ctl->epoch, par = epoch & 1;
+  auto tag_out = [&](unsigned long long v) { if constexpr (FA) __hip_atomic_store(D.spec_tag + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else D.spec_tag[b] = v; };
+  if (b == 0 && lane == 0) { if constexpr (FA) xf_store_i(D.spec_n + par, 0); else D.spec_n[par] = 0; }   // the list this iteration's k_mid fills
   const int n = min(D.spec_n[par ^ 1], SPEC_CAP);
   // every block leaves a tag, valid or not: the tags k_mid sees are always those of the k_front in front of it
-  if (b >= n) { if (lane == 0) D.spec_tag[b] = 0ull; return; }
+  if (b >= n) { if (lane == 0) tag_out(0ull); return; }
   const unsigned key = (unsigned)D.spec_list[(par ^ 1) * SPEC_CAP + b];
   const int tr = (int)(key & 0x1ff), p0 = (int)((key >> 9) & 0x7ff), q = (int)((key >> 20) & 0x7ff);
-  if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) D.spec_tag[b] = 0ull; return; }   // (cannot happen: the list is this context's own)
+  if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) tag_out(0ull); return; }   // (cannot happen: the list is this context's own)
   const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_INFO_STRIDE;
   const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_INFO_STRIDE;
-  if (D.xf_all) {   // coupled chain: the records are being written by this launch's obstacle units (LATER in the grid: not waited for) -- the two hulls straight from the control nets
+  if constexpr (FA) {   // the records are written by this launch's obstacle units (later in the grid: not waited for): the two hulls from the nets, behind the robots' commit flags, read past the caches
+    const int r = lane < 18 ? p0 : q, e = min(lane < 18 ? lane : lane - 18, 17);
+    double bk[6];
+    const double* Bs = D.basis + (size_t)tr * 36 + (e / 3) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) bk[k] = Bs[k];
+    const double* col = D.spline + (size_t)r * 3 * D.T + div_small(tr, D.res) * 3 + D.T * (e % 3);
+    fa_wait_flag(D, D.fa_commit(p0), D.fa_seq);
+    fa_wait_flag(D, D.fa_commit(q), D.fa_seq);
+    if (lane < 36) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += bk[k] * xf_load(col + k);   // = hull_entry
+      lds[lane] = acc;
+    }
+    blk_sync<true>();
+    A = lds; B = lds + 18;
+  } else
+  if (D.xf_all || D.fa) {   // coupled chain: the records are being written by this launch's obstacle units (LATER in the grid: not waited for) -- the two hulls straight from the control nets
     if (lane < 36) { const int r = lane < 18 ? p0 : q, e = lane < 18 ? lane : lane - 18; lds[lane] = hull_entry(D, D.spline + (size_t)r * 3 * D.T, tr, e / 3, e % 3); }
     blk_sync<true>();
     A = lds; B = lds + 18;
@@ -231,13 +261,15 @@ __device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds)
   gjk_wave_run(BodyHull{A}, BodyHull{B}, lane, st, true, D.spec_budget, fin);
   if (lane == 0) {
     double* o = D.spec_state + (size_t)b * SPEC_STATE_DOUBLES;
-    o[0] = st.v.x; o[1] = st.v.y; o[2] = st.v.z;
-    o[3] = st.s.v0.x; o[4] = st.s.v0.y; o[5] = st.s.v0.z; o[6] = st.s.v1.x; o[7] = st.s.v1.y; o[8] = st.s.v1.z;
-    o[9] = st.s.v2.x; o[10] = st.s.v2.y; o[11] = st.s.v2.z; o[12] = st.s.v3.x; o[13] = st.s.v3.y; o[14] = st.s.v3.z;
-    o[15] = st.s.l0; o[16] = st.s.l1; o[17] = st.s.l2; o[18] = st.s.l3; o[19] = st.wmax2;
+    const double ov[SPEC_STATE_DOUBLES] = {st.v.x, st.v.y, st.v.z, st.s.v0.x, st.s.v0.y, st.s.v0.z, st.s.v1.x, st.s.v1.y, st.s.v1.z, st.s.v2.x, st.s.v2.y, st.s.v2.z,
+                                           st.s.v3.x, st.s.v3.y, st.s.v3.z, st.s.l0, st.s.l1, st.s.l2, st.s.l3, st.wmax2};
     int* oi = D.spec_sti + (size_t)b * SPEC_STATE_INTS;
-    oi[0] = st.s.n; oi[1] = st.s.w0; oi[2] = st.s.w1; oi[3] = st.s.w2; oi[4] = st.s.w3; oi[5] = st.c1; oi[6] = st.c2; oi[7] = st.k; oi[8] = fin ? 1 : 0;
-    D.spec_tag[b] = ((unsigned long long)(unsigned)epoch << 32) | key;
+    const int iv[9] = {st.s.n, st.s.w0, st.s.w1, st.s.w2, st.s.w3, st.c1, st.c2, st.k, fin ? 1 : 0};
+#pragma unroll
+    for (int i = 0; i < SPEC_STATE_DOUBLES; i++) { if constexpr (FA) xf_store(o + i, ov[i]); else o[i] = ov[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { if constexpr (FA) xf_store_i(oi + i, iv[i]); else oi[i] = iv[i]; }
+    tag_out(((unsigned long long)(unsigned)epoch << 32) | key);
   }
 }
 // the state entry b holds, fetched by the whole wave (one load per lane, then broadcasts).  The values go straight back into
@@ -248,9 +280,12 @@ __device__ __forceinline__ double spec_bcast(double x, int l) {
   asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vlo), "=v"(vhi) : "s"(lo), "s"(hi));
   return __hiloint2double(vhi, vlo);
 }
+template <bool FA = false>
 __device__ __forceinline__ void spec_state_load(const Dev& D, int b, int lane, GjkState& st, bool& fin) {
-  const double x = D.spec_state[(size_t)b * SPEC_STATE_DOUBLES + min(lane, SPEC_STATE_DOUBLES - 1)];
-  const int y = D.spec_sti[(size_t)b * SPEC_STATE_INTS + (lane & (SPEC_STATE_INTS - 1))];
+  const double* px_ = D.spec_state + (size_t)b * SPEC_STATE_DOUBLES + min(lane, SPEC_STATE_DOUBLES - 1);
+  const int* py_ = D.spec_sti + (size_t)b * SPEC_STATE_INTS + (lane & (SPEC_STATE_INTS - 1));
+  const double x = FA ? xf_load(px_) : *px_;
+  const int y = FA ? xf_load_i(py_) : *py_;
   st.v = V3{spec_bcast(x, 0), spec_bcast(x, 1), spec_bcast(x, 2)};
   st.s.v0 = V3{spec_bcast(x, 3), spec_bcast(x, 4), spec_bcast(x, 5)}; st.s.v1 = V3{spec_bcast(x, 6), spec_bcast(x, 7), spec_bcast(x, 8)};
   st.s.v2 = V3{spec_bcast(x, 9), spec_bcast(x, 10), spec_bcast(x, 11)}; st.s.v3 = V3{spec_bcast(x, 12), spec_bcast(x, 13), spec_bcast(x, 14)};
@@ -273,15 +308,20 @@ __global__ __launch_bounds__(64) void k_sep_self_rows(Dev D) {
 // 8-byte loads per lane and GJK iteration -- the producers' GJK phase took 4 ... 58 us depending on what else the memory pipeline was doing (phase stamps,
 // round 5), from LDS it does not depend on it.
 constexpr int PAIR_TILE_LANES = 32, PAIR_TILE_DOUBLES = 36 * PAIR_TILE_LANES;
+// FA (asynchronous front, Dev::fa_mid): the k_front of the same iteration ended while THIS launch was already running -- its work lists, head-start states and hull records are read past the caches
+template <bool FA = false>
 __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int nwaves, bool head_start, double* tile) {   // head_start: k_mid only -- the k_front of the same iteration ran in front of it
   const int lane = lane_id();
   __shared__ double A[18], B[18];
   __shared__ int wpre[513];
+  auto ldi = [&](const int* p) { if constexpr (FA) return xf_load_i(p); else return *p; };
+  auto ldd = [&](const double* p) { if constexpr (FA) return xf_load(p); else return *p; };
+  auto ldt = [&](const unsigned long long* p) { if constexpr (FA) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p; };
   // (SPEC_CAP = 128: two tags per lane) issued first, used after the work item has arrived; the list takes the pairs within
   // SPEC_GJK_WINDOW iterations of the previous launch's longest query, so that it holds the tail and not the first to report
-  const unsigned long long spec_tag0 = head_start ? D.spec_tag[lane] : 0ull, spec_tag1 = head_start ? D.spec_tag[64 + lane] : 0ull;
+  const unsigned long long spec_tag0 = head_start ? ldt(D.spec_tag + lane) : 0ull, spec_tag1 = head_start ? ldt(D.spec_tag + 64 + lane) : 0ull;
   const int spec_thr = head_start ? max(D.spec_min, D.ctl->gjk_prev - SPEC_GJK_WINDOW) : 0;
-  const int n = pair_work_prefix(D, wpre, lane), U = D.U;
+  const int n = pair_work_prefix<FA>(D, wpre, lane), U = D.U;
   const double dist = D.offset + 2 * D.margin, m = D.margin, off = D.offset;
   const int epoch = D.ctl->epoch;
   // Long work list (hundreds of robots): a wave per pair is the lowest LATENCY but occupies 64 lanes for one chain of
@@ -322,7 +362,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
         if (i == bid - np) TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
         const int tr = (int)(e & 0x1ff), p0 = (int)((e >> 9) & 0x7ff), q = (int)((e >> 20) & 0x7ff);   // 9 + 11 + 11 bits, bit 31 = PAIR_OVF_STOP
         __syncthreads();
-        if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
+        if (lane < 18) { A[lane] = ldd(D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE + lane); B[lane] = ldd(D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE + lane); }
         __syncthreads();
         double e0, e1c, e2c, dpl; bool capped; int nit = 0, gkc = 0;
         const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gkc);
@@ -346,14 +386,14 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
       const int w = base + lane;
       if (w < n && lane < lpw) {
         const size_t sl = (size_t)pair_work_slot(D, wpre, w);
-        const int tr = D.pair_work[3 * sl], p0 = D.pair_work[3 * sl + 1], q = D.pair_work[3 * sl + 2];
+        const int tr = ldi(D.pair_work + 3 * sl), p0 = ldi(D.pair_work + 3 * sl + 1), q = ldi(D.pair_work + 3 * sl + 2);
         const double* Ag = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE;
         const double* Bg = D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE;
         constexpr int hst = PAIR_TILE_LANES;
         {   // this lane's column of the tile (private to the lane: no synchronisation)
           double* col = tile + lane;
 #pragma unroll 6
-          for (int e = 0; e < 18; e++) { col[e * hst] = Ag[e]; col[(18 + e) * hst] = Bg[e]; }
+          for (int e = 0; e < 18; e++) { col[e * hst] = ldd(Ag + e); col[(18 + e) * hst] = ldd(Bg + e); }
           Ag = col; Bg = col + 18 * hst;
         }
         double e0, e1c, e2c, dpl; bool capped; int nit = 0;
@@ -444,13 +484,13 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     const int tr = (int)(key & 0x1ff), p0 = (int)((key >> 9) & 0x7ff), q = (int)((key >> 20) & 0x7ff);
     if (tr >= D.S || p0 >= U || q >= U) return;   // (cannot happen)
     // in flight together: both hulls, the saved state, this segment's part of the work list
-    if (lane < 18) { A[lane] = D.hullinfo[((size_t)p0 * D.S + tr) * HULL_STRIDE + lane]; B[lane] = D.hullinfo[((size_t)q * D.S + tr) * HULL_STRIDE + lane]; }
+    if (lane < 18) { A[lane] = ldd(D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE + lane); B[lane] = ldd(D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE + lane); }
     GjkState hs; bool hs_fin = false;
-    spec_state_load(D, bid, lane, hs, hs_fin);
+    spec_state_load<FA>(D, bid, lane, hs, hs_fin);
     const int cnt = wpre[tr + 1] - wpre[tr];
     const int* wl = D.pair_work + 3 * (size_t)tr * pair_work_cap_seg(D);
     bool member = false;
-    for (int i = lane; i < cnt; i += 64) member = member || (wl[3 * i + 1] == p0 && wl[3 * i + 2] == q);
+    for (int i = lane; i < cnt; i += 64) member = member || (ldi(wl + 3 * i + 1) == p0 && ldi(wl + 3 * i + 2) == q);
     __syncthreads();
     TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
     double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
@@ -475,13 +515,13 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   if (n_mine > 64) { if (lane == 0) atomicOr(&D.ctl->error, ERR_PAIR_OVERFLOW); return; }   // (cannot happen: a lane holds one item)
   if (lane < n_mine) {
     const size_t sl = (size_t)pair_work_slot(D, wpre, r + lane * Wg);
-    it_tr = D.pair_work[3 * sl]; it_p0 = D.pair_work[3 * sl + 1]; it_q = D.pair_work[3 * sl + 2];
+    it_tr = ldi(D.pair_work + 3 * sl); it_p0 = ldi(D.pair_work + 3 * sl + 1); it_q = ldi(D.pair_work + 3 * sl + 2);
   }
   int tr = __builtin_amdgcn_readlane(it_tr, 0), p0 = __builtin_amdgcn_readlane(it_p0, 0), q = __builtin_amdgcn_readlane(it_q, 0);
   // this lane's entry of the pair's two hulls: lanes 0..17 A, 18..35 B
   auto hull_entry_of = [&](int tr_, int p0_, int q_) -> double {
     const int robot = lane < 18 ? p0_ : q_, e = lane < 18 ? lane : lane - 18;
-    return lane < 36 ? D.hullinfo[((size_t)robot * D.S + tr_) * HULL_STRIDE + e] : 0.0;
+    return lane < 36 ? ldd(D.hullinfo + ((size_t)robot * D.S + tr_) * HULL_STRIDE + e) : 0.0;
   };
   double hv = hull_entry_of(tr, p0, q);
   for (int j = 0; j < n_mine; j++) {

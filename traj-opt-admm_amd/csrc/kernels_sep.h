@@ -480,10 +480,14 @@ constexpr int OBS_LDS_DOUBLES = 264 + (2 * FRONT_CAP + 128) / 2;   // P[18] klo[
 // True in the iteration chains of the multi-robot modes, false in the stage API (the cache is rebuilt after this stage there).
 // publish (coupled chain, Dev::xf_all; implies !use_cache): the unit also leaves the hull-cache record of its (robot, segment) -- what k_hullinfo would -- written through,
 // and counts itself done on the segment's counter: the pair tiles of this launch wait for it
-template <int PRIM>
+// FA (asynchronous front, Dev::fa_seq; implies publish): this launch runs next to the k_linesearch that commits the control net -- the unit fetches what does not depend
+// on the net (its basis row, the top BVH boxes), waits for the robot's commit flag, reads the net past the caches (two robots' nets share cache lines) and forms the
+// hull with hull_entry's sums in their order (same bits); everything it leaves for later kernels is written through (k_front's block then counts itself done).
+template <int PRIM, bool FA = false>
 __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* lds, bool use_cache, bool publish = false) {
   const int u = D.u0 + bid / D.S, tr = bid % D.S;
   const int lane = lane_id();
+  auto sti = [&](int* p, int v) { if constexpr (FA) xf_store_i(p, v); else *p = v; };
   double* P = lds; double* klo = P + 18; double* khi = klo + 49;
   int* fa = (int*)(lds + 264); int* fb = fa + FRONT_CAP; int* cand = fb + FRONT_CAP;
   bool kax_ready = false;
@@ -499,6 +503,22 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
 #pragma unroll
     for (int k = 0; k < 3; k++) { q.lo[k] = h[18 + k]; q.hi[k] = h[21 + k]; }
   } else {
+    if constexpr (FA) {
+      double bk[6] = {0, 0, 0, 0, 0, 0};
+      const int e = min(lane, 17);
+      const double* B = D.basis + (size_t)tr * 36 + (e / 3) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) bk[k] = B[k];
+      const double* col = net + div_small(tr, D.res) * 3 + D.T * (e % 3);
+      fa_wait_flag(D, D.fa_commit(u), D.fa_seq);
+      TJ_TIC(D, K_SEP_OBS, 6);
+      if (lane < 18) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc += bk[k] * xf_load(col + k);   // = hull_entry
+        P[lane] = acc;
+      }
+    } else
     if (lane < 18) P[lane] = hull_entry(D, net, tr, lane / 3, lane % 3);
     __syncthreads();
     kdop_intervals(D, P, 6, klo, khi);
@@ -538,14 +558,14 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
     const unsigned long long mask = ballot(ok);
     const int idx = base + prefix_count(mask);
     if (ok) {
-      if (idx < D.cap_obs) list[idx] = pt;
+      if (idx < D.cap_obs) sti(list + idx, pt);
       else atomicOr(&D.ctl->error, ERR_PLANE_OVERFLOW);
     }
     base += __popcll(mask);
   }, &topb);
   TJ_TIC(D, K_SEP_OBS, 4);
   const int cnt = min(base, D.cap_obs);
-  if (cnt > 0 && lane < 18) D.ohull[seg * 18 + lane] = P[lane];   // read by the solve waves of this segment's candidates only
+  if (cnt > 0 && lane < 18) { if constexpr (FA) xf_store(D.ohull + seg * 18 + lane, P[lane]); else D.ohull[seg * 18 + lane] = P[lane]; }   // read by the solve waves of this segment's candidates only
   // Work items: a segment with few candidates hands each one to its own wave (cooperative GJK, lowest latency); a
   // segment in a dense part of the cloud hands them over in batches of up to 64, one candidate per lane (per-lane GJK,
   // highest throughput).  slot >= 0: single candidate; slot < 0: batch starting at candidate -(slot + 1).
@@ -553,34 +573,36 @@ __device__ __forceinline__ void obs_query_body(const Dev& D, int bid, double* ld
   const int items = batched ? (cnt + 63) / 64 : cnt;
   int w0 = 0;
   if (lane == 0) {
-    D.ocand_n[seg] = cnt;
+    sti(D.ocand_n + seg, cnt);
     if (items > 0) w0 = atomicAdd(D.obs_work_n, items);
     unsigned long long* st = D.seg_stats + seg * 6;   // fire-and-forget atomics instead of a read-modify-write round trip
     atomicAdd(&st[0], visits); atomicAdd(&st[1], (unsigned long long)found);
   }
   w0 = __shfl(w0, 0);
-  for (int i = lane; i < items; i += 64) { D.obs_work[2 * (size_t)(w0 + i)] = (int)seg; D.obs_work[2 * (size_t)(w0 + i) + 1] = batched ? -(i * 64) - 1 : i; }
+  for (int i = lane; i < items; i += 64) { sti(D.obs_work + 2 * (size_t)(w0 + i), (int)seg); sti(D.obs_work + 2 * (size_t)(w0 + i) + 1, batched ? -(i * 64) - 1 : i); }
   TJ_TIC(D, K_SEP_OBS, 5);
 }
 
 // Separate::opengjk (Separate.h:18-163) for one candidate, by one wave
-template <int PRIM>
+// FA (asynchronous front, Dev::fa_mid): the k_front whose lists this body reads ended while THIS launch was already running -- everything of it is read past the caches
+template <int PRIM, bool FA = false>
 __device__ __forceinline__ void obs_solve_body(const Dev& D, int bid, int nwaves) {
   const int lane = lane_id();
   __shared__ double P[18];
-  const int n = *D.obs_work_n;
+  auto ldi = [&](const int* p) { if constexpr (FA) return xf_load_i(p); else return *p; };
+  const int n = ldi(D.obs_work_n);
   const double dist = D.offset + D.margin;
   const int epoch = D.ctl->epoch;
   for (int w = bid; w < n; w += nwaves) {
-    const int seg = D.obs_work[2 * (size_t)w], slot = D.obs_work[2 * (size_t)w + 1];
+    const int seg = ldi(D.obs_work + 2 * (size_t)w), slot = ldi(D.obs_work + 2 * (size_t)w + 1);
     __syncthreads();
-    if (lane < 18) P[lane] = D.ohull[(size_t)seg * 18 + lane];
+    if (lane < 18) { if constexpr (FA) P[lane] = xf_load(D.ohull + (size_t)seg * 18 + lane); else P[lane] = D.ohull[(size_t)seg * 18 + lane]; }
     __syncthreads();
     const bool batch = slot < 0;
     const int first = batch ? -(slot + 1) : slot;
     const int mine = batch ? first + lane : first;                     // candidate of this lane
-    const bool live = !batch || mine < D.ocand_n[seg];
-    const int pt = D.ocand[(size_t)seg * D.cap_obs + (live ? mine : first)];
+    const bool live = !batch || mine < ldi(D.ocand_n + seg);
+    const int pt = ldi(D.ocand + (size_t)seg * D.cap_obs + (live ? mine : first));
     const typename PrimOf<PRIM>::Body qb = PrimOf<PRIM>::load(D, pt);
     V3 v;
     if (batch) v = gjk(BodyHull{P}, qb);                               // one candidate per lane

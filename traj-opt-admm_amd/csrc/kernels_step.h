@@ -812,10 +812,18 @@ __global__ __launch_bounds__(64) void k_slack(Dev D, int deferred) {
 //   k_front  obstacle candidate query (owned * S)  |  robot-pair rows (S * U)
 //   k_mid    slack + dual update the previous iteration still owes (owned * P)  |  robot-pair solves  |  obstacle-candidate solves
 //   k_ccd    obstacle CCD clamp (owned * S)  |  robot-pair CCD selection (S * U)
-template <int PRIM>
+// FA (asynchronous front, dev_common.h Dev::fa_seq): this launch runs on the second queue NEXT TO the previous iteration's k_linesearch (behind k_fa_gate).  Stop flag
+// and epoch come from fa_early_begin's record -- the control block still belongs to the running iteration --, units wait for their robots' commit flags, every
+// store a later kernel reads is written through, and each block counts itself done behind them (the last k_linesearch block waits for that count).
+template <int PRIM, bool FA = false>
 __global__ __launch_bounds__(64) void k_front(Dev D) {
   if (D.keep_seq > 0 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(D.keep_go(), D.keep_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // opens the gate of the asynchronous plane refinement
-  if (TJ_DONE(D)) return;
+  int fa_epoch = 0;
+  if constexpr (FA) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(D.fa_fstart(blockIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (the last k_linesearch block may wait for that)
+    fa_epoch = xf_load_i(D.fa_rec() + 1);
+    if (xf_load_i(D.fa_rec() + 2)) { fa_count(D.fa_fdone(blockIdx.x)); return; }   // (the begun iteration's stop test has fired)
+  } else if (TJ_DONE(D)) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
   __shared__ double lds[OBS_LDS_DOUBLES > PAIR_LDS_DOUBLES ? OBS_LDS_DOUBLES : PAIR_LDS_DOUBLES];   // one buffer for whichever body this block runs
@@ -826,21 +834,36 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_xf = D.xf_units();   // sharded contexts: hull cache of the other ranks' robots (coupled chain: of every robot), AHEAD of everything that reads it (head starts, pair tiles)
   const int bx = (int)blockIdx.x;
   const int b = bx - n_ord - n_xf - n_spec;
-  if (bx < n_ord) grad_order_body(D, bx, (int*)lds);
+  const bool pub = D.xf_all != 0 || D.fa != 0;   // the query forms its hull itself and publishes the record (coupled chain; Dev::fa)
+  if (bx < n_ord) grad_order_body<FA>(D, bx, (int*)lds);
   else if (bx < n_ord + n_xf) xf_hull_body(D, bx - n_ord);
-  else if (b < 0) spec_pair_body(D, bx - n_ord - n_xf, lds);
-  else if (b < n_obs) obs_query_body<PRIM>(D, b, lds, !D.xf_all, D.xf_all != 0);   // (xf_all: the query forms its hull itself and publishes the record)
-  else sep_self_rows_body(D, b - n_obs, lds, D.xf != 0);
+  else if (b < 0) spec_pair_body<FA>(D, bx - n_ord - n_xf, lds, fa_epoch);
+  else if (b < n_obs) obs_query_body<PRIM, FA>(D, b, lds, !pub, pub);
+  else sep_self_rows_body<FA>(D, b - n_obs, lds, D.xf != 0 || D.fa != 0);
   TJ_TIC(D, K_FRONT, 1);
+  if constexpr (FA) fa_count(D.fa_fdone(blockIdx.x));
 }
+// asynchronous front: the gate in front of k_front on the second queue (one wave, no LDS) -- it ends when every block of the k_linesearch launch of this pairing has
+// started, i.e. when all of them are resident: the k_front blocks that then sleep on commit flags cannot keep a k_linesearch block off its compute unit
+__global__ __launch_bounds__(64) void k_fa_gate(Dev D, int want) { fa_wait16(D, D.fa_res(0), want); }
 // two waves per SIMD (<= 256 VGPRs; 244 used, no spills since the slack body was rewritten): 2 048 one-wave blocks are resident
 // at once -- on SCN-C the 320 slack blocks, the 1 024 pair waves and the first 704 of the 1 024 obstacle-solve waves (its ~250
 // candidates all fall to those); the rest follow as slack blocks retire after ~13 us.  At the natural 340 VGPRs of round 1 a
 // third of the blocks started only when an earlier one had finished, 18-33 us into the kernel.
-template <int PRIM>
+// FA (asynchronous front, Dev::fa_mid): this launch started while the iteration's k_front was still running on the other queue.  Block 0 is the WATCHER: it polls k_front's
+// done counters (every block of it counts itself behind its acknowledged write-through stores) and then raises the 64 go words; a pair / obstacle solve wave sleeps on
+// one of them before it touches anything k_front leaves, and reads that past the caches.  The slack blocks start at once.
+template <int PRIM, bool FA = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mid(Dev D, int n_pair_waves, int n_obs_waves) {
   const int n_slack = (D.u1 - D.u0) * D.P;
-  const int b = blockIdx.x;
+  if constexpr (FA) {
+    if (blockIdx.x == 0) {
+      fa_wait16(D, D.fa_fdone(0), (int)((unsigned)D.fa_seq * (unsigned)D.fa_nfront));
+      xf_store_i(D.fa_go(threadIdx.x), D.fa_seq);
+      return;
+    }
+  }
+  const int b = (int)blockIdx.x - (FA ? 1 : 0);
   TJ_TIC(D, K_MID, 0);
 #ifdef TJ_PHASE_TIMING
   if (threadIdx.x == 0 && blockIdx.x < TJ_TIC_BLOCKS) {   // where the block runs: HW_ID (wave, SIMD, CU, SE) and XCC_ID
@@ -857,15 +880,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int s0 = n_pair_waves + n_obs_waves;
     if (b >= s0) { if (D.ctl->slack_now) slack_body(D, b - s0, 1, mid_lds); TJ_TIC(D, K_MID, 1); return; }
     if (TJ_DONE(D)) return;
-    if (b < n_pair_waves) sep_self_solve_body(D, b, n_pair_waves, D.spec != 0, mid_lds);
-    else obs_solve_body<PRIM>(D, b - n_pair_waves, n_obs_waves);
+    if constexpr (FA) fa_wait_flag(D, D.fa_go(b), D.fa_seq);
+    if (b < n_pair_waves) sep_self_solve_body<FA>(D, b, n_pair_waves, D.spec != 0, mid_lds);
+    else obs_solve_body<PRIM, FA>(D, b - n_pair_waves, n_obs_waves);
     TJ_TIC(D, K_MID, 1);
     return;
   }
   if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1, mid_lds); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
   else if (TJ_DONE(D)) return;
-  else if (b < n_slack + n_pair_waves) sep_self_solve_body(D, b - n_slack, n_pair_waves, D.spec != 0, mid_lds);
-  else obs_solve_body<PRIM>(D, b - n_slack - n_pair_waves, n_obs_waves);
+  if constexpr (FA) { fa_wait_flag(D, D.fa_go(b), D.fa_seq); TJ_TIC(D, K_MID, 4); }
+  if (b < n_slack + n_pair_waves) sep_self_solve_body<FA>(D, b - n_slack, n_pair_waves, D.spec != 0, mid_lds);
+  else obs_solve_body<PRIM, FA>(D, b - n_slack - n_pair_waves, n_obs_waves);
   TJ_TIC(D, K_MID, 1);
 }
 template <int PRIM, bool LEAN>

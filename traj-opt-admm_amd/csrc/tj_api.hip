@@ -48,6 +48,10 @@ struct tj_ctx {
   // sequence number of that pairing; xs_seq_gated: the last one a gate was launched for; xs_same_queue_now: tj_profile_kernels keeps everything on one queue)
   hipStream_t stream3 = nullptr; int keep_seq = 0; bool keep_two_queues = false;   // asynchronous plane refinement (Dev::keep_async)
   hipStream_t stream2 = nullptr; int xs_seq = 0, xs_seq_gated = 0; bool xs_two_queues = false, xs_same_queue_now = false;
+  // asynchronous front (Dev::fa): fa_seq = pairings k_linesearch(i) <-> k_front(i + 1) launched so far (the device's words are monotonic in it); fa_armed: the last
+  // k_linesearch enqueued belongs to pairing fa_seq and the k_front that follows goes to the second queue behind k_fa_gate
+  int fa_seq = 0; bool fa_armed = false;
+  bool fa_mid_ok = false, fa_mid_now = false;   // Dev::fa_mid: k_front's whole grid is resident at once next to one k_linesearch block (tj_create) / the k_mid about to be enqueued waits for k_front itself
   bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
   bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
   bool ccd_valid = false;    // Dev::fuse: the swept-hull cache of the owned robots matches their direction records (k_xsolve's tail wrote it; tj_set_direction / tj_set_state clear it)
@@ -141,6 +145,9 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const bool keep2q = in_graph && c->keep_two_queues && !c->xs_same_queue_now && !c->use_graph;
   if (!keep2q) d_.keep_async = 0;
   if (kid == K_GRAD && d_.xs_async && c->xs_two_queues && !c->xs_same_queue_now && !c->use_graph) d_.xs_seq = ++c->xs_seq;   // this k_grad opens the gate of its k_xsolve
+  d_.fa_seq = 0; d_.fa_mid = 0;
+  if (!in_graph) d_.fa = 0;   // (the context switch belongs to the single-GPU chain like xs_async; fa contexts are never sharded, and the stage API rebuilds the hull cache itself)
+  const bool fa2q = in_graph && d_.fa && c->xs_two_queues && !c->xs_same_queue_now && !c->use_graph;
   const Dev& d = d_;
   const int owned = d.u1 - d.u0;
   const bool multi = d.mode >= 1, coupled = d.mode == 2, tri = d.prim == 3;
@@ -158,6 +165,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + n_xf + (d.spec ? SPEC_CAP : 0) + (d.grad_bal ? (owned * d.P + 63) / 64 : 0);
   const bool chained = in_graph || in_phase;          // an iteration chain (one context, or the phases of a sharded schedule) as opposed to the stage API
   const int n_mid_slack = owned * d.P;
+  d_.fa_nfront = n_front; d_.fa_nls = owned * d.ls_help;
   switch (kid) {
     case K_BEGIN: if (chain_pos & 1) return false; TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d); c->xf_used[0] = c->xf_used[1] = false; return true;
     case K_HULLINFO: if ((chained && (d.fuse || d.xf_all)) || !multi) return false; TJ_LAUNCH(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // unfused sharded phases (coupled mode): always (all robots, after the gather)
@@ -172,6 +180,13 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if (d.xf) { if (c->xf_used[0]) (void)hipMemsetAsync(d.xf_seg, 0, (size_t)d.S * XF_SEG_STRIDE * sizeof(int), s); c->xf_used[0] = true; }
       if (d.xch && c->xch_wait_kernel) TJ_LAUNCH(k_xch_wait, dim3(1), dim3(64), 0, s, d, 0);   // ranks sharing a device: the wait for the peers' control points is a launch of its own
       if (keep2q) d_.keep_seq = ++c->keep_seq;   // this k_front opens the gate of the iteration's plane refinement (third queue)
+      if (c->fa_armed && fa2q && (chain_pos & 1)) {   // asynchronous front: on the second queue, next to the k_linesearch just enqueued (pairing fa_seq), behind the residency gate
+        c->fa_armed = false;
+        d_.fa_seq = c->fa_seq; d_.fa_mid = c->fa_mid_ok ? 1 : 0; c->fa_mid_now = c->fa_mid_ok;
+        TJ_LAUNCH(k_fa_gate, dim3(1), dim3(64), 0, c->stream2, d, (int)((unsigned)c->fa_seq * (unsigned)d.fa_nls));
+        if (tri) TJ_LAUNCH((k_front<3, true>), dim3(n_front), dim3(64), 0, c->stream2, d); else TJ_LAUNCH((k_front<1, true>), dim3(n_front), dim3(64), 0, c->stream2, d);
+        return true;
+      }
       if (tri) TJ_LAUNCH((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else TJ_LAUNCH((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
       if (keep2q) {
         d_.keep_seq = 0;
@@ -187,6 +202,12 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       return true;
     case K_SEP_SELF_ROWS: if (in_graph || in_phase || !multi) return false; TJ_LAUNCH(k_sep_self_rows, dim3(n_rows), dim3(64), 0, s, d); return true;
     case K_MID: if (!in_graph && !in_phase) return false;
+      if (in_graph && c->fa_mid_now) {   // asynchronous front, small grids: this launch starts while the iteration's k_front (pairing fa_seq) still runs -- its solve waves wait for it themselves (+ the watcher block)
+        c->fa_mid_now = false;
+        d_.fa_seq = c->fa_seq; d_.fa_mid = 1;
+        if (tri) TJ_LAUNCH((k_mid<3, true>), dim3(1 + n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else TJ_LAUNCH((k_mid<1, true>), dim3(1 + n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
+        return true;
+      }
       if (tri) TJ_LAUNCH((k_mid<3>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve); else TJ_LAUNCH((k_mid<1>), dim3(n_mid_slack + n_solve + n_obs_solve), dim3(64), 0, s, d, n_solve, n_obs_solve);
       return true;
     case K_SEP_SELF_SOLVE: if (in_graph || !n_solve) return false; TJ_LAUNCH(k_sep_self_solve, dim3(n_solve), dim3(64), 0, s, d); return true;
@@ -251,7 +272,8 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if ((in_graph || in_phase) && d.seq_fold && !(c->split_unions && multi)) return false;   // the last block of k_ccd has done it
       if (!multi && in_graph) return false;   // single UAV: no pairs to replay, and k_xsolve has left gnorm = |g| itself -- one launch less in the chain
       TJ_LAUNCH(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
-    case K_LINESEARCH: if (!coupled) { TJ_LAUNCH(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // (its last block runs begin_body)
+    case K_LINESEARCH: if (!coupled) { if (fa2q && (chain_pos & 2)) { d_.fa_seq = ++c->fa_seq; d_.fa_mid = c->fa_mid_ok ? 1 : 0; c->fa_armed = true; }   // the next iteration of the batch follows: its k_front runs next to this launch
+      TJ_LAUNCH(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // (its last block runs begin_body)
       return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED:
@@ -651,6 +673,23 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     }
     if (const char* e = getenv("TJ_LS_HELP_LATE")) d.ls_help_late = std::max(0, std::min(4000, atoi(e)));   // test hook (same bits): helper blocks idle that many microseconds before staging
     if (const char* e = getenv("TJ_LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
+    // asynchronous front (dev_common.h, Dev::fa): one context, decoupled mode, the asynchronous solve's second queue, and a k_linesearch grid that is resident all at once
+    // (one block per compute unit at most -- the residency gate's premise).  TJ_FRONT_ASYNC=0: k_linesearch publishes the hull cache and k_front follows it on the chain's queue (same bits)
+    d.fa = (d.xs_async && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && d.fuse && !d.optimal_plane && !c->split_unions && !c->use_graph && owned * d.ls_help <= d.num_cu) ? 1 : 0;
+    if (const char* e = getenv("TJ_FRONT_ASYNC")) d.fa = d.fa && atoi(e) != 0;
+    if (d.fa) {
+      // Dev::fa_mid: k_mid may start while k_front still runs only if k_front's whole grid is resident before k_mid's first wave is -- the last k_linesearch block waits
+      // until every k_front block has started, so the grid must fit the device next to that one block: blocks per compute unit by LDS, registers and wave slots
+      const int n_rows = d.S * pair_units(d.U, d.pair_rows);
+      const int n_front = owned * d.S + n_rows + (d.spec ? SPEC_CAP : 0) + (d.grad_bal ? (owned * d.P + 63) / 64 : 0);
+      hipFuncAttributes af;
+      if (hipFuncGetAttributes(&af, (const void*)k_front<1, true>) == hipSuccess) {
+        hipFuncAttributes a3; if (hipFuncGetAttributes(&a3, (const void*)k_front<3, true>) == hipSuccess) { af.numRegs = std::max(af.numRegs, a3.numRegs); af.sharedSizeBytes = std::max(af.sharedSizeBytes, a3.sharedSizeBytes); } else (void)hipGetLastError();
+        const int by_lds = (int)(((size_t)160 * 1024) / std::max<size_t>(af.sharedSizeBytes, 1)), by_regs = 4 * (512 / std::max((af.numRegs + 7) / 8 * 8, 8)), per_cu = std::min(std::min(by_lds, by_regs), 32);
+        c->fa_mid_ok = (long long)n_front <= (long long)(d.num_cu - 1) * per_cu;
+      } else (void)hipGetLastError();
+      if (const char* e = getenv("TJ_FRONT_ASYNC_MID")) c->fa_mid_ok = c->fa_mid_ok && atoi(e) != 0;   // launch-shape switch (same bits): 0 = k_linesearch waits for k_front's end, k_mid follows plainly
+    }
   }
   if (c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double) > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
     c->err = "problem does not fit the 160 KB LDS of one CU (segments per robot / fleet size too large for this version)";
@@ -697,7 +736,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
       (r = dalloc(c, &d.oraw, U * S * d.cap_obs * 4)) || (r = dalloc(c, &d.ostamp, U * S * d.cap_obs)) ||
       (r = dalloc(c, &d.grad_scr, (size_t)(d.u1 - d.u0) * P * 16 * (size_t)(d.cap_obs + d.cap_self))) ||
       (r = dalloc(c, &d.xs_scr, d.xs_band ? (size_t)(d.u1 - d.u0) * ((size_t)n * n + 4 * n) : 1)) ||
-      (r = dalloc(c, &d.xf_seg, 2 * S * XF_SEG_STRIDE)) || (r = dalloc(c, &d.xs_sync, (2 * U + 2) * 32)) || (r = dalloc(c, &d.keep_sync, 17 * 32))) return r;
+      (r = dalloc(c, &d.xf_seg, 2 * S * XF_SEG_STRIDE)) || (r = dalloc(c, &d.xs_sync, (2 * U + 2) * 32)) || (r = dalloc(c, &d.keep_sync, 17 * 32)) || (r = dalloc(c, &d.fa_sync, Dev::fa_sync_ints(d.U)))) return r;
   if (d.optimal_plane) {
     const bool m0 = d.mode == 0;
     if ((r = dalloc(c, &d.kobs_id, m0 ? U * S * d.cap_obs : 1)) || (r = dalloc(c, &d.kobs_n, U * S)) || (r = dalloc(c, &d.kobs_cd, m0 ? U * S * d.cap_obs * 4 : 1)) ||
@@ -894,6 +933,7 @@ int tj_init_state(tj_ctx* c, const double* wp, double pt0) {
   if (c->xch_block) HIPCHK(c, hipMemsetAsync(d.xcnt, 0, 2 * XCH_MAX * sizeof(unsigned long long), c->stream));
   if (d.xf) HIPCHK(c, hipMemsetAsync(d.xf_seg, 0, (size_t)2 * d.S * XF_SEG_STRIDE * sizeof(int), c->stream));
   HIPCHK(c, hipMemsetAsync(d.xs_sync, 0, ((size_t)2 * d.U + 1) * 32 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(d.fa_sync, 0, Dev::fa_sync_ints(d.U) * sizeof(int), c->stream)); c->fa_seq = 0; c->fa_armed = false;   // (the words are monotonic in the pairing number, which restarts here)
   Ctl h;
   memset(&h, 0, sizeof(h));
   h.gnorm = 1.0;  // Main/multiPathPlanning3D.cpp:594
