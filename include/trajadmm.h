@@ -209,6 +209,8 @@ typedef struct tj_stats {
                                      do not report): / iters = unit count of the pair stage's critical path */
   int ls_giveups;         /* line search, helper blocks: primaries that found a helper's post missing after 10 us and searched on alone (same result) */
   int ls_helper_timeouts; /* ... helper blocks that left after 5 ms without a word from their primary.  Both 0 on a GPU of the solver's own */
+  int async_fallbacks;    /* batches that were run again on ONE hardware queue because a wait between the context's queues had run out (error bit 2048: a GPU shared with
+                             another process).  The context keeps the one-queue chain from then on; the results are the same bits, the incident costs its 2 s limit once */
 } tj_stats;
 int tj_get_stats(tj_ctx* c, tj_stats* s);
 /* the obstacle BVH of the last tj_set_cloud / tj_set_mesh: device time of the build (Morton keys, radix sort, box pyramid;

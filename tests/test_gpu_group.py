@@ -3,6 +3,7 @@ thread per rank, peer stores + events for the exchanges.  A one-GPU box runs the
 may repeat), which exercises everything but the xGMI hop: the schedule, the receive-buffer parity, the event choreography
 between the host threads."""
 import subprocess
+import os
 import numpy as np
 import pytest
 
@@ -353,6 +354,88 @@ def test_asynchronous_front_changes_no_bit(pkg, scenes, monkeypatch, scene_name)
     assert ta["energy_evals"] == tb["energy_evals"] == tm["energy_evals"]
     pairings = sum(b - 1 for b in batches)
     assert la == lb + pairings and lm == lb + pairings, f"expected one gate launch per pairing ({pairings}) on top of {lb} launches: {la}, {lm}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,opt", [("scn_b", 0), ("scn_c", 0), ("scn_b", 1)])
+def test_cross_queue_timeout_heals_itself(pkg, scenes, monkeypatch, scene_name, opt):
+    """A wait between the queues of a context that runs out (error bit 2048: in practice a second process on the GPU) must not fail the run: the library abandons the batch
+    (what is still enqueued returns at once), restores the state the batch started from, runs the same iterations again on ONE queue, and keeps the one-queue chain from
+    then on.  Driven by the test hook TJ_XS_FAULT=n (the n-th gate of the asynchronous solve reports a time-out without waiting for it): the healed run ends in the same state
+    bit for bit as an undisturbed one, with the same counters, no error bit, one fallback counted -- in the middle of the second of three batches, with the asynchronous front
+    and (opt: "optimal_plane":1) the asynchronous plane refinement and its persistent tables in play."""
+    scene = {"scn_b": scenes.scn_b, "scn_c": scenes.scn_c}[scene_name]()
+    for k in ("TJ_XS_ASYNC", "TJ_XS_ONE_QUEUE", "TJ_FRONT_ASYNC", "TJ_HEAL", "TJ_XS_FAULT", "TJ_KEEP_ASYNC"):
+        monkeypatch.delenv(k, raising=False)
+    def run():
+        s = pkg.Solver(scene, stop=0.0, optimal_plane=1) if opt else pkg.Solver(scene, stop=0.0)
+        for b in (7, 20, 9):
+            s.iterate_async(b); s.sync()
+        st, ts = s.get_state(), s.stats()
+        s.close()
+        return st, ts
+    sa, ta = run()
+    monkeypatch.setenv("TJ_XS_FAULT", "12")   # the gate of the 12th iteration = the fifth of the second batch
+    sb, tb = run()
+    assert ta["async_fallbacks"] == 0 and tb["async_fallbacks"] == 1, (ta["async_fallbacks"], tb["async_fallbacks"])
+    assert ta["error_bits"] == 0 and tb["error_bits"] == 0, (ta["error_bits"], tb["error_bits"])
+    for n in sa:
+        assert np.array_equal(sa[n], sb[n]), f"{n}: the healed run differs from the undisturbed one"
+    assert ta["iters"] == tb["iters"] == 36 and ta["energy_evals"] == tb["energy_evals"] and ta["planes_obs"] == tb["planes_obs"] and ta["planes_self"] == tb["planes_self"]
+    # TJ_HEAL=0: the incident is reported as in round 5
+    monkeypatch.setenv("TJ_HEAL", "0")
+    s = pkg.Solver(scene, stop=0.0)
+    s.iterate_async(20)
+    with pytest.raises(pkg.TrajAdmmError):
+        s.iterate(1)
+    s.close()
+
+
+_SHARE_CODE = r"""
+import sys, os, importlib, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+pkg = importlib.import_module("traj-opt-admm_amd"); sc = pkg.scenes
+s = pkg.Solver(sc.scn_c(), stop=0.0)
+time.sleep(max(0.0, float(sys.argv[1]) - time.time()))   # both processes start their batches at the same wall-clock time
+t0 = time.time()
+for _ in range(4):
+    s.iterate_async(50); s.sync()
+st, ts = s.get_state(), s.stats()
+np.savez(sys.argv[2], **st)
+print("RESULT", ts["error_bits"], ts["async_fallbacks"], round(time.time() - t0, 3), flush=True)
+"""
+
+
+@pytest.mark.gpu
+def test_two_processes_on_one_gpu_with_default_settings(pkg, scenes, tmp_path):
+    """Round 5's probe as a test: two planner PROCESSES on one GPU, default settings (both sleep across queues; this device runs one process's waves at a time, so they shut
+    each other out until the 2 s limits fire: round 5 ended in 13 s and error bits 2052 there).  Now each process heals itself: no error bit, and the same state bit for bit
+    as a process that has the GPU to itself.  (Whether an incident happens at all is up to the scheduler -- counted and printed, not asserted; the deterministic test is
+    test_cross_queue_timeout_heals_itself.)"""
+    import subprocess, sys, time
+    env = dict(os.environ)
+    for k in ("TJ_XS_ASYNC", "TJ_FRONT_ASYNC", "TJ_HEAL", "TJ_XS_FAULT"):
+        env.pop(k, None)
+    go = time.time() + 8.0
+    ps = [subprocess.Popen([sys.executable, "-c", _SHARE_CODE, str(go), str(tmp_path / f"p{i}.npz")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for i in range(2)]
+    outs = []
+    for p in ps:
+        out, _ = p.communicate(timeout=240)
+        outs.append(out)
+    ref = pkg.Solver(scenes.scn_c(), stop=0.0)
+    for _ in range(4):
+        ref.iterate_async(50); ref.sync()
+    sr = ref.get_state(); ref.close()
+    for i, out in enumerate(outs):
+        line = [l for l in out.splitlines() if l.startswith("RESULT")]
+        assert line, f"process {i} failed:\n{out[-2000:]}"
+        err, fb, secs = line[0].split()[1:4]
+        print(f"process {i}: error bits {err}, fallbacks {fb}, {secs} s")
+        assert int(err) == 0, out[-2000:]
+        got = np.load(tmp_path / f"p{i}.npz")
+        for n in sr:
+            assert np.array_equal(got[n], sr[n]), f"process {i}: {n} differs from a process that has the GPU to itself"
 
 
 @pytest.mark.gpu

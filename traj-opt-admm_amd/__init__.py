@@ -47,7 +47,7 @@ class TjStats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in ("iters", "nodes_dcd", "nodes_ccd", "cand_dcd", "cand_ccd", "planes_obs",
                                              "planes_self", "energy_evals", "pair_tests", "llt_fail_piece", "llt_fail_robot", "newton_iters", "pair_solves")] + \
                [("order_ambiguous", C.c_int), ("error_bits", C.c_int), ("order_unresolved", C.c_int), ("head_starts", C.c_int), ("gjk_max_sum", C.c_ulonglong),
-                ("ls_giveups", C.c_int), ("ls_helper_timeouts", C.c_int)]
+                ("ls_giveups", C.c_int), ("ls_helper_timeouts", C.c_int), ("async_fallbacks", C.c_int)]
 
 
 class TrajAdmmError(RuntimeError):

@@ -45,7 +45,9 @@ enum : int {
 #ifdef TJ_NO_DONE_CHECK
 #define TJ_DONE(D) false
 #else
-#define TJ_DONE(D) ((D).ctl->done)
+// ... or a wait between the queues of the context has run out (ERR_XS_TIMEOUT: a GPU shared with another process): what is still enqueued of the batch then returns at
+// once instead of running into one 2 s limit after the other -- the host restores the batch's first state and runs it again on one queue (tj_api.hip: heal_check)
+#define TJ_DONE(D) ((D).ctl->done | ((D).ctl->error & ERR_XS_TIMEOUT))
 #endif
 struct Ctl {
   int iter;            // completed iterations (reference global `iter`)
@@ -333,6 +335,7 @@ struct Dev {
   unsigned long long* blk_stats;    // [U*P] PSD repairs per piece (k_grad), then [U] energy evaluations per robot (line search): single-writer words, no atomics
   unsigned long long* pair_stats;   // [U*S][2] Optimal_plane::optimal_d iterations / robot pairs solved, spread over (lower robot, segment)
   Ctl* ctl;
+  int* err_mirror;   // pinned host memory: k_flush leaves the error bits there for the host's self-healing check (null: off)
   long long* dbg;  // phase stamps (TJ_PHASE_TIMING builds only, else null)
 };
 // P, D, obstacle box, pair box, 49 k-DOP intervals (lo,hi): 146 values in a record of 160 doubles = ten 128-byte lines of its own.  No line is shared between

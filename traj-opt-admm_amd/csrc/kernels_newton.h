@@ -742,7 +742,8 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
 }
 
 // asynchronous solve: the gate in front of k_xsolve on the second queue (one wave, no LDS: it may sit there through the rest of the previous iteration)
-__global__ __launch_bounds__(64) void k_xs_gate(Dev D, int seq) {
+__global__ __launch_bounds__(64) void k_xs_gate(Dev D, int seq, int fault = 0) {
+  if (fault) { if (threadIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return; }   // test hook (TJ_XS_FAULT): as if the wait below had run out
   const int* w = D.xs_go();
   const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s
   while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq < 0) {

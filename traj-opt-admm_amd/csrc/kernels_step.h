@@ -822,7 +822,7 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   if constexpr (FA) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(D.fa_fstart(blockIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (the last k_linesearch block may wait for that)
     fa_epoch = xf_load_i(D.fa_rec() + 1);
-    if (xf_load_i(D.fa_rec() + 2)) { fa_count(D.fa_fdone(blockIdx.x)); return; }   // (the begun iteration's stop test has fired)
+    if (xf_load_i(D.fa_rec() + 2) | (D.ctl->error & ERR_XS_TIMEOUT)) { fa_count(D.fa_fdone(blockIdx.x)); return; }   // (the begun iteration's stop test has fired, or a cross-queue wait has run out: the batch is being abandoned)
   } else if (TJ_DONE(D)) return;
   const int n_obs = (D.u1 - D.u0) * D.S;
   TJ_TIC(D, K_FRONT, 0);
@@ -1019,11 +1019,34 @@ __global__ void k_begin(Dev D) {
   if ((int)threadIdx.x < np) __hip_atomic_fetch_add(xp->cnt[threadIdx.x] + D.rank, (unsigned long long)own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x == 0) atomicAdd(&D.ctl->xpush[0], own);
 }
+// ---- self-healing of the cross-queue schedules (tj_api.hip: heal_check) ----
+// One launch copies every region of a table (dir = 0: state -> snapshot arena at the start of a batch; 1: back).  The control block is handled apart: on a restore
+// the epoch stays where the abandoned batch left it (stamps of its iterations must never look current again) and the error bits of the incident are cleared.
+struct SnapRegion { char* live; char* snap; unsigned long long bytes; };
+__global__ void k_snapshot(const SnapRegion* tab, int n, int dir, Ctl* ctl, Ctl* ctl_snap) {
+  for (int r = blockIdx.y; r < n; r += gridDim.y) {
+    const SnapRegion R = tab[r];
+    const unsigned long long n16 = R.bytes / 16;
+    const uint4* src = (const uint4*)(dir ? R.snap : R.live); uint4* dst = (uint4*)(dir ? R.live : R.snap);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < (R.bytes & 15)) (dir ? R.live : R.snap)[n16 * 16 + threadIdx.x] = (dir ? R.snap : R.live)[n16 * 16 + threadIdx.x];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (!dir) *ctl_snap = *ctl;
+    else {
+      const int epoch = ctl->epoch, err = ctl->error & ~(ERR_XS_TIMEOUT | ERR_LOOP_CAP | ERR_PASS_TIMEOUT), give = ctl->ls_giveups, hto = ctl->ls_helper_timeouts;
+      *ctl = *ctl_snap;
+      ctl->epoch = epoch; ctl->error = ctl_snap->error | err; ctl->ls_giveups = give; ctl->ls_helper_timeouts = hto;
+    }
+  }
+}
+// test hook (TJ_XS_FAULT=<n>): the n-th gate launch of the asynchronous solve behaves as if its wait had run out
 // only used by the stage API: commit the iteration counter explicitly
 // hand a still-owed slack/dual update to the next k_slack(deferred) launch without starting an iteration
 // cancel = 1: the last k_linesearch has already begun an iteration (begin_next) that the host then did not enqueue -- take that back: the update owed is the
 // finished iteration's (already in slack_now), nothing is pending
 __global__ void k_flush(Dev D, int cancel) {
+  if (D.err_mirror) *D.err_mirror = D.ctl->error;   // (every cross-queue wait of the batch is over when this runs: the host looks at the word right after the queues have drained)
   if (cancel) { D.ctl->pending = 0; D.ctl->slack_next = 0; return; }
   D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0;
 }

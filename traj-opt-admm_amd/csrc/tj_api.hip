@@ -51,6 +51,12 @@ struct tj_ctx {
   // asynchronous front (Dev::fa): fa_seq = pairings k_linesearch(i) <-> k_front(i + 1) launched so far (the device's words are monotonic in it); fa_armed: the last
   // k_linesearch enqueued belongs to pairing fa_seq and the k_front that follows goes to the second queue behind k_fa_gate
   int fa_seq = 0; bool fa_armed = false;
+  // Self-healing of the cross-queue schedules: a wait between the queues that runs out (ERR_XS_TIMEOUT -- in practice a GPU shared with another process, whose time slices
+  // keep one of the queues off the hardware) must not fail a run.  The first tj_iterate_async after a point at which the host has looked at the device takes a snapshot of the
+  // state (one launch); when the host next looks and finds the bit, it latches every two-queue schedule off, restores the snapshot, enqueues the same iterations again on
+  // the one queue and counts the incident (tj_stats.async_fallbacks).  TJ_HEAL=0: off (the bit is reported as TJ_ERR_NO_PROGRESS, as in round 5).
+  bool heal = false, heal_busy = false; long long snap_iters = 0; int async_fallbacks = 0, xs_fault = 0;
+  SnapRegion* snap_tab = nullptr; int snap_n = 0; Ctl* ctl_snap = nullptr; int* host_err = nullptr;
   bool fa_mid_ok = false, fa_mid_now = false;   // Dev::fa_mid: k_front's whole grid is resident at once next to one k_linesearch block (tj_create) / the k_mid about to be enqueued waits for k_front itself
   bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
   bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
@@ -227,7 +233,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if (c->xs_seq_gated != c->xs_seq) {   // asynchronous solve: on the second queue, behind a gate that this iteration's k_grad opens (profiling, graphs: it simply follows k_grad on this queue)
         c->xs_seq_gated = c->xs_seq;
         s = c->stream2;
-        TJ_LAUNCH(k_xs_gate, dim3(1), dim3(64), 0, s, d, c->xs_seq);
+        TJ_LAUNCH(k_xs_gate, dim3(1), dim3(64), 0, s, d, c->xs_seq, (c->xs_fault > 0 && c->xs_seq == c->xs_fault) ? 1 : 0);
       }
       if (d.xs_band) TJ_LAUNCH(k_xsolve_band, dim3(owned), dim3(XB_THREADS), c->lds_xs, s, d);
       else switch (9 * d.P - 2) {   // the register factorisation is inlined per size (kernels_newton.h); 61 rows and the LDS forms: the generic kernel
@@ -338,7 +344,8 @@ int flush_deferred(tj_ctx* c) {
   return TJ_OK;
 }
 
-// every host-visible read or write of solver state first pays a deferred slack/dual update
+int heal_check(tj_ctx* c);
+// every host-visible read or write of solver state first pays a deferred slack/dual update -- and, where a batch ran on several queues, looks whether it has to be run again (heal_check)
 #define QUIESCE(c)                                              \
   do {                                                          \
     int qr_ = flush_deferred(c);                                \
@@ -346,6 +353,7 @@ int flush_deferred(tj_ctx* c) {
     HIPCHK(c, hipStreamSynchronize((c)->stream));               \
     if ((c)->stream2) HIPCHK(c, hipStreamSynchronize((c)->stream2)); \
     if ((c)->stream3) HIPCHK(c, hipStreamSynchronize((c)->stream3)); \
+    if ((c)->snap_iters > 0 && !(c)->heal_busy) { qr_ = heal_check(c); if (qr_) return qr_; } \
   } while (0)
 
 // Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two all-gathers), 3 = one full
@@ -424,9 +432,14 @@ void choose_builds(tj_ctx* c, const int* found64) {
 
 int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
   Ctl h; int found64[64];
+  const int fb0 = c->async_fallbacks;
   HIPCHK(c, hipMemcpyAsync(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(found64, c->d.ccd_found, sizeof(found64), hipMemcpyDeviceToHost, c->stream));
   QUIESCE(c);
+  if (c->async_fallbacks != fb0) {   // the batch was run again on one queue (heal_check): what was copied above belongs to the abandoned attempt
+    HIPCHK(c, hipMemcpy(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(found64, c->d.ccd_found, sizeof(found64), hipMemcpyDeviceToHost));
+  }
   if (out) *out = h;
   choose_builds(c, found64);
   if (h.error & ERR_PEER_TIMEOUT) { c->err = "tj_group: a peer rank's slice did not arrive within 2 s (flag transport); the group must be re-initialised"; return TJ_ERR_DEVICE; }
@@ -457,6 +470,34 @@ int ensure_hull_cache(tj_ctx* c) {
   HIPCHK(c, hipGetLastError());
   c->hull_valid = true;
   return TJ_OK;
+}
+
+// The batch enqueued since the last snapshot is through (every queue drained).  No incident: forget the snapshot.  ERR_XS_TIMEOUT: one queue from now on, the snapshot's
+// state back in place, the same iterations again.
+int heal_check(tj_ctx* c) {
+  const int err = *(volatile int*)c->host_err;   // (left in pinned host memory by k_flush, which QUIESCE's flush has just run behind the batch: no copy, no extra synchronisation)
+  const long long n = c->snap_iters;
+  c->snap_iters = 0;
+  if (!(err & ERR_XS_TIMEOUT)) return TJ_OK;
+  c->heal_busy = true;
+  c->async_fallbacks++;
+  c->xs_two_queues = false; c->keep_two_queues = false; c->fa_armed = false; c->fa_mid_now = false; c->xs_fault = 0;   // (the tickets / flags of the asynchronous solve work on one queue as well: TJ_XS_ONE_QUEUE's schedule)
+  Dev& d = c->d;
+  hipLaunchKernelGGL(k_snapshot, dim3(64, std::max(c->snap_n, 1)), dim3(256), 0, c->stream, c->snap_tab, c->snap_n, 1, d.ctl, c->ctl_snap);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemsetAsync(d.xs_sync, 0, ((size_t)2 * d.U + 2) * 32 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(d.fa_sync, 0, Dev::fa_sync_ints(d.U) * sizeof(int), c->stream)); c->fa_seq = 0;
+  HIPCHK(c, hipMemsetAsync(d.keep_sync, 0, 17 * 32 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(d.xf_seg, 0, (size_t)2 * d.S * XF_SEG_STRIDE * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(d.spec_n, 0, 8, c->stream));   // (head-start lists of the abandoned iterations: launch shape only, dropped)
+  c->hull_valid = false; c->ccd_valid = false; c->begin_folded = false; c->maybe_deferred = false;   // (what the snapshot's control block owes is owed again: the next k_mid / flush pays it)
+  c->xs_seq = c->xs_seq_gated = 0; c->keep_seq = 0;
+  int r = tj_iterate_async(c, (int)n);
+  if (r == TJ_OK) r = flush_deferred(c);
+  if (r == TJ_OK) { HIPCHK(c, hipStreamSynchronize(c->stream)); if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3)); }
+  c->snap_iters = 0;
+  c->heal_busy = false;
+  return r;
 }
 
 bool ready(tj_ctx* c) {
@@ -743,6 +784,31 @@ int tj_create(const tj_params* p, tj_ctx** out) {
         (r = dalloc(c, &d.kpair_on, m0 ? 1 : S * U * U)) || (r = dalloc(c, &d.kpair_list, m0 ? 1 : S * U * U)) || (r = dalloc(c, &d.kpair_n, 2)) ||
         (r = dalloc(c, &d.kpair_cd, m0 ? 1 : S * U * U * 4))) return r;
   }
+  {   // self-healing: what a batch's first state consists of (everything an iteration reads that an earlier iteration wrote and that is not rebuilt or re-stamped anyway)
+    c->heal = !(getenv("TJ_HEAL") && atoi(getenv("TJ_HEAL")) == 0);
+    if (c->heal) {   // the error word's mirror in pinned host memory (written by k_flush)
+      void* hp = nullptr; void* dp = nullptr;
+      if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { c->host_err = (int*)hp; *c->host_err = 0; d.err_mirror = (int*)dp; }
+      else { (void)hipGetLastError(); if (hp) (void)hipHostFree(hp); c->heal = false; }
+    }
+    if (const char* e = getenv("TJ_XS_FAULT")) c->xs_fault = atoi(e);   // test hook: the n-th gate of the asynchronous solve reports a time-out
+    std::vector<std::pair<void*, size_t>> reg = {
+      {d.spline, U * 3 * T * 8}, {d.p_slack, U * 18 * P * 8}, {d.p_lambda, U * 18 * P * 8}, {d.t_slack, U * P * 8}, {d.t_lambda, U * P * 8}, {d.piece_time, U * 8},
+      {d.xdir, U * d.xs * 8}, {d.ls_hist, U * 4}, {d.step_out, U * 8}, {d.seg_stats, U * S * 6 * 8}, {d.pair_stats, U * S * 2 * 8}, {d.blk_stats, (U * P + U) * 8}, {d.ccd_found, 64 * 4}};
+    if (d.optimal_plane) {
+      const bool m0 = d.mode == 0;
+      if (m0) { reg.push_back({d.kobs_id, U * S * d.cap_obs * 4}); reg.push_back({d.kobs_n, U * S * 4}); reg.push_back({d.kobs_cd, U * S * d.cap_obs * 32}); }
+      else { reg.push_back({d.kpair_on, S * U * U * 4}); reg.push_back({d.kpair_list, S * U * U * 4}); reg.push_back({d.kpair_n, 8}); reg.push_back({d.kpair_cd, S * U * U * 32}); }
+    }
+    std::vector<SnapRegion> tab;
+    for (auto& pr : reg) {
+      char* snap = nullptr;
+      if ((r = dalloc(c, &snap, (pr.second + 15) / 16 * 16))) return r;
+      tab.push_back(SnapRegion{(char*)pr.first, snap, (unsigned long long)pr.second});
+    }
+    c->snap_n = (int)tab.size();
+    if ((r = dalloc(c, &c->snap_tab, tab.size())) || (r = dalloc(c, &c->ctl_snap, 1)) || (r = upload(c, c->snap_tab, tab.data(), tab.size() * sizeof(SnapRegion)))) return r;
+  }
   if (d.mode == TJ_MODE_MULTI_COUPLED &&
       ((r = dalloc(c, &d.xL, U * (d.xs_band ? (size_t)(n - 1) * BAND_BS + n : (size_t)n * n))) || (r = dalloc(c, &d.xy, U * (size_t)n)) || (r = dalloc(c, &d.xg, U * (size_t)n)) ||
        (r = dalloc(c, &d.xcorner, U * 4)) || (r = dalloc(c, &d.k_obs_f, U)) || (r = dalloc(c, &d.ls_e, (size_t)LSC_ROUNDS * U * LS_GROUPS)))) return r;
@@ -755,6 +821,7 @@ void tj_destroy(tj_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+  if (c->host_err) (void)hipHostFree(c->host_err);
   for (void* p : c->xch_ipc_opened) (void)hipIpcCloseMemHandle(p);
   if (c->xch_block) (void)hipFree(c->xch_block);
   for (void* p : c->allocs) hipFree(p);
@@ -1004,6 +1071,13 @@ int tj_set_state(tj_ctx* c, int u, const double* spline, const double* p_slack, 
 int tj_iterate_async(tj_ctx* c, int n_iters) {
   if (!c || n_iters < 0) return TJ_ERR_INVALID;
   if (!ready(c)) return TJ_ERR_INVALID;
+  if (c->heal && n_iters > 0 && (c->xs_two_queues || c->keep_two_queues)) {   // self-healing: the state this batch starts from (one launch), unless iterations the host has not looked at yet are already outstanding
+    if (c->snap_iters == 0 && !c->heal_busy) {
+      hipLaunchKernelGGL(k_snapshot, dim3(64, std::max(c->snap_n, 1)), dim3(256), 0, c->stream, c->snap_tab, c->snap_n, 0, c->d.ctl, c->ctl_snap);
+      HIPCHK(c, hipGetLastError());
+    }
+    if (!c->heal_busy) c->snap_iters += n_iters;
+  }
   if (n_iters > 0) { int r = ensure_hull_cache(c); if (r) return r; }
   // inside a batch the begin work of iteration i+1 rides on iteration i's k_linesearch (not in coupled mode, whose line search
   // is several kernels, and not in the captured-graph replay, which is one fixed iteration)
@@ -1687,6 +1761,7 @@ int tj_get_stats(tj_ctx* c, tj_stats* s) {
   s->gjk_max_sum = h.gjk_max_sum + (unsigned long long)h.gjk_max;
   s->ls_giveups = h.ls_giveups; s->ls_helper_timeouts = h.ls_helper_timeouts;
   s->head_starts = h.spec_taken;
+  s->async_fallbacks = c->async_fallbacks;
   return TJ_OK;
 }
 
