@@ -200,6 +200,88 @@ def test_hot_kernels_use_no_scratch_memory(pkg, tmp_path):
     assert not bad, f"scratch memory in hot kernels: {bad}"
 
 
+def _disassemble(pkg, tmp_path):
+    """{kernel symbol: [(mnemonic, operand text)]} of the gfx950 code object inside the shipped library"""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("LLVM binutils of the ROCm image not found")
+    so = tmp_path / "lib.so"
+    so.write_bytes(open(pkg.LIB_PATH, "rb").read())
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    cos = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert cos, "no gfx950 code object embedded in libtrajadmm.so"
+    dis = subprocess.run([objdump, "-d", str(tmp_path / cos[0])], check=True, capture_output=True, text=True).stdout
+    body, cur = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1); body[cur] = []
+        elif cur and line.strip():
+            text = line.split("//")[0].strip()
+            if text:
+                parts = text.split(None, 1)
+                body[cur].append((parts[0], parts[1] if len(parts) > 1 else ""))
+    return body
+
+
+def test_signalling_sites_keep_their_order(pkg, tmp_path):
+    """Every cross-block / cross-queue protocol of the library ("Synchronisation protocols") rests on one idiom: records out with write-through
+    stores, `s_waitcnt vmcnt(0)` (+ a barrier where several waves stored), THEN the signal -- a relaxed atomic; the consumer polls the word and reads afterwards.  Relaxed
+    atomics promise no such order in the HIP memory model; the instruction stream does.  This test reads the shipped code object and fails if a compiler change takes the
+    order away.  The sites carry `s_nop` immediates no compiler emits (dev_common.h: sig_acked 0x2a1 / sig_sent 0x2a2, wait_begin 0x2b1 / wait_end 0x2b2, and 0x2c1 / 0x2c2
+    around "the DONE word is performed before the commit stores" in k_linesearch):
+      * right behind 0x2a1 stands the full `s_waitcnt vmcnt(0) ...`; from there to 0x2a2 there is no memory write but the signal itself -- a 32-bit or 64-bit atomic, or
+        a single 32-bit write-through store (a record store is 64 bits wide, and one sunk below the wait would show here);
+      * the first memory instruction behind 0x2b1 is the poll itself, a 32- or 64-bit load past the caches (sc1) -- a record load hoisted to the head of the wait would
+        stand there instead (the block layout between the loop's markers is not its control flow, so the loop body is not scanned further);
+      * between 0x2c1 and 0x2c2 stand the wait and the barrier and no store at all."""
+    body = _disassemble(pkg, tmp_path)
+    chain = [k for k in body if re.search(r"tj\d+(k_grad|k_xsolve|k_linesearch|k_front|k_mid|k_ccd_lean|k_ccd|k_keep|k_begin|k_xs_gate|k_fa_gate|k_keep_gate|k_ls_coupled)(I|E)", k)]
+    assert len(chain) >= 12, sorted(body)[:5]
+    n_sig = n_wait = n_word = 0
+    writes = ("global_store", "flat_store", "scratch_store", "buffer_store", "global_atomic", "flat_atomic", "buffer_atomic")
+    for k in chain:
+        ins = body[k]
+        assert any(m == "s_endpgm" for m, _ in ins) and any(m.startswith("global_load") for m, _ in ins), f"disassembly of {k} not parsed into mnemonics"
+        i = 0
+        while i < len(ins):
+            m, ops = ins[i]
+            if m == "s_nop" and ops.strip() in ("0x2a1", "673"):
+                n_sig += 1
+                assert ins[i + 1][0] == "s_waitcnt" and "vmcnt(0)" in ins[i + 1][1], f"{k}: no s_waitcnt vmcnt(0) right behind the 'acknowledged' marker: {ins[i + 1]}"
+                j = i + 2
+                while j < len(ins) and not (ins[j][0] == "s_nop" and ins[j][1].strip() in ("0x2a2", "674")) and ins[j][0] != "s_endpgm":
+                    mm, oo = ins[j]
+                    if mm.startswith(writes):
+                        is_signal = "atomic" in mm or (mm == "global_store_dword" and "sc1" in oo)
+                        assert is_signal, f"{k}: a store between 'acknowledged' and the signal: {mm} {oo}"
+                    j += 1
+                assert j < len(ins) and ins[j][0] == "s_nop", f"{k}: 'acknowledged' marker without a 'sent' marker behind it"
+                i = j
+            elif m == "s_nop" and ops.strip() in ("0x2b1", "689"):
+                n_wait += 1
+                j = i + 1
+                while not ins[j][0].startswith(("global_", "flat_", "buffer_", "scratch_")):   # the first memory instruction behind the marker, in layout order, is the poll
+                    assert ins[j][0] != "s_endpgm", f"{k}: a wait without a poll"
+                    j += 1
+                assert ins[j][0] in ("global_load_dword", "global_load_dwordx2") and "sc1" in ins[j][1], f"{k}: the first memory access of a wait is not a poll past the caches: {ins[j]}"
+            elif m == "s_nop" and ops.strip() in ("0x2c1", "705"):
+                n_word += 1
+                j = i + 1
+                seen_wait = seen_barrier = False
+                while not (ins[j][0] == "s_nop" and ins[j][1].strip() in ("0x2c2", "706")):
+                    mm, oo = ins[j]
+                    seen_wait |= mm == "s_waitcnt" and "vmcnt(0)" in oo
+                    seen_barrier |= mm == "s_barrier"
+                    assert not mm.startswith(writes), f"{k}: a memory write between the DONE word's wait and the commit: {mm} {oo}"
+                    j += 1
+                assert seen_wait and seen_barrier, f"{k}: the DONE word's wait / barrier is gone"
+                i = j
+            i += 1
+    # the sites exist (a refactoring that drops the markers must not turn this test into a no-op): producers in k_grad, k_xsolve, k_linesearch, k_front, k_ccd, k_keep, k_mid's watcher, ...
+    assert n_sig >= 20 and n_wait >= 20 and n_word >= 1, (n_sig, n_wait, n_word)
+
+
 def test_rccl_entry_points_resolve(pkg):
     """the "rccl" transport of tj_group binds librccl.so at run time (dlopen): the library must open here and export
     ncclCommInitAll / ncclAllGather / ncclCommDestroy / ncclGetErrorString -- the link step of that transport, which needs no GPU"""

@@ -439,6 +439,19 @@ def test_two_processes_on_one_gpu_with_default_settings(pkg, scenes, tmp_path):
 
 
 @pytest.mark.gpu
+def test_rank_isolated_replay_reproduces_the_one_context_run(tmp_path):
+    """tools/rank_replay.py (round 6): rank r of world N alone on the device, the other ranks' slices copied in from a one-context recording before each consuming phase.
+    The tool asserts that every replayed rank's owned robots end bit for bit in the one-context state; here on the 8-robot scene with 1, 2 and 4 ranks."""
+    import json, sys
+    out = tmp_path / "replay.json"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rank_replay.py"), "--scene", "B", "--worlds", "1,2,4", "--steps", "6",
+                        "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.load(open(out))
+    assert set(d["worlds"]) == {"1", "2", "4"} and all(len(w["ranks"]) == int(n) for n, w in d["worlds"].items())
+
+
+@pytest.mark.gpu
 def test_large_fleet_launch_shapes_change_no_bit(pkg, scenes, monkeypatch):
     """256 robots x 1 M obstacle points (the one-pair-per-lane path of k_mid, the deep BVH): the launch-shape switches of round 5 -- pairs per producer wave
     (TJ_PAIR_LPW, the LDS tile of their hulls), producer priority, two BVH levels per step -- against the defaults: three iterations, states bitwise equal"""

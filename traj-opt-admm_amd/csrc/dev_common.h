@@ -345,6 +345,21 @@ constexpr int CCD_STRIDE = 160;
 constexpr int CCD_REC = 18 + 18 + 6 + 6 + 98;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---- the signalling idiom of every cross-block / cross-queue protocol in this library ("Synchronisation protocols") ----
+// PRODUCER: the records go out with write-through stores (agent / system scope: `global_store ... sc1`), the wave then waits until every one of them has been
+// ACKNOWLEDGED (`s_waitcnt vmcnt(0)`: the counter is per wave; a barrier hands it to the other waves of a block) and only then issues the signal -- a relaxed atomic on a word
+// of its own cache line.  CONSUMER: polls the word with a relaxed atomic load (`global_load ... sc1`) and reads the records afterwards, either past the caches (sc1 loads) or
+// from lines its XCD's L2 cannot hold yet.  No fence instruction on either side (a release is `buffer_wbl2`: it writes back the whole L2 of the XCD, measured +14 us when
+// every block of a large grid does it).  What the HIP memory model does not promise for relaxed atomics the ISA does; so that a compiler change cannot silently take it
+// away, the sites are marked with `s_nop` immediates no compiler emits and tests/test_abi_and_host.py::test_signalling_sites_keep_their_order checks, in the disassembly of
+// the shipped code object, that between "acknowledged" (0x2a1 + the s_waitcnt) and "sent" (0x2a2) there is no store but the signal itself, and that a wait loop (0x2b1 ...
+// 0x2b2) contains no load that is not a poll.
+#define TJ_MARK_(imm) asm volatile("s_nop " #imm ::: "memory")
+__device__ __forceinline__ void sig_acked() { TJ_MARK_(0x2a1); __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory"); }   // every store this wave has issued is acknowledged
+__device__ __forceinline__ void sig_sent() { TJ_MARK_(0x2a2); }                                                                   // the signal has been issued
+__device__ __forceinline__ void wait_begin() { TJ_MARK_(0x2b1); }
+__device__ __forceinline__ void wait_end() { TJ_MARK_(0x2b2); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int prefix_count(unsigned long long m) { return __popcll(m & ((1ull << lane_id()) - 1ull)); }
 
@@ -378,11 +393,11 @@ __device__ __forceinline__ void xch_push_robot(const Dev& D, int kind, int u, in
     double* dst = xp->rx[q][kind] + (size_t)u * per;
     for (int i = tid; i < count; i += nth) xch_store(dst + i, src[i]);
   }
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0);
+  sig_acked();
   if constexpr (!ONE_WAVE) __syncthreads();
   asm volatile("" ::: "memory");
   if (tid < np) __hip_atomic_fetch_add(xp->cnt[tid] + kind * XCH_MAX + D.rank, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  sig_sent();
   if (tid == 0) atomicAdd(&D.ctl->xpush[kind], 1);
 }
 
@@ -393,13 +408,18 @@ constexpr long long XCH_TIMEOUT_TICKS = 200000000ll;   // 2 s of the 100 MHz wal
 __device__ __forceinline__ bool xch_wait_owner(const Dev& D, int kind, int r) {
   const unsigned long long need = (unsigned long long)(D.ctl->xpush[kind] / (D.u1 - D.u0)) * (unsigned long long)D.owned_by(r);
   const unsigned long long* w = D.xcnt + kind * XCH_MAX + r;
-  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return true;
-  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
-  for (;;) {
-    __builtin_amdgcn_s_sleep(4);
-    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return true;
-    if (wall_clock64() > t_end) { atomicOr(&D.ctl->error, ERR_PEER_TIMEOUT); return false; }
+  wait_begin();
+  bool ok = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
+  if (!ok) {
+    const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+    for (;;) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) { ok = true; break; }
+      if (wall_clock64() > t_end) { atomicOr(&D.ctl->error, ERR_PEER_TIMEOUT); break; }
+    }
   }
+  wait_end();
+  return ok;
 }
 // Foreign-robot units (kernels_step.h) leave their records with write-through stores, wait for the acknowledgements and count themselves done; the pair
 // tiles of the same launch -- later in the grid, so every unit is resident or finished when a tile starts -- wait for the count.  Records are line
@@ -408,41 +428,51 @@ __device__ __forceinline__ void xf_store(double* p, double v) { __hip_atomic_sto
 __device__ __forceinline__ double xf_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int* xf_word(const Dev& D, int kind, int tr) { return D.xf_seg + ((size_t)kind * D.S + tr) * XF_SEG_STRIDE; }
 __device__ __forceinline__ void xf_signal(const Dev& D, int kind, int tr) {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0);
-  asm volatile("" ::: "memory");
+  sig_acked();
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(xf_word(D, kind, tr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sig_sent();
 }
 // every foreign unit of segment tr has left its record?  one wave; uniform
 __device__ __forceinline__ bool xf_wait_seg(const Dev& D, int kind, int tr) {
   const int want = D.xf_want();
   const int* w = xf_word(D, kind, tr);
-  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
-  const long long t_end = wall_clock64() + ((D.xch || D.xs_async) ? XCH_TIMEOUT_TICKS + 10000000ll : 500000ll + 100ll * gridDim.x);   // (direct exchange: the units themselves may wait 2 s for a peer)
-  for (;;) {
-    __builtin_amdgcn_s_sleep(2);
-    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
-    if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); return false; }
+  wait_begin();
+  bool ok = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+  if (!ok) {
+    const long long t_end = wall_clock64() + ((D.xch || D.xs_async) ? XCH_TIMEOUT_TICKS + 10000000ll : 500000ll + 100ll * gridDim.x);   // (direct exchange: the units themselves may wait 2 s for a peer)
+    for (;;) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
+      if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_PASS_TIMEOUT); break; }
+    }
   }
+  wait_end();
+  return ok;
 }
 
 // asynchronous Newton solve (Dev::xs_async): wait until word *w has reached `want`.  One wave, uniform; false = timed out (error bit set).
 template <int SLEEP = 2>
 __device__ __forceinline__ bool xs_wait(const Dev& D, const int* w, int want) {
-  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
-  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s: a logic error must not hang the device -- but a GPU shared with another process may leave the
-                                                                // other queue of this context off the hardware for whole time slices (5 ms was too short for that)
-  for (;;) {
-    __builtin_amdgcn_s_sleep(SLEEP);
-    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { asm volatile("" ::: "memory"); return true; }
-    if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return false; }
+  wait_begin();
+  bool ok = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+  if (!ok) {
+    const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s: a logic error must not hang the device -- but a GPU shared with another process may leave the
+                                                                  // other queue of this context off the hardware for whole time slices (5 ms was too short for that)
+    for (;;) {
+      __builtin_amdgcn_s_sleep(SLEEP);
+      if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
+      if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
+    }
   }
+  wait_end();
+  return ok;
 }
 // asynchronous plane refinement (Dev::keep_async): every wave of the refinement launch (third queue) has left its planes?  Called by all threads of a block; uniform.
 __device__ __forceinline__ void keep_wait(const Dev& D) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s (a refinement of thousands of rounds is legitimate: the reference spins on such planes as well)
+    wait_begin();
     for (;;) {
       int v = lane < 16 ? __hip_atomic_load(D.keep_sync + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -451,6 +481,7 @@ __device__ __forceinline__ void keep_wait(const Dev& D) {
       if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
       __builtin_amdgcn_s_sleep(8);
     }
+    wait_end();
   }
   __syncthreads();
   asm volatile("" ::: "memory");
@@ -459,31 +490,39 @@ __device__ __forceinline__ void keep_wait(const Dev& D) {
 __device__ __forceinline__ bool fa_wait16(const Dev& D, const int* base, int want) {
   const int lane = threadIdx.x & 63;
   const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+  bool ok = false;
+  wait_begin();
   for (;;) {
     int v = lane < 16 ? __hip_atomic_load(base + (size_t)lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
     v = __shfl(v, 0);
-    if (v - want >= 0) { asm volatile("" ::: "memory"); return true; }
-    if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return false; }
+    if (v - want >= 0) { ok = true; break; }
+    if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
     __builtin_amdgcn_s_sleep(4);
   }
+  wait_end();
+  return ok;
 }
 // ... one word has reached `want` (a robot's commit flag)
 __device__ __forceinline__ bool fa_wait_flag(const Dev& D, const int* w, int want) {
-  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0) { asm volatile("" ::: "memory"); return true; }
-  const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
-  for (;;) {
-    __builtin_amdgcn_s_sleep(4);
-    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0) { asm volatile("" ::: "memory"); return true; }
-    if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return false; }
+  wait_begin();
+  bool ok = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0;
+  if (!ok) {
+    const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+    for (;;) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0) { ok = true; break; }
+      if (wall_clock64() > t_end) { if ((threadIdx.x & 63) == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
+    }
   }
+  wait_end();
+  return ok;
 }
 // a block's stores (write-through) have been acknowledged -> it counts itself on one of sixteen words (fire and forget)
 __device__ __forceinline__ void fa_count(int* w) {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0);
-  asm volatile("" ::: "memory");
+  sig_acked();
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sig_sent();
 }
 __device__ __forceinline__ void xf_store_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int xf_load_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

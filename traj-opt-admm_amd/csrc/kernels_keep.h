@@ -124,10 +124,9 @@ __global__ __launch_bounds__(64) void k_keep(Dev D, int part) {
   // (hundreds of robots): one plane per LANE, the same arithmetic bit for bit, for throughput.  The switch is grid-uniform.
   auto count_done = [&]() {   // asynchronous refinement: this wave's planes are out (acknowledged) -> one of sixteen counters, fire and forget
     if (!wt) return;
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0);
-    asm volatile("" ::: "memory");
+    sig_acked();
     if (lane == 0) __hip_atomic_fetch_add(D.keep_sync + (blockIdx.x & 15) * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sig_sent();
   };
   if (nwork + nold <= 4 * (int)gridDim.x) {
     if (part != 2)

@@ -491,8 +491,7 @@ __device__ __forceinline__ void fa_early_begin(const Dev& D) {
     if (threadIdx.x == 0) xf_store_i(D.obs_work_n, 0);
     for (int i = threadIdx.x; i < D.S; i += blockDim.x) xf_store_i(D.xf_seg + (size_t)i * XF_SEG_STRIDE, 0);
   }
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0);
+  sig_acked();   // (the signal: this block's count on the residency words, first thing in k_linesearch)
   __syncthreads();
   asm volatile("" ::: "memory");
 }
@@ -503,6 +502,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   if (D.fa_seq > 0) {   // asynchronous front: the early begin (last block of the grid: a helper where there are helpers), then every block counts itself started
     if (blockIdx.x == gridDim.x - 1) fa_early_begin(D);
     if (threadIdx.x == 0) __hip_atomic_fetch_add(D.fa_res(blockIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sig_sent();
   }
   if (TJ_DONE(D)) {
     // converged: the only begin work left for the next iteration is to retire the slack/dual update that k_mid has just paid
@@ -770,16 +770,16 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   }
   TJ_TIC(D, K_LS_COUPLED, 5);
   if (commit_late) {   // (uniform) accepted in a team round: commit now -- with helpers about, wave 0's DONE word must have been performed before the first of these stores is issued
-    if (H > 1) { asm volatile("" ::: "memory"); if (tid < 64) __builtin_amdgcn_s_waitcnt(0); __syncthreads(); asm volatile("" ::: "memory"); }   // (s_waitcnt vmcnt(0): wave 0's DONE store has been acknowledged; the barrier hands that to the other waves; the compiler keeps the commit stores below)
+    if (H > 1) { TJ_MARK_(0x2c1); if (tid < 64) __builtin_amdgcn_s_waitcnt(0); __syncthreads(); TJ_MARK_(0x2c2); }   // (s_waitcnt vmcnt(0): wave 0's DONE store has been acknowledged; the barrier hands that to the other waves; the compiler keeps the commit stores below)
     const double* win = sm + L.gnet + (size_t)wg * 3 * T;
     for (int i = tid; i < 3 * T; i += LS_THREADS) xs_out(D.fa_seq > 0, gspline + i, win[i]);
   }
   if (D.fa_seq > 0) {   // (uniform) asynchronous front: the control net is out (written through) and acknowledged -> the robot's commit flag; k_front's units on the other queue wait for it
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0);
+    sig_acked();
     __syncthreads();
     asm volatile("" ::: "memory");
     if (tid == 0) __hip_atomic_store(D.fa_commit(u), D.fa_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sig_sent();
   }
   TJ_TIC(D, K_LINESEARCH, 5);
   if (tid == 0) { D.piece_time[u] = pt_acc; D.step_out[u] = step_acc; D.ls_hist[u] = k_acc; D.blk_stats[(size_t)D.U * D.P + u] += (unsigned long long)evals; }   // per robot: one writer, no atomic in front of the ticket
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
   // there waits for it (inside a batch only: the first iteration of a batch is fed by k_begin, which pushes whatever the state is then)
   if (D.xch && begin_next) xch_push_robot<false>(D, 0, u, 3 * T, sm + L.gnet + (size_t)wg * 3 * T, 3 * T, tid, LS_THREADS);
 ticket:
-  if (h > 0) __builtin_amdgcn_s_waitcnt(0);   // a helper's posts are performed before its ticket: begin_body's reset of the table cannot be overtaken by them
+  if (h > 0 && begin_next) sig_acked();   // a helper's posts are performed before its ticket: begin_body's reset of the table cannot be overtaken by them
   if (begin_next) {
     // No fence: nothing another block of THIS kernel writes is read here (gnorm and the counters come from earlier kernels;
     // what begin_body resets was consumed by every block before its ticket), and what is written here is read by later
@@ -800,6 +800,7 @@ ticket:
       const int add = 1 + ((h == 0 && k_acc != 0) ? 0x10000 : 0), old = atomicAdd(&D.ctl->ticket, add);
       s_last = (old & 0xffff) == nown * H - 1 ? 1 + (((old + add) >> 16) != 0) : 0;
     }
+    sig_sent();
     __syncthreads();
     if (s_last) {
       if (tid == 0) D.ctl->ticket = 0;

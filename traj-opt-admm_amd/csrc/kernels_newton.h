@@ -483,11 +483,11 @@ __global__ __launch_bounds__(FOLD ? GRAD_FOLD_THREADS : GRAD_THREADS) void k_gra
   if (tid == 0 && s_llt == 0) D.blk_stats[(size_t)u * D.P + sp] += 1ull;   // PSD repairs of this piece: only this block writes the word
   if (tid == 0 && D.grad_bal) D.grad_cost[item] = (int)(wall_clock64() - t_entry);   // 10 ns ticks; read by the next iteration's k_front
   if (wt) {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0);   // every store of this wave has been acknowledged ...
+    sig_acked();                     // every store of this wave has been acknowledged ...
     __syncthreads();                 // ... and of the other two
     asm volatile("" ::: "memory");
     if (tid == 0) __hip_atomic_fetch_add(D.xs_ticket(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sig_sent();
   }
   TJ_TIC(D, K_GRAD, 6);
 }
@@ -718,10 +718,9 @@ __device__ __forceinline__ void xs_wave0(const Dev& D, int u, int tid, int n, in
     // asynchronous solve: k_ccd's units of this robot wait for the DIRECTION only -- its flag goes up as soon as those stores are acknowledged; wolfe, |g| and the
     // time direction (read by k_ccd's finisher and by k_linesearch) follow and are counted (xs_done) -- k_ccd does not end before the count is full: its finisher
     // waits for it, and so does every robot's unit of segment 0 when its walk is over (a single UAV's k_ccd has no finisher)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0);
-    asm volatile("" ::: "memory");
+    sig_acked();
     if (tid == 0) __hip_atomic_store(D.xs_flag(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sig_sent();
   }
   for (int i = tid; i < n; i += XS_THREADS) { scr[i] = x0[i] * g0[i]; scr[n + i] = g0[i] * g0[i]; }
   blk_sync<true>();
@@ -746,10 +745,12 @@ __global__ __launch_bounds__(64) void k_xs_gate(Dev D, int seq, int fault = 0) {
   if (fault) { if (threadIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); return; }   // test hook (TJ_XS_FAULT): as if the wait below had run out
   const int* w = D.xs_go();
   const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;   // 2 s
+  wait_begin();
   while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq < 0) {
     if (wall_clock64() > t_end) { if (threadIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); break; }
     __builtin_amdgcn_s_sleep(16);
   }
+  wait_end();
 }
 
 // NREG = n when the system fits one row per lane (n = 9P-2 <= 61, P <= 7: the register factorisation inlined, size known at
@@ -850,13 +851,12 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     __builtin_amdgcn_s_setprio(3); xs_wave0<NREG>(D, u, tid, n, m, H, L, g0, x0, scr); __builtin_amdgcn_s_setprio(0);   // the factorisation: ahead of the helper wave on its SIMD
     if (wt) {
       // the direction record is out (write-through) and acknowledged: the robot's flag and the count -- k_ccd's units on the other queue are waiting for them
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0);
-      asm volatile("" ::: "memory");
+      sig_acked();
       if (tid == 0) {
         __hip_atomic_store(D.xs_flag(u), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (decoupled / single: raised earlier, right behind the direction)
         __hip_atomic_fetch_add(D.xs_done(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      sig_sent();
       TJ_TIC(D, K_XSOLVE, 6);
       return;
     }

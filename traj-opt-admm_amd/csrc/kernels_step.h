@@ -859,7 +859,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if constexpr (FA) {
     if (blockIdx.x == 0) {
       fa_wait16(D, D.fa_fdone(0), (int)((unsigned)D.fa_seq * (unsigned)D.fa_nfront));
+      sig_acked();   // (nothing of its own to acknowledge: the watcher only relays k_front's count)
       xf_store_i(D.fa_go(threadIdx.x), D.fa_seq);
+      sig_sent();
       return;
     }
   }
@@ -920,8 +922,9 @@ __device__ __forceinline__ void ccd_union_body(const Dev& D) {
   const int lane = lane_id();
   const int n_t = (int)gridDim.x - 1 - n_xf - n_obs;   // selection blocks
   if (b >= n_obs) {
-    __builtin_amdgcn_s_waitcnt(0);
+    sig_acked();
     if (lane == 0) atomicAdd(&D.ctl->ccd_sub[(b - n_obs) & 15], 1 + (found ? 0x10000 : 0));
+    sig_sent();
   }
   if (blockIdx.x != 0) return;
   __syncthreads();
@@ -1012,11 +1015,11 @@ __global__ void k_begin(Dev D) {
   const int np = xp->n, T = D.T, own = D.u1 - D.u0;
   const size_t off = (size_t)D.u0 * 3 * T, cnt = (size_t)own * 3 * T;
   for (int q = 0; q < np; q++) for (size_t i = threadIdx.x; i < cnt; i += blockDim.x) xch_store(xp->rx[q][0] + off + i, D.spline[off + i]);
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0);
+  sig_acked();
   __syncthreads();
   asm volatile("" ::: "memory");
   if ((int)threadIdx.x < np) __hip_atomic_fetch_add(xp->cnt[threadIdx.x] + D.rank, (unsigned long long)own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  sig_sent();
   if (threadIdx.x == 0) atomicAdd(&D.ctl->xpush[0], own);
 }
 // ---- self-healing of the cross-queue schedules (tj_api.hip: heal_check) ----
