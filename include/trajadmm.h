@@ -309,6 +309,14 @@ int tj_xch_enable(tj_ctx* c, int on, int wait_mode);
  * must be 1).  UNVERIFIED ON HARDWARE: a group whose devices are all distinct (the configuration the feature exists for) has
  * not run yet -- no multi-GPU box was available to rounds 1-3; same-device groups are tested bitwise against one context. */
 typedef struct tj_group tj_group;
+/* Coupled mode ("decouple":0) on SHARDED contexts: the Armijo search on the summed energy has no bound in the reference (Optimization3D_multi.h:605-636); one exchange of
+ * buffer 4 carries the candidates 0.8^0 .. 0.8^30.  Default: a search that needs more ends in TJ_ERR_NO_PROGRESS (error bit 32), as in round 5.  With follow = 1 phase 5
+ * commits nothing in that case and the caller -- after phase 5 of every iteration -- asks tj_coupled_search_pending (it drains the context's stream: the one host look of the
+ * schedule); while it answers 1: run phase 4, exchange buffer 4, phase 5 again (they evaluate, carry and decide the next 32 candidates) and ask again.  Every rank reads
+ * the same answer.  tj_group does this by itself: a batch that runs into error bit 32 is run again from its first state with the followed search.  One context needs
+ * neither call (its deciding block goes on alone). */
+int tj_set_coupled_follow(tj_ctx* c, int on);
+int tj_coupled_search_pending(tj_ctx* c, int* pending);
 int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_group** out);
 void tj_group_destroy(tj_group* g);
 int tj_group_size(tj_group* g);

@@ -25,7 +25,7 @@ EXPORTS = [
     "tj_default_params", "tj_create", "tj_destroy", "tj_last_error", "tj_set_cloud", "tj_set_mesh", "tj_init_state", "tj_get_state",
     "tj_set_state", "tj_iterate", "tj_iterate_async", "tj_sync", "tj_stream", "tj_run_stage", "tj_get_planes", "tj_get_candidates",
     "tj_set_planes", "tj_get_direction", "tj_set_direction", "tj_get_local_grad", "tj_get_steps", "tj_get_energy", "tj_get_stats", "tj_get_build_info", "tj_exchange_buffer",
-    "tj_iterate_phase", "tj_iterate_phase_chained", "tj_launch_count", "tj_phase_count", "tj_xch_block", "tj_xch_ipc_export", "tj_xch_ipc_open", "tj_xch_attach", "tj_xch_enable", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name",
+    "tj_iterate_phase", "tj_iterate_phase_chained", "tj_set_coupled_follow", "tj_coupled_search_pending", "tj_launch_count", "tj_phase_count", "tj_xch_block", "tj_xch_ipc_export", "tj_xch_ipc_open", "tj_xch_attach", "tj_xch_enable", "tj_set_stream", "tj_host_tables", "tj_profile_kernels", "tj_kernel_count", "tj_kernel_name",
     "tj_get_obs_cache", "tj_set_obs_cache", "tj_get_pair_cache", "tj_set_pair_cache", "tj_edge_collision", "tj_plan_init",
     "tj_group_create", "tj_group_destroy", "tj_group_size", "tj_group_ctx", "tj_group_last_error", "tj_group_set_cloud", "tj_group_set_mesh",
     "tj_group_transport", "tj_group_set_transport", "tj_group_profile_exchange", "tj_rccl_available", "tj_group_rccl_ranks",
@@ -222,6 +222,15 @@ class Solver:
     def iterate_phase(self, phase, more=0):
         """more: another iteration follows in this batch (decoupled schedules then fold its begin into this one's line search)"""
         self._check(self.lib.tj_iterate_phase_chained(self._ctx, C.c_int(phase), C.c_int(1 if more else 0)))
+
+    def set_coupled_follow(self, on=True):
+        """coupled mode, sharded context: follow the Armijo search beyond the candidates one exchange carries (ask coupled_search_pending() after phase 5)"""
+        self._check(self.lib.tj_set_coupled_follow(self._ctx, C.c_int(1 if on else 0)))
+
+    def coupled_search_pending(self):
+        p = C.c_int()
+        self._check(self.lib.tj_coupled_search_pending(self._ctx, C.byref(p)))
+        return bool(p.value)
 
     # ---- direct exchange between processes (include/trajadmm.h tj_xch_*) ----
     def xch_ipc_export(self):

@@ -88,6 +88,11 @@ struct Ctl {
   // Both are zero on a GPU of the solver's own; a regression to the always-timeout path shows here (tj_stats) instead of only as a slower run.
   int ls_giveups, ls_helper_timeouts;
   int c2_cnt;          // coupled chain with the corner solve folded into k_xsolve (Dev::c2_fold): robots whose Schur-corner terms have been written (zeroed by begin_body)
+  // coupled mode, SHARDED context whose caller follows the Armijo search beyond the candidates one exchange carries (Dev::lsc_follow, kernels_ls.h k_ls_commit):
+  // 1 = none of the candidates gathered so far passes, nothing has been committed -- the caller evaluates, gathers and decides the next LSC_ROUNDS rounds;
+  // lsc_e0: the summed E(x) of the search (formed with the first table, needed by the later ones)
+  int lsc_pending, pad4;
+  double lsc_e0;
 };
 
 // kernels of one iteration, in stream order (unit of tj_profile_kernels and of the phase stamps)
@@ -219,6 +224,7 @@ struct Dev {
   __host__ __device__ int* fa_commit(int u) const { return fa_sync + (size_t)(112 + u) * 32; }
   __host__ __device__ int* fa_rec() const { return fa_sync + (size_t)(112 + U) * 32; }
   __host__ __device__ static size_t fa_sync_ints(int U_) { return (size_t)(113 + U_) * 32; }
+  int lsc_follow;   // coupled mode, sharded context: the caller follows the Armijo search to the reference's end (tj_coupled_search_pending); 0: ERR_LS_RANGE beyond 0.8^30 as in round 5
   int xs_band;  // long trajectories (piece_num > 10): the Newton solve runs on band storage (k_xsolve_band) and the swept-hull
                 // cache comes from k_ccd_prep again
   int seq_tree; // k_ccd_self_seq has LDS for the reference's per-segment dynamic tree (dev_dyntree.h)

@@ -864,8 +864,10 @@ __device__ __forceinline__ double lsc_step0(const Dev& D, int tid, double t0, do
 // (round, candidate) adds its column in robot order out of LDS -- the sum the reference forms (e += spline_energy(i)); one
 // lane per candidate walking the robots through global memory was 64 dependent round trips per round, in every block of four
 // launches per iteration.
+// base (sharded contexts that follow the search, Dev::lsc_follow): the table holds the rounds [base, base + LSC_ROUNDS) -- candidates 0.8^(8 base - 1) and smaller; E(x) is
+// the one formed with the first table (Ctl::lsc_e0).  acc[0] = absolute round.
 template <bool FRESH = false>   // FRESH: the table is being written by other blocks of THIS launch (agent-scope stores): read it past the caches
-__device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double step0, int lane, int* acc, double* accstep, double* stage) {
+__device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double step0, int lane, int* acc, double* accstep, double* stage, int base = 0, double* e0_out = nullptr) {
   const double wolfe = D.ctl->wolfe_c;
   constexpr int RC = LSC_ROUNDS * LS_GROUPS;   // 32 columns
   const int r_l = lane / LS_GROUPS, c = lane % LS_GROUPS;
@@ -878,13 +880,14 @@ __device__ __forceinline__ void lsc_decide(const Dev& D, int nrounds, double ste
     if (lane < RC) for (int j = 0; j < nu; j++) tot += stage[j * RC + lane];
   }
   double step = step0;
-  if (lane < RC) { const int k = lsc_cand_k(r_l, c); for (int i = 0; i < k; i++) step *= 0.8; }
-  const double e0 = __shfl(tot, 0);
+  if (lane < RC) { const int k = lsc_cand_k(base + r_l, c); for (int i = 0; i < k; i++) step *= 0.8; }   // same rounding as the reference's repeated step *= 0.8
+  const double e0 = base == 0 ? __shfl(tot, 0) : D.ctl->lsc_e0;
+  if (e0_out && lane == 0) *e0_out = e0;
   int found_r = -1, found_c = 0; double found_step = step0;
   for (int r = 0; r < nrounds && found_r < 0; r++) {
-    const bool ok = r_l == r && lane < RC && !(r == 0 && c == 0) && !(e0 - 1e-4 * wolfe * step < tot);
+    const bool ok = r_l == r && lane < RC && !(base == 0 && r == 0 && c == 0) && !(e0 - 1e-4 * wolfe * step < tot);
     const unsigned long long mask = __ballot(ok);
-    if (mask) { const int l = __ffsll((long long)mask) - 1; found_r = r; found_c = l - r * LS_GROUPS; found_step = __shfl(step, l); }
+    if (mask) { const int l = __ffsll((long long)mask) - 1; found_r = base + r; found_c = l - r * LS_GROUPS; found_step = __shfl(step, l); }
   }
   if (lane == 0) { acc[0] = found_r; acc[1] = found_c; *accstep = found_step; }
 }
@@ -953,7 +956,8 @@ __device__ __forceinline__ void lsc_continue(const Dev& D, const LsLayout& L, do
 // boundaries, ~8 us each with their staging).  Same energies into the same table, same decision.
 // begin_next (wide launch of one context, inside a batch): the committing block also starts the NEXT iteration (begin_body), like k_linesearch's last block does
 // in the decoupled chain -- the host then omits k_begin.
-__global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round0, int wide, int begin_next) {
+// base (sharded context, the caller follows the search: Dev::lsc_follow): the launch evaluates the rounds [base + round0, ...) into the table's rows [round0, ...)
+__global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round0, int wide, int begin_next, int base = 0) {
   if (TJ_DONE(D)) {
     if (begin_next && blockIdx.x == 0 && threadIdx.x == 0) { D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0; }   // (as k_linesearch: retire the slack update k_mid has just paid)
     return;
@@ -962,7 +966,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   __shared__ int pref[1024];
   __shared__ int s_acc[2];
   __shared__ double s_step0, s_accstep;
-  const int nown = D.u1 - D.u0, hb = wide > 1 ? (int)blockIdx.x / nown : 0, round = round0 + hb;
+  const int nown = D.u1 - D.u0, hb = wide > 1 ? (int)blockIdx.x / nown : 0, round = base + round0 + hb;
   const int tid = threadIdx.x, u = D.u0 + (int)blockIdx.x - hb * nown, S = D.S, T = D.T, P = D.P;
   // G = L.groups candidates side by side (8 up to piece_num = 10; 4 or 2 for long trajectories, whose hull buffers are larger): a
   // round's LS_GROUPS candidates then take LS_GROUPS / G passes.  Waves beyond G shadow the last group (same values into the same
@@ -995,7 +999,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
     __syncthreads();
     const double e = x_energy_group(D, u, sm, L, gnet, pt, ghull, sm + L.gcons + (size_t)g * 24 * P, M, in_lds, pref, gl, k >= 0, step);
     if (gl == 0 && !shadow) {
-      double* dst = &D.ls_e[((size_t)u * LSC_ROUNDS + round) * LS_GROUPS + slot];
+      double* dst = &D.ls_e[((size_t)u * LSC_ROUNDS + (round - base)) * LS_GROUPS + slot];
       if (one_ctx) __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = e;   // one context: write-through, read by the deciding block of THIS launch
     }
   }
@@ -1031,7 +1035,10 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
 }
 
 // commit: x_u += step d_u for every robot, the shared piece_time advances by step * t_direction
-__global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
+// base: see k_ls_coupled.  A sharded context whose caller follows the search (Dev::lsc_follow) commits NOTHING when none of the gathered candidates passes: it leaves
+// Ctl::lsc_pending = 1 (every rank takes the same decision on the same gathered table) and the caller evaluates, gathers and decides the next rounds
+// (tj_coupled_search_pending) -- on to the reference's own end, the fixed point of step *= 0.8 (Optimization3D_multi.h:623).
+__global__ __launch_bounds__(64) void k_ls_commit(Dev D, int base = 0) {
   if (TJ_DONE(D)) return;
   __shared__ int s_acc[2];
   __shared__ double s_step0, s_accstep;
@@ -1041,14 +1048,24 @@ __global__ __launch_bounds__(64) void k_ls_commit(Dev D) {
   __shared__ double s_stage[64 * LSC_ROUNDS * LS_GROUPS];
   if (D.u1 - D.u0 == D.U) {   // one context: the last block of the deciding round left the decision (or none was acceptable)
     if (tid == 0) { const bool f = D.ctl->lsf_epoch == D.ctl->epoch; s_acc[0] = f ? D.ctl->lsf_r : -1; s_acc[1] = f ? D.ctl->lsf_c : 0; s_accstep = f ? D.ctl->lsf_step : step0; }
-  } else lsc_decide(D, LSC_ROUNDS, step0, tid, s_acc, &s_accstep, s_stage);
+  } else {
+    __shared__ double s_e0;
+    lsc_decide(D, LSC_ROUNDS, step0, tid, s_acc, &s_accstep, s_stage, base, &s_e0);
+    if (tid == 0 && blockIdx.x == 0 && base == 0) D.ctl->lsc_e0 = s_e0;   // (read by the launches of a continued search only: later kernels)
+  }
   __syncthreads();
   double step = s_accstep;
-  int kacc = s_acc[0] >= 0 ? lsc_cand_k(s_acc[0], s_acc[1]) : lsc_cand_k(LSC_ROUNDS - 1, LS_GROUPS - 1);
-  if (s_acc[0] < 0) {  // no acceptable step within the evaluated range: take the last candidate and report it
+  int kacc = s_acc[0] >= 0 ? lsc_cand_k(s_acc[0], s_acc[1]) : lsc_cand_k(base + LSC_ROUNDS - 1, LS_GROUPS - 1);
+  if (tid == 0 && blockIdx.x == 0 && D.lsc_follow) D.ctl->lsc_pending = 0;
+  if (s_acc[0] < 0) {  // no acceptable step within the evaluated range
+    const bool at_end = kacc >= STEP_CAP;   // the fixed point of step *= 0.8 lies inside this table: the reference's loop would never end -- take the last candidate and report (like lsc_continue)
+    if (D.lsc_follow && !at_end) {          // the caller goes on with the next rounds: nothing is committed
+      if (tid == 0 && blockIdx.x == 0) D.ctl->lsc_pending = 1;
+      return;
+    }
     step = step0;
     for (int i = 0; i < kacc; i++) step *= 0.8;
-    if (tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_LS_RANGE);
+    if (tid == 0 && blockIdx.x == 0) atomicOr(&D.ctl->error, at_end ? ERR_LOOP_CAP : (ERR_LOOP_CAP | ERR_LS_RANGE));
   }
   double* gspline = D.spline + (size_t)u * 3 * T;
   const double* dir = D.dirp(u);

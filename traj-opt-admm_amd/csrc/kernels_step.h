@@ -1037,7 +1037,7 @@ __global__ void k_snapshot(const SnapRegion* tab, int n, int dir, Ctl* ctl, Ctl*
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (!dir) *ctl_snap = *ctl;
     else {
-      const int epoch = ctl->epoch, err = ctl->error & ~(ERR_XS_TIMEOUT | ERR_LOOP_CAP | ERR_PASS_TIMEOUT), give = ctl->ls_giveups, hto = ctl->ls_helper_timeouts;
+      const int epoch = ctl->epoch, err = ctl->error & ~(ERR_XS_TIMEOUT | ERR_LOOP_CAP | ERR_PASS_TIMEOUT | ERR_LS_RANGE), give = ctl->ls_giveups, hto = ctl->ls_helper_timeouts;
       *ctl = *ctl_snap;
       ctl->epoch = epoch; ctl->error = ctl_snap->error | err; ctl->ls_giveups = give; ctl->ls_helper_timeouts = hto;
     }

@@ -77,6 +77,7 @@ struct tj_ctx {
   bool graph_failed[4] = {false, false, false, false};
   size_t lds_grad = 0, lds_xs = 0, lds_xs2 = 0, lds_ls = 0, lds_seq = 0;
   bool lsc_wide = false;     // coupled mode: k_ls_coupled evaluates all LSC_ROUNDS rounds in one launch (kernels_ls.h)
+  int lsc_base = 0;          // coupled mode, sharded context that follows the Armijo search (Dev::lsc_follow): first round of the table the next phases 4 / 5 evaluate and decide (0 at every iteration's start)
   bool ccd_lean = true;        // which build of k_ccd the chain launches (kernels_step.h); re-decided whenever the control block is read
   unsigned ccd_found_seen = 0; long long iters_enqueued = 0, iters_seen = 0;
   bool grad_fold = true;       // k_grad compacts its own segments (one launch less); TJ_GRAD_FOLD=0 keeps k_sep_self_compact + the 192-thread k_grad
@@ -284,11 +285,12 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
     case K_LS_COUPLED:
       if (coupled) {
-        if (c->lsc_wide) { TJ_LAUNCH(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // all rounds at once, one block per (robot, round)
-        else for (int r = 0; r < LSC_ROUNDS; r++) TJ_LAUNCH(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r, 1, 0);
+        const int base = (owned != d.U && d.lsc_follow) ? c->lsc_base : 0;   // (a followed search of a sharded context: the rounds beyond the first table)
+        if (c->lsc_wide) { TJ_LAUNCH(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0, base); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // all rounds at once, one block per (robot, round)
+        else for (int r = 0; r < LSC_ROUNDS; r++) TJ_LAUNCH(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r, 1, 0, base);
       }
       return coupled;
-    case K_LS_COMMIT: if (coupled && !(c->lsc_wide && owned == d.U)) TJ_LAUNCH(k_ls_commit, dim3(owned), dim3(64), 0, s, d); return coupled;   // (one context, all rounds in one launch: its last block commits)
+    case K_LS_COMMIT: if (coupled && !(c->lsc_wide && owned == d.U)) TJ_LAUNCH(k_ls_commit, dim3(owned), dim3(64), 0, s, d, (owned != d.U && d.lsc_follow) ? c->lsc_base : 0); return coupled;   // (one context, all rounds in one launch: its last block commits)
     case K_SLACK: if (in_graph) return false; TJ_LAUNCH(k_slack, dim3(owned * d.P), dim3(64), 0, s, d, slack_deferred); return true;
   }
   return false;
@@ -383,7 +385,9 @@ int enqueue_body(tj_ctx* c, int which, int chain_pos = 0, bool whole_iteration =
   if (which == 1 && c->d.fuse) { int hr = ensure_hull_cache(c); if (hr) return hr; }   // fused phases: k_linesearch keeps the owned robots' hull cache; after a host write it is rebuilt once
   for (int i = 0; i < n; i++) launch_kernel(c, list[i], m, 0, false, true, chain_pos);
   HIPCHK(c, hipGetLastError());
-  if (which == (cpl ? 5 : 2)) c->maybe_deferred = true;  // this iteration's slack/dual update is owed to the next k_mid (or the flush)
+  // this iteration's slack/dual update is owed to the next k_mid (or the flush) -- in a followed coupled search only once the search is over (tj_coupled_search_pending says so):
+  // a flush between two tables of candidates would pay the update on the uncommitted control net
+  if (which == (cpl ? 5 : 2) && !(cpl && c->d.lsc_follow && c->d.u1 - c->d.u0 != c->d.U)) c->maybe_deferred = true;
   return TJ_OK;
 }
 
@@ -1188,8 +1192,31 @@ int tj_iterate_phase_chained(tj_ctx* c, int phase, int more) {
     if (phase == 0) { pos = c->begin_folded ? 1 : 0; c->begin_folded = false; }
     if (phase == 2 && more) { pos = 2; c->begin_folded = true; }
   }
-  if (phase == 0) c->iters_enqueued += 1;
+  if (phase == 0) { c->iters_enqueued += 1; c->lsc_base = 0; }
   return enqueue_body(c, phase, pos);
+}
+
+// Coupled mode, sharded contexts: the Armijo search on the summed energy to the reference's own end (Optimization3D_multi.h:605-636: no bound).  One exchange carries the
+// candidates of LSC_ROUNDS rounds (steps 0.8^0 .. 0.8^30 in the first table).  With `follow` on, phase 5 commits nothing when none of them passes and the caller asks here
+// (the stream is drained: this is the one host look of the schedule, paid only by callers that want the exact loop): pending = 1 -> run phase 4, exchange buffer 4, phase 5
+// again -- they evaluate, carry and decide the NEXT rounds -- and ask again.  Every rank of the sharded run reads the same answer (same gathered table, same decision).
+int tj_set_coupled_follow(tj_ctx* c, int on) {
+  if (!c) return TJ_ERR_INVALID;
+  if (c->d.mode != TJ_MODE_MULTI_COUPLED) { c->err = "tj_set_coupled_follow: coupled mode only"; return TJ_ERR_INVALID; }
+  c->d.lsc_follow = on ? 1 : 0; c->lsc_base = 0;
+  return TJ_OK;
+}
+int tj_coupled_search_pending(tj_ctx* c, int* pending) {
+  if (!c || !pending) return TJ_ERR_INVALID;
+  *pending = 0;
+  if (!c->d.lsc_follow || c->d.u1 - c->d.u0 == c->d.U) return TJ_OK;   // (one context follows the search inside its own launch: lsc_continue)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int p = 0;
+  HIPCHK(c, hipMemcpy(&p, &c->d.ctl->lsc_pending, sizeof(int), hipMemcpyDeviceToHost));
+  *pending = p ? 1 : 0;
+  c->lsc_base = p ? c->lsc_base + LSC_ROUNDS : 0;
+  if (!p) c->maybe_deferred = true;   // the step is committed: the iteration's slack/dual update is owed from here on
+  return TJ_OK;
 }
 int tj_iterate_phase(tj_ctx* c, int phase) { return tj_iterate_phase_chained(c, phase, 0); }
 

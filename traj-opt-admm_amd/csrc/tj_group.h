@@ -31,6 +31,7 @@
 // may repeat).  A group whose devices are all distinct has NOT run on hardware yet (no multi-GPU box was available in rounds
 // 1-3): tests/test_gpu_group.py::test_group_on_two_devices runs wherever two devices are visible.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -133,6 +134,7 @@ enum { TJ_TRANSPORT_EVENT = 0, TJ_TRANSPORT_FLAG = 1, TJ_TRANSPORT_RCCL = 2 };
 
 struct tj_group {
   int n = 0;
+  int lsc_followed = 0;                           // coupled mode: batches that were run again with the Armijo search followed beyond the exchanged candidates (tj_group_iterate)
   int transport = TJ_TRANSPORT_EVENT;
   bool distinct = false;                          // every rank on its own device
   std::vector<tj_ctx*> ctx;
@@ -219,7 +221,10 @@ int group_exchange(tj_group* g, int r, int what, long s) {
 const int kGroupDecoupled[][2] = {{0, 0}, {1, 1}, {2, -1}};
 const int kGroupCoupled[][2] = {{0, 0}, {1, 2}, {2, 1}, {3, 3}, {4, 4}, {5, -1}};
 
-int group_rank_loop(tj_group* g, int r, int n_iters) {
+// careful (coupled mode, the re-run of a batch whose Armijo search left the candidates one exchange carries): the rank follows the search -- after phase 5 it asks
+// tj_coupled_search_pending (one host look per iteration) and repeats phase 4 / exchange 4 / phase 5 while the answer is yes; *extra4 = the additional exchanges of
+// buffer 4 it issued (the same number on every rank: same gathered tables, same decisions)
+int group_rank_loop(tj_group* g, int r, int n_iters, bool careful = false, long* extra4 = nullptr) {
   tj_ctx* c = g->ctx[r];
   HIPCHK(c, hipSetDevice(g->dev[r]));
   if (!ready(c)) return TJ_ERR_INVALID;
@@ -231,13 +236,22 @@ int group_rank_loop(tj_group* g, int r, int n_iters) {
   if (g->n > 1 && g->transport == TJ_TRANSPORT_FLAG && c->d.xch) return tj_iterate_async(c, n_iters);
   long s[5];
   for (int w = 0; w < 5; w++) s[w] = g->issued[w];
-  for (int it = 0; it < n_iters; it++)
+  for (int it = 0; it < n_iters; it++) {
     for (int k = 0; k < nph; k++) {
       int rc = tj_iterate_phase_chained(c, sched[k][0], it + 1 < n_iters);   // (decoupled: the next iteration's begin rides in this one's k_linesearch)
       if (rc) return rc;
       const int what = sched[k][1];
       if (what >= 0) { rc = group_exchange(g, r, what, s[what]++); if (rc) return rc; }
     }
+    if (careful && cpl)
+      for (;;) {
+        int pending = 0;
+        int rc = tj_coupled_search_pending(c, &pending); if (rc) return rc;
+        if (!pending) break;
+        if ((rc = tj_iterate_phase_chained(c, 4, 0)) || (rc = group_exchange(g, r, 4, s[4]++)) || (rc = tj_iterate_phase_chained(c, 5, 0))) return rc;
+        if (extra4) (*extra4)++;
+      }
+  }
   return TJ_OK;
 }
 
@@ -439,11 +453,48 @@ int tj_group_iterate(tj_group* g, int n_iters, double* gnorm, int* iters_total, 
   if (g->poisoned) return TJ_ERR_DEVICE;
   g->abort_flag.store(0);
   std::vector<int> rc(g->n, TJ_OK);
-  if (g->n == 1) rc[0] = group_rank_loop(g, 0, n_iters);
-  else {
-    std::vector<std::thread> th;
-    for (int r = 0; r < g->n; r++) th.emplace_back([g, r, n_iters, &rc]() { rc[r] = group_rank_loop(g, r, n_iters); if (rc[r]) g->abort_flag.store(1); });
-    for (auto& t : th) t.join();
+  const bool cpl_sharded = g->n > 1 && g->ctx[0]->d.mode == TJ_MODE_MULTI_COUPLED;
+  if (cpl_sharded)   // the state the batch starts from: a search that leaves the exchanged candidates (error bit 32) is followed in a second, careful run of the batch (below)
+    for (int r = 0; r < g->n; r++) {
+      tj_ctx* c = g->ctx[r];
+      if (hipSetDevice(g->dev[r]) != hipSuccess) return group_fail(g, TJ_ERR_DEVICE, "hipSetDevice failed");
+      if (int fr = flush_deferred(c)) return group_fail(g, fr, tj_last_error(c));   // (the update the previous batch still owes belongs to the state)
+      hipLaunchKernelGGL(k_snapshot, dim3(64, std::max(c->snap_n, 1)), dim3(256), 0, c->stream, c->snap_tab, c->snap_n, 0, c->d.ctl, c->ctl_snap);
+    }
+  auto run_batch = [&](bool careful, std::vector<long>* extra) {
+    if (g->n == 1) rc[0] = group_rank_loop(g, 0, n_iters, careful, extra ? &(*extra)[0] : nullptr);
+    else {
+      std::vector<std::thread> th;
+      for (int r = 0; r < g->n; r++) th.emplace_back([g, r, n_iters, &rc, careful, extra]() { rc[r] = group_rank_loop(g, r, n_iters, careful, extra ? &(*extra)[r] : nullptr); if (rc[r]) g->abort_flag.store(1); });
+      for (auto& t : th) t.join();
+    }
+  };
+  run_batch(false, nullptr);
+  if (cpl_sharded && std::all_of(rc.begin(), rc.end(), [](int x) { return x == TJ_OK; })) {
+    bool range = false;
+    for (int r = 0; r < g->n; r++) {
+      tj_ctx* c = g->ctx[r];
+      int err = 0;
+      if (hipSetDevice(g->dev[r]) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&err, &c->d.ctl->error, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return group_fail(g, TJ_ERR_DEVICE, "tj_group_iterate: reading a rank's error word failed");
+      range = range || (err & ERR_LS_RANGE) != 0;
+    }
+    if (range) {
+      // the Armijo search of some iteration needed more candidates than one exchange carries (never met outside constructed states): every rank back to the batch's
+      // first state, then the same iterations with the search followed to the reference's own end -- one host look per iteration, slow and exact
+      for (int w = 0; w < 5; w++) g->issued[w] += n_iters;   // (the abandoned run's exchanges were issued: the sequence numbers and the buffer parity go on from there)
+      for (int r = 0; r < g->n; r++) {
+        tj_ctx* c = g->ctx[r];
+        (void)hipSetDevice(g->dev[r]);
+        hipLaunchKernelGGL(k_snapshot, dim3(64, std::max(c->snap_n, 1)), dim3(256), 0, c->stream, c->snap_tab, c->snap_n, 1, c->d.ctl, c->ctl_snap);
+        c->hull_valid = false; c->ccd_valid = false; c->maybe_deferred = false; c->begin_folded = false;
+        tj_set_coupled_follow(c, 1);
+      }
+      std::vector<long> extra(g->n, 0);
+      run_batch(true, &extra);
+      for (int r = 0; r < g->n; r++) tj_set_coupled_follow(g->ctx[r], 0);
+      g->issued[4] += extra[0];
+      g->lsc_followed++;
+    }
   }
   for (int r = 0; r < g->n; r++) if (rc[r]) {
     // the ranks have enqueued different numbers of phases and pushes: nothing but tj_group_init_state / destroy may follow

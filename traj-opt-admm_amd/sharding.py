@@ -34,12 +34,19 @@ DECOUPLED_SCHEDULE = ((0, 0), (1, 1), (2, None))
 
 
 def run_schedule(engine, gather, n_iters, schedule):
-    """(phase, what to all-gather after it) pairs, n_iters times"""
+    """(phase, what to all-gather after it) pairs, n_iters times.
+    Coupled schedule, engines that FOLLOW the Armijo search (engine.pending(), the HIP engine's tj_coupled_search_pending): while the search is pending after phase 5
+    -- none of the candidates one exchange carries passed; the reference's loop has no bound (Optimization3D_multi.h:623) -- phase 4, gather 4 and phase 5 run again for
+    the next candidates.  Every rank gets the same answer, so the ranks stay in step."""
+    pending = getattr(engine, "pending", None)
     for _ in range(n_iters):
         for phase, what in schedule:
             engine.phase(phase)
             if what is not None:
                 gather(what)
+        if pending is not None and schedule is COUPLED_SCHEDULE:
+            while pending():
+                engine.phase(4); gather(4); engine.phase(5)
 
 
 def run_sharded(engine, gather, n_iters, gather_begin=None):
