@@ -231,7 +231,8 @@ def test_signalling_sites_keep_their_order(pkg, tmp_path):
     order away.  The sites carry `s_nop` immediates no compiler emits (dev_common.h: sig_acked 0x2a1 / sig_sent 0x2a2, wait_begin 0x2b1 / wait_end 0x2b2, and 0x2c1 / 0x2c2
     around "the DONE word is performed before the commit stores" in k_linesearch):
       * right behind 0x2a1 stands the full `s_waitcnt vmcnt(0) ...`; from there to 0x2a2 there is no memory write but the signal itself -- a 32-bit or 64-bit atomic, or
-        a single 32-bit write-through store (a record store is 64 bits wide, and one sunk below the wait would show here);
+        a single 32-bit write-through store, or ONE 64-bit write-through store on its own (a head-start entry's tag); record stores are 64 bits wide and come in
+        numbers: one sunk below the wait would show here;
       * the first memory instruction behind 0x2b1 is the poll itself, a 32- or 64-bit load past the caches (sc1) -- a record load hoisted to the head of the wait would
         stand there instead (the block layout between the loop's markers is not its control flow, so the loop body is not scanned further);
       * between 0x2c1 and 0x2c2 stand the wait and the barrier and no store at all."""
@@ -250,12 +251,18 @@ def test_signalling_sites_keep_their_order(pkg, tmp_path):
                 n_sig += 1
                 assert ins[i + 1][0] == "s_waitcnt" and "vmcnt(0)" in ins[i + 1][1], f"{k}: no s_waitcnt vmcnt(0) right behind the 'acknowledged' marker: {ins[i + 1]}"
                 j = i + 2
+                wide = other = 0
                 while j < len(ins) and not (ins[j][0] == "s_nop" and ins[j][1].strip() in ("0x2a2", "674")) and ins[j][0] != "s_endpgm":
                     mm, oo = ins[j]
                     if mm.startswith(writes):
-                        is_signal = "atomic" in mm or (mm == "global_store_dword" and "sc1" in oo)
-                        assert is_signal, f"{k}: a store between 'acknowledged' and the signal: {mm} {oo}"
+                        if mm == "global_store_dwordx2" and "sc1" in oo:
+                            wide += 1      # a 64-bit word that IS the signal (a head-start entry's tag); allowed only alone
+                        else:
+                            other += 1
+                            is_signal = "atomic" in mm or (mm == "global_store_dword" and "sc1" in oo)
+                            assert is_signal, f"{k}: a store between 'acknowledged' and the signal: {mm} {oo}"
                     j += 1
+                assert wide == 0 or (wide == 1 and other == 0), f"{k}: 64-bit stores between 'acknowledged' and the signal ({wide} of them, {other} other writes): a record store sunk below the wait?"
                 assert j < len(ins) and ins[j][0] == "s_nop", f"{k}: 'acknowledged' marker without a 'sent' marker behind it"
                 i = j
             elif m == "s_nop" and ops.strip() in ("0x2b1", "689"):
@@ -280,6 +287,25 @@ def test_signalling_sites_keep_their_order(pkg, tmp_path):
             i += 1
     # the sites exist (a refactoring that drops the markers must not turn this test into a no-op): producers in k_grad, k_xsolve, k_linesearch, k_front, k_ccd, k_keep, k_mid's watcher, ...
     assert n_sig >= 20 and n_wait >= 20 and n_word >= 1, (n_sig, n_wait, n_word)
+
+
+def test_every_environment_switch_is_documented():
+    """Every environment switch the library reads goes through tune("KEY") (csrc/tj_api.hip; TJ_TUNE="KEY=value,..." or TJ_KEY=value) -- no bare getenv of a TJ_ variable
+    anywhere in csrc -- and every KEY is listed in INTEGRATION.md's table; the table lists no switch the source no longer reads."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ""
+    for f in sorted(os.listdir(os.path.join(root, "traj-opt-admm_amd", "csrc"))):
+        if f.endswith((".h", ".hip", ".cpp")):
+            src += open(os.path.join(root, "traj-opt-admm_amd", "csrc", f)).read()
+    bare = set(re.findall(r'getenv\("(TJ_[A-Z0-9_]+)"\)', src)) - {"TJ_TUNE"}
+    assert not bare, f"environment switches read outside tune(): {sorted(bare)}"
+    keys = set(re.findall(r'tune\("([A-Z0-9_]+)"\)', src))
+    assert len(keys) >= 30
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    table = doc[doc.index("### Environment switches"):doc.index("## 3. Python")]
+    listed = set(re.findall(r"`TJ_([A-Z0-9_]+)", table)) - {"TUNE", "KEY", "PRINT_OBSERVED", "ERR_NO_PROGRESS", "ERR_UNSUPPORTED", "LS_EXACT_HULLS", "LS_HELP_FORCE", "SHARD_UNFUSED"}
+    assert keys - listed == set(), f"switches missing from INTEGRATION.md: {sorted(keys - listed)}"
+    assert listed - keys == set(), f"INTEGRATION.md lists switches the source does not read: {sorted(listed - keys)}"
 
 
 def test_rccl_entry_points_resolve(pkg):

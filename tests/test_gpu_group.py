@@ -329,7 +329,7 @@ def test_asynchronous_front_changes_no_bit(pkg, scenes, monkeypatch, scene_name)
     uneven length, no error bit, the same number of energy evaluations; the launch count shows the gate (one per pairing = per iteration that has a successor in its batch).
     fleet100: 100 robots -- one k_linesearch block per robot, k_front's grid too large to be resident at once (k_mid follows plainly)."""
     scene = {"scn_c": scenes.scn_c, "scn_b": scenes.scn_b, "hard": lambda: scenes.hard(8, 8000), "fleet100": lambda: scenes.crossing(100, 20000, seed=121)}[scene_name]()
-    for k in ("TJ_XS_ASYNC", "TJ_XS_ONE_QUEUE", "TJ_FRONT_ASYNC", "TJ_FRONT_ASYNC_MID"):
+    for k in ("TJ_XS_ASYNC", "TJ_XS_ONE_QUEUE", "TJ_FRONT_ASYNC", "TJ_FRONT_ASYNC_MID", "TJ_FRONT_ASYNC_ONE_QUEUE"):
         monkeypatch.delenv(k, raising=False)
     batches = (1, 7, 20, 2, 30)
     def run():
@@ -345,8 +345,14 @@ def test_asynchronous_front_changes_no_bit(pkg, scenes, monkeypatch, scene_name)
     monkeypatch.setenv("TJ_FRONT_ASYNC_MID", "0")
     sm, tm, lm = run()
     monkeypatch.delenv("TJ_FRONT_ASYNC_MID")
+    monkeypatch.setenv("TJ_XS_ONE_QUEUE", "1"); monkeypatch.setenv("TJ_FRONT_ASYNC_ONE_QUEUE", "1")   # the schedule's data flow on one queue (what the counter passes run)
+    se, te, le = run()
+    monkeypatch.delenv("TJ_XS_ONE_QUEUE"); monkeypatch.delenv("TJ_FRONT_ASYNC_ONE_QUEUE")
     monkeypatch.setenv("TJ_FRONT_ASYNC", "0")
     sb, tb, lb = run()
+    for n in sa:
+        assert np.array_equal(se[n], sb[n]), f"{n} differs between the one-queue emulation of the asynchronous front and the one-queue front"
+    assert te["error_bits"] == 0 and te["energy_evals"] == tb["energy_evals"]
     for n in sa:
         assert np.array_equal(sa[n], sb[n]), f"{n} differs between the asynchronous front and the one-queue front"
         assert np.array_equal(sm[n], sb[n]), f"{n} differs between the asynchronous front (k_linesearch waits for its end) and the one-queue front"

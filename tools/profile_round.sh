@@ -19,24 +19,33 @@ DB=$(find $OUT/kt -name '*_results.db' | head -1)
 python3 $REPO/tools/rocpd_timeline.py "$DB" --csv $OUT/kernel_stats.csv --regime 303:20 > $OUT/timeline.txt 2>&1      # statistics over the TIMED window only (300 ramp + 3 warm-up iterations come first)
 python3 $REPO/tools/rocpd_timeline.py "$DB" --csv $OUT/kernel_stats_all_launches.csv > /dev/null 2>&1
 python3 $REPO/tools/rocpd_periter.py "$DB" --regime 303:20 > $OUT/per_iteration.txt 2>&1                               # one row per timed iteration, one column per kernel
-# Counter collection SERIALISES the dispatches of all queues -- in an order of its own: the gate kernel of the asynchronous solve can be held back behind the very k_grad it
-# waits for, and every wait then runs into its 2 s limit.  The counter passes therefore run the one-queue chain (TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0: same arithmetic, same bits;
-# per kernel the swept-hull records are then written by k_xsolve's tail instead of k_ccd's units).
-export TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0
+# Counter collection SERIALISES the dispatches of all queues -- in an order of its own: a gate kernel on the second queue can be held back behind the very kernel it waits for,
+# and every wait then runs into its 2 s limit.  The counter passes therefore keep everything on ONE queue -- but with the TIMED schedule's kernels (round 6):
+# TJ_XS_ASYNC=1 TJ_XS_ONE_QUEUE=1 runs the asynchronous solve's protocol (tickets, flags, k_ccd's units building the swept-hull records) and TJ_FRONT_ASYNC_ONE_QUEUE=1 the
+# asynchronous front's data flow (k_front's units forming and publishing the hull records, k_linesearch writing none) -- the traffic of the timed two-queue run, serially.
+# (pmc_one_queue_chain.json: the sibling schedule TJ_XS_ASYNC=0 TJ_FRONT_ASYNC=0 -- swept-hull tail in k_xsolve, hull cache from k_linesearch -- that rounds 4 and 5 reported.)
+export TJ_XS_ASYNC=1 TJ_XS_ONE_QUEUE=1 TJ_FRONT_ASYNC_ONE_QUEUE=1 TJ_KEEP_ASYNC=0
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o x -- python3 $REPO/bench.py $ARGS > $OUT/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o x -- python3 $REPO/bench.py $ARGS > $OUT/pw.log 2>&1
 F=$(find $OUT/pf -name '*_results.db' | head -1); W=$(find $OUT/pw -name '*_results.db' | head -1)
 SCENE=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['workload'].split(':')[0])")
-python3 $REPO/tools/pmc_traffic.py "$F" "$W" --scene "$SCENE" --command "python3 bench.py $ARGS" --regime 303:20 --out $OUT/pmc.json > $OUT/pmc.txt 2>&1      # the TIMED window only, like the kernel statistics
+python3 $REPO/tools/pmc_traffic.py "$F" "$W" --scene "$SCENE" --command "TJ_XS_ASYNC=1 TJ_XS_ONE_QUEUE=1 TJ_FRONT_ASYNC_ONE_QUEUE=1 python3 bench.py $ARGS" --regime 303:20 --out $OUT/pmc.json > $OUT/pmc.txt 2>&1      # the TIMED window only, like the kernel statistics
 # 3. SQ counters in their own pass: waves, busy cycles, VALU instructions, cycles some wave waited -- "latency bound" in counters
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY -d $OUT/ps -o x -- python3 $REPO/bench.py $ARGS > $OUT/ps.log 2>&1
 S=$(find $OUT/ps -name '*_results.db' | head -1)
 python3 $REPO/tools/pmc_sq.py "$S" --out $OUT/sq.json > $OUT/sq.txt 2>&1
-unset TJ_XS_ASYNC TJ_KEEP_ASYNC
+rm -rf $OUT/pf $OUT/pw
+export TJ_XS_ASYNC=0 TJ_FRONT_ASYNC=0
+unset TJ_XS_ONE_QUEUE TJ_FRONT_ASYNC_ONE_QUEUE
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o x -- python3 $REPO/bench.py $ARGS > $OUT/pf0.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o x -- python3 $REPO/bench.py $ARGS > $OUT/pw0.log 2>&1
+F=$(find $OUT/pf -name '*_results.db' | head -1); W=$(find $OUT/pw -name '*_results.db' | head -1)
+python3 $REPO/tools/pmc_traffic.py "$F" "$W" --scene "$SCENE" --command "TJ_XS_ASYNC=0 TJ_FRONT_ASYNC=0 python3 bench.py $ARGS" --regime 303:20 --out $OUT/pmc_one_queue_chain.json > $OUT/pmc_one_queue_chain.txt 2>&1
+unset TJ_XS_ASYNC TJ_KEEP_ASYNC TJ_FRONT_ASYNC
 python3 - "$OUT/pmc.json" <<'PYEOF'
 import json, sys
 try:
-    d = json.load(open(sys.argv[1])); d["note"] = (d.get("note") or "") + " | counter passes ran the one-queue chain (TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0): counter collection serialises dispatches across queues, which the asynchronous solve's gate does not survive; same arithmetic, the swept-hull records are written by k_xsolve there"
+    d = json.load(open(sys.argv[1])); d["note"] = (d.get("note") or "") + " | counter passes ran the TIMED schedule's kernels on one queue (TJ_XS_ASYNC=1 TJ_XS_ONE_QUEUE=1 TJ_FRONT_ASYNC_ONE_QUEUE=1: counter collection serialises dispatches across queues; tickets, flags, k_ccd-built swept-hull records and -- asynchronous front -- k_front-built hull records as in the timed run); the sibling one-queue chain of rounds 4 - 5 is in pmc_one_queue_chain.json"
     json.dump(d, open(sys.argv[1], "w"), indent=1)
 except Exception as e:
     print("pmc.json not annotated:", e)

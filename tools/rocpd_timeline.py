@@ -35,12 +35,16 @@ def main():
             if any(short(r[0]) == "k_xs_gate" for r in stat_rows):
                 print("# asynchronous solve: k_xs_gate / k_xsolve run on a second queue; the gate's duration is one wave asleep until k_grad starts, k_xsolve's includes its blocks' sleep on the tickets,")
                 print("# k_ccd's the units' sleep on the robots' flags -- durations overlap and do not add up to the iteration (see the timeline below; TJ_XS_ASYNC=0: the one-queue chain)")
+            if any(short(r[0]) == "k_fa_gate" for r in stat_rows):
+                print("# asynchronous front: k_fa_gate / k_front of iteration i + 1 run on the second queue NEXT TO k_linesearch of iteration i (an 'iteration' of this table still begins with its")
+                print("# k_front: the k_linesearch listed in it is the one it overlaps, i.e. the previous iteration's); k_front's duration includes its units' sleep on the robots' commit flags,")
+                print("# k_mid's the solve waves' sleep until k_front is through (TJ_FRONT_ASYNC=0: k_front behind k_linesearch on the chain's queue)")
         else:
             print(f"# --regime {a.regime}: the run has only {len(b_all)} iterations; statistics over all launches")
     st = {}
     for n, s, e, _, _ in stat_rows:
         nm = short(n)
-        if nm in ("k_xs_gate", "k_keep_gate"):
+        if nm in ("k_xs_gate", "k_keep_gate", "k_fa_gate"):
             nm += " [one wave asleep until the kernel it gates starts: not work; excluded from Percentage]"
         st.setdefault(nm, []).append(e - s)
     tot = sum(sum(v) for k_, v in st.items() if "gate [" not in k_)

@@ -164,7 +164,7 @@ struct Dev {
   int xf_all;                    // coupled mode, one context: nobody publishes a hull / swept-hull cache there (one block commits every robot, the direction comes from k_xsolve_c2),
                                  // so the obstacle units of k_front / k_ccd -- one per (robot, segment) -- publish that record themselves (write-through + the segment's counter) before
                                  // they walk, and the k_hullinfo / k_ccd_prep launches drop out of the chain
-  __host__ __device__ int xf_want() const { return (xf_all || xs_async || fa) ? U : U - (u1 - u0); }                           // robots the units cover (= units per segment)
+  __host__ __device__ int xf_want() const { return (xf_all || xs_async || fa_units) ? U : U - (u1 - u0); }                           // robots the units cover (= units per segment)
   __host__ __device__ int xf_units() const { return (xf && !xf_all) ? xf_want() * S : 0; }   // extra one-wave units in the grid (xf_all: the obstacle units of k_front / k_ccd publish their own robot's record instead)
   __host__ __device__ int xf_robot(int i) const { return xf_all ? i : (i < u0 ? i : i + (u1 - u0)); }
   int xch, xch_poll;             // xch_poll = 1: the foreign units poll the arrival counters themselves; 0: a k_xch_wait launch in front of the kernel has (ranks sharing a device)
@@ -208,7 +208,10 @@ struct Dev {
   // and launch).  Everything k_front leaves for later kernels goes out written through and every block counts itself done behind its acknowledged stores;
   // the LAST block of k_linesearch -- the one that begins the next iteration -- waits for that count, so k_linesearch does not end before k_front has: k_mid
   // follows on the first queue as before, and the two kernel boundaries k_linesearch -> k_front -> k_mid become one.
-  //   fa      context switch: k_front's units build and publish the hull records (with or without the second queue), k_linesearch publishes none
+  //   fa      the context is eligible (tj_create)
+  //   fa_units (per launch) k_linesearch: publish no hull cache -- the k_front that follows forms the records in its units; k_front: do so.  Set for the two launches of a
+  //           pairing, and for the one-queue emulation of the schedule (TJ_FRONT_ASYNC_ONE_QUEUE=1: what the counter passes of tools/profile_round.sh run).  An unpaired
+  //           k_linesearch -- the last of a batch, every one of a caller that asks for one iteration at a time -- publishes the cache as before and the next k_front reads it
   //   fa_seq  > 0: THIS launch is part of pairing number fa_seq (k_linesearch(i) <-> k_front(i + 1) [<-> k_mid(i + 1)]); all words below are monotonic in it -- nothing is reset
   //   fa_mid  (with fa_seq; grids of k_front that are resident all at once next to the last k_linesearch block): k_linesearch only waits until every k_front block has
   //           STARTED -- so that k_mid's waves, which then follow at once, can never keep a k_front block off the device -- and k_mid<FA> waits for k_front's end ITSELF: its
@@ -216,7 +219,7 @@ struct Dev {
   //           left past the caches; the slack blocks need nothing of k_front and start at once.  The second boundary (k_linesearch -> k_mid) then overlaps k_front's tail.
   //   fa_sync ints, a 128-byte line per word: [16] k_linesearch blocks started | [16] k_front blocks done | [16] k_front blocks started | [64] go words of k_mid |
   //           [U] commit flags | record {-, epoch, done} of the begun iteration
-  int fa, fa_seq, fa_mid, fa_nls, fa_nfront; int* fa_sync;
+  int fa, fa_units, fa_seq, fa_mid, fa_nls, fa_nfront; int* fa_sync;
   __host__ __device__ int* fa_res(int i) const { return fa_sync + (size_t)(i & 15) * 32; }
   __host__ __device__ int* fa_fdone(int i) const { return fa_sync + (size_t)(16 + (i & 15)) * 32; }
   __host__ __device__ int* fa_fstart(int i) const { return fa_sync + (size_t)(32 + (i & 15)) * 32; }

@@ -758,8 +758,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_linesearch(Dev D, LsLayout L, in
     }
     __syncthreads();
   }
-  if (D.fuse && D.multi() && !D.fa) {   // (Dev::fa: the next k_front's units form the records themselves, from the committed control net; written through from here the
-                                          //  40 KB per robot put ~4 us in front of every commit flag -- measured)
+  if (D.fuse && D.multi() && !D.fa_units) {   // (Dev::fa_units: the next k_front's units form the records themselves, from the committed control net; written through from here
+                                                //  the 40 KB per robot put ~4 us in front of every commit flag -- measured)
     double* wh = sm + L.ghull + (size_t)wg * S * 18;
     if (L.affine) {   // the published hulls are exactly basis * (accepted control net), like k_hullinfo's
       const double* win = sm + L.gnet + (size_t)wg * 3 * T;

@@ -215,6 +215,7 @@ __device__ __forceinline__ void sep_self_rows_body(const Dev& D, int bid, double
 // on / off, bitwise).  A listed pair that left the broad phase costs two waves that publish nothing; the list's order is free.
 constexpr int SPEC_CAP = 128, SPEC_GJK_MIN = 5, SPEC_GJK_WINDOW = 10, SPEC_GJK_BUDGET = 3;
 constexpr int SPEC_STATE_DOUBLES = 20, SPEC_STATE_INTS = 16;
+constexpr unsigned SPEC_KEY_NONE = 0xffffffffu;   // asynchronous front: "this entry's block has run for the epoch in the upper half and has no pair" (a plain 0 could be a tag not written yet)
 __device__ __forceinline__ unsigned pair_key(int tr, int p0, int q) { return (unsigned)(tr | (p0 << 9) | (q << 20)); }   // 9 + 11 + 11 bits
 // FA (asynchronous front): the launch runs next to the k_linesearch that commits the control nets -- the epoch is the begun iteration's (fa_early_begin's record, the
 // control block still shows the running one), the block waits for its two robots' commit flags and forms the hulls from the nets read past the caches, and what
@@ -228,10 +229,10 @@ __device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds,
   if (b == 0 && lane == 0) { if constexpr (FA) xf_store_i(D.spec_n + par, 0); else D.spec_n[par] = 0; }   // the list this iteration's k_mid fills
   const int n = min(D.spec_n[par ^ 1], SPEC_CAP);
   // every block leaves a tag, valid or not: the tags k_mid sees are always those of the k_front in front of it
-  if (b >= n) { if (lane == 0) tag_out(0ull); return; }
+  if (b >= n) { if (lane == 0) tag_out(FA ? (((unsigned long long)(unsigned)epoch << 32) | SPEC_KEY_NONE) : 0ull); return; }
   const unsigned key = (unsigned)D.spec_list[(par ^ 1) * SPEC_CAP + b];
   const int tr = (int)(key & 0x1ff), p0 = (int)((key >> 9) & 0x7ff), q = (int)((key >> 20) & 0x7ff);
-  if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) tag_out(0ull); return; }   // (cannot happen: the list is this context's own)
+  if (tr >= D.S || p0 >= D.U || q >= D.U) { if (lane == 0) tag_out(FA ? (((unsigned long long)(unsigned)epoch << 32) | SPEC_KEY_NONE) : 0ull); return; }   // (cannot happen: the list is this context's own)
   const double* A = D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_INFO_STRIDE;
   const double* B = D.hullinfo + ((size_t)q * D.S + tr) * HULL_INFO_STRIDE;
   if constexpr (FA) {   // the records are written by this launch's obstacle units (later in the grid: not waited for): the two hulls from the nets, behind the robots' commit flags, read past the caches
@@ -252,7 +253,7 @@ __device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds,
     blk_sync<true>();
     A = lds; B = lds + 18;
   } else
-  if (D.xf_all || D.fa) {   // coupled chain: the records are being written by this launch's obstacle units (LATER in the grid: not waited for) -- the two hulls straight from the control nets
+  if (D.xf_all || D.fa_units) {   // coupled chain: the records are being written by this launch's obstacle units (LATER in the grid: not waited for) -- the two hulls straight from the control nets
     if (lane < 36) { const int r = lane < 18 ? p0 : q, e = lane < 18 ? lane : lane - 18; lds[lane] = hull_entry(D, D.spline + (size_t)r * 3 * D.T, tr, e / 3, e % 3); }
     blk_sync<true>();
     A = lds; B = lds + 18;
@@ -269,8 +270,10 @@ __device__ __forceinline__ void spec_pair_body(const Dev& D, int b, double* lds,
     for (int i = 0; i < SPEC_STATE_DOUBLES; i++) { if constexpr (FA) xf_store(o + i, ov[i]); else o[i] = ov[i]; }
 #pragma unroll
     for (int i = 0; i < 9; i++) { if constexpr (FA) xf_store_i(oi + i, iv[i]); else oi[i] = iv[i]; }
-    tag_out(((unsigned long long)(unsigned)epoch << 32) | key);
   }
+  if constexpr (FA) sig_acked();   // asynchronous front: the dedicated wave of k_mid polls the TAG and then reads the state -- the state is in memory before the tag goes out
+  if (lane == 0) tag_out(((unsigned long long)(unsigned)epoch << 32) | key);
+  if constexpr (FA) sig_sent();
 }
 // the state entry b holds, fetched by the whole wave (one load per lane, then broadcasts).  The values go straight back into
 // vector registers: left in scalar ones (50 of them, live across the merge with the fresh query's start) they cost k_mid a stack frame.
@@ -319,6 +322,50 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   auto ldt = [&](const unsigned long long* p) { if constexpr (FA) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p; };
   // (SPEC_CAP = 128: two tags per lane) issued first, used after the work item has arrived; the list takes the pairs within
   // SPEC_GJK_WINDOW iterations of the previous launch's longest query, so that it holds the tail and not the first to report
+  // Asynchronous front (FA): this launch started while k_front still runs.  A wave that may be DEDICATED to a head-start entry does not wait for k_front's end to begin: it
+  // polls its entry's tag (the entry's k_front block leaves it behind its acknowledged state -- a few microseconds after the pair's two robots have committed), and runs the
+  // rest of the pair's GJK and the offset Newton at once, from the saved state and the two hulls formed from the committed control nets (hull_entry's sums: the records' bits).
+  // Only then does it wait -- like every other solve wave -- for k_front's end, to see whether the broad phase listed the pair again, and publishes.  The slow pairs of the
+  // previous iteration, which set this kernel's length, thus run under k_front's tail.
+  bool early = false, e_okp = false, e_capped = false; double e_e0 = 0, e_e1 = 0, e_e2 = 0, e_dpl = 0; int e_nit = 0, e_gk = 0;
+  if constexpr (FA) {
+    const int epoch_now = D.ctl->epoch;
+    if (head_start && bid < min(nwaves / 2, SPEC_CAP)) {
+      unsigned long long tg = 0;
+      wait_begin();
+      {
+        const long long t_end = wall_clock64() + XCH_TIMEOUT_TICKS;
+        for (;;) {
+          tg = __hip_atomic_load(D.spec_tag + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(tg >> 32) == epoch_now) break;
+          if (wall_clock64() > t_end) { if (lane == 0) atomicOr(&D.ctl->error, ERR_LOOP_CAP | ERR_XS_TIMEOUT); tg = ((unsigned long long)(unsigned)epoch_now << 32) | SPEC_KEY_NONE; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      wait_end();
+      const unsigned key = (unsigned)tg;
+      const int tr = (int)(key & 0x1ff), p0 = (int)((key >> 9) & 0x7ff), q = (int)((key >> 20) & 0x7ff);
+      if (key != SPEC_KEY_NONE && tr < D.S && p0 < D.U && q < D.U) {
+        __builtin_amdgcn_s_setprio(3);
+        if (lane < 36) {
+          const int r = lane < 18 ? p0 : q, e = lane < 18 ? lane : lane - 18;
+          const double* Bs = D.basis + (size_t)tr * 36 + (e / 3) * 6;
+          const double* col = D.spline + (size_t)r * 3 * D.T + div_small(tr, D.res) * 3 + D.T * (e % 3);
+          double acc = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) acc += Bs[k] * xf_load(col + k);   // = hull_entry
+          if (lane < 18) A[lane] = acc; else B[lane - 18] = acc;
+        }
+        GjkState hs; bool hs_fin = false;
+        spec_state_load<true>(D, bid, lane, hs, hs_fin);
+        __syncthreads();
+        e_okp = plane_pair_wave(A, B, D.offset + 2 * D.margin, D.margin, D.offset, lane, e_e0, e_e1, e_e2, e_dpl, e_capped, &e_nit, &e_gk, nullptr, hs, true, hs_fin);
+        early = true;
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    fa_wait_flag(D, D.fa_go(bid), D.fa_seq);   // k_front is through: its work lists, tags and records are complete (read past the caches below)
+  }
   const unsigned long long spec_tag0 = head_start ? ldt(D.spec_tag + lane) : 0ull, spec_tag1 = head_start ? ldt(D.spec_tag + 64 + lane) : 0ull;
   const int spec_thr = head_start ? max(D.spec_min, D.ctl->gjk_prev - SPEC_GJK_WINDOW) : 0;
   const int n = pair_work_prefix<FA>(D, wpre, lane), U = D.U;
@@ -446,7 +493,7 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
   // At most half of the launched waves are dedicated (an entry beyond that stays with the generic wave that meets it in the list), so
   // the generic waves are never fewer than nwaves / 2 and a wave's share of the list stays <= 8 items whatever TJ_N_SOLVE / TJ_HS_MIN say.
   const int n_ded = min(nwaves / 2, SPEC_CAP);
-  const bool tv0 = head_start && (int)(spec_tag0 >> 32) == epoch && lane < n_ded, tv1 = head_start && (int)(spec_tag1 >> 32) == epoch && 64 + lane < n_ded;
+  const bool tv0 = head_start && (int)(spec_tag0 >> 32) == epoch && (unsigned)spec_tag0 != SPEC_KEY_NONE && lane < n_ded, tv1 = head_start && (int)(spec_tag1 >> 32) == epoch && (unsigned)spec_tag1 != SPEC_KEY_NONE && 64 + lane < n_ded;
   const unsigned long long vm0 = ballot(tv0), vm1 = ballot(tv1);
   const int nd = __popcll(vm0) + __popcll(vm1);
   const bool dedicated = bid < SPEC_CAP && (((bid < 64 ? vm0 >> bid : vm1 >> (bid - 64)) & 1ull) != 0);
@@ -484,17 +531,19 @@ __device__ __forceinline__ void sep_self_solve_body(const Dev& D, int bid, int n
     const int tr = (int)(key & 0x1ff), p0 = (int)((key >> 9) & 0x7ff), q = (int)((key >> 20) & 0x7ff);
     if (tr >= D.S || p0 >= U || q >= U) return;   // (cannot happen)
     // in flight together: both hulls, the saved state, this segment's part of the work list
-    if (lane < 18) { A[lane] = ldd(D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE + lane); B[lane] = ldd(D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE + lane); }
     GjkState hs; bool hs_fin = false;
-    spec_state_load<FA>(D, bid, lane, hs, hs_fin);
+    if (!early) {
+      if (lane < 18) { A[lane] = ldd(D.hullinfo + ((size_t)p0 * D.S + tr) * HULL_STRIDE + lane); B[lane] = ldd(D.hullinfo + ((size_t)q * D.S + tr) * HULL_STRIDE + lane); }
+      spec_state_load<FA>(D, bid, lane, hs, hs_fin);
+    }
     const int cnt = wpre[tr + 1] - wpre[tr];
     const int* wl = D.pair_work + 3 * (size_t)tr * pair_work_cap_seg(D);
     bool member = false;
     for (int i = lane; i < cnt; i += 64) member = member || (ldi(wl + 3 * i + 1) == p0 && ldi(wl + 3 * i + 2) == q);
     __syncthreads();
     TJ_TIC(D, K_SEP_SELF_SOLVE, 1);
-    double e0, e1c, e2c, dpl; bool capped; int nit = 0, gk = 0;
-    const bool okp = plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk, nullptr, hs, true, hs_fin);
+    double e0 = e_e0, e1c = e_e1, e2c = e_e2, dpl = e_dpl; bool capped = e_capped; int nit = e_nit, gk = e_gk;
+    const bool okp = early ? e_okp : plane_pair_wave(A, B, dist, m, off, lane, e0, e1c, e2c, dpl, capped, &nit, &gk, nullptr, hs, true, hs_fin);   // (early: solved under k_front's tail, above)
 #ifdef TJ_PHASE_TIMING
     if (lane == 0 && blockIdx.x < TJ_TIC_BLOCKS) { D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 6] = gk + 1000; D.dbg[((size_t)K_SEP_SELF_SOLVE * TJ_TIC_BLOCKS + blockIdx.x) * TJ_TIC_SLOTS + 7] = okp ? nit : -1; }
 #endif

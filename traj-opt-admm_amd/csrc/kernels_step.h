@@ -834,12 +834,12 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_xf = D.xf_units();   // sharded contexts: hull cache of the other ranks' robots (coupled chain: of every robot), AHEAD of everything that reads it (head starts, pair tiles)
   const int bx = (int)blockIdx.x;
   const int b = bx - n_ord - n_xf - n_spec;
-  const bool pub = D.xf_all != 0 || D.fa != 0;   // the query forms its hull itself and publishes the record (coupled chain; Dev::fa)
+  const bool pub = D.xf_all != 0 || D.fa_units != 0;   // the query forms its hull itself and publishes the record (coupled chain; Dev::fa_units: the k_linesearch before this launch published none)
   if (bx < n_ord) grad_order_body<FA>(D, bx, (int*)lds);
   else if (bx < n_ord + n_xf) xf_hull_body(D, bx - n_ord);
   else if (b < 0) spec_pair_body<FA>(D, bx - n_ord - n_xf, lds, fa_epoch);
   else if (b < n_obs) obs_query_body<PRIM, FA>(D, b, lds, !pub, pub);
-  else sep_self_rows_body<FA>(D, b - n_obs, lds, D.xf != 0 || D.fa != 0);
+  else sep_self_rows_body<FA>(D, b - n_obs, lds, D.xf != 0 || D.fa_units != 0);
   TJ_TIC(D, K_FRONT, 1);
   if constexpr (FA) fa_count(D.fa_fdone(blockIdx.x));
 }
@@ -882,17 +882,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int s0 = n_pair_waves + n_obs_waves;
     if (b >= s0) { if (D.ctl->slack_now) slack_body(D, b - s0, 1, mid_lds); TJ_TIC(D, K_MID, 1); return; }
     if (TJ_DONE(D)) return;
-    if constexpr (FA) fa_wait_flag(D, D.fa_go(b), D.fa_seq);
-    if (b < n_pair_waves) sep_self_solve_body<FA>(D, b, n_pair_waves, D.spec != 0, mid_lds);
-    else obs_solve_body<PRIM, FA>(D, b - n_pair_waves, n_obs_waves);
+    if (b < n_pair_waves) sep_self_solve_body<FA>(D, b, n_pair_waves, D.spec != 0, mid_lds);   // (FA: waits for k_front's end itself -- a dedicated wave after its early solve)
+    else { if constexpr (FA) fa_wait_flag(D, D.fa_go(b), D.fa_seq); obs_solve_body<PRIM, FA>(D, b - n_pair_waves, n_obs_waves); }
     TJ_TIC(D, K_MID, 1);
     return;
   }
   if (b < n_slack) { if (D.ctl->slack_now) slack_body(D, b, 1, mid_lds); TJ_TIC(D, K_MID, 1); return; }   // long single-wave tasks first
   else if (TJ_DONE(D)) return;
-  if constexpr (FA) { fa_wait_flag(D, D.fa_go(b), D.fa_seq); TJ_TIC(D, K_MID, 4); }
-  if (b < n_slack + n_pair_waves) sep_self_solve_body<FA>(D, b - n_slack, n_pair_waves, D.spec != 0, mid_lds);
-  else obs_solve_body<PRIM, FA>(D, b - n_slack - n_pair_waves, n_obs_waves);
+  if (b < n_slack + n_pair_waves) sep_self_solve_body<FA>(D, b - n_slack, n_pair_waves, D.spec != 0, mid_lds);   // (FA: waits for k_front's end itself -- a dedicated wave after its early solve)
+  else { if constexpr (FA) { fa_wait_flag(D, D.fa_go(b), D.fa_seq); TJ_TIC(D, K_MID, 4); } obs_solve_body<PRIM, FA>(D, b - n_slack - n_pair_waves, n_obs_waves); }
   TJ_TIC(D, K_MID, 1);
 }
 template <int PRIM, bool LEAN>

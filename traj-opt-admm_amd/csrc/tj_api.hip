@@ -51,6 +51,7 @@ struct tj_ctx {
   // asynchronous front (Dev::fa): fa_seq = pairings k_linesearch(i) <-> k_front(i + 1) launched so far (the device's words are monotonic in it); fa_armed: the last
   // k_linesearch enqueued belongs to pairing fa_seq and the k_front that follows goes to the second queue behind k_fa_gate
   int fa_seq = 0; bool fa_armed = false;
+  bool hull_from_units = false, fa_emulate = false;   // the last k_linesearch enqueued published no hull cache (the next k_front forms the records in its units) / TJ_FRONT_ASYNC_ONE_QUEUE=1: the schedule's data flow on one queue
   // Self-healing of the cross-queue schedules: a wait between the queues that runs out (ERR_XS_TIMEOUT -- in practice a GPU shared with another process, whose time slices
   // keep one of the queues off the hardware) must not fail a run.  The first tj_iterate_async after a point at which the host has looked at the device takes a snapshot of the
   // state (one launch); when the host next looks and finds the bit, it latches every two-queue schedule off, restores the snapshot, enqueues the same iterations again on
@@ -91,6 +92,24 @@ struct tj_ctx {
   double bvh_build_ms = 0;   // device time of the last BVH build (tj_get_build_info)
   int bvh_on_device = 0;
 };
+
+// EVERY environment switch of the library is read through this one function (tj_group.h included): TJ_TUNE="KEY=value,KEY=value" or, equivalently, TJ_KEY=value
+// (an entry of TJ_TUNE wins over the single variable).  INTEGRATION.md lists them all with their kind -- feature switch, launch-shape switch (same bits), test hook --, and
+// tests/test_abi_and_host.py::test_every_environment_switch_is_documented compares that table with the keys that appear here.
+static const char* tune(const char* key) {
+  static thread_local std::string hold;
+  if (const char* t = getenv("TJ_TUNE")) {
+    const std::string all(t), k(key);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos); if (end == std::string::npos) end = all.size();
+      const size_t eq = all.find('=', pos);
+      if (eq != std::string::npos && eq < end && all.compare(pos, eq - pos, k) == 0) { hold = all.substr(eq + 1, end - eq - 1); return hold.c_str(); }
+      pos = end + 1;
+    }
+  }
+  return getenv((std::string("TJ_") + key).c_str());
+}
 
 namespace {
 
@@ -152,7 +171,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const bool keep2q = in_graph && c->keep_two_queues && !c->xs_same_queue_now && !c->use_graph;
   if (!keep2q) d_.keep_async = 0;
   if (kid == K_GRAD && d_.xs_async && c->xs_two_queues && !c->xs_same_queue_now && !c->use_graph) d_.xs_seq = ++c->xs_seq;   // this k_grad opens the gate of its k_xsolve
-  d_.fa_seq = 0; d_.fa_mid = 0;
+  d_.fa_seq = 0; d_.fa_mid = 0; d_.fa_units = 0;
   if (!in_graph) d_.fa = 0;   // (the context switch belongs to the single-GPU chain like xs_async; fa contexts are never sharded, and the stage API rebuilds the hull cache itself)
   const bool fa2q = in_graph && d_.fa && c->xs_two_queues && !c->xs_same_queue_now && !c->use_graph;
   const Dev& d = d_;
@@ -189,11 +208,12 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if (keep2q) d_.keep_seq = ++c->keep_seq;   // this k_front opens the gate of the iteration's plane refinement (third queue)
       if (c->fa_armed && fa2q && (chain_pos & 1)) {   // asynchronous front: on the second queue, next to the k_linesearch just enqueued (pairing fa_seq), behind the residency gate
         c->fa_armed = false;
-        d_.fa_seq = c->fa_seq; d_.fa_mid = c->fa_mid_ok ? 1 : 0; c->fa_mid_now = c->fa_mid_ok;
+        d_.fa_seq = c->fa_seq; d_.fa_units = 1; d_.fa_mid = c->fa_mid_ok ? 1 : 0; c->fa_mid_now = c->fa_mid_ok;
         TJ_LAUNCH(k_fa_gate, dim3(1), dim3(64), 0, c->stream2, d, (int)((unsigned)c->fa_seq * (unsigned)d.fa_nls));
         if (tri) TJ_LAUNCH((k_front<3, true>), dim3(n_front), dim3(64), 0, c->stream2, d); else TJ_LAUNCH((k_front<1, true>), dim3(n_front), dim3(64), 0, c->stream2, d);
         return true;
       }
+      d_.fa_units = (in_graph && c->hull_from_units) ? 1 : 0;   // (the k_linesearch before it published no hull cache: one-queue emulation of the asynchronous front)
       if (tri) TJ_LAUNCH((k_front<3>), dim3(n_front), dim3(64), 0, s, d); else TJ_LAUNCH((k_front<1>), dim3(n_front), dim3(64), 0, s, d);
       if (keep2q) {
         d_.keep_seq = 0;
@@ -279,7 +299,9 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
       if ((in_graph || in_phase) && d.seq_fold && !(c->split_unions && multi)) return false;   // the last block of k_ccd has done it
       if (!multi && in_graph) return false;   // single UAV: no pairs to replay, and k_xsolve has left gnorm = |g| itself -- one launch less in the chain
       TJ_LAUNCH(k_ccd_self_seq, dim3(1), dim3(64), c->lds_seq, s, d); return true;
-    case K_LINESEARCH: if (!coupled) { if (fa2q && (chain_pos & 2)) { d_.fa_seq = ++c->fa_seq; d_.fa_mid = c->fa_mid_ok ? 1 : 0; c->fa_armed = true; }   // the next iteration of the batch follows: its k_front runs next to this launch
+    case K_LINESEARCH: if (!coupled) { c->hull_from_units = false;
+      if (fa2q && (chain_pos & 2)) { d_.fa_seq = ++c->fa_seq; d_.fa_units = 1; d_.fa_mid = c->fa_mid_ok ? 1 : 0; c->fa_armed = true; c->hull_from_units = true; }
+      else if (in_graph && d_.fa && c->fa_emulate && (chain_pos & 2)) { d_.fa_units = 1; c->hull_from_units = true; }   // the next iteration of the batch follows: its k_front runs next to this launch
       TJ_LAUNCH(k_linesearch, dim3(owned * d.ls_help), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, (chain_pos & 2) ? 1 : 0); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // (its last block runs begin_body)
       return !coupled;
     // coupled mode ("decouple":0): evaluation rounds of the summed-energy Armijo search, commit
@@ -472,7 +494,7 @@ int ensure_hull_cache(tj_ctx* c) {
   if (!c->d.fuse || c->hull_valid) return TJ_OK;
   launch_kernel(c, K_HULLINFO, c->stream);
   HIPCHK(c, hipGetLastError());
-  c->hull_valid = true;
+  c->hull_valid = true; c->hull_from_units = false;
   return TJ_OK;
 }
 
@@ -566,15 +588,15 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   Dev& d = c->d;
   memset(&d, 0, sizeof(d));
   d.mode = p->mode; d.U = p->uav_num; d.P = p->piece_num; d.res = p->res; d.S = d.P * d.res; d.T = 3 * d.P + 3; d.N = 0; d.prim = 1;
-  c->use_graph = getenv("TJ_USE_GRAPH") != nullptr;
+  c->use_graph = tune("USE_GRAPH") != nullptr;
   // the fused chain (k_linesearch leaves the hull cache, k_xsolve's tail the swept-hull cache) -- sharded contexts too since round 5: the other ranks' robots
   // are handled by foreign units inside k_front / k_ccd (Dev::xf).  Coupled mode keeps its own kernels (and, sharded, k_hullinfo / k_ccd_prep for all robots).
-  const bool split_env = getenv("TJ_SPLIT_UNIONS") && atoi(getenv("TJ_SPLIT_UNIONS")) != 0;
-  d.fuse = (p->mode != TJ_MODE_MULTI_COUPLED && !(p->world > 1 && (split_env || getenv("TJ_SHARD_UNFUSED")))) ? 1 : 0;
+  const bool split_env = tune("SPLIT_UNIONS") && atoi(tune("SPLIT_UNIONS")) != 0;
+  d.fuse = (p->mode != TJ_MODE_MULTI_COUPLED && !(p->world > 1 && split_env)) ? 1 : 0;
   d.rank = p->rank; d.world = p->world;
   d.xf = (p->world > 1 && d.fuse && p->mode == TJ_MODE_MULTI_DECOUPLE) ? 1 : 0;
   // coupled mode, one context: every robot's cache records by units inside k_front / k_ccd (two launches less per iteration; TJ_COUPLED_UNITS=0: k_hullinfo / k_ccd_prep)
-  if (p->mode == TJ_MODE_MULTI_COUPLED && p->world == 1 && !split_env && !(getenv("TJ_COUPLED_UNITS") && atoi(getenv("TJ_COUPLED_UNITS")) == 0)) { d.xf = 1; d.xf_all = 1; }
+  if (p->mode == TJ_MODE_MULTI_COUPLED && p->world == 1 && !split_env && !(tune("COUPLED_UNITS") && atoi(tune("COUPLED_UNITS")) == 0)) { d.xf = 1; d.xf_all = 1; }
   d.u0 = (int)((long long)p->rank * d.U / p->world); d.u1 = (int)((long long)(p->rank + 1) * d.U / p->world);
   d.lambda = p->lambda; d.margin = p->margin; d.offset = p->offset; d.mu = p->mu; d.vel_limit = p->vel_limit; d.acc_limit = p->acc_limit;
   d.ks = p->ks; d.kt = p->kt; d.stop = p->stop;
@@ -583,23 +605,19 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   d.cap_pairs = p->cap_pairs > 0 ? p->cap_pairs : d.U;
   d.optimal_plane = p->optimal_plane ? 1 : 0;
   d.pair_rows = d.U <= 128 ? 8 : 16;   // tile height: 64 robots -- 8 rows: k_front 13.3 -> 12.5 us, k_ccd 9.6 -> 8.7 (with eight interval records in flight); 256 robots -- 16 rows (8: +1.3 us, 4: +13)
-  if (const char* e = getenv("TJ_PAIR_ROWS")) { const int r = atoi(e); if (r == 2 || r == 4 || r == 8 || r == 16) d.pair_rows = r; }
+  if (const char* e = tune("PAIR_ROWS")) { const int r = atoi(e); if (r == 2 || r == 4 || r == 8 || r == 16) d.pair_rows = r; }
   d.cap_work = d.mode >= 1 ? (int)std::min<long long>((long long)d.S * d.U * (d.U - 1) / 2 + 1, 1 << 22) : 1;  // robot pairs per iteration
   d.xs = 3 * d.T + 4;
   const int n = 9 * d.P - 2;
   d.grad_npl = std::min(d.cap_obs + d.cap_self, 64);   // what a batch of segments really carries (SCN-C: <= 40); more goes through grad_scr.  64: five workgroups per CU (96: four)
-  if (const char* e = getenv("TJ_GRAD_NPL")) { const int r = atoi(e); if (r >= 8 && r <= 4096) d.grad_npl = std::min(d.cap_obs + d.cap_self, r); }
+  if (const char* e = tune("GRAD_NPL")) { const int r = atoi(e); if (r >= 8 && r <= 4096) d.grad_npl = std::min(d.cap_obs + d.cap_self, r); }
   c->lds_grad = grad_lds_doubles(d.grad_npl, d.res) * sizeof(double);
   const size_t lds_max = 160 * 1024 - 1024;
   // long trajectories: the dense per-robot system no longer fits LDS -> band storage (decoupled / single-UAV modes)
-  d.xs_band = (xsolve_lds_doubles(n) * sizeof(double) > lds_max || getenv("TJ_XS_BAND")) ? 1 : 0;
+  d.xs_band = (xsolve_lds_doubles(n) * sizeof(double) > lds_max || tune("XS_BAND")) ? 1 : 0;
   c->lds_xs = (d.xs_band ? xsolve_band_lds_doubles(n) : xsolve_lds_doubles(n)) * sizeof(double);
   c->lds_xs2 = (d.xs_band ? (size_t)(n - 1) * BAND_BS + 5 * (size_t)n : (size_t)n * n + 4 * (size_t)n) * sizeof(double);   // k_xsolve_c2 / k_xsolve_c2_band
   c->lsl = ls_layout(d.S, d.T, d.P, 120 * 1024);
-  if (const char* e = getenv("TJ_LS_EXACT_HULLS")) if (atoi(e)) {   // A/B hook: every trial hull as basis * (x + step d)
-    c->lsl = ls_layout_g(d.S, d.T, d.P, 120 * 1024, LS_GROUPS);
-    for (int G = LS_GROUPS / 2; G >= 1 && c->lsl.total * 8 > 155 * 1024; G /= 2) c->lsl = ls_layout_g(d.S, d.T, d.P, 120 * 1024, G);
-  }
   c->lds_ls = c->lsl.total * sizeof(double);
 #ifdef TJ_PHASE_TIMING
   { int r_ = dalloc(c, &d.dbg, (size_t)K_COUNT * TJ_TIC_BLOCKS * TJ_TIC_SLOTS); if (r_) return r_; }
@@ -608,28 +626,28 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if (d.S > 511) { c->err = "more than 511 segments per robot are not supported by the line-search kernel"; return TJ_ERR_UNSUPPORTED; }
   if (d.res > GRAD_MAXRES) { c->err = "res > 16 segments per piece is not supported by the gradient kernel"; return TJ_ERR_UNSUPPORTED; }
   d.seq_tree = (d.mode == TJ_MODE_MULTI_DECOUPLE && seq_lds_bytes(d.U, d.S, true) <= lds_max) ? 1 : 0;
-  if (getenv("TJ_NO_SEQ_TREE")) d.seq_tree = 0;  // test hook: behave like a fleet too large for the LDS-resident tree
+  if (tune("NO_SEQ_TREE")) d.seq_tree = 0;  // test hook: behave like a fleet too large for the LDS-resident tree
   c->lds_seq = seq_lds_bytes(d.U, d.S, d.seq_tree != 0);
   c->split_unions = false;
-  if (const char* e = getenv("TJ_CCD_LEAN")) c->ccd_lean = atoi(e) != 0;
+  if (const char* e = tune("CCD_LEAN")) c->ccd_lean = atoi(e) != 0;
   // hundreds of robots: the 512-thread folded k_grad is limited to ~2 workgroups per CU by wave slots; the 192-thread one (5 per CU)
   // plus a separate compaction launch is faster once there are more pieces than that (SCN-D: k_grad 109 -> 72 + 14 us)
   c->grad_fold = (d.u1 - d.u0) * d.P <= 512;
-  if (const char* e = getenv("TJ_GRAD_FOLD")) c->grad_fold = atoi(e) != 0;
+  if (const char* e = tune("GRAD_FOLD")) c->grad_fold = atoi(e) != 0;
   d.bvh_skip = 0;    // decided when the obstacle set is known (set_obstacles); TJ_BVH_SKIP=0 / 1 forces it (launch-shape switch, same bits)
-  if (const char* e = getenv("TJ_BVH_SKIP")) d.bvh_skip = atoi(e) != 0;
+  if (const char* e = tune("BVH_SKIP")) d.bvh_skip = atoi(e) != 0;
   d.pair_prio = 1;
   d.mid_order = (d.mode >= 1 && d.U >= 192) ? 1 : 0;   // k_mid's grid order (kernels_step.h): config 5 -15 us; small fleets: nothing or slightly worse
-  if (const char* e = getenv("TJ_MID_ORDER")) d.mid_order = atoi(e) != 0;   // launch-shape switch (same bits)
-  if (const char* e = getenv("TJ_PAIR_PRIO")) d.pair_prio = atoi(e) != 0;   // launch-shape switch (same bits)
+  if (const char* e = tune("MID_ORDER")) d.mid_order = atoi(e) != 0;   // launch-shape switch (same bits)
+  if (const char* e = tune("PAIR_PRIO")) d.pair_prio = atoi(e) != 0;   // launch-shape switch (same bits)
   d.pair_lpw = 64;
-  if (const char* e = getenv("TJ_PAIR_LPW")) { const int r = atoi(e); if (r == 8 || r == 16 || r == 32 || r == 64) d.pair_lpw = r; }   // launch-shape switch (same bits)
+  if (const char* e = tune("PAIR_LPW")) { const int r = atoi(e); if (r == 8 || r == 16 || r == 32 || r == 64) d.pair_lpw = r; }   // launch-shape switch (same bits)
   d.pair_pass_on = 1;
-  if (const char* e = getenv("TJ_PAIR_PASS_ON")) d.pair_pass_on = atoi(e) != 0;
-  if (const char* e = getenv("TJ_SPLIT_UNIONS")) c->split_unions = atoi(e) != 0;
+  if (const char* e = tune("PAIR_PASS_ON")) d.pair_pass_on = atoi(e) != 0;
+  if (const char* e = tune("SPLIT_UNIONS")) c->split_unions = atoi(e) != 0;
   // GJK head start for last iteration's slow robot pairs (kernels_pairs.h: spec_pair_body); TJ_PAIR_HEAD_START=0 switches it off (test hook: same bits)
   d.spec = (d.mode >= 1 && !d.optimal_plane && !c->split_unions) ? 1 : 0;
-  if (const char* e = getenv("TJ_PAIR_HEAD_START")) d.spec = d.spec && atoi(e) != 0;
+  if (const char* e = tune("PAIR_HEAD_START")) d.spec = d.spec && atoi(e) != 0;
   // k_ccd's last block finishes with the sequential pair replay + gnorm (kernels_step.h): decoupled mode, when the replay's small
   // arrays fit k_ccd's static LDS buffer with room for at least 256 acting-pair keys (the value is that capacity)
   d.seq_fold = 0;
@@ -639,14 +657,14 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     while (cap >= 256 && seq_fold_lds_bytes(d.U, cap) > buf) cap >>= 1;
     if (cap >= 256 && (size_t)d.S * pair_units(d.U, d.pair_rows) < 65536) d.seq_fold = cap;   // (the finisher counts the selection blocks in 16 bits)
   }
-  if (const char* e = getenv("TJ_SEQ_FOLD")) if (atoi(e) == 0) d.seq_fold = 0;   // launch-shape switch (same bits)
+  if (const char* e = tune("SEQ_FOLD")) if (atoi(e) == 0) d.seq_fold = 0;   // launch-shape switch (same bits)
   c->n_solve_env = 0;
-  if (const char* e = getenv("TJ_N_SOLVE")) c->n_solve_env = std::max(1, atoi(e));
+  if (const char* e = tune("N_SOLVE")) c->n_solve_env = std::max(1, atoi(e));
   d.spec_budget = SPEC_GJK_BUDGET; d.spec_min = SPEC_GJK_MIN;
-  if (const char* e = getenv("TJ_HS_BUDGET")) d.spec_budget = std::max(1, atoi(e));   // development hooks (same bits for any value)
-  if (const char* e = getenv("TJ_HS_MIN")) d.spec_min = std::max(1, atoi(e));
+  if (const char* e = tune("HS_BUDGET")) d.spec_budget = std::max(1, atoi(e));   // development hooks (same bits for any value)
+  if (const char* e = tune("HS_MIN")) d.spec_min = std::max(1, atoi(e));
   d.ls_fast = 1;
-  if (const char* e = getenv("TJ_LS_FAST")) d.ls_fast = atoi(e) != 0;   // launch-shape switch (same bits): round 0 of k_linesearch in the team shape
+  if (const char* e = tune("LS_FAST")) d.ls_fast = atoi(e) != 0;   // launch-shape switch (same bits): round 0 of k_linesearch in the team shape
   {   // helper blocks of k_linesearch: one CU each, so as many per robot as the device has compute units to spare (64 robots on 256 CUs: 4)
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, p->device));
@@ -656,8 +674,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     c->lsc_wide = p->mode == TJ_MODE_MULTI_COUPLED && owned * LSC_ROUNDS <= d.num_cu;
     // ... and the corner solve inside k_xsolve where every robot's block is resident at once (one block per compute unit: 242 registers x 8 waves), dense storage
     d.c2_fold = (p->mode == TJ_MODE_MULTI_COUPLED && p->world == 1 && d.U <= d.num_cu && !d.xs_band) ? 1 : 0;
-    if (const char* e = getenv("TJ_C2_FOLD")) d.c2_fold = d.c2_fold && atoi(e) != 0;   // launch-shape switch (same bits)
-    if (const char* e = getenv("TJ_LSC_WIDE")) c->lsc_wide = atoi(e) != 0;   // launch-shape switch (same bits)
+    if (const char* e = tune("C2_FOLD")) d.c2_fold = d.c2_fold && atoi(e) != 0;   // launch-shape switch (same bits)
+    if (const char* e = tune("LSC_WIDE")) c->lsc_wide = atoi(e) != 0;   // launch-shape switch (same bits)
     // k_grad's launch order follows the items' last durations where blocks outnumber the compute units (kernels_newton.h: grad_order_body)
     // -- between one and two blocks per unit, the case it was measured on: SCN-C -1.5 us per iteration, the 64 hard robots -1.4; at five blocks per unit
     // (256 robots) longest-first ordering bought nothing in k_grad and the run was 1.5 % slower, so larger fleets keep the identity
@@ -693,35 +711,36 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     // wait into its 2 s limit.  Under it the context keeps everything on the one queue (an explicit TJ_XS_ASYNC=1 / TJ_KEEP_ASYNC=1 overrides).
     const char* cc_ = getenv("ROCPROF_COUNTER_COLLECTION");
     const bool counters_on = cc_ && cc_[0] && strcmp(cc_, "0") != 0 && strcasecmp(cc_, "false") != 0;
-    if (counters_on && !getenv("TJ_XS_ASYNC")) d.xs_async = 0;
-    if (const char* e = getenv("TJ_XS_ASYNC")) d.xs_async = d.xs_async && atoi(e) != 0;
+    if (counters_on && !tune("XS_ASYNC")) d.xs_async = 0;
+    if (const char* e = tune("XS_ASYNC")) d.xs_async = d.xs_async && atoi(e) != 0;
     if (d.xs_async) {
       const bool ok = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); c->stream2 = nullptr; }   // (the tickets and flags work on one queue as well)
-      c->xs_two_queues = ok && getenv("TJ_XS_ONE_QUEUE") == nullptr;
+      c->xs_two_queues = ok && tune("XS_ONE_QUEUE") == nullptr;
     }
     // asynchronous plane refinement ("optimal_plane":1, multi-UAV decoupled mode, one context; TJ_KEEP_ASYNC=0: k_keep stays one launch between k_mid and k_grad -- same bits)
     d.keep_async = (d.optimal_plane && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && !c->split_unions) ? 1 : 0;
-    if (counters_on && !getenv("TJ_KEEP_ASYNC")) d.keep_async = 0;
-    if (const char* e = getenv("TJ_KEEP_ASYNC")) d.keep_async = d.keep_async && atoi(e) != 0;
+    if (counters_on && !tune("KEEP_ASYNC")) d.keep_async = 0;
+    if (const char* e = tune("KEEP_ASYNC")) d.keep_async = d.keep_async && atoi(e) != 0;
     d.keep_waves = 1024;
     if (d.keep_async) {
       if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) == hipSuccess) c->keep_two_queues = true;
       else { (void)hipGetLastError(); c->stream3 = nullptr; d.keep_async = 0; }
     }
-    if (const char* e = getenv("TJ_GRAD_BALANCE")) d.grad_bal = (atoi(e) != 0 && owned * d.P <= 65536) ? 1 : 0;   // launch-shape switch (same bits)
+    if (const char* e = tune("GRAD_BALANCE")) d.grad_bal = (atoi(e) != 0 && owned * d.P <= 65536) ? 1 : 0;   // launch-shape switch (same bits)
     d.ls_help = (d.ls_fast && p->mode != TJ_MODE_MULTI_COUPLED) ? std::max(1, std::min(LS_HELP_MAX, prop.multiProcessorCount / owned)) : 1;
-    if (const char* e = getenv("TJ_LS_HELP")) {   // launch-shape switch (same bits); 1 = no helpers.  More blocks per robot than the compute units hold at once would leave helpers waiting for a
-                                                  // unit while every primary runs into its 10 us give-up per super-round: clamped unless TJ_LS_HELP_FORCE=1 says so
+    if (const char* e = tune("LS_HELP")) {   // launch-shape switch (same bits); 1 = no helpers.  More blocks per robot than the compute units hold at once would leave helpers waiting for a
+                                                  // unit while every primary runs into its 10 us give-up per super-round: clamped to the units the device has
       d.ls_help = std::max(1, std::min(LS_HELP_MAX, atoi(e)));
-      if (!getenv("TJ_LS_HELP_FORCE")) d.ls_help = std::min(d.ls_help, std::max(1, prop.multiProcessorCount / owned));
+      d.ls_help = std::min(d.ls_help, std::max(1, prop.multiProcessorCount / owned));
     }
-    if (const char* e = getenv("TJ_LS_HELP_LATE")) d.ls_help_late = std::max(0, std::min(4000, atoi(e)));   // test hook (same bits): helper blocks idle that many microseconds before staging
-    if (const char* e = getenv("TJ_LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
+    if (const char* e = tune("LS_HELP_LATE")) d.ls_help_late = std::max(0, std::min(4000, atoi(e)));   // test hook (same bits): helper blocks idle that many microseconds before staging
+    if (const char* e = tune("LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
     // asynchronous front (dev_common.h, Dev::fa): one context, decoupled mode, the asynchronous solve's second queue, and a k_linesearch grid that is resident all at once
     // (one block per compute unit at most -- the residency gate's premise).  TJ_FRONT_ASYNC=0: k_linesearch publishes the hull cache and k_front follows it on the chain's queue (same bits)
     d.fa = (d.xs_async && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && d.fuse && !d.optimal_plane && !c->split_unions && !c->use_graph && owned * d.ls_help <= d.num_cu) ? 1 : 0;
-    if (const char* e = getenv("TJ_FRONT_ASYNC")) d.fa = d.fa && atoi(e) != 0;
+    if (const char* e = tune("FRONT_ASYNC")) d.fa = d.fa && atoi(e) != 0;
+    c->fa_emulate = tune("FRONT_ASYNC_ONE_QUEUE") && atoi(tune("FRONT_ASYNC_ONE_QUEUE")) != 0;   // the asynchronous front's data flow (k_front's units form the records, k_linesearch publishes none) on the chain's queue: counter passes
     if (d.fa) {
       // Dev::fa_mid: k_mid may start while k_front still runs only if k_front's whole grid is resident before k_mid's first wave is -- the last k_linesearch block waits
       // until every k_front block has started, so the grid must fit the device next to that one block: blocks per compute unit by LDS, registers and wave slots
@@ -733,7 +752,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
         const int by_lds = (int)(((size_t)160 * 1024) / std::max<size_t>(af.sharedSizeBytes, 1)), by_regs = 4 * (512 / std::max((af.numRegs + 7) / 8 * 8, 8)), per_cu = std::min(std::min(by_lds, by_regs), 32);
         c->fa_mid_ok = (long long)n_front <= (long long)(d.num_cu - 1) * per_cu;
       } else (void)hipGetLastError();
-      if (const char* e = getenv("TJ_FRONT_ASYNC_MID")) c->fa_mid_ok = c->fa_mid_ok && atoi(e) != 0;   // launch-shape switch (same bits): 0 = k_linesearch waits for k_front's end, k_mid follows plainly
+      if (const char* e = tune("FRONT_ASYNC_MID")) c->fa_mid_ok = c->fa_mid_ok && atoi(e) != 0;   // launch-shape switch (same bits): 0 = k_linesearch waits for k_front's end, k_mid follows plainly
     }
   }
   if (c->lds_grad + grad_fold_extra_doubles(d.res) * sizeof(double) > lds_max || c->lds_xs > lds_max || c->lds_ls > lds_max || c->lds_seq > lds_max) {
@@ -789,13 +808,13 @@ int tj_create(const tj_params* p, tj_ctx** out) {
         (r = dalloc(c, &d.kpair_cd, m0 ? 1 : S * U * U * 4))) return r;
   }
   {   // self-healing: what a batch's first state consists of (everything an iteration reads that an earlier iteration wrote and that is not rebuilt or re-stamped anyway)
-    c->heal = !(getenv("TJ_HEAL") && atoi(getenv("TJ_HEAL")) == 0);
+    c->heal = !(tune("HEAL") && atoi(tune("HEAL")) == 0);
     if (c->heal) {   // the error word's mirror in pinned host memory (written by k_flush)
       void* hp = nullptr; void* dp = nullptr;
       if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { c->host_err = (int*)hp; *c->host_err = 0; d.err_mirror = (int*)dp; }
       else { (void)hipGetLastError(); if (hp) (void)hipHostFree(hp); c->heal = false; }
     }
-    if (const char* e = getenv("TJ_XS_FAULT")) c->xs_fault = atoi(e);   // test hook: the n-th gate of the asynchronous solve reports a time-out
+    if (const char* e = tune("XS_FAULT")) c->xs_fault = atoi(e);   // test hook: the n-th gate of the asynchronous solve reports a time-out
     std::vector<std::pair<void*, size_t>> reg = {
       {d.spline, U * 3 * T * 8}, {d.p_slack, U * 18 * P * 8}, {d.p_lambda, U * 18 * P * 8}, {d.t_slack, U * P * 8}, {d.t_lambda, U * P * 8}, {d.piece_time, U * 8},
       {d.xdir, U * d.xs * 8}, {d.ls_hist, U * 4}, {d.step_out, U * 8}, {d.seg_stats, U * S * 6 * 8}, {d.pair_stats, U * S * 2 * 8}, {d.blk_stats, (U * P + U) * 8}, {d.ccd_found, 64 * 4}};
@@ -867,7 +886,7 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
   QUIESCE(c);
   drop_graph(c);
   c->have_cloud = false;
-  d.N = 0; d.nlevels = 0; if (!getenv("TJ_BVH_SKIP")) d.bvh_skip = 0; d.px = d.py = d.pz = d.tri = nullptr; d.boxes = d.leafbox = nullptr;
+  d.N = 0; d.nlevels = 0; if (!tune("BVH_SKIP")) d.bvh_skip = 0; d.px = d.py = d.pz = d.tri = nullptr; d.boxes = d.leafbox = nullptr;
   for (void* p : c->cloud_allocs) hipFree(p);
   c->cloud_allocs.clear();
   c->cloud_order.clear();
@@ -881,7 +900,7 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
     if (prim == 1) { if ((r = dalloc(c, &px, n, &c->cloud_allocs)) || (r = dalloc(c, &py, n, &c->cloud_allocs)) || (r = dalloc(c, &pz, n, &c->cloud_allocs))) return r; }
     else if ((r = dalloc(c, &tri, (size_t)n * 9, &c->cloud_allocs)) || (r = dalloc(c, &lb, (size_t)n * 6, &c->cloud_allocs))) return r;
     std::vector<int> order(n);
-    c->bvh_on_device = getenv("TJ_BVH_HOST") ? 0 : 1;   // TJ_BVH_HOST=1: the host build of host_tables.h (the checker of the device build)
+    c->bvh_on_device = tune("BVH_HOST") ? 0 : 1;   // TJ_BVH_HOST=1: the host build of host_tables.h (the checker of the device build)
     if (!c->bvh_on_device) {
       HostBvh b;
       build_bvh(verts, n, prim, b);
@@ -931,7 +950,7 @@ int set_obstacles(tj_ctx* c, const double* verts, int n, int prim) {
     d.nlevels = (int)lvl_n.size();
     // two levels per step at the top of the walk (kernels_sep.h): pays where the pyramid is deep AND the query waves outnumber the resident slots, i.e. where a
     // query's latency is the launch's throughput (256 robots x 1 M primitives: k_front 40.2 -> 36.3 us, k_ccd 34.0 -> 31.0); 64 robots through 1 M points: no change
-    if (!getenv("TJ_BVH_SKIP")) d.bvh_skip = (d.nlevels >= 5 && (d.u1 - d.u0) * d.S > 3584) ? 1 : 0;
+    if (!tune("BVH_SKIP")) d.bvh_skip = (d.nlevels >= 5 && (d.u1 - d.u0) * d.S > 3584) ? 1 : 0;
     for (int i = 0; i < d.nlevels; i++) { d.lvl_off[i] = lvl_off[i]; d.lvl_n[i] = lvl_n[i]; }
     d.N = n;
   }

@@ -285,12 +285,12 @@ int group_select_transport(tj_group* g, int t) {
     // ranks sharing a device: k_linesearch's helper blocks (one compute unit each) only where the ranks run in lockstep (flag: the kernels of the ranks overlap and every
     // helper is resident; measured with 2 x 32 robots on one device: 0.147 -> 0.137 ms) -- under the event transport, which orders whole kernels, the helpers of one rank
     // queue behind the other rank's blocks and the primaries run into their 10 us give-up (0.166 -> 0.279 ms)
-    if (sharers > 1 && !getenv("TJ_LS_HELP") && c->d.ls_fast && c->d.mode != TJ_MODE_MULTI_COUPLED) {
+    if (sharers > 1 && !tune("LS_HELP") && c->d.ls_fast && c->d.mode != TJ_MODE_MULTI_COUPLED) {
       const int owned = std::max(1, c->d.u1 - c->d.u0);
       c->d.ls_help = t == TJ_TRANSPORT_FLAG ? std::max(1, std::min(LS_HELP_MAX, c->d.num_cu / (owned * sharers))) : 1;
     }
     int wait_mode = sharers == 1 ? 1 : 0;
-    if (const char* e = getenv("TJ_XCH_POLL")) wait_mode = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = tune("XCH_POLL")) wait_mode = atoi(e) != 0 ? 1 : 0;
     if (t == TJ_TRANSPORT_EVENT) wait_mode = 2;   // events order the streams
     const int rc = tj_xch_enable(c, t != TJ_TRANSPORT_RCCL ? 1 : 0, wait_mode);
     if (rc) return group_fail(g, rc, std::string("rank ") + std::to_string(r) + ": " + tj_last_error(c));
@@ -375,7 +375,7 @@ int tj_group_create(const tj_params* p, int n_ranks, const int* devices, tj_grou
   // on one device, but it has not crossed xGMI yet: it is opt-in (TJ_GROUP_TRANSPORT=flag / tj_group_set_transport) until
   // test_group_on_two_devices[flag] has passed on a multi-GPU box; bench.py tries flag -> event -> rccl and validates each bitwise.
   int t = TJ_TRANSPORT_EVENT;
-  if (const char* e = getenv("TJ_GROUP_TRANSPORT")) {
+  if (const char* e = tune("GROUP_TRANSPORT")) {
     if (!strcmp(e, "flag")) t = TJ_TRANSPORT_FLAG; else if (!strcmp(e, "event")) t = TJ_TRANSPORT_EVENT; else if (!strcmp(e, "rccl")) t = TJ_TRANSPORT_RCCL;
     else return bail(TJ_ERR_INVALID, std::string("TJ_GROUP_TRANSPORT=") + e + ": expected flag, event or rccl");
   }
