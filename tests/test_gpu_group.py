@@ -320,7 +320,7 @@ def test_asynchronous_newton_solve_changes_no_bit(pkg, scenes, monkeypatch, scen
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene_name", ["scn_c", "scn_b", "hard", "fleet100"])
+@pytest.mark.parametrize("scene_name", ["scn_c", "scn_b", "hard", "fleet100", "scn_a", "scn_b_coupled", "hard_coupled"])
 def test_asynchronous_front_changes_no_bit(pkg, scenes, monkeypatch, scene_name):
     """Round 6: inside a batch the NEXT iteration's k_front runs on the second hardware queue next to k_linesearch (residency gate, per-robot commit flags behind the
     written-through control nets, units that form and publish the hull records, done counters), and -- where k_front's whole grid is resident at once -- k_mid starts while
@@ -328,7 +328,8 @@ def test_asynchronous_front_changes_no_bit(pkg, scenes, monkeypatch, scene_name)
     k_front follows on the chain's queue) and against TJ_FRONT_ASYNC_MID=0 (k_linesearch waits for k_front's end): the same state bit for bit over 60 iterations in batches of
     uneven length, no error bit, the same number of energy evaluations; the launch count shows the gate (one per pairing = per iteration that has a successor in its batch).
     fleet100: 100 robots -- one k_linesearch block per robot, k_front's grid too large to be resident at once (k_mid follows plainly)."""
-    scene = {"scn_c": scenes.scn_c, "scn_b": scenes.scn_b, "hard": lambda: scenes.hard(8, 8000), "fleet100": lambda: scenes.crossing(100, 20000, seed=121)}[scene_name]()
+    scene = {"scn_c": scenes.scn_c, "scn_b": scenes.scn_b, "hard": lambda: scenes.hard(8, 8000), "fleet100": lambda: scenes.crossing(100, 20000, seed=121), "scn_a": scenes.scn_a,
+             "scn_b_coupled": lambda: dict(scenes.scn_b(), mode=2), "hard_coupled": lambda: dict(scenes.hard(8, 8000), mode=2)}[scene_name]()   # all three modes (coupled: the one-launch search commits every robot and raises every flag)
     for k in ("TJ_XS_ASYNC", "TJ_XS_ONE_QUEUE", "TJ_FRONT_ASYNC", "TJ_FRONT_ASYNC_MID", "TJ_FRONT_ASYNC_ONE_QUEUE"):
         monkeypatch.delenv(k, raising=False)
     batches = (1, 7, 20, 2, 30)

@@ -958,6 +958,11 @@ __device__ __forceinline__ void lsc_continue(const Dev& D, const LsLayout& L, do
 // in the decoupled chain -- the host then omits k_begin.
 // base (sharded context, the caller follows the search: Dev::lsc_follow): the launch evaluates the rounds [base + round0, ...) into the table's rows [round0, ...)
 __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, int round0, int wide, int begin_next, int base = 0) {
+  if (D.fa_seq > 0) {   // asynchronous front (one context, all rounds in this launch): as in k_linesearch -- the early begin by the last block of the grid, then every block counts itself started
+    if (blockIdx.x == gridDim.x - 1) fa_early_begin(D);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(D.fa_res(blockIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sig_sent();
+  }
   if (TJ_DONE(D)) {
     if (begin_next && blockIdx.x == 0 && threadIdx.x == 0) { D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0; }   // (as k_linesearch: retire the slack update k_mid has just paid)
     return;
@@ -1026,12 +1031,23 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_coupled(Dev D, LsLayout L, in
   for (int idx = tid; idx < nown * 3 * T; idx += LS_THREADS) {
     const int uu = D.u0 + idx / (3 * T), i = idx % (3 * T);
     double* gs = D.spline + (size_t)uu * 3 * T;
-    gs[i] = gs[i] + step * D.dirp(uu)[i];
+    xs_out(D.fa_seq > 0, gs + i, gs[i] + step * D.dirp(uu)[i]);
+  }
+  if (D.fa_seq > 0) {   // (uniform) asynchronous front: every robot's control net is out (written through) and acknowledged -> every robot's commit flag
+    sig_acked();
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    for (int uu = D.u0 + tid; uu < D.u1; uu += LS_THREADS) __hip_atomic_store(D.fa_commit(uu), D.fa_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sig_sent();
   }
   for (int uu = D.u0 + tid; uu < D.u1; uu += LS_THREADS) {
     D.piece_time[uu] = D.piece_time[uu] + step * D.tdir(uu); D.step_out[uu] = step; D.blk_stats[(size_t)D.U * D.P + uu] += (unsigned long long)(2 + kacc);
   }
-  if (begin_next) { __syncthreads(); begin_body(D); }
+  if (begin_next) {
+    __syncthreads();
+    begin_body(D, 0, D.fa_seq > 0);
+    if (D.fa_seq > 0 && tid < 64) fa_wait16(D, D.fa_mid ? D.fa_fstart(0) : D.fa_fdone(0), (int)((unsigned)D.fa_seq * (unsigned)D.fa_nfront));   // (as k_linesearch's last block)
+  }
 }
 
 // commit: x_u += step d_u for every robot, the shared piece_time advances by step * t_direction

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(64) void k_front(Dev D) {
   const int n_xf = D.xf_units();   // sharded contexts: hull cache of the other ranks' robots (coupled chain: of every robot), AHEAD of everything that reads it (head starts, pair tiles)
   const int bx = (int)blockIdx.x;
   const int b = bx - n_ord - n_xf - n_spec;
-  const bool pub = D.xf_all != 0 || D.fa_units != 0;   // the query forms its hull itself and publishes the record (coupled chain; Dev::fa_units: the k_linesearch before this launch published none)
+  const bool pub = D.xf_all != 0 || (D.fa_units != 0 && D.multi());   // the query forms its hull itself and publishes the record (coupled chain; Dev::fa_units: the k_linesearch before this launch published none)
   if (bx < n_ord) grad_order_body<FA>(D, bx, (int*)lds);
   else if (bx < n_ord + n_xf) xf_hull_body(D, bx - n_ord);
   else if (b < 0) spec_pair_body<FA>(D, bx - n_ord - n_xf, lds, fa_epoch);

@@ -191,7 +191,7 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_ccd = owned * d.S + n_rows, n_front = n_ccd + n_xf + (d.spec ? SPEC_CAP : 0) + (d.grad_bal ? (owned * d.P + 63) / 64 : 0);
   const bool chained = in_graph || in_phase;          // an iteration chain (one context, or the phases of a sharded schedule) as opposed to the stage API
   const int n_mid_slack = owned * d.P;
-  d_.fa_nfront = n_front; d_.fa_nls = owned * d.ls_help;
+  d_.fa_nfront = n_front; d_.fa_nls = coupled ? owned * LSC_ROUNDS : owned * d.ls_help;
   switch (kid) {
     case K_BEGIN: if (chain_pos & 1) return false; TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d); c->xf_used[0] = c->xf_used[1] = false; return true;
     case K_HULLINFO: if ((chained && (d.fuse || d.xf_all)) || !multi) return false; TJ_LAUNCH(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // unfused sharded phases (coupled mode): always (all robots, after the gather)
@@ -308,6 +308,8 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
     case K_LS_COUPLED:
       if (coupled) {
         const int base = (owned != d.U && d.lsc_follow) ? c->lsc_base : 0;   // (a followed search of a sharded context: the rounds beyond the first table)
+        c->hull_from_units = false;
+        if (fa2q && c->lsc_wide && owned == d.U && (chain_pos & 2)) { d_.fa_seq = ++c->fa_seq; d_.fa_units = 1; d_.fa_mid = c->fa_mid_ok ? 1 : 0; c->fa_armed = true; }   // asynchronous front: the next k_front runs next to this launch
         if (c->lsc_wide) { TJ_LAUNCH(k_ls_coupled, dim3(owned * LSC_ROUNDS), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, 0, LSC_ROUNDS, (chain_pos & 2) ? 1 : 0, base); if (chain_pos & 2) c->xf_used[0] = c->xf_used[1] = false; }   // all rounds at once, one block per (robot, round)
         else for (int r = 0; r < LSC_ROUNDS; r++) TJ_LAUNCH(k_ls_coupled, dim3(owned), dim3(LS_THREADS), c->lds_ls, s, d, c->lsl, r, 1, 0, base);
       }
@@ -738,7 +740,8 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     if (const char* e = tune("LS_HELP_MUTE")) d.ls_help_mute = atoi(e) != 0;                          // test hook (same bits): the helpers never post, the primaries time out
     // asynchronous front (dev_common.h, Dev::fa): one context, decoupled mode, the asynchronous solve's second queue, and a k_linesearch grid that is resident all at once
     // (one block per compute unit at most -- the residency gate's premise).  TJ_FRONT_ASYNC=0: k_linesearch publishes the hull cache and k_front follows it on the chain's queue (same bits)
-    d.fa = (d.xs_async && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && d.fuse && !d.optimal_plane && !c->split_unions && !c->use_graph && owned * d.ls_help <= d.num_cu) ? 1 : 0;
+    d.fa = (d.xs_async && p->world == 1 && !d.optimal_plane && !c->split_unions && !c->use_graph &&
+            (p->mode != TJ_MODE_MULTI_COUPLED ? (d.fuse && owned * d.ls_help <= d.num_cu) : (c->lsc_wide && d.xf_all && owned * LSC_ROUNDS <= d.num_cu))) ? 1 : 0;   // (coupled: the one-launch search, whose last block commits every robot)
     if (const char* e = tune("FRONT_ASYNC")) d.fa = d.fa && atoi(e) != 0;
     c->fa_emulate = tune("FRONT_ASYNC_ONE_QUEUE") && atoi(tune("FRONT_ASYNC_ONE_QUEUE")) != 0;   // the asynchronous front's data flow (k_front's units form the records, k_linesearch publishes none) on the chain's queue: counter passes
     if (d.fa) {
