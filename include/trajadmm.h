@@ -89,16 +89,18 @@ int tj_host_tables(int piece_num, int res, double* convert, double* mdyn, double
  *                                   (tests/golden/backoff_kat.npz pins the regime boundary).
  *   back-off loops                  followed to where the reference's own loop ends (step *= 0.8 to its fixed point 1e-323 after 3332 factors);
  *                                   TJ_ERR_NO_PROGRESS only where the reference would spin forever -- in all three modes since round 5 (the coupled search
- *                                   beyond 0.8^30 is continued by one block, tests/golden/coupled_long_kat.npz).  Exception: a SHARDED coupled context
- *                                   (world > 1) decides on the 31 steps its exchange carries and reports TJ_ERR_NO_PROGRESS (detail bit 32) beyond.
+ *                                   beyond 0.8^30 is continued by one block, tests/golden/coupled_long_kat.npz).  A SHARDED coupled context (world > 1)
+ *                                   exchanges 31 steps at a time: tj_group follows the search by itself, a caller that drives the phases uses
+ *                                   tj_set_coupled_follow / tj_coupled_search_pending (below); without them TJ_ERR_NO_PROGRESS (detail bit 32) beyond 0.8^30.
  *   cap_obs / cap_self / cap_pairs  list capacities of tj_params; an overflow is TJ_ERR_CAPACITY with the bit that says which.
- *   one process per GPU             one context (world == 1) of a fleet up to about one robot per compute unit enqueues its Newton solve on a SECOND stream of its
- *                                   own, next to the gradient kernel, and "optimal_plane":1 its stored planes' refinement on a third: kernels of one
- *                                   queue sleep on words kernels of the other write.  Streams of ONE process run side by side; two PROCESSES that both do this on one
- *                                   GPU shut each other out (the device runs one process's waves at a time) until the 2 s limits of the waits fire:
- *                                   TJ_ERR_NO_PROGRESS with error bit 2048 and a message that names the switch -- TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0 in the environment
- *                                   of tj_create keep everything on the context's stream (same results bit for bit).  Under rocprofv3's counter collection
- *                                   (which serialises dispatches across queues) the library does that by itself. */
+ *   several processes per GPU       one context (world == 1) of a fleet up to about one robot per compute unit enqueues its Newton solve and the next iteration's
+ *                                   k_front on a SECOND stream of its own, and "optimal_plane":1 its stored planes' refinement on a third: kernels
+ *                                   of one queue sleep on words kernels of the other write.  Streams of ONE process run side by side; two PROCESSES that both do this on
+ *                                   one GPU shut each other out (the device runs one process's waves at a time) until a 2 s limit fires.  Not an error since round 6:
+ *                                   the library restores the state the batch started from, runs the batch again on ONE queue and keeps the one-queue chain for the
+ *                                   life of the context (tj_stats.async_fallbacks counts it; same results bit for bit; the incident costs its 2 s once).  TJ_HEAL=0
+ *                                   restores round 5's report (TJ_ERR_NO_PROGRESS, error bit 2048); TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0 avoid the stall up front.  Under
+ *                                   rocprofv3's counter collection (which serialises dispatches across queues) the library keeps one queue by itself. */
 int tj_create(const tj_params* p, tj_ctx** out);
 void tj_destroy(tj_ctx* c);
 const char* tj_last_error(const tj_ctx* c);

@@ -198,16 +198,16 @@ struct Dev {
   // counters.  keep_sync: ints [16][32] counters (zeroed by begin_body) | [32] go word.
   int keep_async, keep_seq, keep_waves; int* keep_sync;
   __host__ __device__ int* keep_go() const { return keep_sync + 16 * 32; }
-  // ASYNCHRONOUS FRONT (round 6; one context, decoupled mode, every k_linesearch block resident at once): the NEXT iteration's k_front runs on the second
-  // hardware queue next to this iteration's k_linesearch.  Its launch is held back by a one-wave gate (k_fa_gate) until every block of k_linesearch has
-  // started (residency counters: all of them are resident then, so a k_front block that sleeps on a flag can never keep a k_linesearch block off a compute
-  // unit); the primary block of robot u stores the accepted control net written through and raises the robot's COMMIT FLAG; k_front's obstacle unit of
-  // (u, segment) prefetches what does not depend on the net, waits for the flag, forms hull / box / k-DOP intervals itself (the expressions of k_hullinfo:
-  // same bits), publishes the record written through and counts itself on the segment's completion counter (xf_seg, kind 0) -- the pair tiles of the
-  // launch wait for that count, a GJK head start for its two robots' flags.  k_linesearch no longer writes a hull cache at all (Dev::fa: 976 B x S per robot
-  // and launch).  Everything k_front leaves for later kernels goes out written through and every block counts itself done behind its acknowledged stores;
-  // the LAST block of k_linesearch -- the one that begins the next iteration -- waits for that count, so k_linesearch does not end before k_front has: k_mid
-  // follows on the first queue as before, and the two kernel boundaries k_linesearch -> k_front -> k_mid become one.
+  // ASYNCHRONOUS FRONT (round 6; one context, all three modes, every block of the line-search kernel resident at once): inside a batch the NEXT iteration's k_front
+  // runs on the second hardware queue next to this iteration's k_linesearch (coupled mode: the one-launch k_ls_coupled).  Its launch is held back by a one-wave gate
+  // (k_fa_gate) until every block of the line search has started (residency counters: all of them are resident then, so a k_front block that sleeps on a flag can never
+  // keep a line-search block off a compute unit); the primary block of robot u stores the accepted control net written through and raises the robot's COMMIT FLAG;
+  // k_front's obstacle unit of (u, segment) prefetches what does not depend on the net, waits for the flag, forms hull / box / k-DOP intervals itself (the expressions of
+  // k_hullinfo: same bits), publishes the record written through and counts itself on the segment's completion counter (xf_seg, kind 0) -- the pair tiles of the launch
+  // wait for that count, a GJK head start for its two robots' flags.  The paired line search writes no hull cache (976 B x S per robot and launch: the units' job now).
+  // Everything k_front leaves for later kernels goes out written through and every block counts itself done behind its acknowledged stores; the LAST block of the line
+  // search -- the one that begins the next iteration -- waits for k_front (its end, or with fa_mid only its blocks' start), so the queue order k_linesearch -> k_mid still
+  // holds what k_mid needs of the line search, and the two kernel boundaries k_linesearch -> k_front -> k_mid overlap k_front's work.
   //   fa      the context is eligible (tj_create)
   //   fa_units (per launch) k_linesearch: publish no hull cache -- the k_front that follows forms the records in its units; k_front: do so.  Set for the two launches of a
   //           pairing, and for the one-queue emulation of the schedule (TJ_FRONT_ASYNC_ONE_QUEUE=1: what the counter passes of tools/profile_round.sh run).  An unpaired
@@ -344,7 +344,6 @@ struct Dev {
   unsigned long long* blk_stats;    // [U*P] PSD repairs per piece (k_grad), then [U] energy evaluations per robot (line search): single-writer words, no atomics
   unsigned long long* pair_stats;   // [U*S][2] Optimal_plane::optimal_d iterations / robot pairs solved, spread over (lower robot, segment)
   Ctl* ctl;
-  int* err_mirror;   // pinned host memory: k_flush leaves the error bits there for the host's self-healing check (null: off)
   long long* dbg;  // phase stamps (TJ_PHASE_TIMING builds only, else null)
 };
 // P, D, obstacle box, pair box, 49 k-DOP intervals (lo,hi): 146 values in a record of 160 doubles = ten 128-byte lines of its own.  No line is shared between

@@ -1006,7 +1006,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // ---- iteration bookkeeping ---------------------------------------------------------------------
 // the first iteration of a batch; direct exchange (sharded contexts): it also feeds the peers with this rank's control points as they stand now (inside a
 // batch k_linesearch does, robot by robot) -- so a tj_set_state between batches reaches every rank like it did through the all-gather
-__global__ void k_begin(Dev D) {
+// (self-healing, below: a region of the state and its place in the snapshot arena)
+struct SnapRegion { char* live; char* snap; unsigned long long bytes; };
+__device__ __forceinline__ void snapshot_copy(const SnapRegion* tab, int n, int dir, unsigned long long first, unsigned long long stride) {
+  for (int r = 0; r < n; r++) {
+    const SnapRegion R = tab[r];
+    const unsigned long long n16 = R.bytes / 16;
+    const uint4* src = (const uint4*)(dir ? R.snap : R.live); uint4* dst = (uint4*)(dir ? R.live : R.snap);
+    for (unsigned long long i = first; i < n16; i += stride) dst[i] = src[i];
+    if (first < (R.bytes & 15)) (dir ? R.live : R.snap)[n16 * 16 + first] = (dir ? R.snap : R.live)[n16 * 16 + first];
+  }
+}
+// snap_n > 0 (self-healing): the launch also takes the batch's snapshot -- blocks 1 .. gridDim.x - 1 copy the state regions (nothing of block 0's begin work touches them),
+// block 0 the control block before it begins the iteration; one launch instead of two at the head of every batch
+__global__ void k_begin(Dev D, const SnapRegion* snap_tab, int snap_n, Ctl* ctl_snap) {
+  if (blockIdx.x > 0) { snapshot_copy(snap_tab, snap_n, 0, (unsigned long long)(blockIdx.x - 1) * blockDim.x + threadIdx.x, (unsigned long long)(gridDim.x - 1) * blockDim.x); return; }
+  if (snap_n > 0) { if (threadIdx.x == 0) *ctl_snap = *D.ctl; __syncthreads(); }
   const bool done = begin_body(D);
   if (!D.xch || done) return;
   const XchPeers* xp = D.xp;
@@ -1023,15 +1038,8 @@ __global__ void k_begin(Dev D) {
 // ---- self-healing of the cross-queue schedules (tj_api.hip: heal_check) ----
 // One launch copies every region of a table (dir = 0: state -> snapshot arena at the start of a batch; 1: back).  The control block is handled apart: on a restore
 // the epoch stays where the abandoned batch left it (stamps of its iterations must never look current again) and the error bits of the incident are cleared.
-struct SnapRegion { char* live; char* snap; unsigned long long bytes; };
 __global__ void k_snapshot(const SnapRegion* tab, int n, int dir, Ctl* ctl, Ctl* ctl_snap) {
-  for (int r = blockIdx.y; r < n; r += gridDim.y) {
-    const SnapRegion R = tab[r];
-    const unsigned long long n16 = R.bytes / 16;
-    const uint4* src = (const uint4*)(dir ? R.snap : R.live); uint4* dst = (uint4*)(dir ? R.live : R.snap);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x) dst[i] = src[i];
-    if (blockIdx.x == 0 && threadIdx.x < (R.bytes & 15)) (dir ? R.live : R.snap)[n16 * 16 + threadIdx.x] = (dir ? R.snap : R.live)[n16 * 16 + threadIdx.x];
-  }
+  for (int r = blockIdx.y; r < n; r += gridDim.y) snapshot_copy(tab + r, 1, dir, (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, (unsigned long long)gridDim.x * blockDim.x);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (!dir) *ctl_snap = *ctl;
     else {
@@ -1047,7 +1055,6 @@ __global__ void k_snapshot(const SnapRegion* tab, int n, int dir, Ctl* ctl, Ctl*
 // cancel = 1: the last k_linesearch has already begun an iteration (begin_next) that the host then did not enqueue -- take that back: the update owed is the
 // finished iteration's (already in slack_now), nothing is pending
 __global__ void k_flush(Dev D, int cancel) {
-  if (D.err_mirror) *D.err_mirror = D.ctl->error;   // (every cross-queue wait of the batch is over when this runs: the host looks at the word right after the queues have drained)
   if (cancel) { D.ctl->pending = 0; D.ctl->slack_next = 0; return; }
   D.ctl->slack_now = D.ctl->slack_next; D.ctl->slack_next = 0;
 }

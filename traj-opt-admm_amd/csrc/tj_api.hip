@@ -4,8 +4,9 @@
 // One iteration = the stage sequence of Optimization3D_multi::optimization_decouple
 // (Optimization3D_multi.h:29-118) / Optimization3D_admm::optimization (Optimization3D_admm.h:29-67),
 // enqueued with plain launches and no host synchronisation inside or between iterations: a linear chain on the context's
-// stream, plus -- one context, decoupled / single-UAV mode -- the Newton solve on a second stream next to the gradient
-// kernel (Dev::xs_async, dev_common.h; TJ_USE_GRAPH=1 replays a captured hipGraph instead).  The stop test of the mains
+// stream, plus -- one context -- the Newton solve on a second stream next to the gradient kernel (Dev::xs_async, dev_common.h)
+// and, inside a batch, the NEXT iteration's k_front on that stream next to the line search (Dev::fa; TJ_USE_GRAPH=1 replays a
+// captured hipGraph of the one-queue chain instead).  A wait between the queues that runs out is healed, not reported (heal_check).  The stop test of the mains
 // runs on the device (begin_body), so a converged problem turns the remaining launches into early-exit kernels.
 //
 // There is deliberately no CPU path in this file: every entry point either runs HIP kernels or
@@ -56,8 +57,8 @@ struct tj_ctx {
   // keep one of the queues off the hardware) must not fail a run.  The first tj_iterate_async after a point at which the host has looked at the device takes a snapshot of the
   // state (one launch); when the host next looks and finds the bit, it latches every two-queue schedule off, restores the snapshot, enqueues the same iterations again on
   // the one queue and counts the incident (tj_stats.async_fallbacks).  TJ_HEAL=0: off (the bit is reported as TJ_ERR_NO_PROGRESS, as in round 5).
-  bool heal = false, heal_busy = false; long long snap_iters = 0; int async_fallbacks = 0, xs_fault = 0;
-  SnapRegion* snap_tab = nullptr; int snap_n = 0; Ctl* ctl_snap = nullptr; int* host_err = nullptr;
+  bool heal = false, heal_busy = false, snap_in_begin = false; long long snap_iters = 0; int async_fallbacks = 0, xs_fault = 0;
+  SnapRegion* snap_tab = nullptr; int snap_n = 0; Ctl* ctl_snap = nullptr;
   bool fa_mid_ok = false, fa_mid_now = false;   // Dev::fa_mid: k_front's whole grid is resident at once next to one k_linesearch block (tj_create) / the k_mid about to be enqueued waits for k_front itself
   bool use_graph = false;    // TJ_USE_GRAPH=1: replay a captured hipGraph per iteration instead of plain launches
   bool hull_valid = false;   // Dev::fuse: the hull cache matches the control points (else k_hullinfo runs before the next iteration)
@@ -193,7 +194,10 @@ bool launch_kernel(tj_ctx* c, int kid, hipStream_t s, int slack_deferred = 0, bo
   const int n_mid_slack = owned * d.P;
   d_.fa_nfront = n_front; d_.fa_nls = coupled ? owned * LSC_ROUNDS : owned * d.ls_help;
   switch (kid) {
-    case K_BEGIN: if (chain_pos & 1) return false; TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d); c->xf_used[0] = c->xf_used[1] = false; return true;
+    case K_BEGIN: if (chain_pos & 1) return false;
+      if (c->snap_in_begin) { c->snap_in_begin = false; TJ_LAUNCH(k_begin, dim3(1 + 128), dim3(256), 0, s, d, c->snap_tab, c->snap_n, c->ctl_snap); }   // (self-healing: the batch's snapshot rides in this launch)
+      else TJ_LAUNCH(k_begin, dim3(1), dim3(256), 0, s, d, nullptr, 0, nullptr);
+      c->xf_used[0] = c->xf_used[1] = false; return true;
     case K_HULLINFO: if ((chained && (d.fuse || d.xf_all)) || !multi) return false; TJ_LAUNCH(k_hullinfo, dim3(d.U * d.S), dim3(64), 0, s, d); return true;  // unfused sharded phases (coupled mode): always (all robots, after the gather)
     case K_FRONT: if (!in_graph && !in_phase) return false;
       if (c->split_unions && multi) {
@@ -370,16 +374,22 @@ int flush_deferred(tj_ctx* c) {
   return TJ_OK;
 }
 
-int heal_check(tj_ctx* c);
-// every host-visible read or write of solver state first pays a deferred slack/dual update -- and, where a batch ran on several queues, looks whether it has to be run again (heal_check)
-#define QUIESCE(c)                                              \
+int heal_check(tj_ctx* c, int err_known);
+// drain: pay a deferred slack/dual update, then wait for every queue of the context
+#define QUIESCE_NOHEAL(c)                                       \
   do {                                                          \
     int qr_ = flush_deferred(c);                                \
     if (qr_) return qr_;                                        \
     HIPCHK(c, hipStreamSynchronize((c)->stream));               \
     if ((c)->stream2) HIPCHK(c, hipStreamSynchronize((c)->stream2)); \
     if ((c)->stream3) HIPCHK(c, hipStreamSynchronize((c)->stream3)); \
-    if ((c)->snap_iters > 0 && !(c)->heal_busy) { qr_ = heal_check(c); if (qr_) return qr_; } \
+  } while (0)
+// every host-visible read or write of solver state first drains the context -- and, where a batch ran on several queues, looks whether it has to be run again (heal_check:
+// one 4-byte read-back; tj_sync alone does not look -- whoever reads a result afterwards does; tj_iterate uses the control block it reads anyway)
+#define QUIESCE(c)                                              \
+  do {                                                          \
+    QUIESCE_NOHEAL(c);                                          \
+    if ((c)->snap_iters > 0 && !(c)->heal_busy) { int hr_ = heal_check(c, -1); if (hr_) return hr_; } \
   } while (0)
 
 // Work of graph slot `which`: 0,1,2 = the phases of a sharded iteration (split at the two all-gathers), 3 = one full
@@ -461,9 +471,11 @@ void choose_builds(tj_ctx* c, const int* found64) {
 int check_device_errors(tj_ctx* c, Ctl* out = nullptr) {
   Ctl h; int found64[64];
   const int fb0 = c->async_fallbacks;
+  { int fr_ = flush_deferred(c); if (fr_) return fr_; }   // (in front of the copies: they are to see the state behind the last slack / dual update)
   HIPCHK(c, hipMemcpyAsync(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(found64, c->d.ccd_found, sizeof(found64), hipMemcpyDeviceToHost, c->stream));
-  QUIESCE(c);
+  QUIESCE_NOHEAL(c);
+  if (c->snap_iters > 0 && !c->heal_busy) { int hr_ = heal_check(c, h.error); if (hr_) return hr_; }   // (the error word has come with the control block: no extra read-back)
   if (c->async_fallbacks != fb0) {   // the batch was run again on one queue (heal_check): what was copied above belongs to the abandoned attempt
     HIPCHK(c, hipMemcpy(&h, c->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(found64, c->d.ccd_found, sizeof(found64), hipMemcpyDeviceToHost));
@@ -502,8 +514,9 @@ int ensure_hull_cache(tj_ctx* c) {
 
 // The batch enqueued since the last snapshot is through (every queue drained).  No incident: forget the snapshot.  ERR_XS_TIMEOUT: one queue from now on, the snapshot's
 // state back in place, the same iterations again.
-int heal_check(tj_ctx* c) {
-  const int err = *(volatile int*)c->host_err;   // (left in pinned host memory by k_flush, which QUIESCE's flush has just run behind the batch: no copy, no extra synchronisation)
+int heal_check(tj_ctx* c, int err_known) {
+  int err = err_known;
+  if (err < 0) HIPCHK(c, hipMemcpy(&err, &c->d.ctl->error, sizeof(int), hipMemcpyDeviceToHost));   // (every queue has drained: QUIESCE)
   const long long n = c->snap_iters;
   c->snap_iters = 0;
   if (!(err & ERR_XS_TIMEOUT)) return TJ_OK;
@@ -812,11 +825,6 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   }
   {   // self-healing: what a batch's first state consists of (everything an iteration reads that an earlier iteration wrote and that is not rebuilt or re-stamped anyway)
     c->heal = !(tune("HEAL") && atoi(tune("HEAL")) == 0);
-    if (c->heal) {   // the error word's mirror in pinned host memory (written by k_flush)
-      void* hp = nullptr; void* dp = nullptr;
-      if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { c->host_err = (int*)hp; *c->host_err = 0; d.err_mirror = (int*)dp; }
-      else { (void)hipGetLastError(); if (hp) (void)hipHostFree(hp); c->heal = false; }
-    }
     if (const char* e = tune("XS_FAULT")) c->xs_fault = atoi(e);   // test hook: the n-th gate of the asynchronous solve reports a time-out
     std::vector<std::pair<void*, size_t>> reg = {
       {d.spline, U * 3 * T * 8}, {d.p_slack, U * 18 * P * 8}, {d.p_lambda, U * 18 * P * 8}, {d.t_slack, U * P * 8}, {d.t_lambda, U * P * 8}, {d.piece_time, U * 8},
@@ -847,7 +855,6 @@ void tj_destroy(tj_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
-  if (c->host_err) (void)hipHostFree(c->host_err);
   for (void* p : c->xch_ipc_opened) (void)hipIpcCloseMemHandle(p);
   if (c->xch_block) (void)hipFree(c->xch_block);
   for (void* p : c->allocs) hipFree(p);
@@ -1099,8 +1106,8 @@ int tj_iterate_async(tj_ctx* c, int n_iters) {
   if (!ready(c)) return TJ_ERR_INVALID;
   if (c->heal && n_iters > 0 && (c->xs_two_queues || c->keep_two_queues)) {   // self-healing: the state this batch starts from (one launch), unless iterations the host has not looked at yet are already outstanding
     if (c->snap_iters == 0 && !c->heal_busy) {
-      hipLaunchKernelGGL(k_snapshot, dim3(64, std::max(c->snap_n, 1)), dim3(256), 0, c->stream, c->snap_tab, c->snap_n, 0, c->d.ctl, c->ctl_snap);
-      HIPCHK(c, hipGetLastError());
+      if (!c->begin_folded) c->snap_in_begin = true;   // the batch's first launch is k_begin: the snapshot rides in it
+      else { hipLaunchKernelGGL(k_snapshot, dim3(64, std::max(c->snap_n, 1)), dim3(256), 0, c->stream, c->snap_tab, c->snap_n, 0, c->d.ctl, c->ctl_snap); HIPCHK(c, hipGetLastError()); }
     }
     if (!c->heal_busy) c->snap_iters += n_iters;
   }
@@ -1121,7 +1128,7 @@ int tj_iterate_async(tj_ctx* c, int n_iters) {
 int tj_sync(tj_ctx* c) {
   if (!c) return TJ_ERR_INVALID;
   { int r = flush_deferred(c); if (r) return r; }
-  QUIESCE(c);
+  QUIESCE_NOHEAL(c);   // (no read-back here: a batch that has to be run again -- heal_check -- is noticed by the next call that reads a result or the statistics)
   return TJ_OK;
 }
 
