@@ -614,7 +614,7 @@ def main():
                "config": {"workload": f"{scene['name']}: {scene['U']} UAVs crossing, {scene['tris'].shape[0] if scene.get('tris') is not None else scene['cloud'].shape[0]} obstacle {'triangles (fp64 narrow phase, fp32 outward-rounded BVH boxes)' if scene.get('tris') is not None else 'points'}, "
                                       f"{scene['P']} pieces x res 8 = {slv.S} segments/robot, {'coupled mode (decouple:0)' if args.coupled else 'decoupled mode (3D.json defaults)'}{', optimal_plane:1' if args.optimal_plane else ''}",
                           "parallelism": f"robots sharded over {world} GPU(s), one process per GPU, {'direct exchange (in-kernel pushes / waits through hipIpc-mapped receive blocks), six kernels per iteration and rank' if sharded and path['name'] == 'direct' else str(5 if args.coupled else 2) + ' RCCL all-gathers/iter on the library exchange buffers'}; expectation: {EXPECT.get(scene['name'].split('-coupled')[0], '')}" if world > 1 else (f"1 GPU, whole iteration resident on the device: a linear chain of 6 kernels on one queue (union kernels), enqueued ahead, no host sync" if args.coupled or os.environ.get("TJ_XS_ASYNC") == "0"
-                                           else "1 GPU, whole iteration resident on the device: six kernels per iteration enqueued ahead, no host sync -- five in a chain on one queue, the Newton solve on a second queue next to the gradient kernel (in-kernel tickets / flags; TJ_XS_ASYNC=0: all six on one queue)"),
+                                           else "1 GPU, whole iteration resident on the device: six kernels per iteration enqueued ahead, no host sync -- four in a chain on one queue; on a second queue the Newton solve next to the gradient kernel and the next iteration's plane queries next to the line search (in-kernel tickets / flags / commit flags; TJ_XS_ASYNC=0 TJ_FRONT_ASYNC=0: all six on one queue)"),
                           "iters_timed_from": "initial trajectory"}}
         if scene["name"] == "SCN-C" and not (args.coupled or args.optimal_plane):
             out["config"]["parity_pin"] = ("the timed SCN-C is pinned against the unmodified reference PER ITERATION (tests/golden/stages_scn_c.npz) and end to end only inside the reference's own "

@@ -23,3 +23,16 @@ run Cc $Q --scene C --coupled
 run Coptplane $Q --scene C --optimal-plane
 run Cdist1 $Q --scene C --force-dist
 run Cgroup2same $Q --scene C --group-devices 0,0
+run H8 $Q --scene H8
+# the asynchronous front's A/B (round 6): the same lines with k_front behind k_linesearch on the chain's queue
+export TJ_FRONT_ASYNC=0
+run C_fa0 $Q --scene C
+run C100_fa0 $Q --scene C --steps 100
+run A_fa0 $Q --scene A
+run B_fa0 $Q --scene B
+run Dtri_fa0 $Q --scene Dtri
+run E_fa0 $Q --scene E
+run Bc_fa0 $Q --scene B --coupled
+run Cc_fa0 $Q --scene C --coupled
+run H8_fa0 $Q --scene H8
+unset TJ_FRONT_ASYNC
