@@ -100,7 +100,10 @@ int tj_host_tables(int piece_num, int res, double* convert, double* mdyn, double
  *                                   the library restores the state the batch started from, runs the batch again on ONE queue and keeps the one-queue chain for the
  *                                   life of the context (tj_stats.async_fallbacks counts it; same results bit for bit; the incident costs its 2 s once).  TJ_HEAL=0
  *                                   restores round 5's report (TJ_ERR_NO_PROGRESS, error bit 2048); TJ_XS_ASYNC=0 TJ_KEEP_ASYNC=0 avoid the stall up front.  Under
- *                                   rocprofv3's counter collection (which serialises dispatches across queues) the library keeps one queue by itself. */
+ *                                   rocprofv3's counter collection (which serialises dispatches across queues) the library keeps one queue by itself.  Several
+ *                                   contexts in ONE process: HIP lets streams beyond GPU_MAX_HW_QUEUES (4) share hardware queues, where a sleeping kernel would keep another
+ *                                   context's kernels back; the contexts that sleep across queues therefore claim their streams out of a per-device budget of that many
+ *                                   minus one, and a context that does not fit keeps the one-queue chain from the start (same bits). */
 int tj_create(const tj_params* p, tj_ctx** out);
 void tj_destroy(tj_ctx* c);
 const char* tj_last_error(const tj_ctx* c);

@@ -446,6 +446,35 @@ def test_two_processes_on_one_gpu_with_default_settings(pkg, scenes, tmp_path):
 
 
 @pytest.mark.gpu
+def test_several_contexts_of_one_process_run_their_two_queue_schedules_side_by_side(pkg, scenes, monkeypatch):
+    """Three contexts of ONE process, default settings, batches enqueued on all of them before any is waited for: each has its two hardware queues, its gates, flags and
+    counters; their kernels share the device.  Every wait of the cross-queue protocols has its producer resident when it begins, so contexts cannot block each other for
+    good -- and if a 2 s limit fires all the same, the context heals itself.  Each must end bit for bit where it ends alone, without an error bit."""
+    for k in ("TJ_XS_ASYNC", "TJ_FRONT_ASYNC", "TJ_HEAL", "TJ_XS_FAULT", "TJ_XS_ONE_QUEUE", "TJ_FRONT_ASYNC_ONE_QUEUE"):
+        monkeypatch.delenv(k, raising=False)
+    makers = (scenes.scn_c, scenes.scn_b, lambda: dict(scenes.scn_b(), mode=2))
+    alone = []
+    for mk in makers:
+        s = pkg.Solver(mk(), stop=0.0)
+        for b in (25, 1, 34):
+            s.iterate_async(b); s.sync()
+        alone.append(s.get_state()); s.close()
+    ctxs = [pkg.Solver(mk(), stop=0.0) for mk in makers]
+    for b in (25, 1, 34):
+        for s in ctxs:
+            s.iterate_async(b)
+        for s in reversed(ctxs):
+            s.sync()
+    for i, s in enumerate(ctxs):
+        st, ts = s.get_state(), s.stats()
+        print(f"context {i}: error bits {ts['error_bits']}, fallbacks {ts['async_fallbacks']}")
+        assert ts["error_bits"] == 0 and ts["iters"] == 60, (i, ts["error_bits"], ts["iters"])
+        for n in st:
+            assert np.array_equal(st[n], alone[i][n]), f"context {i}: {n} differs from the run that had the device to itself"
+        s.close()
+
+
+@pytest.mark.gpu
 def test_rank_isolated_replay_reproduces_the_one_context_run(tmp_path):
     """tools/rank_replay.py (round 6): rank r of world N alone on the device, the other ranks' slices copied in from a one-context recording before each consuming phase.
     The tool asserts that every replayed rank's owned robots end bit for bit in the one-context state; here on the 8-robot scene with 1, 2 and 4 ranks."""

@@ -36,6 +36,11 @@
 
 using namespace tj;
 
+#include <atomic>
+// streams claimed by the contexts of this process whose kernels sleep across queues, per device (tj_create)
+static std::atomic<int> g_async_queues[64];
+static int hw_queue_budget() { const char* e = getenv("GPU_MAX_HW_QUEUES"); const int n = e ? atoi(e) : 4; return std::max(n, 2) - 1; }
+
 struct tj_ctx {
   tj_params prm;
   Dev d;
@@ -52,6 +57,7 @@ struct tj_ctx {
   // asynchronous front (Dev::fa): fa_seq = pairings k_linesearch(i) <-> k_front(i + 1) launched so far (the device's words are monotonic in it); fa_armed: the last
   // k_linesearch enqueued belongs to pairing fa_seq and the k_front that follows goes to the second queue behind k_fa_gate
   int fa_seq = 0; bool fa_armed = false;
+  int hwq_claim = 0; bool hwq_refused = false;   // hardware queues this context claimed out of the process's budget for contexts that sleep across queues (tj_create)
   bool hull_from_units = false, fa_emulate = false;   // the last k_linesearch enqueued published no hull cache (the next k_front forms the records in its units) / TJ_FRONT_ASYNC_ONE_QUEUE=1: the schedule's data flow on one queue
   // Self-healing of the cross-queue schedules: a wait between the queues that runs out (ERR_XS_TIMEOUT -- in practice a GPU shared with another process, whose time slices
   // keep one of the queues off the hardware) must not fail a run.  The first tj_iterate_async after a point at which the host has looked at the device takes a snapshot of the
@@ -522,6 +528,7 @@ int heal_check(tj_ctx* c, int err_known) {
   if (!(err & ERR_XS_TIMEOUT)) return TJ_OK;
   c->heal_busy = true;
   c->async_fallbacks++;
+  if (c->hwq_claim) { g_async_queues[std::min(std::max(c->prm.device, 0), 63)].fetch_sub(c->hwq_claim); c->hwq_claim = 0; }   // (one queue from now on: the budget is free for another context)
   c->xs_two_queues = false; c->keep_two_queues = false; c->fa_armed = false; c->fa_mid_now = false; c->xs_fault = 0;   // (the tickets / flags of the asynchronous solve work on one queue as well: TJ_XS_ONE_QUEUE's schedule)
   Dev& d = c->d;
   hipLaunchKernelGGL(k_snapshot, dim3(64, std::max(c->snap_n, 1)), dim3(256), 0, c->stream, c->snap_tab, c->snap_n, 1, d.ctl, c->ctl_snap);
@@ -728,13 +735,29 @@ int tj_create(const tj_params* p, tj_ctx** out) {
     const bool counters_on = cc_ && cc_[0] && strcmp(cc_, "0") != 0 && strcasecmp(cc_, "false") != 0;
     if (counters_on && !tune("XS_ASYNC")) d.xs_async = 0;
     if (const char* e = tune("XS_ASYNC")) d.xs_async = d.xs_async && atoi(e) != 0;
+    // Hardware queues.  HIP maps a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues per device and lets further streams SHARE them; a gate kernel that sleeps at the
+    // head of a shared queue keeps back whatever another context put behind it -- possibly the very kernel a gate of THAT context, asleep on a queue of this one, waits for:
+    // measured with three default contexts in one process, two of them ran into the 2 s limit (and healed themselves).  So the contexts of a process that sleep across queues
+    // claim their streams (main + second + third) out of a per-device budget of GPU_MAX_HW_QUEUES - 1 (the null stream has one); a context that does not fit keeps the one-queue
+    // chain (same bits).  An explicit TJ_XS_ASYNC=1 / TJ_KEEP_ASYNC=1 overrides; self-healing stays the net under it.
+    {
+      const bool want_keep = d.optimal_plane && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && !c->split_unions && !(counters_on && !tune("KEEP_ASYNC")) && !(tune("KEEP_ASYNC") && atoi(tune("KEEP_ASYNC")) == 0);
+      const int need = 1 + (d.xs_async ? 1 : 0) + (want_keep ? 1 : 0);
+      const bool forced = (tune("XS_ASYNC") && atoi(tune("XS_ASYNC")) != 0) || (tune("KEEP_ASYNC") && atoi(tune("KEEP_ASYNC")) != 0);
+      if (need > 1) {
+        std::atomic<int>& g = g_async_queues[std::min(std::max(p->device, 0), 63)];
+        const int had = g.fetch_add(need);
+        if (had + need > hw_queue_budget() && !forced) { g.fetch_sub(need); d.xs_async = 0; c->hwq_refused = true; }
+        else c->hwq_claim = need;
+      }
+    }
     if (d.xs_async) {
       const bool ok = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); c->stream2 = nullptr; }   // (the tickets and flags work on one queue as well)
       c->xs_two_queues = ok && tune("XS_ONE_QUEUE") == nullptr;
     }
     // asynchronous plane refinement ("optimal_plane":1, multi-UAV decoupled mode, one context; TJ_KEEP_ASYNC=0: k_keep stays one launch between k_mid and k_grad -- same bits)
-    d.keep_async = (d.optimal_plane && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && !c->split_unions) ? 1 : 0;
+    d.keep_async = (d.optimal_plane && p->mode == TJ_MODE_MULTI_DECOUPLE && p->world == 1 && !c->split_unions && !c->hwq_refused) ? 1 : 0;
     if (counters_on && !tune("KEEP_ASYNC")) d.keep_async = 0;
     if (const char* e = tune("KEEP_ASYNC")) d.keep_async = d.keep_async && atoi(e) != 0;
     d.keep_waves = 1024;
@@ -852,6 +875,7 @@ int tj_create(const tj_params* p, tj_ctx** out) {
 void tj_destroy(tj_ctx* c) {
   if (!c) return;
   drop_graph(c);
+  if (c->hwq_claim) { g_async_queues[std::min(std::max(c->prm.device, 0), 63)].fetch_sub(c->hwq_claim); c->hwq_claim = 0; }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
