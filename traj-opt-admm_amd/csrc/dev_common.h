@@ -287,6 +287,7 @@ struct Dev {
                                    // address is hot; the host sums them when it reads the control block and picks k_ccd's build from the rate
   int pair_rows;                   // rows per tile of the robot-pair broad phase (kernels_pairs.h)
   int mid_order;      // k_mid's grid: 0 slack | pair waves | obstacle solves; 1 (hundreds of robots) pair waves | obstacle solves | slack (kernels_step.h; TJ_MID_ORDER)
+  const int* xs_gather;   // k_xsolve's overlap-add as a table (tj_create): [n*n][2] piece-block entries per entry of the reduced system, then [n][2] for the gradient; -1 none, -2 every piece (time entry)
   int pair_prio;      // large fleets: producer waves of k_mid run at wave priority 3 (TJ_PAIR_PRIO=0: off)
   int pair_lpw;       // large fleets, one pair per lane: pairs a producer wave of k_mid takes per pass (64 = every lane; TJ_PAIR_LPW)
   int pair_pass_on;   // 1 (default): large fleets pass long pair solves on to idle waves; TJ_PAIR_PASS_ON=0 keeps every pair on its lane (test hook: same bits either way)

@@ -782,6 +782,18 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   double* lhu = scr + 6 * n;          // [P*361]
   double* lgu = lhu + D.P * 361;      // [P*19]
   const bool wt = D.xs_async != 0;   // asynchronous solve (Dev::xs_async): this launch started next to k_grad, on the other queue
+  // the overlap-add's sources (Dev::xs_gather): fetched BEFORE the wait for the tickets -- the index arithmetic they replace (covering pieces of a row and a column, local
+  // offsets: ~100 instructions per entry) was 1.8 us between the last ticket and the factorisation
+  constexpr int XS_EPT = NREG > 0 ? (NREG * NREG + XS_LOAD_THREADS - 1) / XS_LOAD_THREADS : 1;   // entries of the reduced system per thread
+  int gs0[XS_EPT], gs1[XS_EPT], gv0 = -1, gv1 = -1;
+  if constexpr (NREG > 0) {
+#pragma unroll
+    for (int k = 0; k < XS_EPT; k++) {
+      const int idx = tid + k * XS_LOAD_THREADS;
+      gs0[k] = idx < n * n ? D.xs_gather[2 * idx] : -1; gs1[k] = idx < n * n ? D.xs_gather[2 * idx + 1] : -1;
+    }
+    if (tid < n) { gv0 = D.xs_gather[2 * n * n + 2 * tid]; gv1 = D.xs_gather[2 * n * n + 2 * tid + 1]; }
+  }
   if (wt) {
     // the robot's P piece blocks are in (each took a ticket after its write-through stores were acknowledged): wave 0 sleeps on the word, the others at the barrier
     if (tid < 64) xs_wait(D, D.xs_ticket(u), D.P);
@@ -803,7 +815,24 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
   }
   __syncthreads();
   TJ_TIC(D, K_XSOLVE, 1);
-  {
+  if constexpr (NREG > 0) {   // the same sums in the same order (0 + first covering piece + second), sources from the table
+#pragma unroll
+    for (int k = 0; k < XS_EPT; k++) {
+      const int idx = tid + k * XS_LOAD_THREADS;
+      if (idx < n * n) {
+        double acc = 0;
+        if (gs0[k] == -2) { for (int sp = 0; sp < D.P; sp++) acc += lhu[(size_t)sp * 361 + 18 * 19 + 18]; }
+        else { if (gs0[k] >= 0) acc += lhu[gs0[k]]; if (gs1[k] >= 0) acc += lhu[gs1[k]]; }
+        H[idx] = acc; L[idx] = acc;
+      }
+    }
+    if (tid < n) {
+      double acc = 0;
+      if (gv0 == -2) { for (int sp = 0; sp < D.P; sp++) acc += lgu[sp * 19 + 18]; }
+      else { if (gv0 >= 0) acc += lgu[gv0]; if (gv1 >= 0) acc += lgu[gv1]; }
+      g0[tid] = acc; x0[tid] = acc;
+    }
+  } else {
     int ra = tid / n, rb = tid % n;  // (row, column) of entry idx, advanced incrementally
     const int dra = XS_LOAD_THREADS / n, drb = XS_LOAD_THREADS % n;
     for (int idx = tid; idx < n * n; idx += XS_LOAD_THREADS) {
@@ -821,7 +850,6 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
       ra += dra; rb += drb;
       if (rb >= n) { rb -= n; ra++; }
     }
-  }
   for (int ra = tid; ra < n; ra += XS_LOAD_THREADS) {
     const int ga = ra == m ? -1 : ra + 6;
     int lo = 0, hi = D.P - 1;
@@ -829,6 +857,7 @@ __global__ __launch_bounds__(XS_LOAD_THREADS) void k_xsolve(Dev D) {
     double acc = 0;
     for (int sp = max(lo, 0); sp <= hi; sp++) acc += lgu[sp * 19 + (ga < 0 ? 18 : ga - 9 * sp)];
     g0[ra] = acc; x0[ra] = acc;
+  }
   }
   __syncthreads();
   // From here on wave 0 works alone (its sync points are wave-local: blk_sync<true>).  Without the swept-hull tail the other

@@ -822,6 +822,34 @@ int tj_create(const tj_params* p, tj_ctx** out) {
   if ((r = upload(c, basis, t.basis.data(), t.basis.size() * 8)) || (r = upload(c, convert, t.convert.data(), t.convert.size() * 8)) ||
       (r = upload(c, mdyn, t.mdyn, 36 * 8)) || (r = upload(c, kdop, t.kdop, 147 * 8)) || (r = upload(c, pow08, t.pow08.data(), t.pow08.size() * 8))) return r;
   d.basis = basis; d.convert = convert; d.mdyn = mdyn; d.kdop = kdop; d.pow08 = pow08;
+  {   // k_xsolve's overlap-add as a table: per entry of the reduced system the (at most two) piece-block entries that cover it, in piece order; -2: the time-time entry (every piece)
+    const int Pn = d.P, m = 9 * Pn - 3, n = m + 1;
+    std::vector<int> gt((size_t)2 * n * n + 2 * n, -1);
+    auto cover = [&](int g, int& lo, int& hi) { if (g >= 0) { lo = std::max(lo, (g - 17 + 8) / 9); hi = std::min(hi, g / 9); } };
+    for (int idx = 0; idx < n * n; idx++) {
+      const int ra = idx / n, rb = idx % n, ga = ra == m ? -1 : ra + 6, gb = rb == m ? -1 : rb + 6;
+      if (ga < 0 && gb < 0) { gt[2 * (size_t)idx] = -2; continue; }
+      int lo = 0, hi = Pn - 1, k = 0;
+      cover(ga, lo, hi); cover(gb, lo, hi);
+      for (int sp = std::max(lo, 0); sp <= hi; sp++) {
+        const int a = ga < 0 ? 18 : ga - 9 * sp, b = gb < 0 ? 18 : gb - 9 * sp;
+        if (k < 2) gt[2 * (size_t)idx + k] = sp * 361 + a * 19 + b;
+        k++;
+      }
+      if (k > 2) { c->err = "internal: an entry of the reduced system is covered by more than two piece blocks"; return TJ_ERR_INVALID; }
+    }
+    for (int ra = 0; ra < n; ra++) {
+      const int ga = ra == m ? -1 : ra + 6;
+      if (ga < 0) { gt[(size_t)2 * n * n + 2 * ra] = -2; continue; }
+      int lo = 0, hi = Pn - 1, k = 0;
+      cover(ga, lo, hi);
+      for (int sp = std::max(lo, 0); sp <= hi; sp++) { if (k < 2) gt[(size_t)2 * n * n + 2 * ra + k] = sp * 19 + (ga - 9 * sp); k++; }
+      if (k > 2) { c->err = "internal: a row of the reduced system is covered by more than two piece blocks"; return TJ_ERR_INVALID; }
+    }
+    int* gtd = nullptr;
+    if ((r = dalloc(c, &gtd, gt.size())) || (r = upload(c, gtd, gt.data(), gt.size() * sizeof(int)))) return r;
+    d.xs_gather = gtd;
+  }
   const size_t U = d.U, S = d.S, P = d.P, T = d.T;
   if ((r = dalloc(c, &d.spline, U * 3 * T)) || (r = dalloc(c, &d.p_slack, U * 18 * P)) || (r = dalloc(c, &d.p_lambda, U * 18 * P)) ||
       (r = dalloc(c, &d.t_slack, U * P)) || (r = dalloc(c, &d.t_lambda, U * P)) || (r = dalloc(c, &d.piece_time, U)) ||
